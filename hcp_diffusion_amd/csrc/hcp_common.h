@@ -1,0 +1,36 @@
+// hcp_common.h — C-ABI conventions shared by every translation unit of libhcp_mi355x.so.
+// Every exported function returns int (0 ok, <0 error, message via hcp_last_error()),
+// takes raw device pointers + explicit shapes + a hipStream_t, never allocates and never
+// synchronises the stream (SURVEY.md §8(b) "What a C-ABI replacement must export").
+#pragma once
+#include "hcp_device.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#define HCP_API extern "C" __attribute__((visibility("default")))
+
+extern "C" int hcp_set_error(const char* fmt, ...);
+
+#define HCP_REQUIRE(cond, ...)                         \
+    do {                                               \
+        if (!(cond)) return hcp_set_error(__VA_ARGS__); \
+    } while (0)
+
+#if defined(HCP_EMU)
+#define HCP_LAUNCH_CHECK(name) return 0
+static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+#else
+#define HCP_LAUNCH_CHECK(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) return hcp_set_error("%s: %s", name, hipGetErrorString(e_)); \
+        return 0;                                                                     \
+    } while (0)
+static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t s) {
+    return hipMemsetAsync(p, v, n, s) == hipSuccess ? 0 : -1;
+}
+#endif
+
+static inline int hcp_cdiv(int a, int b) { return (a + b - 1) / b; }
+typedef unsigned short hcp_bf16;  // raw bf16 bits

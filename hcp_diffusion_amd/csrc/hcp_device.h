@@ -1,0 +1,76 @@
+// hcp_device.h — the single device-abstraction header every kernel in csrc/ includes.
+//
+// Product build (hipcc --offload-arch=gfx950): thin inline wrappers over the CDNA4
+// builtins (MFMA 16x16x32 / 32x32x16 bf16, wave64 shuffles, LDS, launch).
+//
+// Test build (-DHCP_EMU, host clang++, ONLY ever produced by tests/emu/build_emu.py):
+// the same wrappers are provided by tests/emu/hcp_emu.h, a fibre-based wave64
+// interpreter that lets `pytest -m "not gpu"` execute the *identical kernel source*
+// on tiny shapes on the CPU.  The product library never contains that path:
+// __graft_entry__.build() compiles without HCP_EMU and the Python loader only opens
+// libhcp_mi355x.so.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(HCP_EMU)
+#include "hcp_emu.h"
+#else
+#include <hip/hip_runtime.h>
+
+#define HCP_DEVICE __device__ __forceinline__
+#define HCP_KERNEL(maxthreads) __global__ void __launch_bounds__(maxthreads)
+// all LDS is dynamic and 16-byte aligned (guide §6 G17)
+#define HCP_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define HCP_SYNC() __syncthreads()
+#define HCP_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
+
+typedef short hcp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short hcp_bf16x4 __attribute__((ext_vector_type(4)));
+typedef float hcp_f32x4 __attribute__((ext_vector_type(4)));
+typedef float hcp_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 hcp_bf16x8_hw __attribute__((ext_vector_type(8)));
+
+// D(16x16) += A(16x32) * B(32x16).  lane l: A row l&15, B col l&15, k-chunk (l>>4)*8..+7
+// D: col = l&15, row = (l>>4)*4 + r  (cdna_hip_programming.md §3).
+HCP_DEVICE hcp_f32x4 hcp_mfma16(hcp_bf16x8 a, hcp_bf16x8 b, hcp_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hcp_bf16x8_hw, a),
+                                                   __builtin_bit_cast(hcp_bf16x8_hw, b), c, 0, 0, 0);
+}
+// D(32x32) += A(32x16) * B(16x32). lane l: A row l&31, B col l&31, k-chunk (l>>5)*8..+7
+// D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+HCP_DEVICE hcp_f32x16 hcp_mfma32(hcp_bf16x8 a, hcp_bf16x8 b, hcp_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hcp_bf16x8_hw, a),
+                                                   __builtin_bit_cast(hcp_bf16x8_hw, b), c, 0, 0, 0);
+}
+HCP_DEVICE float hcp_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+HCP_DEVICE float hcp_shfl(float v, int src) { return __shfl(v, src, 64); }
+HCP_DEVICE int hcp_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
+HCP_DEVICE void hcp_atomic_add(float* p, float v) { atomicAdd(p, v); }
+HCP_DEVICE int hcp_lane() { return threadIdx.x & 63; }
+#endif  // HCP_EMU
+
+// ---------------------------------------------------------------- bf16 helpers (bit-exact RNE)
+HCP_DEVICE float hcp_bf2f(unsigned short h) {
+    union { uint32_t u; float f; } x; x.u = ((uint32_t)h) << 16; return x.f;
+}
+HCP_DEVICE unsigned short hcp_f2bf(float f) {
+    union { uint32_t u; float f; } x; x.f = f;
+    if ((x.u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((x.u >> 16) | 0x40);  // NaN
+    uint32_t r = x.u + 0x7fffu + ((x.u >> 16) & 1u);
+    return (unsigned short)(r >> 16);
+}
+HCP_DEVICE float hcp_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += hcp_shfl_xor(v, m);
+    return v;
+}
+HCP_DEVICE float hcp_wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { float o = hcp_shfl_xor(v, m); v = v > o ? v : o; }
+    return v;
+}
+HCP_DEVICE hcp_bf16x8 hcp_zero8() { hcp_bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
+HCP_DEVICE float hcp_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+HCP_DEVICE float hcp_silu(float x) { return x * hcp_sigmoid(x); }

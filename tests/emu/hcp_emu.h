@@ -1,0 +1,90 @@
+// hcp_emu.h — TEST INFRASTRUCTURE ONLY (never part of libhcp_mi355x.so).
+//
+// A minimal wave64 interpreter for the kernels in hcp_diffusion_amd/csrc: every GPU thread
+// is a user-space fibre; __syncthreads() and the wave collectives (MFMA, shuffles) are
+// rendezvous points resolved by a round-robin scheduler (hcp_emu.cpp).  MFMA fragment
+// layouts follow cdna_hip_programming.md §3, so an indexing bug in a kernel shows up as a
+// wrong answer on the CPU, before a GPU-minute is spent.  Built only by tests/emu/build_emu.py
+// with host clang++ and -DHCP_EMU.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+
+namespace hcp_emu {
+struct uint3_t { unsigned x, y, z; };
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+enum { ST_RUN = 0, ST_BARRIER = 1, ST_WAVE = 2, ST_DONE = 3 };
+enum { OP_SHFL = 1, OP_MFMA16 = 2, OP_MFMA32 = 3 };
+struct Fiber {
+    void* sp;
+    uint3_t tid;
+    int lin, wave, lane, state;
+    int op;
+    uint32_t in[24];
+    uint32_t out[16];
+    int src_lane;
+    char* stack;
+};
+extern Fiber* g_cur;
+extern uint3_t g_block;
+extern dim3 g_bdim, g_gdim;
+extern unsigned char* g_smem;
+void yield_barrier();
+void wave_collective();
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+}  // namespace hcp_emu
+
+using hcp_emu::dim3;
+typedef void* hipStream_t;
+
+#define threadIdx (hcp_emu::g_cur->tid)
+#define blockIdx (hcp_emu::g_block)
+#define blockDim (hcp_emu::g_bdim)
+#define gridDim (hcp_emu::g_gdim)
+
+#define HCP_DEVICE static inline
+#define HCP_KERNEL(maxthreads) static void
+#define HCP_DYN_SMEM(name) unsigned char* name = hcp_emu::g_smem
+#define HCP_SYNC() hcp_emu::yield_barrier()
+#define HCP_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hcp_emu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
+
+typedef short hcp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short hcp_bf16x4 __attribute__((ext_vector_type(4)));
+typedef float hcp_f32x4 __attribute__((ext_vector_type(4)));
+typedef float hcp_f32x16 __attribute__((ext_vector_type(16)));
+
+HCP_DEVICE hcp_f32x4 hcp_mfma16(hcp_bf16x8 a, hcp_bf16x8 b, hcp_f32x4 c) {
+    hcp_emu::Fiber* f = hcp_emu::g_cur;
+    f->op = hcp_emu::OP_MFMA16;
+    memcpy(&f->in[0], &a, 16); memcpy(&f->in[4], &b, 16); memcpy(&f->in[8], &c, 16);
+    hcp_emu::wave_collective();
+    hcp_f32x4 d; memcpy(&d, hcp_emu::g_cur->out, 16); return d;
+}
+HCP_DEVICE hcp_f32x16 hcp_mfma32(hcp_bf16x8 a, hcp_bf16x8 b, hcp_f32x16 c) {
+    hcp_emu::Fiber* f = hcp_emu::g_cur;
+    f->op = hcp_emu::OP_MFMA32;
+    memcpy(&f->in[0], &a, 16); memcpy(&f->in[4], &b, 16); memcpy(&f->in[8], &c, 64);
+    hcp_emu::wave_collective();
+    hcp_f32x16 d; memcpy(&d, hcp_emu::g_cur->out, 64); return d;
+}
+HCP_DEVICE uint32_t hcp_emu_shfl_u32(uint32_t v, int src) {
+    hcp_emu::Fiber* f = hcp_emu::g_cur;
+    f->op = hcp_emu::OP_SHFL; f->in[0] = v; f->src_lane = src & 63;
+    hcp_emu::wave_collective();
+    return hcp_emu::g_cur->out[0];
+}
+HCP_DEVICE float hcp_shfl(float v, int src) {
+    uint32_t u; memcpy(&u, &v, 4); u = hcp_emu_shfl_u32(u, src); memcpy(&v, &u, 4); return v;
+}
+HCP_DEVICE float hcp_shfl_xor(float v, int mask) { return hcp_shfl(v, hcp_emu::g_cur->lane ^ mask); }
+HCP_DEVICE int hcp_shfl_xor_i(int v, int mask) {
+    return (int)hcp_emu_shfl_u32((uint32_t)v, hcp_emu::g_cur->lane ^ mask);
+}
+HCP_DEVICE void hcp_atomic_add(float* p, float v) { *p += v; }
+HCP_DEVICE int hcp_lane() { return hcp_emu::g_cur->lane; }
