@@ -1,0 +1,91 @@
+"""ctypes binding of libhcp_mi355x.so (the C-ABI declared in include/hcp_mi355x.h).
+
+The product path opens exactly one file — ``hcp_diffusion_amd/libhcp_mi355x.so`` built for gfx950 by
+``hcp_diffusion_amd.build`` — and raises if it is missing: there is no CPU or PyTorch fallback.
+(Tests may bind another shared object exporting the same ABI — the CPU interpreter build in
+``tests/emu`` — through :func:`bind`; the package itself never does.)
+"""
+import ctypes
+from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_char_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libhcp_mi355x.so"
+
+P, I, L, F = c_void_p, c_int, c_long, c_float
+
+_PROTOTYPES = {
+    "hcp_last_error": (c_char_p, []),
+    "hcp_is_emulated": (I, []),
+    "hcp_abi_version": (I, []),
+    # A, lda, B, ldb, D, ldd, M, N, K, A2, lda2, B2, ldb2, K2, bias, rowbias, rowbias_ld, rows_per_group,
+    # residual, ldr, alpha, out_f32, stream
+    "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, F, I, P]),
+    # X1, C1, X2, C2, B, Hs, Ws, Ho, Wo, mode, stride, upsample, Wp, Cout, D, ldd, bias, rowbias, rowbias_ld,
+    # residual, ldr, out_f32, stream
+    "hcp_conv3x3_bf16": (I, [P, I, P, I, I, I, I, I, I, I, I, I, P, I, P, I, P, P, I, P, I, I, P]),
+    # Q, K, V, O, lse, B, H, Nq, Nk, D, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale, stream
+    "hcp_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P]),
+    # Q, K, V, O, dO, lse, delta, dQ, dK, dV, B, H, Nq, Nk, D, strides..., scale, stream
+    "hcp_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P]),
+    "hcp_groupnorm_workspace_bytes": (c_size_t, [I, I, I, I]),
+    # x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream
+    "hcp_groupnorm_silu_fwd": (I, [P, P, P, P, P, P, I, I, I, I, F, I, P]),
+    # x, dy, gamma, beta, stats, dx, ws, B, HW, C, G, silu, stream
+    "hcp_groupnorm_silu_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "hcp_layernorm_fwd": (I, [P, P, P, P, P, I, I, F, P]),
+    "hcp_layernorm_bwd": (I, [P, P, P, P, P, I, I, P]),
+    "hcp_geglu_fwd": (I, [P, P, L, I, P]),
+    "hcp_geglu_bwd": (I, [P, P, P, L, I, P]),
+    "hcp_add_bf16": (I, [P, P, P, L, P]),
+    "hcp_silu_fwd": (I, [P, P, L, P]),
+    "hcp_silu_bwd": (I, [P, P, P, L, P]),
+    "hcp_nchw_to_nhwc_bf16": (I, [P, I, P, I, I, I, I, P]),
+    "hcp_nhwc_to_nchw_f32": (I, [P, P, I, I, I, I, P]),
+    "hcp_upsample2x_bwd": (I, [P, P, I, I, I, I, P]),
+    "hcp_timestep_embedding": (I, [P, P, I, I, F, P]),
+    "hcp_add_noise": (I, [P, P, P, P, P, I, L, P]),
+    "hcp_mse_masked_mean": (I, [P, P, P, I, P, P, I, I, I, F, P]),
+    # L, ldl, R, ldr, out, ldo, M, P, Q, scale, transpose_out, stream
+    "hcp_lora_wgrad": (I, [P, I, P, I, P, I, I, I, I, F, I, P]),
+    "hcp_lora_pack": (I, [P, I, P]),
+    "hcp_lora_pack_desc_bytes": (I, []),
+    "hcp_sumsq_f32": (I, [P, L, P, P]),
+    # p, g, m, v, n, lr, beta1, beta2, eps, wd, sumsq, grad_scale, max_norm, step, stream
+    "hcp_adamw_clip_fused": (I, [P, P, P, P, L, P, F, F, F, F, P, F, F, P, P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+
+class HcpError(RuntimeError):
+    pass
+
+
+def bind(cdll):
+    """Attach argtypes/restype for every exported symbol; raises AttributeError if one is missing."""
+    for name, (res, args) in _PROTOTYPES.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+_lib = None
+
+
+def load():
+    """Return the bound product library, loading it on first use.  Fails loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise HcpError(
+                f"{LIB_PATH} not found: build it with `python -m hcp_diffusion_amd.build` "
+                "(hipcc, gfx950). hcp_diffusion_amd has no CPU/PyTorch fallback path.")
+        _lib = bind(ctypes.CDLL(str(LIB_PATH)))
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().hcp_last_error() if _lib is not None else b""
+        raise HcpError(f"{what} failed: {msg.decode() if msg else rc}")

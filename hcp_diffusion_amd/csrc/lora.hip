@@ -1,0 +1,152 @@
+// lora.hip — LoRA-specific kernels: operand packing and the rank-r weight gradients.
+//
+// Reference semantics (hcpdiff/models/lora_base_patch.py:59-74, lora_layers_patch.py:31-57):
+//   y = x (W + alpha * W_up W_down)^T + b,  alpha = cfg_alpha / rank, W_down[r,in], W_up[out,r].
+// Native formulation (side path):  T = x W_down^T ; y = x W^T + T (alpha W_up)^T
+//   dW_down = alpha * (dY W_up)^T x = alpha * U^T x,   dW_up = alpha * dY^T T
+// Both gradients are skinny reductions over the token dimension M (HBM-bound: x and dY are read once),
+// computed with MFMA 16x16x32 (reduction dim = tokens) and accumulated with fp32 atomics straight
+// into the flat gradient bucket the optimizer / all-reduce operate on.
+#include "hcp_common.h"
+
+namespace {
+
+constexpr int WG_BQ = 128;        // columns of R per block
+constexpr int WG_BM = 64;         // token rows per LDS tile
+constexpr int WG_RS = WG_BQ + 2;  // LDS row stride (bf16) of the R tile: 65 dwords -> conflict-free u16 gathers
+constexpr int WG_LS = 32 + 2;     // LDS row stride of the L tile
+
+// out[p, q] (+)= scale * sum_m L[m, p] * R[m, q]      p < P (<= 32), q < Q
+// transpose_out: element (p,q) lives at out[q * ldo + p] instead of out[p * ldo + q]
+HCP_KERNEL(256) lora_wgrad_kernel(const hcp_bf16* L, int ldl, const hcp_bf16* R, int ldr, float* out, int ldo, int M, int P,
+                                  int Q, float scale, int transpose_out, int rows_per_split) {
+    HCP_DYN_SMEM(smem);
+    hcp_bf16* sL = (hcp_bf16*)smem;              // [WG_BM][WG_LS]
+    hcp_bf16* sR = sL + WG_BM * WG_LS;           // [WG_BM][WG_RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.x * WG_BQ;
+    const int mb = blockIdx.y * rows_per_split;
+    int me = mb + rows_per_split; if (me > M) me = M;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    hcp_f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+
+    for (int m0 = mb; m0 < me; m0 += WG_BM) {
+        // stage L tile: 64 rows x 32 cols = 256 chunks of 8
+        {
+            int r = tid >> 2, c = (tid & 3) * 8;
+            hcp_bf16x8 v = hcp_zero8();
+            if (m0 + r < me) v = *(const hcp_bf16x8*)(L + (size_t)(m0 + r) * ldl + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sL[r * WG_LS + c + i] = (hcp_bf16)v[i];
+        }
+        // stage R tile: 64 rows x 128 cols = 1024 chunks
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int cidx = tid + 256 * it;
+            int r = cidx >> 4, c = (cidx & 15) * 8;
+            hcp_bf16x8 v = hcp_zero8();
+            if (m0 + r < me && q0 + c < Q) v = *(const hcp_bf16x8*)(R + (size_t)(m0 + r) * ldr + q0 + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sR[r * WG_RS + c + i] = (hcp_bf16)v[i];
+        }
+        HCP_SYNC();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kb = ks * 32 + fg * 8;   // this lane's 8 token rows
+            hcp_bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fa[i][e] = (short)sL[(kb + e) * WG_LS + i * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fb[j][e] = (short)sR[(kb + e) * WG_RS + wave * 32 + j * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = hcp_mfma16(fa[i], fb[j], acc[i][j]);
+        }
+        HCP_SYNC();
+    }
+    // lane holds D[p = i*16 + 4*fg + r][q = q0 + wave*32 + j*16 + fr]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = q0 + wave * 32 + j * 16 + fr;
+            if (q >= Q) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = i * 16 + 4 * fg + r;
+                if (p >= P) continue;
+                float* dst = transpose_out ? out + (size_t)q * ldo + p : out + (size_t)p * ldo + q;
+                hcp_atomic_add(dst, acc[i][j][r] * scale);
+            }
+        }
+}
+
+struct LoraPackDesc {
+    const float* w_down;   // [r, K]  fp32 master
+    const float* w_up;     // [N, r]
+    hcp_bf16* ad;          // [32, K]   W_down, rows >= r zero         (B operand of T = x Ad^T)
+    hcp_bf16* adt;         // [K, 32]   alpha * W_down^T               (K-extension operand of dX)
+    hcp_bf16* bu;          // [N, 32]   alpha * W_up                   (K-extension operand of y)
+    hcp_bf16* but;         // [32, N]   W_up^T                         (B operand of U = dY Bu)
+    int K, N, r;
+    float alpha;
+};
+
+HCP_KERNEL(256) lora_pack_kernel(const LoraPackDesc* descs) {
+    const LoraPackDesc d = descs[blockIdx.x];
+    for (int i = threadIdx.x; i < 32 * d.K; i += blockDim.x) {
+        int p = i / d.K, k = i - p * d.K;
+        float w = p < d.r ? d.w_down[(size_t)p * d.K + k] : 0.f;
+        d.ad[i] = hcp_f2bf(w);
+        d.adt[(size_t)k * 32 + p] = hcp_f2bf(w * d.alpha);
+    }
+    for (int i = threadIdx.x; i < 32 * d.N; i += blockDim.x) {
+        int n = i >> 5, p = i & 31;
+        float w = p < d.r ? d.w_up[(size_t)n * d.r + p] : 0.f;
+        d.bu[i] = hcp_f2bf(w * d.alpha);
+        d.but[(size_t)p * d.N + n] = hcp_f2bf(w);
+    }
+}
+
+}  // namespace
+
+// out (fp32, accumulated atomically; caller zeroes the bucket once per step)
+//   [p, q] += scale * sum_m L[m,p] R[m,q],  L:[M,32] bf16 (ldl), R:[M,Q] bf16 (ldr), p < P <= 32.
+// dW_down: L = U = dY W_up, R = x, out = grad[r,K] (transpose_out=0, ldo=K)
+// dW_up  : L = T = x W_down^T, R = dY, out = grad[N,r] (transpose_out=1, ldo=r)
+HCP_API int hcp_lora_wgrad(const void* L, int ldl, const void* R, int ldr, float* out, int ldo, int M, int P, int Q,
+                           float scale, int transpose_out, hipStream_t stream) {
+    HCP_REQUIRE(L && R && out && M > 0 && Q > 0, "hcp_lora_wgrad: bad arguments");
+    HCP_REQUIRE(P > 0 && P <= 32 && ldl % 8 == 0 && ldl >= 32 && ldr % 8 == 0 && Q % 8 == 0, "hcp_lora_wgrad: P<=32, ldl>=32, 8-aligned leading dims required");
+    const int qt = hcp_cdiv(Q, WG_BQ);
+    int splits = hcp_cdiv(1024, qt);
+    int maxs = hcp_cdiv(M, 2 * WG_BM);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    int rows = hcp_cdiv(hcp_cdiv(M, splits), WG_BM) * WG_BM;
+    splits = hcp_cdiv(M, rows);
+    size_t smem = (size_t)(WG_BM * WG_LS + WG_BM * WG_RS) * sizeof(hcp_bf16);
+    HCP_LAUNCH(lora_wgrad_kernel, dim3(qt, splits), dim3(256), smem, stream, (const hcp_bf16*)L, ldl, (const hcp_bf16*)R, ldr,
+               out, ldo, M, P, Q, scale, transpose_out, rows);
+    HCP_LAUNCH_CHECK("lora_wgrad");
+}
+
+// One launch converts the fp32 master LoRA factors of `count` layers into the four bf16 operand
+// layouts the GEMMs consume. `descs` is a DEVICE array of 64-byte descriptors:
+//   { const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r; float alpha; }
+HCP_API int hcp_lora_pack(const void* descs, int count, hipStream_t stream) {
+    HCP_REQUIRE(descs && count > 0, "hcp_lora_pack: bad arguments");
+    HCP_LAUNCH(lora_pack_kernel, dim3(count), dim3(256), 0, stream, (const LoraPackDesc*)descs);
+    HCP_LAUNCH_CHECK("lora_pack");
+}
+HCP_API int hcp_lora_pack_desc_bytes(void) { return (int)sizeof(LoraPackDesc); }

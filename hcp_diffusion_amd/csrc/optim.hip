@@ -1,0 +1,70 @@
+// optim.hip — global-norm clip + AdamW over ONE flat fp32 bucket (all trainable parameters).
+//
+// Replaces accelerator.clip_grad_norm_ + torch.optim.AdamW.step + zero_grad
+// (reference hcpdiff/train_ac.py:485-494, cfgs/train/train_base.yaml:17,37-40).  The reference
+// launches hundreds of tiny per-tensor kernels for 320 LoRA tensors; here it is three launches,
+// no host synchronisation (norm, lr and step count stay in device memory so the step can be
+// captured in a hipGraph).
+#include "hcp_common.h"
+
+namespace {
+
+HCP_KERNEL(256) sumsq_kernel(const float* g, long n, float* out) {
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) acc += g[i] * g[i];
+    acc = hcp_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) hcp_atomic_add(out, acc);
+}
+
+HCP_KERNEL(64) step_inc_kernel(int* step) {
+    if (threadIdx.x == 0) *step += 1;
+}
+
+HCP_KERNEL(256) adamw_kernel(float* p, float* g, float* m, float* v, long n, const float* lr_p, float beta1, float beta2,
+                             float eps, float wd, const float* sumsq, float grad_scale, float max_norm, const int* step_p) {
+    const float lr = *lr_p;
+    const int t = *step_p;
+    float clip = grad_scale;
+    if (sumsq && max_norm > 0.f) {
+        float norm = sqrtf(*sumsq) * grad_scale;
+        float c = max_norm / (norm + 1e-6f);
+        if (c < 1.f) clip *= c;
+    }
+    const float bc1 = 1.f - powf(beta1, (float)t), bc2 = 1.f - powf(beta2, (float)t);
+    const float step_size = lr / bc1;
+    const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] * clip;
+        float pi = p[i] * (1.f - lr * wd);
+        float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi; g[i] = 0.f;
+    }
+}
+
+inline int opt_grid(long n) { long g = (n + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1; return (int)g; }
+
+}  // namespace
+
+// out[0] = sum(g^2)  (device scalar, zeroed here)
+HCP_API int hcp_sumsq_f32(const float* g, long n, float* out, hipStream_t stream) {
+    HCP_REQUIRE(g && out && n > 0, "hcp_sumsq_f32: bad arguments");
+    if (hcp_memset_async(out, 0, sizeof(float), stream)) return hcp_set_error("hcp_sumsq_f32: memset failed");
+    HCP_LAUNCH(sumsq_kernel, dim3(opt_grid(n)), dim3(256), 0, stream, g, n, out);
+    HCP_LAUNCH_CHECK("sumsq");
+}
+
+// One fused optimizer step on a flat bucket: g *= grad_scale (e.g. 1/world after an all-reduce SUM);
+// global-norm clip to max_norm using *sumsq (sum of squares of the UNSCALED g; pass null / max_norm<=0 to skip);
+// AdamW (torch semantics: decoupled weight decay, bias correction with the device-resident step count,
+// which this call increments first); finally g = 0.
+HCP_API int hcp_adamw_clip_fused(float* p, float* g, float* m, float* v, long n, const float* lr, float beta1, float beta2,
+                                 float eps, float weight_decay, const float* sumsq, float grad_scale, float max_norm,
+                                 int* step, hipStream_t stream) {
+    HCP_REQUIRE(p && g && m && v && lr && step && n > 0, "hcp_adamw_clip_fused: bad arguments");
+    HCP_LAUNCH(step_inc_kernel, dim3(1), dim3(64), 0, stream, step);
+    HCP_LAUNCH(adamw_kernel, dim3(opt_grid(n)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+               sumsq, grad_scale, max_norm, (const int*)step);
+    HCP_LAUNCH_CHECK("adamw_clip_fused");
+}

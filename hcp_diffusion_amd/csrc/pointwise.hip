@@ -1,0 +1,250 @@
+// pointwise.hip — HBM-bound elementwise / layout / loss kernels of the SD fine-tuning inner loop.
+//
+//  * GEGLU  hidden*gelu(gate)             (diffusers GEGLU, reference cfgs/unet_struct.txt:28-30)
+//  * residual adds, SiLU                  (ResnetBlock2D / BasicTransformerBlock skip paths)
+//  * NCHW fp32 <-> NHWC bf16 at the UNet boundary (conv_in / conv_out are the only NCHW points)
+//  * nearest-2x upsample backward         (Upsample2D, unet_struct.txt:390-393)
+//  * sinusoidal timestep embedding        (Timesteps(flip_sin_to_cos=True, freq_shift=0), unet_struct.txt:3)
+//  * DDPM add_noise and masked-MSE loss   (reference train_ac.py:437-447, 506-515)
+// All kernels are grid-stride over 16-byte (8 x bf16) vectors.
+#include "hcp_common.h"
+
+namespace {
+
+constexpr int PW_THREADS = 256;
+inline int pw_grid(long nvec) {
+    long g = (nvec + PW_THREADS - 1) / PW_THREADS;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+HCP_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+HCP_DEVICE float gelu_erf_grad(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+HCP_KERNEL(256) geglu_fwd_kernel(const hcp_bf16* h, hcp_bf16* y, long M, int F) {
+    const int fv = F / 8;
+    const long total = M * fv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / fv; int j = (int)(i - m * fv) * 8;
+        hcp_bf16x8 a = *(const hcp_bf16x8*)(h + m * 2 * F + j);
+        hcp_bf16x8 g = *(const hcp_bf16x8*)(h + m * 2 * F + F + j);
+        hcp_bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (short)hcp_f2bf(hcp_bf2f((unsigned short)a[q]) * gelu_erf(hcp_bf2f((unsigned short)g[q])));
+        *(hcp_bf16x8*)(y + m * F + j) = o;
+    }
+}
+
+HCP_KERNEL(256) geglu_bwd_kernel(const hcp_bf16* h, const hcp_bf16* dy, hcp_bf16* dh, long M, int F) {
+    const int fv = F / 8;
+    const long total = M * fv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / fv; int j = (int)(i - m * fv) * 8;
+        hcp_bf16x8 a = *(const hcp_bf16x8*)(h + m * 2 * F + j);
+        hcp_bf16x8 g = *(const hcp_bf16x8*)(h + m * 2 * F + F + j);
+        hcp_bf16x8 d = *(const hcp_bf16x8*)(dy + m * F + j);
+        hcp_bf16x8 da, dg;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float af = hcp_bf2f((unsigned short)a[q]), gf = hcp_bf2f((unsigned short)g[q]), df = hcp_bf2f((unsigned short)d[q]);
+            da[q] = (short)hcp_f2bf(df * gelu_erf(gf));
+            dg[q] = (short)hcp_f2bf(df * af * gelu_erf_grad(gf));
+        }
+        *(hcp_bf16x8*)(dh + m * 2 * F + j) = da;
+        *(hcp_bf16x8*)(dh + m * 2 * F + F + j) = dg;
+    }
+}
+
+HCP_KERNEL(256) add_kernel(const hcp_bf16* a, const hcp_bf16* b, hcp_bf16* o, long nvec) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        hcp_bf16x8 x = *(const hcp_bf16x8*)(a + i * 8), y = *(const hcp_bf16x8*)(b + i * 8), r;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = (short)hcp_f2bf(hcp_bf2f((unsigned short)x[q]) + hcp_bf2f((unsigned short)y[q]));
+        *(hcp_bf16x8*)(o + i * 8) = r;
+    }
+}
+
+// mode 0: y = silu(x); mode 1: dx = dy * silu'(x)
+HCP_KERNEL(256) silu_kernel(const hcp_bf16* x, const hcp_bf16* dy, hcp_bf16* o, long nvec, int mode) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        hcp_bf16x8 v = *(const hcp_bf16x8*)(x + i * 8), r;
+        hcp_bf16x8 d = mode ? *(const hcp_bf16x8*)(dy + i * 8) : hcp_zero8();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float z = hcp_bf2f((unsigned short)v[q]);
+            float sg = hcp_sigmoid(z);
+            r[q] = (short)hcp_f2bf(mode ? hcp_bf2f((unsigned short)d[q]) * sg * (1.f + z * (1.f - sg)) : z * sg);
+        }
+        *(hcp_bf16x8*)(o + i * 8) = r;
+    }
+}
+
+// src NCHW (fp32 or bf16) -> dst NHWC bf16 with channels zero-padded to Cp
+HCP_KERNEL(256) nchw_to_nhwc_kernel(const void* src, int src_f32, hcp_bf16* dst, int B, int C, int HW, int Cp) {
+    const long total = (long)B * HW * Cp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % Cp); long r = i / Cp; int hw = (int)(r % HW); int b = (int)(r / HW);
+        float v = 0.f;
+        if (c < C) {
+            size_t s = ((size_t)b * C + c) * HW + hw;
+            v = src_f32 ? ((const float*)src)[s] : hcp_bf2f(((const hcp_bf16*)src)[s]);
+        }
+        dst[i] = hcp_f2bf(v);
+    }
+}
+
+// src NHWC fp32 [B,HW,Cs] (first C channels used) -> dst NCHW fp32 [B,C,HW]
+HCP_KERNEL(256) nhwc_to_nchw_kernel(const float* src, float* dst, int B, int C, int HW, int Cs) {
+    const long total = (long)B * C * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int hw = (int)(i % HW); long r = i / HW; int c = (int)(r % C); int b = (int)(r / C);
+        dst[i] = src[((size_t)b * HW + hw) * Cs + c];
+    }
+}
+
+// dx[b,y,x,:] = sum of the 2x2 block of dup[b,2y+i,2x+j,:]
+HCP_KERNEL(256) upsample2x_bwd_kernel(const hcp_bf16* dup, hcp_bf16* dx, int B, int H, int W, int C) {
+    const int cv = C / 8;
+    const long total = (long)B * H * W * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % cv) * 8; long r = i / cv; int x = (int)(r % W); r /= W; int y = (int)(r % H); int b = (int)(r / H);
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+            for (int dxx = 0; dxx < 2; ++dxx) {
+                hcp_bf16x8 v = *(const hcp_bf16x8*)(dup + (((size_t)b * 2 * H + 2 * y + dyy) * 2 * W + 2 * x + dxx) * C + c);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += hcp_bf2f((unsigned short)v[q]);
+            }
+        hcp_bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (short)hcp_f2bf(acc[q]);
+        *(hcp_bf16x8*)(dx + (((size_t)b * H + y) * W + x) * C + c) = o;
+    }
+}
+
+// emb[b, 0:half] = cos(t * f_i), emb[b, half:] = sin(t * f_i), f_i = exp(-ln(max_period) * i / half)
+HCP_KERNEL(256) timestep_embedding_kernel(const long long* t, hcp_bf16* emb, int B, int dim, float max_period) {
+    const int half = dim / 2;
+    const int total = B * half;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int b = i / half, k = i - b * half;
+        float f = expf(-logf(max_period) * (float)k / (float)half);
+        float a = (float)t[b] * f;
+        emb[(size_t)b * dim + k] = hcp_f2bf(cosf(a));
+        emb[(size_t)b * dim + half + k] = hcp_f2bf(sinf(a));
+    }
+}
+
+// x_t = sqrt(acp[t]) * x0 + sqrt(1 - acp[t]) * noise      (NCHW fp32 in, NCHW fp32 out)
+HCP_KERNEL(256) add_noise_kernel(const float* x0, const float* noise, const long long* t, const float* acp, float* xt,
+                                 int B, long per) {
+    const long total = (long)B * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int b = (int)(i / per);
+        float a = acp[t[b]];
+        xt[i] = sqrtf(a) * x0[i] + sqrtf(1.0f - a) * noise[i];
+    }
+}
+
+// loss += sum((pred-target)^2 * mask) * scale ; grad = 2*(pred-target)*mask*scale
+HCP_KERNEL(256) mse_kernel(const float* pred, const float* target, const float* mask, int mask_c, float* loss, float* grad,
+                           int B, int C, int HW, float scale) {
+    const long total = (long)B * C * HW;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float m = 1.0f;
+        if (mask) {
+            int hw = (int)(i % HW); long r = i / HW; int c = (int)(r % C); int b = (int)(r / C);
+            m = mask[((size_t)b * mask_c + (mask_c == 1 ? 0 : c)) * HW + hw];
+        }
+        float d = pred[i] - target[i];
+        acc += d * d * m;
+        if (grad) grad[i] = 2.0f * d * m * scale;
+    }
+    acc = hcp_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) hcp_atomic_add(loss, acc * scale);
+}
+
+}  // namespace
+
+HCP_API int hcp_geglu_fwd(const void* h, void* y, long M, int F, hipStream_t stream) {
+    HCP_REQUIRE(h && y && M > 0 && F > 0 && F % 8 == 0, "hcp_geglu_fwd: bad arguments");
+    HCP_LAUNCH(geglu_fwd_kernel, dim3(pw_grid(M * (F / 8))), dim3(PW_THREADS), 0, stream, (const hcp_bf16*)h, (hcp_bf16*)y, M, F);
+    HCP_LAUNCH_CHECK("geglu_fwd");
+}
+HCP_API int hcp_geglu_bwd(const void* h, const void* dy, void* dh, long M, int F, hipStream_t stream) {
+    HCP_REQUIRE(h && dy && dh && M > 0 && F > 0 && F % 8 == 0, "hcp_geglu_bwd: bad arguments");
+    HCP_LAUNCH(geglu_bwd_kernel, dim3(pw_grid(M * (F / 8))), dim3(PW_THREADS), 0, stream, (const hcp_bf16*)h,
+               (const hcp_bf16*)dy, (hcp_bf16*)dh, M, F);
+    HCP_LAUNCH_CHECK("geglu_bwd");
+}
+HCP_API int hcp_add_bf16(const void* a, const void* b, void* out, long n, hipStream_t stream) {
+    HCP_REQUIRE(a && b && out && n > 0 && n % 8 == 0, "hcp_add_bf16: n must be a positive multiple of 8");
+    HCP_LAUNCH(add_kernel, dim3(pw_grid(n / 8)), dim3(PW_THREADS), 0, stream, (const hcp_bf16*)a, (const hcp_bf16*)b,
+               (hcp_bf16*)out, n / 8);
+    HCP_LAUNCH_CHECK("add_bf16");
+}
+HCP_API int hcp_silu_fwd(const void* x, void* y, long n, hipStream_t stream) {
+    HCP_REQUIRE(x && y && n > 0 && n % 8 == 0, "hcp_silu_fwd: n must be a positive multiple of 8");
+    HCP_LAUNCH(silu_kernel, dim3(pw_grid(n / 8)), dim3(PW_THREADS), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)nullptr,
+               (hcp_bf16*)y, n / 8, 0);
+    HCP_LAUNCH_CHECK("silu_fwd");
+}
+HCP_API int hcp_silu_bwd(const void* x, const void* dy, void* dx, long n, hipStream_t stream) {
+    HCP_REQUIRE(x && dy && dx && n > 0 && n % 8 == 0, "hcp_silu_bwd: n must be a positive multiple of 8");
+    HCP_LAUNCH(silu_kernel, dim3(pw_grid(n / 8)), dim3(PW_THREADS), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy,
+               (hcp_bf16*)dx, n / 8, 1);
+    HCP_LAUNCH_CHECK("silu_bwd");
+}
+HCP_API int hcp_nchw_to_nhwc_bf16(const void* src, int src_is_f32, void* dst, int B, int C, int HW, int Cpad,
+                                  hipStream_t stream) {
+    HCP_REQUIRE(src && dst && B > 0 && C > 0 && HW > 0 && Cpad >= C, "hcp_nchw_to_nhwc_bf16: bad arguments");
+    HCP_LAUNCH(nchw_to_nhwc_kernel, dim3(pw_grid((long)B * HW * Cpad)), dim3(PW_THREADS), 0, stream, src, src_is_f32,
+               (hcp_bf16*)dst, B, C, HW, Cpad);
+    HCP_LAUNCH_CHECK("nchw_to_nhwc");
+}
+HCP_API int hcp_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, int HW, int Csrc, hipStream_t stream) {
+    HCP_REQUIRE(src && dst && B > 0 && C > 0 && HW > 0 && Csrc >= C, "hcp_nhwc_to_nchw_f32: bad arguments");
+    HCP_LAUNCH(nhwc_to_nchw_kernel, dim3(pw_grid((long)B * HW * C)), dim3(PW_THREADS), 0, stream, src, dst, B, C, HW, Csrc);
+    HCP_LAUNCH_CHECK("nhwc_to_nchw");
+}
+HCP_API int hcp_upsample2x_bwd(const void* dup, void* dx, int B, int H, int W, int C, hipStream_t stream) {
+    HCP_REQUIRE(dup && dx && B > 0 && H > 0 && W > 0 && C % 8 == 0, "hcp_upsample2x_bwd: bad arguments");
+    HCP_LAUNCH(upsample2x_bwd_kernel, dim3(pw_grid((long)B * H * W * (C / 8))), dim3(PW_THREADS), 0, stream,
+               (const hcp_bf16*)dup, (hcp_bf16*)dx, B, H, W, C);
+    HCP_LAUNCH_CHECK("upsample2x_bwd");
+}
+HCP_API int hcp_timestep_embedding(const long long* timesteps, void* emb, int B, int dim, float max_period,
+                                   hipStream_t stream) {
+    HCP_REQUIRE(timesteps && emb && B > 0 && dim > 0 && dim % 2 == 0, "hcp_timestep_embedding: bad arguments");
+    HCP_LAUNCH(timestep_embedding_kernel, dim3(pw_grid((long)B * dim / 2)), dim3(PW_THREADS), 0, stream, timesteps,
+               (hcp_bf16*)emb, B, dim, max_period);
+    HCP_LAUNCH_CHECK("timestep_embedding");
+}
+HCP_API int hcp_add_noise(const float* x0, const float* noise, const long long* timesteps, const float* alphas_cumprod,
+                          float* xt, int B, long per_sample, hipStream_t stream) {
+    HCP_REQUIRE(x0 && noise && timesteps && alphas_cumprod && xt && B > 0 && per_sample > 0, "hcp_add_noise: bad arguments");
+    HCP_LAUNCH(add_noise_kernel, dim3(pw_grid((long)B * per_sample)), dim3(PW_THREADS), 0, stream, x0, noise, timesteps,
+               alphas_cumprod, xt, B, per_sample);
+    HCP_LAUNCH_CHECK("add_noise");
+}
+// loss (device scalar, zeroed here) = mean((pred-target)^2 * mask) * weight; grad (optional) = d loss / d pred.
+HCP_API int hcp_mse_masked_mean(const float* pred, const float* target, const float* mask, int mask_channels, float* loss,
+                                float* grad, int B, int C, int HW, float weight, hipStream_t stream) {
+    HCP_REQUIRE(pred && target && loss && B > 0 && C > 0 && HW > 0, "hcp_mse_masked_mean: bad arguments");
+    HCP_REQUIRE(!mask || mask_channels == 1 || mask_channels == C, "hcp_mse_masked_mean: mask channels must be 1 or C");
+    if (hcp_memset_async(loss, 0, sizeof(float), stream)) return hcp_set_error("hcp_mse_masked_mean: memset failed");
+    float scale = weight / (float)((long)B * C * HW);
+    HCP_LAUNCH(mse_kernel, dim3(pw_grid((long)B * C * HW)), dim3(PW_THREADS), 0, stream, pred, target, mask, mask_channels,
+               loss, grad, B, C, HW, scale);
+    HCP_LAUNCH_CHECK("mse_masked_mean");
+}

@@ -1,0 +1,314 @@
+"""Raw (non-autograd) tensor-level entry points over the C-ABI.  torch is used only for memory and streams.
+
+Every function takes/returns torch tensors that live on the HIP device, checks layout, and enqueues the
+kernel on torch's *current* stream.  Nothing here computes with torch ops.
+"""
+import ctypes
+import math
+import torch
+
+from . import _lib
+
+_backend = None  # bound CDLL; tests may inject the interpreter build through _set_backend_for_tests
+
+
+def lib():
+    global _backend
+    if _backend is None:
+        _backend = _lib.load()
+    return _backend
+
+
+def _set_backend_for_tests(cdll):
+    """TEST HOOK ONLY: bind a different shared object exporting the same ABI (tests/emu)."""
+    global _backend
+    _backend = _lib.bind(cdll) if cdll is not None else None
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise _lib.HcpError(f"{name}: {lib().hcp_last_error().decode()}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t):
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    if not lib().hcp_is_emulated():
+        raise _lib.HcpError("hcp_diffusion_amd kernels need tensors on the HIP device (no CPU path)")
+    return None
+
+
+def _bf16_2d(t, name):
+    assert t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1, f"{name}: need 2-D bf16, unit inner stride"
+    return t
+
+
+BF16 = torch.bfloat16
+
+
+def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, residual=None, alpha=1.0,
+         out_f32=False, out=None):
+    """out[M,N] = alpha*(a[M,K] @ b[N,K]^T + a2 @ b2^T) + bias + rowbias[m // rows_per_group] + residual."""
+    _bf16_2d(a, "a"); _bf16_2d(b, "b")
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    K2 = 0
+    if a2 is not None:
+        _bf16_2d(a2, "a2"); _bf16_2d(b2, "b2")
+        K2 = a2.shape[1]
+        assert a2.shape[0] == M and b2.shape == (N, K2)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    assert out.stride(1) == 1
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rowbias.shape[1] == N and rowbias.stride(1) == 1
+    if residual is not None:
+        _bf16_2d(residual, "residual"); assert residual.shape == (M, N)
+    _chk(lib().hcp_gemm_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K,
+                             _p(a2), a2.stride(0) if a2 is not None else 0, _p(b2), b2.stride(0) if b2 is not None else 0,
+                             K2, _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, rows_per_group,
+                             _p(residual), residual.stride(0) if residual is not None else 0, float(alpha),
+                             1 if out.dtype == torch.float32 else 0, _stream(a)), "hcp_gemm_bf16")
+    return out
+
+
+def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=None, bias=None, rowbias=None,
+            residual=None, out_f32=False):
+    """3x3 / pad 1 convolution on NHWC bf16. mode 0: forward (wp = [cout][3][3][C1+C2]); mode 1: data gradient
+    (x1 = dY [B,Hs,Ws,C1], wp = [cin][3][3][C1], out_hw = spatial dims of the forward input)."""
+    assert x1.dtype == BF16 and x1.dim() == 4 and x1.is_contiguous()
+    B, Hs, Ws, C1 = x1.shape
+    C2 = 0
+    if x2 is not None:
+        assert x2.dtype == BF16 and x2.is_contiguous() and x2.shape[:3] == x1.shape[:3]
+        C2 = x2.shape[3]
+    assert wp.dtype == BF16 and wp.is_contiguous() and wp.numel() == cout * 9 * (C1 + C2)
+    if mode == 0:
+        up = 2 if upsample else 1
+        Ho = (Hs * up + 2 - 3) // stride + 1
+        Wo = (Ws * up + 2 - 3) // stride + 1
+    else:
+        Ho, Wo = out_hw
+    out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32 if out_f32 else BF16, device=x1.device)
+    if residual is not None:
+        assert residual.dtype == BF16 and residual.is_contiguous() and residual.numel() == out.numel()
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rowbias.shape == (B, cout) and rowbias.stride(1) == 1
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == cout and bias.is_contiguous()
+    _chk(lib().hcp_conv3x3_bf16(_p(x1), C1, _p(x2), C2, B, Hs, Ws, Ho, Wo, mode, stride, 1 if upsample else 0, _p(wp),
+                                cout, _p(out), cout, _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
+                                _p(residual), cout, 1 if out_f32 else 0, _stream(x1)), "hcp_conv3x3_bf16")
+    return out
+
+
+def _attn_strides(t):
+    assert t.dtype == BF16 and t.dim() == 3 and t.stride(2) == 1
+    return t.stride(0), t.stride(1)
+
+
+def attention_fwd(q, k, v, heads, scale=None):
+    """q [B,Nq,H*d], k/v [B,Nk,H*d] (views with arbitrary batch/row strides allowed) -> (o [B,Nq,H*d], lse [B,H,Nq])."""
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    D = C // heads
+    scale = scale if scale is not None else 1.0 / math.sqrt(D)
+    o = torch.empty((B, Nq, C), dtype=BF16, device=q.device)
+    lse = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
+    qb, qr = _attn_strides(q); kb, kr = _attn_strides(k); vb, vr = _attn_strides(v); ob, orr = _attn_strides(o)
+    _chk(lib().hcp_attention_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, heads, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
+                                 float(scale), _stream(q)), "hcp_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, do, lse, heads, scale=None):
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    D = C // heads
+    scale = scale if scale is not None else 1.0 / math.sqrt(D)
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and o.is_contiguous() and do.is_contiguous(), \
+        "attention_bwd: contiguous q/k/v/o/do required (gradients are written with the same strides)"
+    dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
+    delta = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
+    qb, qr = _attn_strides(q); kb, kr = _attn_strides(k); vb, vr = _attn_strides(v); ob, orr = _attn_strides(o)
+    _chk(lib().hcp_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, heads,
+                                 Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr, float(scale), _stream(q)), "hcp_attention_bwd")
+    return dq, dk, dv
+
+
+def _gn_ws(x, B, HW, C, G):
+    n = lib().hcp_groupnorm_workspace_bytes(B, HW, C, G)
+    return torch.empty((max(n, 4) // 4,), dtype=torch.float32, device=x.device)
+
+
+def groupnorm_fwd(x, gamma, beta, groups, eps, silu):
+    """x [B, HW.., C] NHWC bf16 -> (y, stats[B,G,2])."""
+    assert x.dtype == BF16 and x.is_contiguous()
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    ws = _gn_ws(x, B, HW, C, groups)
+    _chk(lib().hcp_groupnorm_silu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), B, HW, C, groups, float(eps),
+                                      1 if silu else 0, _stream(x)), "hcp_groupnorm_silu_fwd")
+    return y, stats
+
+
+def groupnorm_bwd(x, dy, gamma, beta, stats, groups, silu):
+    assert x.dtype == BF16 and x.is_contiguous() and dy.dtype == BF16 and dy.is_contiguous()
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    dx = torch.empty_like(x)
+    ws = _gn_ws(x, B, HW, C, groups)
+    _chk(lib().hcp_groupnorm_silu_bwd(_p(x), _p(dy), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws), B, HW, C, groups,
+                                      1 if silu else 0, _stream(x)), "hcp_groupnorm_silu_bwd")
+    return dx
+
+
+def layernorm_fwd(x, gamma, beta, eps):
+    assert x.dtype == BF16 and x.is_contiguous()
+    C = x.shape[-1]; M = x.numel() // C
+    y = torch.empty_like(x)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    _chk(lib().hcp_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), M, C, float(eps), _stream(x)), "hcp_layernorm_fwd")
+    return y, stats
+
+
+def layernorm_bwd(x, dy, gamma, stats):
+    assert x.is_contiguous() and dy.is_contiguous() and dy.dtype == BF16
+    C = x.shape[-1]; M = x.numel() // C
+    dx = torch.empty_like(x)
+    _chk(lib().hcp_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(stats), _p(dx), M, C, _stream(x)), "hcp_layernorm_bwd")
+    return dx
+
+
+def geglu_fwd(h):
+    assert h.dtype == BF16 and h.is_contiguous()
+    F2 = h.shape[-1]; F = F2 // 2; M = h.numel() // F2
+    y = torch.empty(h.shape[:-1] + (F,), dtype=BF16, device=h.device)
+    _chk(lib().hcp_geglu_fwd(_p(h), _p(y), M, F, _stream(h)), "hcp_geglu_fwd")
+    return y
+
+
+def geglu_bwd(h, dy):
+    assert h.is_contiguous() and dy.is_contiguous() and dy.dtype == BF16
+    F2 = h.shape[-1]; F = F2 // 2; M = h.numel() // F2
+    dh = torch.empty_like(h)
+    _chk(lib().hcp_geglu_bwd(_p(h), _p(dy), _p(dh), M, F, _stream(h)), "hcp_geglu_bwd")
+    return dh
+
+
+def add(a, b):
+    assert a.dtype == BF16 and b.dtype == BF16 and a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    o = torch.empty_like(a)
+    _chk(lib().hcp_add_bf16(_p(a), _p(b), _p(o), a.numel(), _stream(a)), "hcp_add_bf16")
+    return o
+
+
+def silu_fwd(x):
+    assert x.dtype == BF16 and x.is_contiguous()
+    y = torch.empty_like(x)
+    _chk(lib().hcp_silu_fwd(_p(x), _p(y), x.numel(), _stream(x)), "hcp_silu_fwd")
+    return y
+
+
+def silu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    _chk(lib().hcp_silu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream(x)), "hcp_silu_bwd")
+    return dx
+
+
+def nchw_to_nhwc(x, cpad=None):
+    """[B,C,H,W] fp32|bf16 -> [B,H,W,Cpad] bf16 (zero padded channels)."""
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype in (torch.float32, BF16)
+    B, C, H, W = x.shape
+    cp = cpad or C
+    y = torch.empty((B, H, W, cp), dtype=BF16, device=x.device)
+    _chk(lib().hcp_nchw_to_nhwc_bf16(_p(x), 1 if x.dtype == torch.float32 else 0, _p(y), B, C, H * W, cp, _stream(x)),
+         "hcp_nchw_to_nhwc_bf16")
+    return y
+
+
+def nhwc_to_nchw_f32(x, c):
+    """[B,H,W,Cs] fp32 -> [B,c,H,W] fp32 (first c channels)."""
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    B, H, W, Cs = x.shape
+    y = torch.empty((B, c, H, W), dtype=torch.float32, device=x.device)
+    _chk(lib().hcp_nhwc_to_nchw_f32(_p(x), _p(y), B, c, H * W, Cs, _stream(x)), "hcp_nhwc_to_nchw_f32")
+    return y
+
+
+def upsample2x_bwd(dup):
+    assert dup.dtype == BF16 and dup.is_contiguous()
+    B, H2, W2, C = dup.shape
+    dx = torch.empty((B, H2 // 2, W2 // 2, C), dtype=BF16, device=dup.device)
+    _chk(lib().hcp_upsample2x_bwd(_p(dup), _p(dx), B, H2 // 2, W2 // 2, C, _stream(dup)), "hcp_upsample2x_bwd")
+    return dx
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    assert t.dtype == torch.int64 and t.is_contiguous()
+    emb = torch.empty((t.numel(), dim), dtype=BF16, device=t.device)
+    _chk(lib().hcp_timestep_embedding(_p(t), _p(emb), t.numel(), dim, float(max_period), _stream(t)), "hcp_timestep_embedding")
+    return emb
+
+
+def add_noise(x0, noise, t, alphas_cumprod):
+    assert x0.dtype == torch.float32 and noise.dtype == torch.float32 and x0.is_contiguous() and noise.is_contiguous()
+    assert t.dtype == torch.int64 and alphas_cumprod.dtype == torch.float32
+    xt = torch.empty_like(x0)
+    B = x0.shape[0]
+    _chk(lib().hcp_add_noise(_p(x0), _p(noise), _p(t), _p(alphas_cumprod), _p(xt), B, x0.numel() // B, _stream(x0)), "hcp_add_noise")
+    return xt
+
+
+def mse_masked_mean(pred, target, mask=None, weight=1.0, want_grad=True):
+    """(mean((pred-target)^2 * mask) * weight as a device scalar, d loss / d pred)."""
+    assert pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.is_contiguous() and target.is_contiguous()
+    B, C = pred.shape[0], pred.shape[1]
+    HW = pred.numel() // (B * C)
+    loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    mc = 0
+    if mask is not None:
+        mask = mask.to(torch.float32).contiguous()
+        mc = mask.shape[1]
+    _chk(lib().hcp_mse_masked_mean(_p(pred), _p(target), _p(mask), mc, _p(loss), _p(grad), B, C, HW, float(weight), _stream(pred)),
+         "hcp_mse_masked_mean")
+    return loss, grad
+
+
+def lora_wgrad(L, R, out, P, scale, transpose_out):
+    """out (fp32, atomically accumulated) += scale * L[:, :P]^T @ R ; transpose_out writes out[q, p]."""
+    _bf16_2d(L, "L"); _bf16_2d(R, "R")
+    M, Q = R.shape
+    assert L.shape[0] == M and out.dtype == torch.float32 and out.is_contiguous()
+    ldo = out.shape[1]
+    _chk(lib().hcp_lora_wgrad(_p(L), L.stride(0), _p(R), R.stride(0), _p(out), ldo, M, P, Q, float(scale),
+                              1 if transpose_out else 0, _stream(L)), "hcp_lora_wgrad")
+
+
+def lora_pack(desc_tensor, count):
+    _chk(lib().hcp_lora_pack(_p(desc_tensor), count, _stream(desc_tensor)), "hcp_lora_pack")
+
+
+def sumsq(g, out):
+    assert g.dtype == torch.float32 and g.is_contiguous()
+    _chk(lib().hcp_sumsq_f32(_p(g), g.numel(), _p(out), _stream(g)), "hcp_sumsq_f32")
+    return out
+
+
+def adamw_clip_fused(p, g, m, v, lr, step, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, sumsq_t=None,
+                     grad_scale=1.0, max_norm=0.0):
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    assert lr.dtype == torch.float32 and step.dtype == torch.int32
+    _chk(lib().hcp_adamw_clip_fused(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr), beta1, beta2, eps, weight_decay,
+                                    _p(sumsq_t), float(grad_scale), float(max_norm), _p(step), _stream(p)), "hcp_adamw_clip_fused")

@@ -1,0 +1,54 @@
+import ctypes
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+_emu_cdll = None
+
+
+def emu_cdll():
+    """Build (once) and open the TEST-ONLY CPU interpreter build of the kernels (tests/emu)."""
+    global _emu_cdll
+    if _emu_cdll is None:
+        sys.path.insert(0, str(ROOT / "tests" / "emu"))
+        from build_emu import build_emu
+        _emu_cdll = ctypes.CDLL(str(build_emu()))
+    return _emu_cdll
+
+
+class Backend:
+    def __init__(self, name):
+        self.name = name
+        self.device = torch.device("cuda:0" if name == "gpu" else "cpu")
+        self.is_gpu = name == "gpu"
+
+    def to(self, t):
+        return t.to(self.device)
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def backend(request):
+    """'emu': kernels interpreted on the CPU (tiny shapes, logic check);  'gpu': the gfx950 product library."""
+    from hcp_diffusion_amd import kernels
+    if request.param == "gpu":
+        if not torch.cuda.is_available():
+            pytest.skip("no GPU visible")
+        kernels._set_backend_for_tests(None)      # product path: libhcp_mi355x.so, fails loudly if missing
+        assert kernels.lib().hcp_is_emulated() == 0
+    else:
+        kernels._set_backend_for_tests(emu_cdll())
+    yield Backend(request.param)
+    kernels._set_backend_for_tests(None)
