@@ -42,7 +42,7 @@ def build_product(force: bool = False, verbose: bool = False) -> Path:
         objs.append(obj)
         if force or _stale(obj, [src, *headers]):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                   "-ffp-contract=off", "-c", str(src), "-o", str(obj)]
+                   "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -174,6 +174,16 @@ HCP_KERNEL(256) mse_kernel(const float* pred, const float* target, const float* 
     if ((threadIdx.x & 63) == 0) hcp_atomic_add(loss, acc * scale);
 }
 
+// dst[m, 0:C] = src[m, 0:C] with independent row strides (channel concat / split of channels-last tensors)
+HCP_KERNEL(256) copy2d_kernel(const hcp_bf16* src, int sld, hcp_bf16* dst, int dld, long M, int C) {
+    const int cv = C / 8;
+    const long total = M * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / cv; int c = (int)(i - m * cv) * 8;
+        *(hcp_bf16x8*)(dst + m * dld + c) = *(const hcp_bf16x8*)(src + m * sld + c);
+    }
+}
+
 }  // namespace
 
 HCP_API int hcp_geglu_fwd(const void* h, void* y, long M, int F, hipStream_t stream) {
@@ -247,4 +257,13 @@ HCP_API int hcp_mse_masked_mean(const float* pred, const float* target, const fl
     HCP_LAUNCH(mse_kernel, dim3(pw_grid((long)B * C * HW)), dim3(PW_THREADS), 0, stream, pred, target, mask, mask_channels,
                loss, grad, B, C, HW, scale);
     HCP_LAUNCH_CHECK("mse_masked_mean");
+}
+
+// dst[m, :C] = src[m, :C]; row strides sld/dld in elements (all multiples of 8). Used for the up-block skip concat
+// (torch.cat(dim=1) in diffusers' UpBlock2D/CrossAttnUpBlock2D) and its backward split.
+HCP_API int hcp_copy2d_bf16(const void* src, int sld, void* dst, int dld, long M, int C, hipStream_t stream) {
+    HCP_REQUIRE(src && dst && M > 0 && C > 0 && C % 8 == 0 && sld % 8 == 0 && dld % 8 == 0, "hcp_copy2d_bf16: bad arguments");
+    HCP_LAUNCH(copy2d_kernel, dim3(pw_grid(M * (C / 8))), dim3(PW_THREADS), 0, stream, (const hcp_bf16*)src, sld,
+               (hcp_bf16*)dst, dld, M, C);
+    HCP_LAUNCH_CHECK("copy2d");
 }

@@ -212,6 +212,30 @@ def add(a, b):
     return o
 
 
+def concat_channels(a, b):
+    """[..., C1] ++ [..., C2] -> [..., C1+C2] (channels-last)."""
+    assert a.dtype == BF16 and b.dtype == BF16 and a.is_contiguous() and b.is_contiguous() and a.shape[:-1] == b.shape[:-1]
+    c1, c2 = a.shape[-1], b.shape[-1]
+    M = a.numel() // c1
+    out = torch.empty(a.shape[:-1] + (c1 + c2,), dtype=BF16, device=a.device)
+    o2 = out.view(M, c1 + c2)
+    _chk(lib().hcp_copy2d_bf16(_p(a), c1, _p(o2), c1 + c2, M, c1, _stream(a)), "hcp_copy2d_bf16")
+    _chk(lib().hcp_copy2d_bf16(_p(b), c2, o2[:, c1:].data_ptr(), c1 + c2, M, c2, _stream(a)), "hcp_copy2d_bf16")
+    return out
+
+
+def split_channels(d, c1):
+    assert d.dtype == BF16 and d.is_contiguous()
+    c = d.shape[-1]; c2 = c - c1
+    M = d.numel() // c
+    d2 = d.view(M, c)
+    a = torch.empty(d.shape[:-1] + (c1,), dtype=BF16, device=d.device)
+    b = torch.empty(d.shape[:-1] + (c2,), dtype=BF16, device=d.device)
+    _chk(lib().hcp_copy2d_bf16(_p(d2), c, _p(a), c1, M, c1, _stream(d)), "hcp_copy2d_bf16")
+    _chk(lib().hcp_copy2d_bf16(d2[:, c1:].data_ptr(), c, _p(b), c2, M, c2, _stream(d)), "hcp_copy2d_bf16")
+    return a, b
+
+
 def silu_fwd(x):
     assert x.dtype == BF16 and x.is_contiguous()
     y = torch.empty_like(x)

@@ -1,0 +1,103 @@
+"""Leaf modules of the native UNet.  They ARE ``nn.Linear`` / ``nn.Conv2d`` / ``nn.GroupNorm`` / ``nn.LayerNorm``
+subclasses with diffusers parameter names and shapes, so the reference's plugin machinery keeps working:
+``isinstance(layer, (nn.Linear, nn.Conv2d))`` LoRA wrapping (reference lora_base_patch.py:39, plugin.py:308),
+``state_dict`` / checkpoint names (ckpt_manager), ``deepcopy`` (controlnet.py:38-44).
+
+fp32 parameters are the masters; each leaf lazily keeps bf16 operand copies in the layouts the kernels consume
+(re-packed when the parameter's version counter changes).  Activations: bf16, channels-last.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+class _Packed:
+    pass
+
+
+def _key(*ts):
+    return tuple((t._version, t.data_ptr(), t.device) if t is not None else None for t in ts)
+
+
+def _pad_last(t, mult):
+    c = t.shape[-1]
+    cp = (c + mult - 1) // mult * mult
+    if cp == c:
+        return t
+    out = t.new_zeros(t.shape[:-1] + (cp,))
+    out[..., :c] = t
+    return out
+
+
+class HipLinear(nn.Linear):
+    supports_fused_residual = True
+    _pk = None
+
+    def packed(self):
+        k = _key(self.weight, self.bias)
+        if self._pk is None or self._pk.key != k:
+            pk = _Packed(); pk.key = k
+            w = self.weight.detach()
+            pk.w = w.to(BF16).contiguous()                 # [N, K]   forward B operand
+            pk.wt = w.t().to(BF16).contiguous()            # [K, N]   dX B operand
+            pk.bias = self.bias.detach().float().contiguous() if self.bias is not None else None
+            self._pk = pk
+        return self._pk
+
+    def forward(self, x, residual=None, out_f32=False):
+        return ops.linear(x, self, None, residual, out_f32)
+
+
+class HipConv2d(nn.Conv2d):
+    """1x1 (a GEMM on channels-last tokens) or 3x3/pad-1 convolution over NHWC bf16 activations."""
+    supports_fused_residual = True
+    _pk = None
+
+    def packed(self):
+        k = _key(self.weight, self.bias)
+        if self._pk is None or self._pk.key != k:
+            pk = _Packed(); pk.key = k
+            w = self.weight.detach()
+            cout, cin = w.shape[0], w.shape[1]
+            pk.cout, pk.cin = cout, cin
+            pk.bias = self.bias.detach().float().contiguous() if self.bias is not None else None
+            if self.kernel_size == (1, 1):
+                w2 = w.reshape(cout, cin)
+                pk.w = w2.to(BF16).contiguous(); pk.wt = w2.t().to(BF16).contiguous()
+            else:
+                assert self.kernel_size == (3, 3) and self.padding == (1, 1), "only 3x3/pad1 and 1x1 convolutions exist in the SD UNet"
+                pk.cin_pad = (cin + 7) // 8 * 8
+                pk.cout_pad = (cout + 7) // 8 * 8
+                pk.w = _pad_last(w.permute(0, 2, 3, 1), 8).to(BF16).contiguous()       # [Cout][ky][kx][Cin_pad]
+                pk.wd = _pad_last(w.permute(1, 2, 3, 0), 8).to(BF16).contiguous()      # [Cin][ky][kx][Cout_pad]
+            self._pk = pk
+        return self._pk
+
+    def forward(self, x, residual=None, x2=None, rowbias=None, upsample=False):
+        if self.kernel_size == (1, 1):
+            assert x2 is None and rowbias is None and not upsample
+            return ops.linear(x, self, None, residual)
+        return ops.conv3x3(x, self, x2=x2, rowbias=rowbias, residual=residual, stride=self.stride[0], upsample=upsample)
+
+
+class _F32Affine:
+    _af = None
+
+    def f32_params(self):
+        k = _key(self.weight, self.bias)
+        if self._af is None or self._af[0] != k:
+            self._af = (k, self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
+        return self._af[1], self._af[2]
+
+
+class HipGroupNorm(_F32Affine, nn.GroupNorm):
+    def forward(self, x, silu=False):
+        return ops.groupnorm(x, self, silu)
+
+
+class HipLayerNorm(_F32Affine, nn.LayerNorm):
+    def forward(self, x):
+        return ops.layernorm(x, self)

@@ -1,0 +1,244 @@
+"""Native LoRA layer — seam 2 of the drop-in boundary: ``lora_layer_map['lora_hip']``.
+
+Same constructor/classmethod surface, parameter names (``layer.W_down [r,in]``, ``layer.W_up [out,r]``, buffer
+``alpha = cfg_alpha / rank``), init (kaiming_uniform(a=sqrt 5) / zeros) and checkpoint keys as the reference's
+``LoraLayer`` (hcpdiff/models/lora_layers_patch.py:26-57, lora_base_patch.py:37-173); the arithmetic differs only in
+formulation: instead of materialising ``W + alpha * W_up @ W_down`` every forward (lora_base_patch.py:61-74), the
+container runs the host GEMM with the low-rank side path folded in as a 32-wide K-extension (csrc/gemm.hip), and the
+rank-r weight gradients are accumulated by csrc/lora.hip directly into a flat fp32 bucket.
+"""
+import math
+import struct
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from . import ops
+from .layers import HipConv2d, HipLinear
+from .patch_api import PatchPluginBlock, PatchPluginContainer, PluginGroup
+
+BF16 = torch.bfloat16
+RANK_SLOT = 32   # the K-extension width every LoRA layer is padded to (one MFMA k-step)
+
+
+class LoraHipContainer(PatchPluginContainer):
+    """Stands where the host Linear stood (reference LoraPatchContainer, lora_base_patch.py:19-35)."""
+    supports_fused_residual = True
+
+    def forward(self, x, residual=None, **kwargs):
+        if kwargs:
+            raise NotImplementedError(f"LoraHipContainer: unsupported call arguments {list(kwargs)}")
+        if len(self.plugin_names) != 1:
+            raise NotImplementedError("hcp_diffusion_amd: more than one LoRA block on a host is not fused yet")
+        return ops.linear(x, self._host, self[self.plugin_names[0]], residual)
+
+
+class _Factors(nn.Module):
+    """`layer` sub-module: holds W_down / W_up with the reference's names, shapes and init."""
+
+    def __init__(self, in_features, out_features, rank):
+        super().__init__()
+        self.rank = rank
+        self.W_down = nn.Parameter(torch.empty(rank, in_features))
+        self.W_up = nn.Parameter(torch.empty(out_features, rank))
+        self.register_parameter("bias", None)
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.W_down, a=math.sqrt(5))
+        nn.init.zeros_(self.W_up)
+
+    def get_weight(self):
+        return torch.mm(self.W_up, self.W_down)
+
+    def get_collapsed_param(self):
+        return self.W_up.data @ self.W_down.data, None
+
+
+class LoraHipLayer(PatchPluginBlock):
+    container_cls = LoraHipContainer
+    wrapable_classes = (nn.Linear, nn.Conv2d)
+
+    def __init__(self, lora_id, host, rank=1, dropout=0.0, alpha=1.0, bias=False, alpha_auto_scale=True, parent_block=None,
+                 host_name=None, **kwargs):
+        super().__init__(f"lora_block_{lora_id}", host, parent_block=parent_block, host_name=host_name)
+        host = self.host()
+        if isinstance(host, HipConv2d) and host.kernel_size != (1, 1) or not isinstance(host, (HipLinear, HipConv2d)):
+            raise NotImplementedError(f"lora_hip: host {type(host).__name__} is not a native Linear/1x1 layer (conv LoRA: later row)")
+        if bias or dropout != 0.0:
+            raise NotImplementedError("lora_hip: bias=True / dropout>0 are not implemented (reference defaults are off)")
+        out_f, in_f = host.weight.shape[0], host.weight.shape[1]
+        if isinstance(rank, float):
+            rank = max(round(out_f * rank), 1)            # fractional rank, lora_base_patch.py:105-106
+        if rank > RANK_SLOT:
+            raise NotImplementedError(f"lora_hip: rank {rank} > {RANK_SLOT}")
+        self.host_type = "linear"
+        self.bias = bias
+        self.layer = _Factors(in_f, out_f, rank).to(host.weight.device)
+        self.dropout = nn.Dropout(dropout)
+        self.rank = rank
+        self.register_buffer("alpha", torch.tensor(alpha / rank if alpha_auto_scale else alpha, device=host.weight.device))
+        self.alpha_f = float(self.alpha)
+        self._bucket = None       # set by LoraBucket.adopt
+        self._pk = None
+
+    # ---- reference API surface
+    def get_weight(self):
+        return self.layer.get_weight() * self.alpha
+
+    def get_bias(self):
+        return None
+
+    def init_weights(self, svd_init=False):
+        if svd_init:
+            raise NotImplementedError("lora_hip: svd_init")
+        self.layer.reset_parameters()
+
+    def reparameterization_to_host(self, alpha=None, base_alpha=1.0):
+        alpha = self.alpha if alpha is None else alpha
+        host = self.host()
+        w, _ = self.layer.get_collapsed_param()
+        host.weight = nn.Parameter(host.weight.data * base_alpha + alpha * w.view_as(host.weight).to(host.weight))
+
+    @classmethod
+    def wrap_layer(cls, lora_id, layer, rank=1, dropout=0.0, alpha=1.0, svd_init=False, bias=False, mask=None, **kwargs):
+        blk = cls(lora_id, layer, rank, dropout, alpha, bias=bias, **kwargs)
+        blk.init_weights(svd_init)
+        return blk
+
+    @classmethod
+    def wrap_model(cls, lora_id, model, **kwargs):
+        return super().wrap_model(lora_id, model, exclude_classes=(LoraHipLayer,), **kwargs)
+
+    # ---- native operand management
+    def packed(self):
+        if self._bucket is None:
+            LoraBucket([self])                 # stand-alone layer: a private one-layer bucket
+        return self._bucket.packed_for(self)
+
+    def grad_views(self):
+        if self._bucket is None:
+            LoraBucket([self])
+        return self._bucket.grad_views_for(self)
+
+
+class _LoraOperands:
+    pass
+
+
+class LoraBucket:
+    """All LoRA factors of a model in ONE flat fp32 parameter buffer + ONE flat gradient buffer.
+
+    * W_down/W_up become views into `params`; their `.grad` are views into `grads` (so torch optimizers, the
+      reference's clip_grad_norm_ and checkpointing still see ordinary parameters);
+    * `pack()` refreshes the bf16 operand copies of every layer with one kernel launch (call once per step,
+      after the optimizer update);
+    * the data-parallel exchange is one all-reduce of `grads` (dist.py), the optimizer one fused launch (optim.py).
+    """
+
+    def __init__(self, blocks):
+        self.blocks = list(blocks)
+        dev = self.blocks[0].layer.W_down.device
+        n = sum(b.layer.W_down.numel() + b.layer.W_up.numel() for b in self.blocks)
+        self.params = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        nb = sum(2 * RANK_SLOT * (b.layer.W_down.shape[1] + b.layer.W_up.shape[0]) for b in self.blocks)
+        self.operands = torch.zeros(nb, dtype=BF16, device=dev)
+        off, ooff = 0, 0
+        descs = bytearray()
+        self._ops = {}
+        self._gviews = {}
+        for b in self.blocks:
+            r, k = b.layer.W_down.shape
+            n_out = b.layer.W_up.shape[0]
+            views = []
+            for p in (b.layer.W_down, b.layer.W_up):
+                v = self.params[off:off + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                g = self.grads[off:off + p.numel()].view_as(p)
+                p.grad = g
+                views.append(g)
+                off += p.numel()
+            self._gviews[id(b)] = tuple(views)
+            o = _LoraOperands()
+            o.ad = self.operands[ooff:ooff + RANK_SLOT * k].view(RANK_SLOT, k); ooff += RANK_SLOT * k
+            o.adt = self.operands[ooff:ooff + RANK_SLOT * k].view(k, RANK_SLOT); ooff += RANK_SLOT * k
+            o.bu = self.operands[ooff:ooff + RANK_SLOT * n_out].view(n_out, RANK_SLOT); ooff += RANK_SLOT * n_out
+            o.but = self.operands[ooff:ooff + RANK_SLOT * n_out].view(RANK_SLOT, n_out); ooff += RANK_SLOT * n_out
+            self._ops[id(b)] = o
+            descs += struct.pack("<6Q3if", b.layer.W_down.data_ptr(), b.layer.W_up.data_ptr(), o.ad.data_ptr(), o.adt.data_ptr(),
+                                 o.bu.data_ptr(), o.but.data_ptr(), k, n_out, r, b.alpha_f)
+            b._bucket = self
+        assert K.lib().hcp_lora_pack_desc_bytes() == 64
+        self.descs = torch.frombuffer(descs, dtype=torch.uint8).to(dev)
+        self._packed_version = None
+        self.pack()
+
+    def pack(self):
+        K.lora_pack(self.descs, len(self.blocks))
+        self._packed_version = self.params._version
+
+    def packed_for(self, blk):
+        if self._packed_version != self.params._version:
+            self.pack()
+        return self._ops[id(blk)]
+
+    def grad_views_for(self, blk):
+        gd, gu = self._gviews[id(blk)]
+        if blk.layer.W_down.grad is None:      # zero_grad(set_to_none=True) dropped the views: re-attach
+            blk.layer.W_down.grad, blk.layer.W_up.grad = gd, gu
+        return gd, gu
+
+    @property
+    def numel(self):
+        return self.params.numel()
+
+
+lora_layer_map = {"lora_hip": LoraHipLayer, "lora": LoraHipLayer}
+
+try:  # register with the reference's registry when it is importable (seam 2)
+    from hcpdiff.models.lora_layers_patch import lora_layer_map as _ref_map   # pragma: no cover
+    _ref_map.setdefault("lora_hip", LoraHipLayer)                              # pragma: no cover
+except Exception:  # noqa: BLE001
+    pass
+
+
+def get_match_layers(patterns, named_modules):
+    """`re:` / plain layer selectors of the reference configs (utils/cfg_net_tools.py:30-75, `re.match` anchored)."""
+    import re
+    out = []
+    for pat in patterns:
+        metas = pat.split(":")
+        name = metas[-1]
+        if "re" in metas[:-1]:
+            rx = re.compile(name)
+            out.extend(k for k in named_modules if rx.match(k) is not None)
+        else:
+            out.append(name)
+    return sorted(set(out), key=out.index)
+
+
+def make_lora(model, cfg_lora):
+    """Restates make_hcpdiff's LoRA half (cfg_net_tools.py:108-123): wrap every matched layer, return
+    ([param groups], PluginGroup, LoraBucket)."""
+    named = dict(model.named_modules())
+    groups, blocks = [], {}
+    for lora_id, item in enumerate(cfg_lora):
+        item = dict(item)
+        layers = item.pop("layers")
+        cls = lora_layer_map[item.pop("type", "lora_hip")]
+        lr = item.pop("lr", 1e-4)
+        params = []
+        for layer_name in get_match_layers(layers, named):
+            parent_name, _, host_name = layer_name.rpartition(".")
+            made = cls.wrap_model(lora_id, named[layer_name], parent_block=named[parent_name], host_name=host_name, **item)
+            for k, v in made.items():
+                path = f"{layer_name}.{k}" if k else layer_name
+                blocks[path] = v
+                v.requires_grad_(True)
+                v.train()
+                params.extend(v.parameters())
+        groups.append({"params": params, "lr": lr})
+    bucket = LoraBucket(blocks.values()) if blocks else None
+    return groups, PluginGroup(blocks), bucket

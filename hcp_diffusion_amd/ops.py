@@ -1,0 +1,267 @@
+"""torch.autograd.Function wrappers: each forward/backward is one or a few C-ABI kernel launches (kernels.py).
+
+Activations are bf16, token-major / NHWC.  Frozen-weight layers produce input gradients only; LoRA factors get
+their gradients accumulated by the wgrad kernel straight into the flat fp32 bucket (their ``.grad`` views).
+Full fine-tuning (weight gradients of the host layers) is not built yet and fails loudly.
+"""
+import torch
+
+from . import kernels as K
+
+BF16 = torch.bfloat16
+
+
+def _no_host_grad(*params):
+    if not torch.is_grad_enabled():
+        return
+    for p in params:
+        if p is not None and p.requires_grad:
+            raise NotImplementedError(
+                "hcp_diffusion_amd: gradients for host (non-LoRA) weights are not implemented yet "
+                "(full fine-tune / DreamBooth is a later SURVEY §8 row); freeze the host or use LoRA")
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T (+ T (alpha Bu)^T) + bias (+ residual);  T = x Ad^T.   Reference arithmetic:
+    LoraPatchContainer.forward / LoraBlock.post_forward (lora_base_patch.py:20-35,68-74)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, w_down, w_up, host, lora, out_f32=False):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
+        pk = host.packed()
+        T = None
+        if lora is not None:
+            lp = lora.packed()
+            T = K.gemm(x2, lp.ad)
+            y = K.gemm(x2, pk.w, a2=T, b2=lp.bu, bias=pk.bias, residual=res2)
+        else:
+            y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2, out_f32=out_f32)
+        ctx.host, ctx.lora = host, lora
+        ctx.save_for_backward(x2 if lora is not None else None, T)
+        ctx.xshape = shp
+        ctx.has_res = residual is not None
+        return y.view(*shp[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, T = ctx.saved_tensors
+        host, lora = ctx.host, ctx.lora
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        pk = host.packed()
+        dx = None
+        if lora is not None:
+            lp = lora.packed()
+            U = K.gemm(dy2, lp.but)
+            if ctx.needs_input_grad[0]:
+                dx = K.gemm(dy2, pk.wt, a2=U, b2=lp.adt)
+            gd, gu = lora.grad_views()
+            K.lora_wgrad(U, x2, gd, lora.rank, lora.alpha_f, False)
+            K.lora_wgrad(T, dy2, gu, lora.rank, lora.alpha_f, True)
+        elif ctx.needs_input_grad[0]:
+            dx = K.gemm(dy2, pk.wt)
+        if dx is not None:
+            dx = dx.view(ctx.xshape)
+        return dx, (dy if ctx.has_res else None), None, None, None, None, None
+
+
+def linear(x, host, lora=None, residual=None, out_f32=False):
+    _no_host_grad(host.weight, host.bias)
+    wd = lora.layer.W_down if lora is not None else None
+    wu = lora.layer.W_up if lora is not None else None
+    if out_f32 and (lora is not None or x.requires_grad):
+        raise NotImplementedError("hcp_diffusion_amd: fp32 linear output is only provided for the gradient-free time-embedding path")
+    return _LinearFn.apply(x, residual, wd, wu, host, lora, out_f32)
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """3x3/pad-1 conv on NHWC bf16 (+bias, + per-sample row bias (time embedding), + residual); optional second
+    input (channel concat), stride 2, fused nearest-2x upsample."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, rowbias, residual, host, stride, upsample):
+        pk = host.packed()
+        y = K.conv3x3(x1, pk.w, pk.cout, x2=x2, stride=stride, upsample=upsample, bias=pk.bias, rowbias=rowbias, residual=residual)
+        ctx.host, ctx.stride, ctx.upsample = host, stride, upsample
+        ctx.in_shape = x1.shape
+        ctx.c2 = x2.shape[-1] if x2 is not None else 0
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pk = ctx.host.packed()
+        dy = dy.contiguous()
+        B, H, W, C1 = ctx.in_shape
+        hw = (H * 2, W * 2) if ctx.upsample else (H, W)
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0]:
+            dx1 = K.conv3x3(dy, pk.wd[:C1], C1, mode=1, stride=ctx.stride, out_hw=hw)
+            if ctx.upsample:
+                dx1 = K.upsample2x_bwd(dx1)
+        if ctx.c2 and ctx.needs_input_grad[1]:
+            dx2 = K.conv3x3(dy, pk.wd[C1:], ctx.c2, mode=1, stride=ctx.stride, out_hw=hw)
+        if ctx.needs_input_grad[2]:
+            raise NotImplementedError("hcp_diffusion_amd: gradient w.r.t. the time-embedding bias is not implemented (frozen time MLP assumed)")
+        return dx1, dx2, None, (dy if ctx.has_res else None), None, None, None
+
+
+def conv3x3(x1, host, *, x2=None, rowbias=None, residual=None, stride=1, upsample=False):
+    _no_host_grad(host.weight, host.bias)
+    return _Conv3x3Fn.apply(x1, x2, rowbias, residual, host, stride, upsample)
+
+
+class _GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gn, silu):
+        g, b = gn.f32_params()
+        y, stats = K.groupnorm_fwd(x, g, b, gn.num_groups, gn.eps, silu)
+        ctx.save_for_backward(x, stats)
+        ctx.gn, ctx.silu = gn, silu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        g, b = ctx.gn.f32_params()
+        return K.groupnorm_bwd(x, dy.contiguous(), g, b, stats, ctx.gn.num_groups, ctx.silu), None, None
+
+
+def groupnorm(x, gn, silu):
+    _no_host_grad(gn.weight, gn.bias)
+    return _GroupNormFn.apply(x, gn, silu)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln):
+        g, b = ln.f32_params()
+        y, stats = K.layernorm_fwd(x, g, b, ln.eps)
+        ctx.save_for_backward(x, stats)
+        ctx.ln = ln
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        g, _ = ctx.ln.f32_params()
+        return K.layernorm_bwd(x, dy.contiguous(), g, stats), None
+
+
+def layernorm(x, ln):
+    _no_host_grad(ln.weight, ln.bias)
+    return _LayerNormFn.apply(x, ln)
+
+
+class _GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return K.geglu_fwd(h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        return K.geglu_bwd(h, dy.contiguous())
+
+
+geglu = _GegluFn.apply
+
+
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        o, lse = K.attention_fwd(q, k, v, heads)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        dq, dk, dv = K.attention_bwd(q.contiguous(), k.contiguous(), v.contiguous(), o, do.contiguous(), lse, ctx.heads)
+        return dq, dk, dv, None
+
+
+def attention(q, k, v, heads):
+    return _AttentionFn.apply(q, k, v, heads)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.add(a, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+add = _AddFn.apply
+
+
+class _ConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.c1 = a.shape[-1]
+        return K.concat_channels(a, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        return K.split_channels(d.contiguous(), ctx.c1)
+
+
+concat_channels = _ConcatFn.apply
+
+
+class _SiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return K.silu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.silu_bwd(x, dy.contiguous())
+
+
+silu = _SiluFn.apply
+
+
+class _ConvOutFn(torch.autograd.Function):
+    """conv_out: NHWC bf16 -> 3x3 conv (fp32 accum/out) -> NCHW fp32 `.sample`.  Backward: NCHW fp32 gradient ->
+    channel-padded NHWC bf16 -> data-gradient conv."""
+
+    @staticmethod
+    def forward(ctx, x, host):
+        pk = host.packed()
+        y = K.conv3x3(x, pk.w, pk.cout, bias=pk.bias, out_f32=True)
+        ctx.host = host
+        ctx.in_shape = x.shape
+        return K.nhwc_to_nchw_f32(y, pk.cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        pk = ctx.host.packed()
+        B, H, W, C = ctx.in_shape
+        g = K.nchw_to_nhwc(dy.contiguous(), pk.cout_pad)
+        return K.conv3x3(g, pk.wd, C, mode=1, stride=1, out_hw=(H, W)), None
+
+
+def conv_out(x, host):
+    _no_host_grad(host.weight, host.bias)
+    return _ConvOutFn.apply(x, host)
+
+
+def conv_in(sample, host):
+    """NCHW fp32/bf16 latents -> channel-padded NHWC bf16 -> 3x3 conv.  The latents never need a gradient."""
+    _no_host_grad(host.weight, host.bias)
+    if sample.requires_grad:
+        raise NotImplementedError("hcp_diffusion_amd: gradient w.r.t. the input latents is not implemented")
+    pk = host.packed()
+    x = K.nchw_to_nhwc(sample.contiguous(), pk.cin_pad)
+    return K.conv3x3(x, pk.w, pk.cout, bias=pk.bias)

@@ -1,0 +1,126 @@
+"""Native inner loop: the arithmetic of ``Trainer.train_one_step`` (reference hcpdiff/train_ac.py:467-504) for the
+benchmark configuration (cached latents — the VAE encode "stays a one-off host call" —, eps-prediction loss, LoRA
+on the UNet), restated step by step:
+
+  make_noise   train_ac.py:437-447   torch RNG for noise/timesteps (kept for parity), add_noise = HIP kernel
+  forward      train_ac.py:449-465   NativeUNet2DConditionModel (HIP kernels)
+  get_loss     train_ac.py:506-515   masked MSE in fp32, one kernel producing loss AND d loss/d pred
+  backward     train_ac.py:482       autograd over the native ops; LoRA grads land in one flat fp32 bucket
+  DDP          accelerate/torch DDP  ONE all-reduce(SUM) of the flat bucket over RCCL (dist.py), 1/world folded
+                                     into the optimizer kernel
+  clip + step  train_ac.py:485-494   global-norm clip + AdamW + zero_grad = 3 launches (csrc/optim.hip)
+
+Everything between two host interactions is stream-ordered device work with static shapes, so the whole step is
+captured once into a hipGraph (two graphs around the all-reduce when world_size > 1) and replayed; the reference's
+per-step ``loss.item()`` sync (train_ac.py:504) is deferred to whenever the caller reads the loss tensor.
+"""
+import torch
+
+from . import kernels as K
+from .lora import make_lora
+
+
+def ddpm_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, device="cpu"):
+    """DDPMScheduler(beta_schedule='scaled_linear') table; constants as in the reference's
+    loggers/preview/image_previewer.py:28."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0).to(device)
+
+
+class NativeTrainer:
+    def __init__(self, unet, lora_cfg, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
+                 scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000):
+        self.unet = unet
+        self.device = next(unet.parameters()).device
+        unet.requires_grad_(False)            # config_model(): freeze host, eval (train_ac.py:264-268)
+        unet.eval()
+        self.param_groups, self.lora_group, self.bucket = make_lora(unet, lora_cfg)
+        assert self.bucket is not None, "no LoRA layer matched"
+        n = self.bucket.numel
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.lr = torch.full((1,), lr * scale_lr_factor, dtype=torch.float32, device=self.device)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.weight_decay, self.betas, self.eps, self.max_grad_norm = weight_decay, betas, eps, max_grad_norm
+        self.loss_weight = loss_weight
+        self.acp = ddpm_alphas_cumprod(num_train_timesteps, device=self.device)
+        self.num_train_timesteps = num_train_timesteps
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or
+                                                                          torch.distributed.is_initialized()) else 1
+        self.use_graph = use_graph
+        self._graphs = None
+        self._static = None
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # ---- the pieces of train_one_step
+    def make_noise(self, latents):
+        noise = torch.randn_like(latents)
+        t = torch.randint(0, self.num_train_timesteps, (latents.shape[0],), device=latents.device).long()
+        return K.add_noise(latents, noise, t, self.acp), noise, t
+
+    def forward_backward(self, latents, encoder_hidden_states, mask=None):
+        noisy, noise, t = self.make_noise(latents)
+        pred = self.unet(noisy, t, encoder_hidden_states).sample          # wrapper.py:29
+        loss, grad = K.mse_masked_mean(pred.detach(), noise, mask, weight=self.loss_weight)    # loss.type == 'eps'
+        torch.autograd.backward(pred, grad)
+        return loss
+
+    def all_reduce(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.bucket.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def optimizer_step(self):
+        b = self.bucket
+        K.sumsq(b.grads, self.sumsq)
+        K.adamw_clip_fused(b.params, b.grads, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count, beta1=self.betas[0],
+                           beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, sumsq_t=self.sumsq,
+                           grad_scale=1.0 / self.world, max_norm=self.max_grad_norm)
+        b.pack()                               # refresh the bf16 LoRA operands for the next forward
+
+    def set_lr(self, lr):
+        self.lr.fill_(lr)
+
+    # ---- one optimisation step
+    def train_one_step(self, latents, encoder_hidden_states, mask=None):
+        """latents [B,4,h,w] fp32 (cached VAE latents), encoder_hidden_states [B,L,D]. Returns the loss as a device
+        tensor (no host sync)."""
+        if not self.use_graph:
+            self.loss = self.forward_backward(latents.float().contiguous(), encoder_hidden_states, mask)
+            self.all_reduce()
+            self.optimizer_step()
+            return self.loss
+        if self._graphs is None:
+            self._capture(latents, encoder_hidden_states, mask)
+        s = self._static
+        s["latents"].copy_(latents)
+        s["ehs"].copy_(encoder_hidden_states)
+        if mask is not None:
+            s["mask"].copy_(mask)
+        g1, g2 = self._graphs
+        g1.replay()
+        self.all_reduce()
+        g2.replay()
+        return self.loss
+
+    def _capture(self, latents, ehs, mask):
+        s = {"latents": latents.float().contiguous().clone(), "ehs": ehs.clone(), "mask": mask.clone() if mask is not None else None}
+        self._static = s
+        # warm-up on a side stream (allocator + lazy weight packing must not happen inside the capture)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.forward_backward(s["latents"], s["ehs"], s["mask"])
+                self.all_reduce()
+                self.optimizer_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            loss = self.forward_backward(s["latents"], s["ehs"], s["mask"])
+        self.loss = loss
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            self.optimizer_step()
+        self._graphs = (g1, g2)

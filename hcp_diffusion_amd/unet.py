@@ -1,0 +1,364 @@
+"""NativeUNet2DConditionModel — seam 1 of the drop-in boundary: the object a reference config
+injects as ``model.unet`` (hcpdiff/train_ac.py:220-222) and the trainer calls as
+``unet(noisy_latents, timesteps, encoder_hidden_states, encoder_attention_mask=...).sample`` (models/wrapper.py:29).
+
+Same module tree / parameter names as diffusers' ``UNet2DConditionModel`` (reference cfgs/unet_struct.txt), real
+``nn.Linear`` / ``nn.Conv2d`` leaves called through ``__call__`` (forward hooks and LoRA containers fire), but every
+op is a hand-written gfx950 kernel (ops.py -> C ABI).  Internally activations are bf16 channels-last
+([B,H,W,C] == [B,HW,C] token-major, no permutes between conv and transformer blocks); NCHW exists only at
+conv_in / conv_out.  GroupNorm+SiLU, bias, time-embedding add, residual adds, the skip concat and the nearest-2x
+upsample are fused into the producing / consuming kernels where the module boundaries allow it.
+"""
+import torch
+from torch import nn
+
+from . import kernels as K
+from . import ops
+from .layers import HipConv2d, HipGroupNorm, HipLayerNorm, HipLinear
+
+BF16 = torch.bfloat16
+
+SD15_CONFIG = dict(
+    in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    num_attention_heads=8, cross_attention_dim=768, norm_num_groups=32, num_train_timesteps=1000)
+
+
+def _call_res(mod, x, residual):
+    """Call a (possibly LoRA-wrapped / hooked) leaf, fusing the residual add when the callee supports it."""
+    if getattr(mod, "supports_fused_residual", False):
+        return mod(x, residual=residual)
+    return ops.add(mod(x), residual)     # e.g. the reference's own LoraPatchContainer swallows extra kwargs
+
+
+class Timesteps(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.num_channels = dim
+
+    def forward(self, t):
+        return K.timestep_embedding(t.contiguous(), self.num_channels)
+
+
+class SiLU(nn.Module):
+    def forward(self, x):
+        return ops.silu(x)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, dim):
+        super().__init__()
+        self.linear_1 = HipLinear(cin, dim)
+        self.act = SiLU()
+        self.linear_2 = HipLinear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(self.act(self.linear_1(x)))
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_dim, groups, eps=1e-5):
+        super().__init__()
+        self.norm1 = HipGroupNorm(groups, cin, eps=eps)
+        self.conv1 = HipConv2d(cin, cout, 3, 1, 1)
+        self.time_emb_proj = HipLinear(temb_dim, cout)
+        self.norm2 = HipGroupNorm(groups, cout, eps=eps)
+        self.dropout = nn.Dropout(0.0)
+        self.conv2 = HipConv2d(cout, cout, 3, 1, 1)
+        self.nonlinearity = SiLU()
+        if cin != cout:
+            self.conv_shortcut = HipConv2d(cin, cout, 1)
+        self.gradient_checkpointing = False
+
+    def forward(self, x, temb_act, skip=None):
+        """x [B,H,W,C] (+ optional skip tensor = the up-path concat, never materialised); temb_act = SiLU(temb)."""
+        if skip is not None:
+            x = ops.concat_channels(x, skip)          # GroupNorm needs the joint tensor once; convs read it back
+        h = self.norm1(x, silu=True)
+        if isinstance(self.time_emb_proj, HipLinear):  # [B, Cout] fp32 row bias fused into conv1's epilogue
+            tb = self.time_emb_proj(temb_act, out_f32=True)
+        else:
+            tb = self.time_emb_proj(temb_act).float()
+        h = self.conv1(h, rowbias=tb)
+        h = self.norm2(h, silu=True)
+        sc = self.conv_shortcut(x) if hasattr(self, "conv_shortcut") else x
+        return self.conv2(h, residual=sc)
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, dim, ctx_dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.to_q = HipLinear(dim, dim, bias=False)
+        self.to_k = HipLinear(ctx_dim, dim, bias=False)
+        self.to_v = HipLinear(ctx_dim, dim, bias=False)
+        self.to_out = nn.ModuleList([HipLinear(dim, dim), nn.Dropout(0.0)])
+
+    def forward(self, x, context=None, residual=None):
+        ctx = x if context is None else context
+        q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
+        o = ops.attention(q, k, v, self.heads)
+        return _call_res(self.to_out[0], o, residual) if residual is not None else self.to_out[0](o)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = HipLinear(dim, inner * 2)
+
+    def forward(self, x):
+        return ops.geglu(self.proj(x))
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), HipLinear(dim * 4, dim)])
+
+    def forward(self, x, residual=None):
+        h = self.net[0](x)
+        return _call_res(self.net[2], h, residual) if residual is not None else self.net[2](h)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, ctx_dim, heads):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, dim, heads)
+        self.ff = FeedForward(dim)
+        self.attn2 = CrossAttention(dim, ctx_dim, heads)
+        self.norm1 = HipLayerNorm(dim)
+        self.norm2 = HipLayerNorm(dim)
+        self.norm3 = HipLayerNorm(dim)
+
+    def forward(self, x, context):
+        x = self.attn1(self.norm1(x), residual=x)
+        x = self.attn2(self.norm2(x), context, residual=x)
+        return self.ff(self.norm3(x), residual=x)
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, dim, ctx_dim, heads, groups):
+        super().__init__()
+        self.norm = HipGroupNorm(groups, dim, eps=1e-6)
+        self.proj_in = HipConv2d(dim, dim, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, ctx_dim, heads)])
+        self.proj_out = HipConv2d(dim, dim, 1)
+        self.gradient_checkpointing = False
+
+    def forward(self, x, context):
+        B, H, W, C = x.shape
+        h = self.proj_in(self.norm(x, silu=False)).view(B, H * W, C)
+        for blk in self.transformer_blocks:
+            h = blk(h, context)
+        return _call_res(self.proj_out, h.view(B, H, W, C), x)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = HipConv2d(c, c, 3, 2, 1)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = HipConv2d(c, c, 3, 1, 1)
+
+    def forward(self, x):
+        return self.conv(x, upsample=True)       # nearest-2x folded into the conv's gather
+
+
+class _DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb_dim, n_layers, cfg, has_attn, add_down):
+        super().__init__()
+        g = cfg["norm_num_groups"]
+        if has_attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)
+                                             for _ in range(n_layers)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_dim, g) for i in range(n_layers)])
+        if add_down:
+            self.downsamplers = nn.ModuleList([Downsample2D(cout)])
+        self.has_attn = has_attn
+        self.gradient_checkpointing = False
+
+    def forward(self, h, temb_act, context):
+        skips = ()
+        for i, res in enumerate(self.resnets):
+            h = res(h, temb_act)
+            if self.has_attn:
+                h = self.attentions[i](h, context)
+            skips += (h,)
+        if hasattr(self, "downsamplers"):
+            h = self.downsamplers[0](h)
+            skips += (h,)
+        return h, skips
+
+
+class CrossAttnDownBlock2D(_DownBlock):
+    pass
+
+
+class DownBlock2D(_DownBlock):
+    pass
+
+
+class UNetMidBlock2DCrossAttn(nn.Module):
+    def __init__(self, c, temb_dim, cfg):
+        super().__init__()
+        g = cfg["norm_num_groups"]
+        self.attentions = nn.ModuleList([Transformer2DModel(c, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb_dim, g), ResnetBlock2D(c, c, temb_dim, g)])
+        self.gradient_checkpointing = False
+
+    def forward(self, h, temb_act, context):
+        h = self.resnets[0](h, temb_act)
+        h = self.attentions[0](h, context)
+        return self.resnets[1](h, temb_act)
+
+
+class _UpBlock(nn.Module):
+    def __init__(self, cin, cout, prev, temb_dim, n_layers, cfg, has_attn, add_up):
+        super().__init__()
+        g = cfg["norm_num_groups"]
+        if has_attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)
+                                             for _ in range(n_layers)])
+        res = []
+        for i in range(n_layers):
+            skip_c = cin if i == n_layers - 1 else cout
+            in_c = prev if i == 0 else cout
+            res.append(ResnetBlock2D(in_c + skip_c, cout, temb_dim, g))
+        self.resnets = nn.ModuleList(res)
+        if add_up:
+            self.upsamplers = nn.ModuleList([Upsample2D(cout)])
+        self.has_attn = has_attn
+        self.gradient_checkpointing = False
+
+    def forward(self, h, skips, temb_act, context):
+        for i, res in enumerate(self.resnets):
+            h = res(h, temb_act, skip=skips[-1])
+            skips = skips[:-1]
+            if self.has_attn:
+                h = self.attentions[i](h, context)
+        if hasattr(self, "upsamplers"):
+            h = self.upsamplers[0](h)
+        return h
+
+
+class UpBlock2D(_UpBlock):
+    pass
+
+
+class CrossAttnUpBlock2D(_UpBlock):
+    pass
+
+
+class UNet2DConditionOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class _Config(dict):
+    __getattr__ = dict.__getitem__
+
+
+class NativeUNet2DConditionModel(nn.Module):
+    def __init__(self, **cfg):
+        super().__init__()
+        cfg = dict(SD15_CONFIG, **cfg)
+        self.config = _Config(cfg)
+        boc = cfg["block_out_channels"]
+        temb_dim = boc[0] * 4
+        self.conv_in = HipConv2d(cfg["in_channels"], boc[0], 3, 1, 1)
+        self.time_proj = Timesteps(boc[0])
+        self.time_embedding = TimestepEmbedding(boc[0], temb_dim)
+        n = cfg["layers_per_block"]
+        downs, out_c = [], boc[0]
+        for i, t in enumerate(cfg["down_block_types"]):
+            in_c, out_c = out_c, boc[i]
+            cls = CrossAttnDownBlock2D if t.startswith("CrossAttn") else DownBlock2D
+            downs.append(cls(in_c, out_c, temb_dim, n, cfg, t.startswith("CrossAttn"), i != len(boc) - 1))
+        self.down_blocks = nn.ModuleList(downs)
+        ups, rev = [], list(reversed(boc))
+        out_c = rev[0]
+        for i, t in enumerate(cfg["up_block_types"]):
+            prev, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, len(boc) - 1)]
+            cls = CrossAttnUpBlock2D if t.startswith("CrossAttn") else UpBlock2D
+            ups.append(cls(in_c, out_c, prev, temb_dim, n + 1, cfg, t.startswith("CrossAttn"), i != len(boc) - 1))
+        self.up_blocks = nn.ModuleList(ups)
+        self.mid_block = UNetMidBlock2DCrossAttn(boc[-1], temb_dim, cfg)
+        self.conv_norm_out = HipGroupNorm(cfg["norm_num_groups"], boc[0], eps=1e-5)
+        self.conv_act = SiLU()
+        self.conv_out = HipConv2d(boc[0], cfg["out_channels"], 3, 1, 1)
+        self.class_embedding = None
+
+    # ---- reference-facing conveniences (train_ac.py:257-278, wrapper.py:39-49)
+    @classmethod
+    def from_config(cls, config=None, **kw):
+        return cls(**dict(config or {}, **kw))
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, **kw):
+        """Load diffusers-format weights (config.json + *.safetensors) — names are identical by construction."""
+        import json
+        import os
+        root = os.path.join(path, subfolder) if subfolder else path
+        cfg = json.load(open(os.path.join(root, "config.json")))
+        heads = cfg.get("attention_head_dim", 8)
+        model = cls(in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
+                    block_out_channels=tuple(cfg["block_out_channels"]), layers_per_block=cfg["layers_per_block"],
+                    down_block_types=tuple(cfg["down_block_types"]), up_block_types=tuple(cfg["up_block_types"]),
+                    num_attention_heads=heads if isinstance(heads, int) else heads[0], cross_attention_dim=cfg["cross_attention_dim"],
+                    norm_num_groups=cfg["norm_num_groups"])
+        from safetensors.torch import load_file
+        model.load_state_dict(load_file(os.path.join(root, "diffusion_pytorch_model.safetensors")))
+        return model
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):
+        return None                                   # attention is always the fused flash kernel
+
+    def enable_gradient_checkpointing(self):
+        raise NotImplementedError("hcp_diffusion_amd: gradient checkpointing is not implemented (288 GB HBM holds all SD1.5/SDXL "
+                                  "activations at the benchmark batch sizes); set model.gradient_checkpointing: False")
+
+    def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, added_cond_kwargs=None,
+                cross_attention_kwargs=None, **kwargs):
+        if encoder_attention_mask is not None:
+            raise NotImplementedError("hcp_diffusion_amd: encoder_attention_mask (additive key mask) is not implemented yet")
+        if added_cond_kwargs:
+            raise NotImplementedError("hcp_diffusion_amd: SDXL added_cond_kwargs are a later SURVEY §8 row")
+        B = sample.shape[0]
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep], dtype=torch.int64, device=sample.device)
+        timestep = timestep.to(torch.int64).reshape(-1).expand(B).contiguous()
+        temb = self.time_embedding(self.time_proj(timestep))
+        temb_act = ops.silu(temb)                      # every ResnetBlock applies SiLU(temb): do it once
+        ctx = encoder_hidden_states
+        if ctx.dtype != BF16:
+            ctx = ctx.to(BF16)
+        ctx = ctx.contiguous()
+        h = ops.conv_in(sample, self.conv_in)
+        skips = (h,)
+        for blk in self.down_blocks:
+            h, s = blk(h, temb_act, ctx)
+            skips += s
+        h = self.mid_block(h, temb_act, ctx)
+        for blk in self.up_blocks:
+            k = len(blk.resnets)
+            h = blk(h, skips[-k:], temb_act, ctx)
+            skips = skips[:-k]
+        h = self.conv_norm_out(h, silu=True)
+        return UNet2DConditionOutput(ops.conv_out(h, self.conv_out))

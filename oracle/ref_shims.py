@@ -1,0 +1,59 @@
+"""ORACLE / test infrastructure: import the reference's OWN LoRA + plugin code, unmodified, from /root/reference.
+
+`import hcpdiff` fails in this container (hcpdiff/__init__.py:1 -> train_ac.py:18 imports diffusers, hydra, ...;
+SURVEY.md §8c), so stub *packages* are registered whose ``__path__`` points into the reference tree (their
+``__init__.py`` files are thereby skipped) plus two tiny shim modules for names imported at module scope:
+``diffusers.optimization`` (needed by hcpdiff/utils/net_utils.py:6) and ``omegaconf`` (hcpdiff/utils/utils.py:7).
+Nothing is copied: the reference files are executed where they lie.  Only available where /root/reference exists
+(NOT on the GPU box) — used to generate tests/golden/*.pt and to pin oracle/lora_ref.py.
+"""
+import importlib
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("HCP_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "hcpdiff", "models"))
+
+
+def _stub_pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def load_reference_lora():
+    """Returns (lora_layers_patch module, plugin module) of the reference, executed from REFERENCE_ROOT."""
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    if "hcpdiff.models.lora_layers_patch" in sys.modules:
+        return sys.modules["hcpdiff.models.lora_layers_patch"], sys.modules["hcpdiff.models.plugin"]
+    if "diffusers" not in sys.modules:
+        d = types.ModuleType("diffusers"); d.__path__ = []
+        opt = types.ModuleType("diffusers.optimization")
+        opt.SchedulerType = type("SchedulerType", (), {})
+        opt.TYPE_TO_SCHEDULER_FUNCTION = {}
+        opt.Optimizer = object
+        sys.modules["diffusers"] = d; sys.modules["diffusers.optimization"] = opt
+    if "omegaconf" not in sys.modules:
+        oc = types.ModuleType("omegaconf")
+        oc.OmegaConf = type("OmegaConf", (), {}); oc.ListConfig = list
+        sys.modules["omegaconf"] = oc
+    base = os.path.join(REFERENCE_ROOT, "hcpdiff")
+    _stub_pkg("hcpdiff", base)
+    utils = _stub_pkg("hcpdiff.utils", os.path.join(base, "utils"))
+    _stub_pkg("hcpdiff.models", os.path.join(base, "models"))
+    net_utils = importlib.import_module("hcpdiff.utils.net_utils")
+    u = importlib.import_module("hcpdiff.utils.utils")
+    for k in dir(u):                      # `from hcpdiff.utils import ...` style imports in the reference
+        if not k.startswith("_"):
+            setattr(utils, k, getattr(u, k))
+    utils.net_utils = net_utils
+    plugin = importlib.import_module("hcpdiff.models.plugin")
+    importlib.import_module("hcpdiff.models.lora_base_patch")
+    layers = importlib.import_module("hcpdiff.models.lora_layers_patch")
+    return layers, plugin

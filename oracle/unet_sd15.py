@@ -1,0 +1,330 @@
+"""ORACLE (test infrastructure — never imported by the product path; see oracle/README.md).
+
+Plain-PyTorch fp32 CPU restatement of the arithmetic behind the reference's hot-path call
+``self.unet(noisy_latents, timesteps, encoder_hidden_states).sample`` (reference hcpdiff/models/wrapper.py:29).
+
+The arithmetic lives in the un-vendored dependency ``diffusers<=0.26.1`` (reference requirements.txt:4), which is
+absent from this container, so this file restates ``UNet2DConditionModel`` from
+  * the complete SD1.5 module tree the reference ships:      cfgs/unet_struct.txt:1-931 (names, channels, eps, bias flags),
+  * the reference's own restatement of the encoder forward:   hcpdiff/models/controlnet.py:88-183 (block call
+    conventions, skip-tuple layout) and :71-82 (decoder concat order [hidden, skip]),
+  * the published diffusers 0.26.1 semantics marked [ext] below (unverifiable offline).
+PARITY STATUS: "parity unpinned" for this file — the reference has no tests / golden vectors for the UNet
+ and diffusers cannot be imported here.  The LoRA half IS pinned (oracle/lora_ref.py).
+
+Module / parameter names equal diffusers' so state_dicts are interchangeable with the native model.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+SD15_CONFIG = dict(
+    in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    num_attention_heads=8, cross_attention_dim=768, norm_num_groups=32, num_train_timesteps=1000)
+
+# A structurally identical miniature (same block types; channel counts chosen so head_dim is 40 / 80 as in SD1.5).
+TINY_CONFIG = dict(SD15_CONFIG, block_out_channels=(80, 160, 160, 160), layers_per_block=1, num_attention_heads=2,
+                   cross_attention_dim=64, norm_num_groups=8)   # head dims 40/80 = the SD1.5 ones
+
+
+def timestep_embedding(timesteps, dim, max_period=10000.0):
+    """Timesteps(num_channels=320, flip_sin_to_cos=True, downscale_freq_shift=0)  [ext]; unet_struct.txt:3."""
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / half
+    emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)  # flip_sin_to_cos=True -> [cos | sin]
+
+
+class Timesteps(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.num_channels = dim
+
+    def forward(self, t):
+        return timestep_embedding(t, self.num_channels)
+
+
+class TimestepEmbedding(nn.Module):  # unet_struct.txt:4-8
+    def __init__(self, cin, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(cin, dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(self.act(self.linear_1(x)))
+
+
+class ResnetBlock2D(nn.Module):  # unet_struct.txt:92-100, :199-208 (conv_shortcut when Cin != Cout)
+    def __init__(self, cin, cout, temb_dim, groups, eps=1e-5):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, 1, 1)
+        self.time_emb_proj = nn.Linear(temb_dim, cout)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.dropout = nn.Dropout(0.0)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1)
+        self.nonlinearity = nn.SiLU()
+        if cin != cout:
+            self.conv_shortcut = nn.Conv2d(cin, cout, 1)
+
+    def forward(self, x, temb):
+        h = self.conv1(self.nonlinearity(self.norm1(x)))
+        h = h + self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]   # [ext] ResnetBlock2D.forward
+        h = self.conv2(self.dropout(self.nonlinearity(self.norm2(h))))
+        if hasattr(self, "conv_shortcut"):
+            x = self.conv_shortcut(x)
+        return x + h                                                            # output_scale_factor = 1
+
+
+class CrossAttention(nn.Module):  # unet_struct.txt:17-25, :34-42
+    def __init__(self, dim, ctx_dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.to_q = nn.Linear(dim, dim, bias=False)
+        self.to_k = nn.Linear(ctx_dim, dim, bias=False)
+        self.to_v = nn.Linear(ctx_dim, dim, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Dropout(0.0)])
+
+    def forward(self, x, context=None):
+        ctx = x if context is None else context
+        B, N, C = x.shape
+        d = C // self.heads
+        q = self.to_q(x).view(B, N, self.heads, d).transpose(1, 2)
+        k = self.to_k(ctx).view(B, -1, self.heads, d).transpose(1, 2)
+        v = self.to_v(ctx).view(B, -1, self.heads, d).transpose(1, 2)
+        p = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1)          # scale = dim_head^-0.5 [ext]
+        o = (p @ v).transpose(1, 2).reshape(B, N, C)
+        return self.to_out[1](self.to_out[0](o))
+
+
+class GEGLU(nn.Module):  # unet_struct.txt:28-30
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner * 2)
+
+    def forward(self, x):
+        hidden, gate = self.proj(x).chunk(2, dim=-1)                            # [ext] hidden first, gate second
+        return hidden * F.gelu(gate)
+
+
+class FeedForward(nn.Module):  # unet_struct.txt:26-33
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+class BasicTransformerBlock(nn.Module):  # unet_struct.txt:16-47 (module order attn1, ff, attn2, norm1-3)
+    def __init__(self, dim, ctx_dim, heads):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, dim, heads)
+        self.ff = FeedForward(dim)
+        self.attn2 = CrossAttention(dim, ctx_dim, heads)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+
+    def forward(self, x, context):
+        x = self.attn1(self.norm1(x)) + x
+        x = self.attn2(self.norm2(x), context) + x
+        x = self.ff(self.norm3(x)) + x
+        return x
+
+
+class Transformer2DModel(nn.Module):  # unet_struct.txt:12-50
+    def __init__(self, dim, ctx_dim, heads, groups):
+        super().__init__()
+        self.norm = nn.GroupNorm(groups, dim, eps=1e-6)
+        self.proj_in = nn.Conv2d(dim, dim, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, ctx_dim, heads)])
+        self.proj_out = nn.Conv2d(dim, dim, 1)
+
+    def forward(self, x, context):
+        B, C, H, W = x.shape
+        h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        for blk in self.transformer_blocks:
+            h = blk(h, context)
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        return self.proj_out(h) + x
+
+
+class Downsample2D(nn.Module):  # unet_struct.txt:111-114
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, 2, 1)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):  # unet_struct.txt:390-393; nearest 2x then conv [ext]
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, 1, 1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class DownBlock(nn.Module):
+    """CrossAttnDownBlock2D / DownBlock2D. Returns (hidden, skip tuple) — reference controlnet.py:149-171."""
+
+    def __init__(self, cin, cout, temb_dim, n_layers, cfg, has_attn, add_down):
+        super().__init__()
+        g = cfg["norm_num_groups"]
+        if has_attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)
+                                             for _ in range(n_layers)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_dim, g) for i in range(n_layers)])
+        if add_down:
+            self.downsamplers = nn.ModuleList([Downsample2D(cout)])
+        self.has_attn = has_attn
+
+    def forward(self, h, temb, context):
+        skips = ()
+        for i, res in enumerate(self.resnets):
+            h = res(h, temb)
+            if self.has_attn:
+                h = self.attentions[i](h, context)
+            skips += (h,)
+        if hasattr(self, "downsamplers"):
+            h = self.downsamplers[0](h)
+            skips += (h,)
+        return h, skips
+
+
+class MidBlock(nn.Module):  # unet_struct.txt:866-928
+    def __init__(self, c, temb_dim, cfg):
+        super().__init__()
+        g = cfg["norm_num_groups"]
+        self.attentions = nn.ModuleList([Transformer2DModel(c, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb_dim, g), ResnetBlock2D(c, c, temb_dim, g)])
+
+    def forward(self, h, temb, context):
+        h = self.resnets[0](h, temb)
+        h = self.attentions[0](h, context)
+        return self.resnets[1](h, temb)
+
+
+class UpBlock(nn.Module):
+    """UpBlock2D / CrossAttnUpBlock2D: concat order is [hidden, skip] (reference controlnet.py:73-75)."""
+
+    def __init__(self, cin, cout, prev, temb_dim, n_layers, cfg, has_attn, add_up):
+        super().__init__()
+        g = cfg["norm_num_groups"]
+        if has_attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(cout, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)
+                                             for _ in range(n_layers)])
+        res = []
+        for i in range(n_layers):
+            skip_c = cin if i == n_layers - 1 else cout
+            in_c = prev if i == 0 else cout
+            res.append(ResnetBlock2D(in_c + skip_c, cout, temb_dim, g))
+        self.resnets = nn.ModuleList(res)
+        if add_up:
+            self.upsamplers = nn.ModuleList([Upsample2D(cout)])
+        self.has_attn = has_attn
+
+    def forward(self, h, skips, temb, context):
+        for i, res in enumerate(self.resnets):
+            h = torch.cat([h, skips[-1]], dim=1)
+            skips = skips[:-1]
+            h = res(h, temb)
+            if self.has_attn:
+                h = self.attentions[i](h, context)
+        if hasattr(self, "upsamplers"):
+            h = self.upsamplers[0](h)
+        return h
+
+
+class UNetOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class OracleUNet2DConditionModel(nn.Module):
+    """fp32 reference of diffusers UNet2DConditionModel (SD1.x family). Call signature: wrapper.py:29."""
+
+    def __init__(self, **cfg):
+        super().__init__()
+        cfg = dict(SD15_CONFIG, **cfg)
+        self.config = cfg
+        boc = cfg["block_out_channels"]
+        temb_dim = boc[0] * 4
+        self.conv_in = nn.Conv2d(cfg["in_channels"], boc[0], 3, 1, 1)
+        self.time_proj = Timesteps(boc[0])
+        self.time_embedding = TimestepEmbedding(boc[0], temb_dim)
+        n = cfg["layers_per_block"]
+        downs, out_c = [], boc[0]
+        for i, t in enumerate(cfg["down_block_types"]):
+            in_c, out_c = out_c, boc[i]
+            downs.append(DownBlock(in_c, out_c, temb_dim, n, cfg, t.startswith("CrossAttn"), i != len(boc) - 1))
+        self.down_blocks = nn.ModuleList(downs)
+        ups, rev = [], list(reversed(boc))
+        out_c = rev[0]
+        for i, t in enumerate(cfg["up_block_types"]):
+            prev, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, len(boc) - 1)]
+            ups.append(UpBlock(in_c, out_c, prev, temb_dim, n + 1, cfg, t.startswith("CrossAttn"), i != len(boc) - 1))
+        self.up_blocks = nn.ModuleList(ups)
+        self.mid_block = MidBlock(boc[-1], temb_dim, cfg)
+        self.conv_norm_out = nn.GroupNorm(cfg["norm_num_groups"], boc[0], eps=1e-5)
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(boc[0], cfg["out_channels"], 3, 1, 1)
+
+    def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, **kwargs):
+        assert encoder_attention_mask is None, "oracle: additive key mask not restated"
+        temb = self.time_embedding(self.time_proj(timestep).to(sample.dtype))
+        h = self.conv_in(sample)
+        skips = (h,)
+        for blk in self.down_blocks:
+            h, s = blk(h, temb, encoder_hidden_states)
+            skips += s
+        h = self.mid_block(h, temb, encoder_hidden_states)
+        for blk in self.up_blocks:
+            k = len(blk.resnets)
+            h = blk(h, skips[-k:], temb, encoder_hidden_states)
+            skips = skips[:-k]
+        return UNetOutput(self.conv_out(self.conv_act(self.conv_norm_out(h))))
+
+
+def ddpm_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+    """DDPMScheduler(beta_schedule='scaled_linear') [ext]; same constants restated in the reference at
+    hcpdiff/loggers/preview/image_previewer.py:28."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def add_noise(x0, noise, timesteps, alphas_cumprod):
+    """DDPMScheduler.add_noise [ext] as called by reference train_ac.py:447."""
+    a = alphas_cumprod[timesteps].to(x0.dtype)
+    shape = (-1,) + (1,) * (x0.dim() - 1)
+    return a.sqrt().view(shape) * x0 + (1 - a).sqrt().view(shape) * noise
+
+
+def seeded_init_(model, seed=0):
+    """Deterministic non-degenerate weights (no pretrained weights exist on this box): default torch init for
+    matrices, but norm affine parameters and biases are perturbed so scale/shift/bias paths are exercised."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("lora_block_0.layer.W_up"):
+                continue
+            if p.dim() == 1:
+                if "norm" in name and name.endswith("weight"):
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.05 * torch.randn(p.shape, generator=g))
+            else:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) / math.sqrt(fan_in))
+    return model
