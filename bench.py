@@ -1,0 +1,161 @@
+"""bench.py — training images/sec, SD1.5 LoRA (rank 8) 512px bs=4/GPU, bf16, on N MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N --steps K --warmup W]            (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (reference train_ac.py:467-504) over one synthetic batch already resident in
+HBM: make_noise -> native UNet forward -> masked MSE -> backward (dX everywhere, LoRA wgrads) -> [RCCL all-reduce of
+the flat LoRA gradient bucket] -> global-norm clip + AdamW -> re-pack LoRA operands.  Random-init weights of the
+SD1.5 architecture, synthetic latents [4,4,64,64] and text states [4,77,768] (no datasets/checkpoints offline).
+Gradient checkpointing is OFF (288 GB HBM holds the activations; the reference default ON is a memory workaround).
+Rank 0 prints ONE JSON line.  The `cpu_baseline` leg (N=1 only) times the oracle — checker code, never the product.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMAGE_LORA_NOCKPT = 1.61e12      # BASELINE.md §2 (fwd 803.3 G + dX backward 803.3 G + LoRA side paths)
+MFMA_BF16_PEAK = 2.5e15                   # MI355X_MICROARCH.md: dense bf16 MFMA
+LORA_PATTERNS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]      # cfgs/train/examples/lora_conventional.yaml:10-12
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Oracle (fp32 PyTorch CPU restatement + merged-weight LoRA, as the reference computes it) on the host cores:
+    ONE training step at batch 1 (fwd + bwd + clip + AdamW), no gradient checkpointing."""
+    import torch.nn.functional as F
+    from oracle.lora_ref import wrap_lora
+    from oracle.unet_sd15 import OracleUNet2DConditionModel, add_noise, ddpm_alphas_cumprod
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = OracleUNet2DConditionModel()
+    m.requires_grad_(False)
+    wr = wrap_lora(m, LORA_PATTERNS, rank=8)
+    params = [p for w in wr.values() for p in w.lora_block_0.parameters()]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-3)
+    x0 = torch.randn(1, 4, 64, 64); ehs = torch.randn(1, 77, 768)
+    acp = ddpm_alphas_cumprod()
+    t0 = time.time()
+    noise = torch.randn_like(x0); t = torch.randint(0, 1000, (1,))
+    pred = m(add_noise(x0, noise, t, acp), t, ehs).sample
+    F.mse_loss(pred, noise).backward()
+    torch.nn.utils.clip_grad_norm_(params, 1.0)
+    opt.step()
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 LoRA(r=8) training step at batch 1, 512px latents, fp32 oracle, no grad-ckpt ({dt:.1f} s)"}
+
+
+def dominant_kernel_roofline(dev):
+    """The dominant kernel of the step is the implicit-GEMM 3x3 convolution (41% of the FLOPs); its most frequent
+    instance is C320->320 at 64x64, batch 4.  Timed with HIP events on the stream it is launched on."""
+    from hcp_diffusion_amd import kernels as K
+    B, H, C = 4, 64, 320
+    x = torch.randn(B, H, H, C, device=dev).to(torch.bfloat16)
+    w = (torch.randn(C, 3, 3, C, device=dev) * 0.02).to(torch.bfloat16)
+    for _ in range(5):
+        K.conv3x3(x, w, C)
+    torch.cuda.synchronize()
+    n = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        K.conv3x3(x, w, C)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = e0.elapsed_time(e1) * 1e-3 / n
+    flops = 2.0 * B * H * H * C * 9 * C
+    ach = flops / dt / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel<128,64,MODE=1> conv3x3 C320 64x64 B4", "achieved": round(ach, 1),
+            "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4), "traffic": None,
+            "avg_launch_us": round(dt * 1e6, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--rank-lora", type=int, default=8)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)       # nccl == RCCL on ROCm
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from hcp_diffusion_amd.trainer import NativeTrainer
+    from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
+
+    torch.manual_seed(114514)                      # same weights on every rank (train_base.yaml:5)
+    unet = NativeUNet2DConditionModel().to(dev)
+    tr = NativeTrainer(unet, [dict(layers=LORA_PATTERNS, rank=args.rank_lora, lr=1e-4)], lr=1e-4, weight_decay=1e-3,
+                       scale_lr_factor=args.batch * world, use_graph=not args.no_graph)
+    torch.manual_seed(114514 + rank)               # set_seed(seed + local_rank), train_ac.py:128
+    with torch.no_grad():                          # non-zero W_up so every LoRA path carries signal
+        for blk in tr.bucket.blocks:
+            blk.layer.W_up.normal_(0, 0.02)
+    if world > 1:                                  # identical LoRA init on every rank (DDP broadcasts rank 0's)
+        torch.distributed.broadcast(tr.bucket.params, 0)
+    tr.bucket.pack()
+    B = args.batch
+    latents = torch.randn(B, 4, 64, 64, device=dev)
+    ehs = torch.randn(B, 77, 768, device=dev).to(torch.bfloat16)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_one_step(latents, ehs)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_one_step(latents, ehs)
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = tmax.item()
+    loss_v = float(loss.item())
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        out = {
+            "metric": "training images/sec (whole node), SD1.5 LoRA 512px bs=4/GPU", "value": round(ips, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SD1.5 UNet LoRA rank=%d bf16, bs=%d/GPU, 512x512 (64x64 latents), 77-token context, "
+                                   "random-init weights, cached latents, grad-ckpt off" % (args.rank_lora, B),
+                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+            "final_loss": round(loss_v, 5),
+            "step_mfma_frac": round(ips / world * FLOP_PER_IMAGE_LORA_NOCKPT / MFMA_BF16_PEAK, 4),
+        }
+        out["roofline"] = dominant_kernel_roofline(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

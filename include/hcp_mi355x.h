@@ -1,0 +1,108 @@
+/* hcp_mi355x.h — C ABI of libhcp_mi355x.so: the MI355X (gfx950) kernels behind HCP-Diffusion's fine-tuning hot path.
+ *
+ * The reference (IrisRainbowNeko/HCP-Diffusion v0.9.1) is pure Python; its hot path
+ *   Trainer.train_one_step            hcpdiff/train_ac.py:467-504
+ *   -> TEUnetWrapper.forward          hcpdiff/models/wrapper.py:14-30   (self.unet(...).sample, :29)
+ *   -> LoraPatchContainer.forward     hcpdiff/models/lora_base_patch.py:20-35
+ * bottoms out in torch / diffusers ops.  Each entry point below replaces one of those ops; the comment on each
+ * names the reference call it stands in for.  Binding a maintainer would add: ctypes, see INTEGRATION.md.
+ *
+ * Conventions: every function returns 0 on success, <0 on error (message: hcp_last_error(), thread-local);
+ * raw DEVICE pointers, explicit shapes/strides (in elements), a hipStream_t; no allocation (workspace sizes are
+ * queryable), no stream synchronisation, re-entrant, callable from any thread (autograd runs backward on its own).
+ * bf16 tensors are raw uint16 bit patterns; "NHWC" = channels-last [B,H,W,C] == token-major [B,H*W,C].
+ */
+#ifndef HCP_MI355X_H
+#define HCP_MI355X_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hcpStream_t; /* == hipStream_t */
+
+const char* hcp_last_error(void);
+int hcp_is_emulated(void); /* 0 for the product library */
+int hcp_abi_version(void);
+
+/* D[M,N] = alpha*(A[M,K] B[N,K]^T + A2[M,K2] B2[N,K2]^T) + bias[N] + rowbias[m/rows_per_group, :] + residual[M,N]
+ * Replaces nn.Linear / 1x1 nn.Conv2d forward and input-gradient of the UNet, and the LoRA container's
+ * torch.mm(x, (W_host + alpha*W_up@W_down)^T) + bias (lora_layers_patch.py:50-57, lora_base_patch.py:68-74):
+ * (A2,B2) is the rank-r side path (x W_down^T, alpha*W_up) appended to the reduction. */
+int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int ldd, int M, int N, int K, const void* A2,
+                  int lda2, const void* B2, int ldb2, int K2, const float* bias, const float* rowbias, int rowbias_ld,
+                  int rows_per_group, const void* residual, int ldr, float alpha, int out_f32, hcpStream_t stream);
+
+/* 3x3 / pad 1 convolution over NHWC bf16 as an implicit GEMM.  mode 0: forward, Wp = [Cout][3][3][C1+C2];
+ * mode 1: data gradient, X1 = dY, Wp = [Cin][3][3][Cout].  Options: stride 1|2, nearest-2x upsampled source,
+ * second source tensor (channel concat), bias, per-sample row bias (time embedding), residual.
+ * Replaces F.conv2d in diffusers ResnetBlock2D / Downsample2D / Upsample2D (reference cfgs/unet_struct.txt:92-114,390-393). */
+int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int B, int Hs, int Ws, int Ho, int Wo, int mode,
+                     int stride, int upsample, const void* Wp, int Cout, void* D, int ldd, const float* bias,
+                     const float* rowbias, int rowbias_ld, const void* residual, int ldr, int out_f32, hcpStream_t stream);
+
+/* Fused attention, element (b,n,h,c) at base + b*bs + n*rs + h*D + c; lse[B,H,Nq] = logsumexp(scale*QK^T).
+ * Replaces diffusers CrossAttention/AttnProcessor2_0 (SDPA) or xformers (reference train_ac.py:258-260). D in {40,64,80,160}. */
+int hcp_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int Nq, int Nk, int D,
+                      long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
+                      hcpStream_t stream);
+int hcp_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                      float* delta_ws /* [B,H,Nq] */, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int D,
+                      long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
+                      hcpStream_t stream);
+
+/* GroupNorm (+SiLU) over NHWC; stats[B,G,2] = (mean, rstd).  Replaces F.group_norm + SiLU
+ * (unet_struct.txt:13,93,97,929).  Backward returns dx only (affine parameters frozen). */
+size_t hcp_groupnorm_workspace_bytes(int B, int HW, int C, int G);
+int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, void* workspace,
+                           int B, int HW, int C, int G, float eps, int silu, hcpStream_t stream);
+int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats,
+                           void* dx, void* workspace, int B, int HW, int C, int G, int silu, hcpStream_t stream);
+
+/* LayerNorm over the last dim; stats[M,2] = (mean, rstd).  Replaces F.layer_norm (unet_struct.txt:44-46). */
+int hcp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int C, float eps,
+                      hcpStream_t stream);
+int hcp_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, void* dx, int M, int C,
+                      hcpStream_t stream);
+
+/* y[M,F] = h[:, :F] * gelu(h[:, F:])   (diffusers GEGLU, unet_struct.txt:28-30) */
+int hcp_geglu_fwd(const void* h, void* y, long M, int F, hcpStream_t stream);
+int hcp_geglu_bwd(const void* h, const void* dy, void* dh, long M, int F, hcpStream_t stream);
+
+int hcp_add_bf16(const void* a, const void* b, void* out, long n, hcpStream_t stream);
+int hcp_copy2d_bf16(const void* src, int sld, void* dst, int dld, long M, int C, hcpStream_t stream); /* skip concat/split */
+int hcp_silu_fwd(const void* x, void* y, long n, hcpStream_t stream);
+int hcp_silu_bwd(const void* x, const void* dy, void* dx, long n, hcpStream_t stream);
+int hcp_nchw_to_nhwc_bf16(const void* src, int src_is_f32, void* dst, int B, int C, int HW, int Cpad, hcpStream_t stream);
+int hcp_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, int HW, int Csrc, hcpStream_t stream);
+int hcp_upsample2x_bwd(const void* dup, void* dx, int B, int H, int W, int C, hcpStream_t stream);
+
+/* Timesteps(flip_sin_to_cos=True, freq_shift=0) (unet_struct.txt:3): emb[b] = [cos(t f_i) | sin(t f_i)] */
+int hcp_timestep_embedding(const long long* timesteps, void* emb, int B, int dim, float max_period, hcpStream_t stream);
+/* DDPMScheduler.add_noise as called by train_ac.py:447 */
+int hcp_add_noise(const float* x0, const float* noise, const long long* timesteps, const float* alphas_cumprod, float* xt,
+                  int B, long per_sample, hcpStream_t stream);
+/* (MSE(reduction none) * mask).mean() * weight and its gradient (train_ac.py:506-515) */
+int hcp_mse_masked_mean(const float* pred, const float* target, const float* mask, int mask_channels, float* loss,
+                        float* grad, int B, int C, int HW, float weight, hcpStream_t stream);
+
+/* out[p,q] (+)= scale * sum_m L[m,p] R[m,q]  (fp32 atomics): the rank-r LoRA weight gradients
+ * dW_down = alpha (dY W_up)^T x, dW_up = alpha dY^T (x W_down^T) (autograd of lora_base_patch.py:61-74). */
+int hcp_lora_wgrad(const void* L, int ldl, const void* R, int ldr, float* out, int ldo, int M, int P, int Q, float scale,
+                   int transpose_out, hcpStream_t stream);
+/* fp32 LoRA factors -> the four bf16 operand layouts, all layers in one launch (descs: device array, 64 B each:
+ * {const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r; float alpha;}) */
+int hcp_lora_pack(const void* descs, int count, hcpStream_t stream);
+int hcp_lora_pack_desc_bytes(void);
+
+/* accelerator.clip_grad_norm_ + torch.optim.AdamW.step + zero_grad (train_ac.py:485-494) on one flat fp32 bucket. */
+int hcp_sumsq_f32(const float* g, long n, float* out, hcpStream_t stream);
+int hcp_adamw_clip_fused(float* p, float* g, float* m, float* v, long n, const float* lr, float beta1, float beta2,
+                         float eps, float weight_decay, const float* sumsq, float grad_scale, float max_norm, int* step,
+                         hcpStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

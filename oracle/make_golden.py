@@ -1,0 +1,141 @@
+"""Generates tests/golden/* (run in the build container, where /root/reference exists; the fixtures travel, the
+reference does not):
+
+  sd15_struct.json       parameter names + shapes parsed from the reference's own structure dump
+                         cfgs/unet_struct.txt (the only thing in the reference that pins the UNet).
+  lora_reference.pt      inputs/outputs/gradients of the reference's REAL LoRA code (LoraLayer.wrap_model ->
+                         LoraPatchContainer.forward/backward, imported unmodified through oracle/ref_shims.py)
+                         on seeded inputs, for a bias / no-bias Linear and a whole attention module.
+  tiny_unet_oracle.pt    oracle outputs for the TINY config (regression pin of oracle + native model).
+
+    python -m oracle.make_golden
+"""
+import json
+import os
+import re
+import sys
+
+import torch
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def parse_unet_struct(path):
+    """{param name: shape} from the printed module tree (Conv2d / Linear / GroupNorm / LayerNorm lines)."""
+    shapes = {}
+    stack = []
+    for line in open(path):
+        indent = (len(line) - len(line.lstrip())) // 2
+        m = re.match(r"\s*\((\w+)\): (\w+)\((.*)$", line)
+        if not m:
+            continue
+        name, kind, rest = m.groups()
+        stack = stack[:indent - 1] + [name]
+        full = ".".join(stack)
+        if kind == "Conv2d":
+            cin, cout, kh, kw = map(int, re.match(r"(\d+), (\d+), kernel_size=\((\d+), (\d+)\)", rest).groups())
+            shapes[full + ".weight"] = [cout, cin, kh, kw]
+            shapes[full + ".bias"] = [cout]
+        elif kind == "Linear":
+            fin, fout, bias = re.match(r"in_features=(\d+), out_features=(\d+), bias=(\w+)", rest).groups()
+            shapes[full + ".weight"] = [int(fout), int(fin)]
+            if bias == "True":
+                shapes[full + ".bias"] = [int(fout)]
+        elif kind == "GroupNorm":
+            g, c = map(int, re.match(r"(\d+), (\d+)", rest).groups())
+            shapes[full + ".weight"] = [c]; shapes[full + ".bias"] = [c]
+        elif kind == "LayerNorm":
+            c = int(re.match(r"\((\d+),\)", rest).group(1))
+            shapes[full + ".weight"] = [c]; shapes[full + ".bias"] = [c]
+    return shapes
+
+
+def lora_reference_vectors():
+    from oracle.ref_shims import load_reference_lora
+    layers, plugin = load_reference_lora()
+    LoraLayer = layers.LoraLayer
+    out = {}
+    g = torch.Generator().manual_seed(1234)
+
+    def rnd(*s, scale=1.0):
+        return torch.randn(*s, generator=g) * scale
+
+    for tag, (fin, fout, bias, rank, alpha) in {"linear_bias_r4": (48, 40, True, 4, 1.0), "linear_nobias_r8": (64, 96, False, 8, 2.0)}.items():
+        parent = nn.Module()
+        parent.fc = nn.Linear(fin, fout, bias=bias)
+        with torch.no_grad():
+            parent.fc.weight.copy_(rnd(fout, fin, scale=fin ** -0.5))
+            if bias:
+                parent.fc.bias.copy_(rnd(fout, scale=0.1))
+        host_w = parent.fc.weight.detach().clone(); host_b = parent.fc.bias.detach().clone() if bias else None
+        blocks = LoraLayer.wrap_model(0, parent.fc, parent_block=parent, host_name="fc", rank=rank, alpha=alpha, dropout=0.0)
+        blk = blocks[""]
+        assert type(parent.fc).__name__ == "LoraPatchContainer"
+        with torch.no_grad():
+            blk.layer.W_down.copy_(rnd(rank, fin, scale=0.3)); blk.layer.W_up.copy_(rnd(fout, rank, scale=0.3))
+        x = rnd(3, 5, fin).requires_grad_(True); dy = rnd(3, 5, fout)
+        y = parent.fc(x)
+        y.backward(dy)
+        out[tag] = dict(host_weight=host_w, host_bias=host_b, W_down=blk.layer.W_down.detach().clone(), W_up=blk.layer.W_up.detach().clone(),
+                        alpha_buffer=blk.alpha.clone(), cfg_alpha=alpha, rank=rank, x=x.detach().clone(), dy=dy, y=y.detach().clone(),
+                        dx=x.grad.clone(), dW_down=blk.layer.W_down.grad.clone(), dW_up=blk.layer.W_up.grad.clone(),
+                        state_keys=sorted(parent.state_dict().keys()))
+    # a whole attention module wrapped the way make_hcpdiff does it (wrap_model on the matched `attn` module)
+    from oracle.unet_sd15 import CrossAttention
+    parent = nn.Module()
+    parent.attn2 = CrossAttention(80, 64, 2)
+    with torch.no_grad():
+        for p in parent.attn2.parameters():
+            p.copy_(rnd(*p.shape, scale=p.shape[-1] ** -0.5))
+    host_sd = {k: v.clone() for k, v in parent.attn2.state_dict().items()}
+    blocks = LoraLayer.wrap_model(0, parent.attn2, parent_block=parent, host_name="attn2", rank=4, alpha=1.0, dropout=0.0)
+    with torch.no_grad():
+        for b in blocks.values():
+            b.layer.W_down.copy_(rnd(*b.layer.W_down.shape, scale=0.2)); b.layer.W_up.copy_(rnd(*b.layer.W_up.shape, scale=0.2))
+    x = rnd(2, 16, 80).requires_grad_(True); ctx = rnd(2, 7, 64); dy = rnd(2, 16, 80)
+    y = parent.attn2(x, ctx)
+    y.backward(dy)
+    out["attn2_r4"] = dict(host_state=host_sd, lora={k: dict(W_down=b.layer.W_down.detach().clone(), W_up=b.layer.W_up.detach().clone(),
+                                                             dW_down=b.layer.W_down.grad.clone(), dW_up=b.layer.W_up.grad.clone())
+                                                     for k, b in blocks.items()},
+                           x=x.detach().clone(), ctx=ctx, dy=dy, y=y.detach().clone(), dx=x.grad.clone(),
+                           state_keys=sorted(parent.state_dict().keys()))
+    return out
+
+
+def tiny_unet_vectors():
+    import torch.nn.functional as F
+    from oracle.lora_ref import wrap_lora
+    from oracle.unet_sd15 import OracleUNet2DConditionModel, TINY_CONFIG, add_noise, ddpm_alphas_cumprod, seeded_init_
+    torch.manual_seed(0)
+    m = seeded_init_(OracleUNet2DConditionModel(**TINY_CONFIG), 1)
+    m.requires_grad_(False)
+    wr = wrap_lora(m, [r"re:.*\.attn.?$", r"re:.*\.ff$"], rank=4)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for w in wr.values():
+            w.lora_block_0.layer.W_up.copy_(torch.randn(w.lora_block_0.layer.W_up.shape, generator=g) * 0.05)
+    g2 = torch.Generator().manual_seed(7)
+    x0 = torch.randn(2, 4, 8, 8, generator=g2); ehs = torch.randn(2, 77, 64, generator=g2); noise = torch.randn(2, 4, 8, 8, generator=g2)
+    t = torch.tensor([10, 500])
+    pred = m(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ehs).sample
+    loss = F.mse_loss(pred, noise)
+    loss.backward()
+    grads = torch.cat([p.grad.flatten() for w in wr.values() for p in (w.lora_block_0.layer.W_down, w.lora_block_0.layer.W_up)])
+    return dict(x0=x0, ehs=ehs, noise=noise, t=t, pred=pred.detach(), loss=loss.detach(), lora_grads=grads, n_lora=len(wr))
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    ref = os.environ.get("HCP_REFERENCE_ROOT", "/root/reference")
+    shapes = parse_unet_struct(os.path.join(ref, "cfgs", "unet_struct.txt"))
+    json.dump({"source": "reference cfgs/unet_struct.txt", "n_params": sum(int(torch.tensor(s).prod()) for s in shapes.values()),
+               "shapes": shapes}, open(os.path.join(GOLD, "sd15_struct.json"), "w"), indent=0)
+    print("sd15_struct.json:", len(shapes), "tensors")
+    torch.save(lora_reference_vectors(), os.path.join(GOLD, "lora_reference.pt"))
+    torch.save(tiny_unet_vectors(), os.path.join(GOLD, "tiny_unet_oracle.pt"))
+    for f in os.listdir(GOLD):
+        print(f, os.path.getsize(os.path.join(GOLD, f)))

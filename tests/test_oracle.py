@@ -1,0 +1,101 @@
+"""Pins the oracle (CPU, no GPU): against the reference's own structure dump and against golden vectors produced by
+the reference's real LoRA code (oracle/make_golden.py -> tests/golden)."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle.lora_ref import OracleLoraLinear
+from oracle.unet_sd15 import OracleUNet2DConditionModel, CrossAttention
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_oracle_unet_matches_reference_struct_dump():
+    """Every parameter name and shape of the oracle == reference cfgs/unet_struct.txt (859.5 M parameters)."""
+    ref = json.load(open(os.path.join(GOLD, "sd15_struct.json")))
+    with torch.device("meta"):
+        m = OracleUNet2DConditionModel()
+    got = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert got == ref["shapes"]
+    assert sum(v.numel() for v in m.state_dict().values()) == ref["n_params"] == 859520964
+
+
+@pytest.mark.parametrize("tag", ["linear_bias_r4", "linear_nobias_r8"])
+def test_lora_restatement_matches_reference_code(tag):
+    g = torch.load(os.path.join(GOLD, "lora_reference.pt"))[tag]
+    fout, fin = g["host_weight"].shape
+    host = torch.nn.Linear(fin, fout, bias=g["host_bias"] is not None)
+    with torch.no_grad():
+        host.weight.copy_(g["host_weight"])
+        if g["host_bias"] is not None:
+            host.bias.copy_(g["host_bias"])
+    host.requires_grad_(False)
+    parent = torch.nn.Module(); parent.fc = OracleLoraLinear(host, g["rank"], g["cfg_alpha"])
+    blk = parent.fc.lora_block_0
+    assert torch.equal(blk.alpha, g["alpha_buffer"])
+    assert sorted(parent.state_dict().keys()) == g["state_keys"]          # _host.*, lora_block_0.layer.W_*, alpha
+    with torch.no_grad():
+        blk.layer.W_down.copy_(g["W_down"]); blk.layer.W_up.copy_(g["W_up"])
+    x = g["x"].clone().requires_grad_(True)
+    y = parent.fc(x)
+    y.backward(g["dy"])
+    for a, b in ((y, g["y"]), (x.grad, g["dx"]), (blk.layer.W_down.grad, g["dW_down"]), (blk.layer.W_up.grad, g["dW_up"])):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_attention_module_with_reference_lora():
+    """Oracle CrossAttention + oracle LoRA == reference LoRA wrapped around the same module (golden)."""
+    from oracle.lora_ref import wrap_lora
+    g = torch.load(os.path.join(GOLD, "lora_reference.pt"))["attn2_r4"]
+    parent = torch.nn.Module(); parent.attn2 = CrossAttention(80, 64, 2)
+    parent.attn2.load_state_dict(g["host_state"])
+    parent.requires_grad_(False)
+    wr = wrap_lora(parent, ["attn2"], rank=4)
+    assert sorted(parent.state_dict().keys()) == g["state_keys"]
+    with torch.no_grad():
+        for path, w in wr.items():
+            sub = path[len("attn2."):]
+            w.lora_block_0.layer.W_down.copy_(g["lora"][sub]["W_down"]); w.lora_block_0.layer.W_up.copy_(g["lora"][sub]["W_up"])
+    x = g["x"].clone().requires_grad_(True)
+    y = parent.attn2(x, g["ctx"])
+    y.backward(g["dy"])
+    assert torch.allclose(y, g["y"], rtol=1e-4, atol=1e-5) and torch.allclose(x.grad, g["dx"], rtol=1e-4, atol=1e-5)
+    for path, w in wr.items():
+        sub = path[len("attn2."):]
+        assert torch.allclose(w.lora_block_0.layer.W_down.grad, g["lora"][sub]["dW_down"], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(w.lora_block_0.layer.W_up.grad, g["lora"][sub]["dW_up"], rtol=1e-4, atol=1e-5)
+
+
+def test_tiny_unet_oracle_regression():
+    import torch.nn.functional as F
+    from oracle.lora_ref import wrap_lora
+    from oracle.unet_sd15 import TINY_CONFIG, add_noise, ddpm_alphas_cumprod, seeded_init_
+    g = torch.load(os.path.join(GOLD, "tiny_unet_oracle.pt"))
+    torch.manual_seed(0)          # W_down's kaiming init draws from the global generator, as in make_golden.py
+    m = seeded_init_(OracleUNet2DConditionModel(**TINY_CONFIG), 1)
+    m.requires_grad_(False)
+    wr = wrap_lora(m, [r"re:.*\.attn.?$", r"re:.*\.ff$"], rank=4)
+    assert len(wr) == g["n_lora"]
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for w in wr.values():
+            w.lora_block_0.layer.W_up.copy_(torch.randn(w.lora_block_0.layer.W_up.shape, generator=gen) * 0.05)
+    pred = m(add_noise(g["x0"], g["noise"], g["t"], ddpm_alphas_cumprod()), g["t"], g["ehs"]).sample
+    assert torch.allclose(pred, g["pred"], rtol=1e-4, atol=1e-5)
+    F.mse_loss(pred, g["noise"]).backward()
+    grads = torch.cat([p.grad.flatten() for w in wr.values() for p in (w.lora_block_0.layer.W_down, w.lora_block_0.layer.W_up)])
+    assert torch.allclose(grads, g["lora_grads"], rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+def test_golden_is_reproducible_from_reference():
+    """Re-run the reference's own LoRA code (through the import shims) and compare with the committed fixture."""
+    from oracle.make_golden import lora_reference_vectors, parse_unet_struct
+    new = lora_reference_vectors()
+    old = torch.load(os.path.join(GOLD, "lora_reference.pt"))
+    for tag in ("linear_bias_r4", "linear_nobias_r8"):
+        for k in ("y", "dx", "dW_down", "dW_up"):
+            assert torch.equal(new[tag][k], old[tag][k])
+    assert parse_unet_struct("/root/reference/cfgs/unet_struct.txt") == json.load(open(os.path.join(GOLD, "sd15_struct.json")))["shapes"]
