@@ -33,7 +33,8 @@ def cpu_baseline(seconds_budget=30.0):
     from oracle.lora_ref import wrap_lora
     from oracle.unet_sd15 import OracleUNet2DConditionModel, add_noise, ddpm_alphas_cumprod
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
     m = OracleUNet2DConditionModel()
     m.requires_grad_(False)
@@ -104,7 +105,17 @@ def main():
     from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
 
     torch.manual_seed(114514)                      # same weights on every rank (train_base.yaml:5)
-    unet = NativeUNet2DConditionModel().to(dev)
+    with torch.device("meta"):
+        unet = NativeUNet2DConditionModel()
+    unet = unet.to_empty(device=dev)
+    with torch.no_grad():                          # random-init weights of the SD1.5 architecture, generated on the GPU
+        for name, p in unet.named_parameters():
+            if p.dim() > 1:
+                p.normal_(0, p[0].numel() ** -0.5)
+            elif "norm" in name and name.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.zero_()
     tr = NativeTrainer(unet, [dict(layers=LORA_PATTERNS, rank=args.rank_lora, lr=1e-4)], lr=1e-4, weight_decay=1e-3,
                        scale_lr_factor=args.batch * world, use_graph=not args.no_graph)
     torch.manual_seed(114514 + rank)               # set_seed(seed + local_rank), train_ac.py:128

@@ -23,8 +23,10 @@
 // all LDS is dynamic and 16-byte aligned (guide §6 G17)
 #define HCP_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define HCP_SYNC() __syncthreads()
+// hipGetLastError() first: drop any stale (non-sticky) error another library left on this thread, so that
+// HCP_LAUNCH_CHECK reports only this launch's status.
 #define HCP_LAUNCH(kernel, grid, block, smem, stream, ...) \
-    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
+    do { (void)hipGetLastError(); hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__); } while (0)
 
 typedef short hcp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short hcp_bf16x4 __attribute__((ext_vector_type(4)));

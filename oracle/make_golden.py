@@ -128,6 +128,53 @@ def tiny_unet_vectors():
     return dict(x0=x0, ehs=ehs, noise=noise, t=t, pred=pred.detach(), loss=loss.detach(), lora_grads=grads, n_lora=len(wr))
 
 
+def grad_fingerprint(named_grads, seed=77):
+    """Size-independent summary of a set of gradient tensors: per-tensor L2 norm and projection on a seeded direction."""
+    import zlib
+    out = {}
+    for name, g in named_grads:
+        gen = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
+        d = torch.randn(g.shape, generator=gen)
+        out[name] = (float(g.float().cpu().norm()), float((g.float().cpu() * d).sum() / d.norm()))
+    return out
+
+
+def sd15_full_inputs():
+    g2 = torch.Generator().manual_seed(42)
+    x0 = torch.randn(1, 4, 64, 64, generator=g2); ehs = torch.randn(1, 77, 768, generator=g2)
+    noise = torch.randn(1, 4, 64, 64, generator=g2); t = torch.tensor([437])
+    return x0, ehs, noise, t
+
+
+def sd15_lora_init_(named_lora_params, seed=5):
+    """Seeded non-zero LoRA factors by parameter name (W_down ~ N(0, 1/in), W_up ~ 0.05 N(0,1))."""
+    import zlib
+    with torch.no_grad():
+        for name, p in named_lora_params:
+            gen = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
+            scale = 0.05 if name.endswith("W_up") else p.shape[1] ** -0.5
+            p.copy_(torch.randn(p.shape, generator=gen) * scale)
+
+
+def sd15_full_vectors():
+    """Full SD1.5 architecture (859.5 M params), batch 1: oracle prediction, loss and LoRA-gradient fingerprint."""
+    import torch.nn.functional as F
+    from oracle.lora_ref import wrap_lora
+    from oracle.unet_sd15 import OracleUNet2DConditionModel, add_noise, ddpm_alphas_cumprod, seeded_init_
+    with torch.device("meta"):
+        m = OracleUNet2DConditionModel()
+    m = seeded_init_(m.to_empty(device="cpu"), 1)
+    m.requires_grad_(False)
+    wr = wrap_lora(m, [r"re:.*\.attn.?$", r"re:.*\.ff$"], rank=8)
+    lora_named = [(n, p) for n, p in m.named_parameters() if "lora_block_" in n]
+    sd15_lora_init_(lora_named)
+    x0, ehs, noise, t = sd15_full_inputs()
+    pred = m(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ehs).sample
+    loss = F.mse_loss(pred, noise)
+    loss.backward()
+    return dict(pred=pred.detach(), loss=float(loss), n_lora=len(wr), fingerprint=grad_fingerprint([(n, p.grad) for n, p in lora_named]))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     ref = os.environ.get("HCP_REFERENCE_ROOT", "/root/reference")
@@ -137,5 +184,6 @@ if __name__ == "__main__":
     print("sd15_struct.json:", len(shapes), "tensors")
     torch.save(lora_reference_vectors(), os.path.join(GOLD, "lora_reference.pt"))
     torch.save(tiny_unet_vectors(), os.path.join(GOLD, "tiny_unet_oracle.pt"))
+    torch.save(sd15_full_vectors(), os.path.join(GOLD, "sd15_full_oracle.pt"))
     for f in os.listdir(GOLD):
         print(f, os.path.getsize(os.path.join(GOLD, f)))

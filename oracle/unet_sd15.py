@@ -312,19 +312,22 @@ def add_noise(x0, noise, timesteps, alphas_cumprod):
 
 
 def seeded_init_(model, seed=0):
-    """Deterministic non-degenerate weights (no pretrained weights exist on this box): default torch init for
-    matrices, but norm affine parameters and biases are perturbed so scale/shift/bias paths are exercised."""
-    g = torch.Generator().manual_seed(seed)
+    """Deterministic non-degenerate weights (no pretrained weights exist on this box).  Every parameter gets its own
+    CPU generator seeded from (seed, crc32(name)), so any model with diffusers parameter names — the oracle, the native
+    UNet, on any device — receives bit-identical values regardless of module registration order.  Matrices ~ N(0, 1/fan_in);
+    norm scales ~ 1 + 0.1 N(0,1); biases / norm shifts ~ 0.05 N(0,1).  LoRA factors are left untouched."""
+    import zlib
     with torch.no_grad():
         for name, p in model.named_parameters():
-            if name.endswith("lora_block_0.layer.W_up"):
+            if "lora_block_" in name:
                 continue
+            g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.replace("._host", "").encode())) % (2 ** 31))
             if p.dim() == 1:
                 if "norm" in name and name.endswith("weight"):
-                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                    v = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
                 else:
-                    p.copy_(0.05 * torch.randn(p.shape, generator=g))
+                    v = 0.05 * torch.randn(p.shape, generator=g)
             else:
-                fan_in = p[0].numel()
-                p.copy_(torch.randn(p.shape, generator=g) / math.sqrt(fan_in))
+                v = torch.randn(p.shape, generator=g) / math.sqrt(p[0].numel())
+            p.copy_(v)
     return model

@@ -123,20 +123,35 @@ def test_lora_layer_api_surface(backend):
 
 
 @pytest.mark.gpu
-def test_sd15_full_size_forward_and_lora_grads_vs_oracle():
-    """Full SD1.5 architecture (859.5 M params, random-init), batch 1, 64x64 latents, 77x768 context, LoRA rank 8."""
+def test_sd15_full_size_forward_and_lora_grads_vs_golden():
+    """Full SD1.5 architecture (859.5 M params, seeded init), batch 1, 64x64 latents, 77x768 context, LoRA rank 8.
+    The fp32 oracle ran in the build container (oracle/make_golden.py -> tests/golden/sd15_full_oracle.pt: full prediction,
+    loss, and a per-tensor fingerprint (norm, seeded projection) of all 320 LoRA gradient tensors)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    from oracle.make_golden import grad_fingerprint, sd15_full_inputs, sd15_lora_init_
     K._set_backend_for_tests(None)
-
-    class B:
-        device = torch.device("cuda:0"); is_gpu = True
-
-        @staticmethod
-        def to(t):
-            return t.to("cuda:0")
-    torch.set_num_threads(os.cpu_count() or 8)
-    lo, ln, go, tr, wr = _train_step_pair(SD15_CONFIG, B, 8, (1, 4, 64, 64), 77, 768)
-    assert len(wr) == 160 and tr.bucket.numel == 2_990_080           # SURVEY §3.3: 160 LoRA'd layers, 2.99 M params @ r=8
-    assert abs(lo - ln) / abs(lo) < 2e-2
-    assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.99
+    dev = torch.device("cuda:0")
+    g = torch.load(os.path.join(GOLD, "sd15_full_oracle.pt"))
+    with torch.device("meta"):
+        nat = NativeUNet2DConditionModel()
+    nat = seeded_init_(nat.to_empty(device=dev), 1)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=8)], lr=1e-4)
+    assert len(tr.bucket.blocks) == g["n_lora"] == 160 and tr.bucket.numel == 2_990_080   # SURVEY §3.3
+    lora_named = [(n, p) for n, p in nat.named_parameters() if "lora_block_" in n]
+    sd15_lora_init_(lora_named)
+    tr.bucket.pack()
+    x0, ehs, noise, t = sd15_full_inputs()
+    tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
+    with torch.no_grad():
+        pred = nat(K.add_noise(x0.to(dev), noise.to(dev), t.to(dev), tr.acp), t.to(dev), ehs.to(dev)).sample.cpu()
+    assert ((pred - g["pred"]).norm() / g["pred"].norm()).item() < 2e-2
+    loss = tr.forward_backward(x0.to(dev), ehs.to(dev)).item()
+    assert abs(loss - g["loss"]) / g["loss"] < 2e-2
+    fp = grad_fingerprint([(n, p.grad) for n, p in lora_named])
+    import math
+    num = sum(fp[n][1] * g["fingerprint"][n][1] for n in fp); da = math.sqrt(sum(v[1] ** 2 for v in fp.values()))
+    db = math.sqrt(sum(v[1] ** 2 for v in g["fingerprint"].values()))
+    assert num / (da * db) > 0.99                                # projections agree in sign and size across 320 tensors
+    bad = [n for n in fp if g["fingerprint"][n][0] > 1e-7 and abs(fp[n][0] - g["fingerprint"][n][0]) / g["fingerprint"][n][0] > 0.1]
+    assert len(bad) <= 3, bad                                    # per-tensor gradient norms within 10% (bf16 pipeline)
