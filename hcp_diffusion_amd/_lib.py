@@ -78,6 +78,7 @@ def load():
     """Return the bound product library, loading it on first use.  Fails loudly when it is absent."""
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  torch must map ITS libamdhip64 first: our .so then binds to the same HIP runtime
         if not LIB_PATH.exists():
             raise HcpError(
                 f"{LIB_PATH} not found: build it with `python -m hcp_diffusion_amd.build` "

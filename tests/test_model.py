@@ -137,7 +137,7 @@ def test_sd15_full_size_forward_and_lora_grads_vs_golden():
         nat = NativeUNet2DConditionModel()
     nat = seeded_init_(nat.to_empty(device=dev), 1)
     tr = NativeTrainer(nat, [dict(layers=PATS, rank=8)], lr=1e-4)
-    assert len(tr.bucket.blocks) == g["n_lora"] == 160 and tr.bucket.numel == 2_990_080
+    assert len(tr.bucket.blocks) == g["n_lora"] == 160 and tr.bucket.numel == 2_992_128   # 160 layers: 224*sum(C)+16*12288
     lora_named = [(n, p) for n, p in nat.named_parameters() if "lora_block_" in n]
     sd15_lora_init_(lora_named)
     tr.bucket.pack()
