@@ -18,15 +18,18 @@ _PROTOTYPES = {
     "hcp_is_emulated": (I, []),
     "hcp_abi_version": (I, []),
     # A, lda, B, ldb, D, ldd, M, N, K, A2, lda2, B2, ldb2, K2, bias, rowbias, rowbias_ld, rows_per_group,
-    # residual, ldr, alpha, out_f32, stream
-    "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, F, I, P]),
+    # residual, ldr, alpha, out_f32, workspace, workspace_bytes, stream
+    "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, F, I, P, c_size_t, P]),
+    "hcp_gemm_workspace_bytes": (c_size_t, [I, I]),
+    "hcp_debug_set_gemm_config": (I, [I]),
     # X1, C1, X2, C2, B, Hs, Ws, Ho, Wo, mode, stride, upsample, Wp, Cout, D, ldd, bias, rowbias, rowbias_ld,
-    # residual, ldr, out_f32, stream
-    "hcp_conv3x3_bf16": (I, [P, I, P, I, I, I, I, I, I, I, I, I, P, I, P, I, P, P, I, P, I, I, P]),
+    # residual, ldr, out_f32, workspace, workspace_bytes, stream
+    "hcp_conv3x3_bf16": (I, [P, I, P, I, I, I, I, I, I, I, I, I, P, I, P, I, P, P, I, P, I, I, P, c_size_t, P]),
     # Q, K, V, O, lse, B, H, Nq, Nk, D, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale, stream
     "hcp_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P]),
     # Q, K, V, O, dO, lse, delta, dQ, dK, dV, B, H, Nq, Nk, D, strides..., scale, stream
     "hcp_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P]),
+    "hcp_debug_set_attention_config": (I, [I]),
     "hcp_groupnorm_workspace_bytes": (c_size_t, [I, I, I, I]),
     # x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream
     "hcp_groupnorm_silu_fwd": (I, [P, P, P, P, P, P, I, I, I, I, F, I, P]),

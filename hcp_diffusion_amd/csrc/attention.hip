@@ -11,6 +11,9 @@
 //  * P^T never leaves registers: MFMA sums over its 32 k-slots in any order as long as A and B agree, so the
 //    lane's own 8 exponentiated scores ARE its B fragment for O^T = V^T P^T, and the matching A fragment is
 //    two 8-byte reads of a transposed V copy in LDS;
+//  * K/V (or Q/dO) tiles are double-buffered in LDS; the next tile's global loads are issued into registers
+//    before the current tile's MFMAs and written to the other buffer after them: one barrier per tile;
+//  * softmax runs in the exp2 domain with scale*log2(e) folded into one multiply; fully valid tiles skip masking;
 //  * backward = delta pre-pass + a dQ kernel (same walk as forward) + a dK/dV kernel (walks query tiles with
 //    S = Q K^T un-transposed so each lane owns one KEY column) — no atomics, deterministic.
 #include "hcp_common.h"
@@ -20,7 +23,7 @@ namespace {
 struct AttnParams {
     const hcp_bf16 *Q, *K, *V, *O, *dO;
     hcp_bf16 *Out, *dQ, *dK, *dV;
-    float* lse;          // [B, H, Nq]
+    float* lse;          // [B, H, Nq]  natural-log logsumexp of the scaled scores
     float* delta;        // [B, H, Nq]
     long q_bs, k_bs, v_bs, o_bs;   // batch strides (elements)
     int q_rs, k_rs, v_rs, o_rs;    // token-row strides (elements); head h starts at column h*D
@@ -28,8 +31,10 @@ struct AttnParams {
     float scale;
 };
 
-constexpr int KVT = 64;            // keys per tile
+constexpr int KVT = 64;            // keys (or queries, in the dK/dV kernel) per tile
 constexpr int TS = KVT + 8;        // row stride (bf16) of transposed [d][64] LDS tiles
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
 
 HCP_DEVICE hcp_bf16x8 pack8(const hcp_f32x4& a, const hcp_f32x4& b) {
     hcp_bf16x8 r;
@@ -44,39 +49,63 @@ HCP_DEVICE hcp_bf16x8 join8(hcp_bf16x4 a, hcp_bf16x4 b) {
     return r;
 }
 
-// Stage `rows` x D of a token-major tensor into LDS: row-major [64][RS] zero-padded to DP columns (if rm)
-// and/or transposed [DV][TS] (if tr).  Rows >= nvalid are zero.
-template <int D, int DP, int DV>
-HCP_DEVICE void stage_tile(const hcp_bf16* src, int rs, int nvalid, hcp_bf16* rm, hcp_bf16* tr, int tid) {
-    constexpr int RS = DP + 8;
-    constexpr int NC = (DP > DV ? DP : DV) / 8;
-    for (int c = tid; c < KVT * NC; c += 256) {
-        const int row = c / NC, dc = c - row * NC;
-        hcp_bf16x8 v = hcp_zero8();
-        if (row < nvalid && dc * 8 < D) v = *(const hcp_bf16x8*)(src + (size_t)row * rs + dc * 8);
-        if (rm && dc * 8 < DP) *(hcp_bf16x8*)(rm + row * RS + dc * 8) = v;
-        if (tr && dc * 8 < DV) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tr[(dc * 8 + i) * TS + row] = (hcp_bf16)v[i];
-        }
-    }
-}
-
 template <int D> struct AttnGeom {
     static constexpr int DP = (D + 31) / 32 * 32;   // reduction length of the score MFMAs (zero padded)
     static constexpr int NQK = DP / 32;
     static constexpr int DV = (D + 15) / 16 * 16;   // output columns (zero padded)
     static constexpr int NDV = DV / 16;
-    static constexpr int RS = DP + 8;
+    static constexpr int RS = DP + 8;               // row stride (bf16) of row-major [64][DP] LDS tiles
+    static constexpr int RM_ELEMS = KVT * RS;
+    static constexpr int TR_ELEMS = DV * TS;
 };
+
+// Per-thread staging registers for one [64][D] tile (only the D/8 real 16-byte chunks of each row move;
+// the zero padding of the LDS images is written once at kernel start).
+template <int D>
+struct TileStage {
+    static constexpr int NC = D / 8;
+    static constexpr int IT = (KVT * NC + 255) / 256;
+    hcp_bf16x8 r[IT];
+    HCP_MEMBER void load(const hcp_bf16* src, int rs, int nvalid, int tid) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / NC, dc = c - row * NC;
+            r[i] = (c < KVT * NC && row < nvalid) ? *(const hcp_bf16x8*)(src + (size_t)row * rs + dc * 8) : hcp_zero8();
+        }
+    }
+    HCP_MEMBER void store_rm(hcp_bf16* rm, int RSv, int tid) const {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / NC, dc = c - row * NC;
+            if (c < KVT * NC) *(hcp_bf16x8*)(rm + row * RSv + dc * 8) = r[i];
+        }
+    }
+    HCP_MEMBER void store_tr(hcp_bf16* tr, int tid) const {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / NC, dc = c - row * NC;
+            if (c < KVT * NC) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tr[(dc * 8 + e) * TS + row] = (hcp_bf16)r[i][e];
+            }
+        }
+    }
+};
+
+HCP_DEVICE void zero_lds(hcp_bf16* p, int elems, int tid) {
+    for (int i = tid * 8; i < elems; i += 256 * 8) *(hcp_bf16x8*)(p + i) = hcp_zero8();
+}
 
 // ------------------------------------------------------------------------------------------ forward
 template <int D, int QT>
 HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
-    hcp_bf16* sK = (hcp_bf16*)smem;                 // [64][RS]
-    hcp_bf16* sVt = sK + KVT * G::RS;               // [DV][TS]
+    hcp_bf16* lds = (hcp_bf16*)smem;                // 2 x { K [64][RS] | Vt [DV][TS] }
+    constexpr int BUF = G::RM_ELEMS + G::TR_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -84,6 +113,13 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
     const hcp_bf16* Qb = p.Q + (size_t)b * p.q_bs + h * D;
     const hcp_bf16* Kb = p.K + (size_t)b * p.k_bs + h * D;
     const hcp_bf16* Vb = p.V + (size_t)b * p.v_bs + h * D;
+    const float c2 = p.scale * LOG2E;
+
+    zero_lds(lds, 2 * BUF, tid);
+    TileStage<D> sk, sv;
+    const int nt = (p.Nk + KVT - 1) / KVT;
+    sk.load(Kb, p.k_rs, p.Nk < KVT ? p.Nk : KVT, tid);
+    sv.load(Vb, p.v_rs, p.Nk < KVT ? p.Nk : KVT, tid);
 
     hcp_bf16x8 qf[QT][G::NQK];
 #pragma unroll
@@ -101,12 +137,20 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int d = 0; d < G::NDV; ++d) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; o[t][d] = z; }
     }
+    HCP_SYNC();                                      // zero fill complete
+    sk.store_rm(lds, G::RS, tid); sv.store_tr(lds + G::RM_ELEMS, tid);
+    HCP_SYNC();
 
-    for (int kv0 = 0; kv0 < p.Nk; kv0 += KVT) {
+    for (int it = 0; it < nt; ++it) {
+        const int kv0 = it * KVT;
         const int nvalid = p.Nk - kv0 < KVT ? p.Nk - kv0 : KVT;
-        stage_tile<D, G::DP, G::DV>(Kb + (size_t)kv0 * p.k_rs, p.k_rs, nvalid, sK, nullptr, tid);
-        stage_tile<D, G::DP, G::DV>(Vb + (size_t)kv0 * p.v_rs, p.v_rs, nvalid, nullptr, sVt, tid);
-        HCP_SYNC();
+        const hcp_bf16* sK = lds + (it & 1) * BUF;
+        const hcp_bf16* sVt = sK + G::RM_ELEMS;
+        if (it + 1 < nt) {
+            const int nv = p.Nk - kv0 - KVT < KVT ? p.Nk - kv0 - KVT : KVT;
+            sk.load(Kb + (size_t)(kv0 + KVT) * p.k_rs, p.k_rs, nv, tid);
+            sv.load(Vb + (size_t)(kv0 + KVT) * p.v_rs, p.v_rs, nv, tid);
+        }
         hcp_f32x4 sc[QT][4];
 #pragma unroll
         for (int t = 0; t < QT; ++t)
@@ -124,23 +168,29 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             float mx = -INFINITY;
+            if (nvalid == KVT) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + 4 * fg + r;
-                    float v = key < nvalid ? sc[t][kt][r] * p.scale : -INFINITY;
-                    sc[t][kt][r] = v; mx = v > mx ? v : mx;
-                }
+                    for (int r = 0; r < 4; ++r) { float v = sc[t][kt][r] * c2; sc[t][kt][r] = v; mx = v > mx ? v : mx; }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = (kt * 16 + 4 * fg + r) < nvalid ? sc[t][kt][r] * c2 : -INFINITY;
+                        sc[t][kt][r] = v; mx = v > mx ? v : mx;
+                    }
+            }
             float o1 = hcp_shfl_xor(mx, 16); mx = o1 > mx ? o1 : mx;
             o1 = hcp_shfl_xor(mx, 32); mx = o1 > mx ? o1 : mx;
             const float m_new = mx > m_i[t] ? mx : m_i[t];
-            const float alpha = expf(m_i[t] - m_new);
+            const float alpha = hcp_exp2(m_i[t] - m_new);
             float rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { float e = expf(sc[t][kt][r] - m_new); sc[t][kt][r] = e; rs += e; }
+                for (int r = 0; r < 4; ++r) { float e = hcp_exp2(sc[t][kt][r] - m_new); sc[t][kt][r] = e; rs += e; }
             rs += hcp_shfl_xor(rs, 16); rs += hcp_shfl_xor(rs, 32);
             l_i[t] = l_i[t] * alpha + rs; m_i[t] = m_new;
 #pragma unroll
@@ -157,6 +207,10 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int t = 0; t < QT; ++t) o[t][d] = hcp_mfma16(vf, pf[t][s2], o[t][d]);
             }
+        if (it + 1 < nt) {
+            hcp_bf16* nK = lds + ((it + 1) & 1) * BUF;
+            sk.store_rm(nK, G::RS, tid); sv.store_tr(nK + G::RM_ELEMS, tid);
+        }
         HCP_SYNC();
     }
     // epilogue: lane holds O[q = q_base + t*16 + fr][d*16 + 4*fg + r]
@@ -176,7 +230,7 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
                 *(hcp_bf16x4*)(orow + col) = w;
             }
         }
-        if (fg == 0) p.lse[((size_t)b * p.H + h) * p.Nq + row] = m_i[t] + logf(l_i[t]);
+        if (fg == 0) p.lse[((size_t)b * p.H + h) * p.Nq + row] = (m_i[t] + log2f(l_i[t])) * LN2;
     }
 }
 
@@ -204,9 +258,8 @@ template <int D, int QT>
 HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
-    hcp_bf16* sK = (hcp_bf16*)smem;                 // [64][RS]
-    hcp_bf16* sV = sK + KVT * G::RS;                // [64][RS]
-    hcp_bf16* sKt = sV + KVT * G::RS;               // [DV][TS]
+    hcp_bf16* lds = (hcp_bf16*)smem;                // 2 x { K [64][RS] | V [64][RS] | Kt [DV][TS] }
+    constexpr int BUF = 2 * G::RM_ELEMS + G::TR_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -215,9 +268,16 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
     const hcp_bf16* Kb = p.K + (size_t)b * p.k_bs + h * D;
     const hcp_bf16* Vb = p.V + (size_t)b * p.v_bs + h * D;
     const hcp_bf16* dOb = p.dO + (size_t)b * p.o_bs + h * D;
+    const float c2 = p.scale * LOG2E;
+
+    zero_lds(lds, 2 * BUF, tid);
+    TileStage<D> sk, sv;
+    const int nt = (p.Nk + KVT - 1) / KVT;
+    sk.load(Kb, p.k_rs, p.Nk < KVT ? p.Nk : KVT, tid);
+    sv.load(Vb, p.v_rs, p.Nk < KVT ? p.Nk : KVT, tid);
 
     hcp_bf16x8 qf[QT][G::NQK], gf[QT][G::NQK];
-    float lse_i[QT], del_i[QT];
+    float lse2[QT], del_i[QT];
     hcp_f32x4 dq[QT][G::NDV];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -229,16 +289,26 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
             qf[t][s] = ok ? *(const hcp_bf16x8*)(Qb + (size_t)row * p.q_rs + dc) : hcp_zero8();
             gf[t][s] = ok ? *(const hcp_bf16x8*)(dOb + (size_t)row * p.o_rs + dc) : hcp_zero8();
         }
-        lse_i[t] = row < p.Nq ? p.lse[((size_t)b * p.H + h) * p.Nq + row] : INFINITY;
+        lse2[t] = row < p.Nq ? p.lse[((size_t)b * p.H + h) * p.Nq + row] * LOG2E : INFINITY;
         del_i[t] = row < p.Nq ? p.delta[((size_t)b * p.H + h) * p.Nq + row] : 0.f;
 #pragma unroll
         for (int d = 0; d < G::NDV; ++d) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; dq[t][d] = z; }
     }
-    for (int kv0 = 0; kv0 < p.Nk; kv0 += KVT) {
+    HCP_SYNC();
+    sk.store_rm(lds, G::RS, tid); sk.store_tr(lds + 2 * G::RM_ELEMS, tid); sv.store_rm(lds + G::RM_ELEMS, G::RS, tid);
+    HCP_SYNC();
+
+    for (int it = 0; it < nt; ++it) {
+        const int kv0 = it * KVT;
         const int nvalid = p.Nk - kv0 < KVT ? p.Nk - kv0 : KVT;
-        stage_tile<D, G::DP, G::DV>(Kb + (size_t)kv0 * p.k_rs, p.k_rs, nvalid, sK, sKt, tid);
-        stage_tile<D, G::DP, G::DV>(Vb + (size_t)kv0 * p.v_rs, p.v_rs, nvalid, sV, nullptr, tid);
-        HCP_SYNC();
+        const hcp_bf16* sK = lds + (it & 1) * BUF;
+        const hcp_bf16* sV = sK + G::RM_ELEMS;
+        const hcp_bf16* sKt = sV + G::RM_ELEMS;
+        if (it + 1 < nt) {
+            const int nv = p.Nk - kv0 - KVT < KVT ? p.Nk - kv0 - KVT : KVT;
+            sk.load(Kb + (size_t)(kv0 + KVT) * p.k_rs, p.k_rs, nv, tid);
+            sv.load(Vb + (size_t)(kv0 + KVT) * p.v_rs, p.v_rs, nv, tid);
+        }
         hcp_f32x4 sc[QT][4], dp[QT][4];
 #pragma unroll
         for (int t = 0; t < QT; ++t)
@@ -263,8 +333,8 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + 4 * fg + r;
-                    float pr = key < nvalid ? expf(sc[t][kt][r] * p.scale - lse_i[t]) : 0.f;
+                    float pr = hcp_exp2(sc[t][kt][r] * c2 - lse2[t]);
+                    if (nvalid != KVT && (kt * 16 + 4 * fg + r) >= nvalid) pr = 0.f;
                     sc[t][kt][r] = pr * (dp[t][kt][r] - del_i[t]) * p.scale;
                 }
             df[t][0] = pack8(sc[t][0], sc[t][1]);
@@ -279,6 +349,10 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
                 for (int t = 0; t < QT; ++t) dq[t][d] = hcp_mfma16(kf, df[t][s2], dq[t][d]);
             }
+        if (it + 1 < nt) {
+            hcp_bf16* nb = lds + ((it + 1) & 1) * BUF;
+            sk.store_rm(nb, G::RS, tid); sk.store_tr(nb + 2 * G::RM_ELEMS, tid); sv.store_rm(nb + G::RM_ELEMS, G::RS, tid);
+        }
         HCP_SYNC();
     }
 #pragma unroll
@@ -304,11 +378,9 @@ template <int D, int KT>
 HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
-    hcp_bf16* sQ = (hcp_bf16*)smem;                 // [64][RS]
-    hcp_bf16* sG = sQ + KVT * G::RS;                // [64][RS]   dO
-    hcp_bf16* sQt = sG + KVT * G::RS;               // [DV][TS]
-    hcp_bf16* sGt = sQt + G::DV * TS;               // [DV][TS]
-    float* sL = (float*)(sGt + G::DV * TS);         // [64] lse, [64] delta
+    hcp_bf16* lds = (hcp_bf16*)smem;     // 2 x { Q [64][RS] | dO [64][RS] | Qt [DV][TS] | dOt [DV][TS] | lse2[64], delta[64] (fp32) }
+    constexpr int BUF = 2 * G::RM_ELEMS + 2 * G::TR_ELEMS + 4 * KVT;   // 2*64 floats = 4*64 bf16 slots
+    constexpr int NB = (2 * BUF * 2 <= 160 * 1024) ? 2 : 1;            // head_dim 160: one buffer, two barriers per tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -317,6 +389,21 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     const hcp_bf16* Kb = p.K + (size_t)b * p.k_bs + h * D;
     const hcp_bf16* Vb = p.V + (size_t)b * p.v_bs + h * D;
     const hcp_bf16* dOb = p.dO + (size_t)b * p.o_bs + h * D;
+    const float* lse_b = p.lse + ((size_t)b * p.H + h) * p.Nq;
+    const float* del_b = p.delta + ((size_t)b * p.H + h) * p.Nq;
+    const float c2 = p.scale * LOG2E;
+
+    zero_lds(lds, NB * BUF, tid);
+    TileStage<D> sq, sg;
+    float rl = 0.f;                                  // staged lse2 (tid < 64) / delta (64 <= tid < 128)
+    const int nt = (p.Nq + KVT - 1) / KVT;
+    auto load_stats = [&](int q0) {
+        if (tid < KVT) rl = q0 + tid < p.Nq ? lse_b[q0 + tid] * LOG2E : INFINITY;
+        else if (tid < 2 * KVT) rl = q0 + tid - KVT < p.Nq ? del_b[q0 + tid - KVT] : 0.f;
+    };
+    sq.load(Qb, p.q_rs, p.Nq < KVT ? p.Nq : KVT, tid);
+    sg.load(dOb, p.o_rs, p.Nq < KVT ? p.Nq : KVT, tid);
+    load_stats(0);
 
     hcp_bf16x8 kf[KT][G::NQK], vf[KT][G::NQK];
     hcp_f32x4 dk[KT][G::NDV], dv[KT][G::NDV];
@@ -333,16 +420,29 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int d = 0; d < G::NDV; ++d) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; dk[t][d] = z; dv[t][d] = z; }
     }
-    for (int q0 = 0; q0 < p.Nq; q0 += KVT) {
-        const int nvalid = p.Nq - q0 < KVT ? p.Nq - q0 : KVT;
-        stage_tile<D, G::DP, G::DV>(Qb + (size_t)q0 * p.q_rs, p.q_rs, nvalid, sQ, sQt, tid);
-        stage_tile<D, G::DP, G::DV>(dOb + (size_t)q0 * p.o_rs, p.o_rs, nvalid, sG, sGt, tid);
-        if (tid < KVT) {
-            const bool ok = tid < nvalid;
-            sL[tid] = ok ? p.lse[((size_t)b * p.H + h) * p.Nq + q0 + tid] : INFINITY;
-            sL[KVT + tid] = ok ? p.delta[((size_t)b * p.H + h) * p.Nq + q0 + tid] : 0.f;
+    auto store_all = [&](hcp_bf16* base) {
+        sq.store_rm(base, G::RS, tid); sg.store_rm(base + G::RM_ELEMS, G::RS, tid);
+        sq.store_tr(base + 2 * G::RM_ELEMS, tid); sg.store_tr(base + 2 * G::RM_ELEMS + G::TR_ELEMS, tid);
+        float* sl = (float*)(base + 2 * G::RM_ELEMS + 2 * G::TR_ELEMS);
+        if (tid < 2 * KVT) sl[tid] = rl;
+    };
+    HCP_SYNC();
+    store_all(lds);
+    HCP_SYNC();
+
+    for (int it = 0; it < nt; ++it) {
+        const int q0 = it * KVT;
+        const hcp_bf16* sQ = lds + (NB == 2 ? (it & 1) : 0) * BUF;
+        const hcp_bf16* sG = sQ + G::RM_ELEMS;
+        const hcp_bf16* sQt = sG + G::RM_ELEMS;
+        const hcp_bf16* sGt = sQt + G::TR_ELEMS;
+        const float* sL = (const float*)(sGt + G::TR_ELEMS);
+        if (it + 1 < nt) {
+            const int nv = p.Nq - q0 - KVT < KVT ? p.Nq - q0 - KVT : KVT;
+            sq.load(Qb + (size_t)(q0 + KVT) * p.q_rs, p.q_rs, nv, tid);
+            sg.load(dOb + (size_t)(q0 + KVT) * p.o_rs, p.o_rs, nv, tid);
+            load_stats(q0 + KVT);
         }
-        HCP_SYNC();
         hcp_f32x4 sc[KT][4], dp[KT][4];
 #pragma unroll
         for (int t = 0; t < KT; ++t)
@@ -365,14 +465,16 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
         for (int t = 0; t < KT; ++t) {
             const bool kok = k_base + t * 16 + fr < p.Nk;
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt)
+            for (int qt = 0; qt < 4; ++qt) {
+                const hcp_f32x4 l4 = *(const hcp_f32x4*)(sL + qt * 16 + 4 * fg);
+                const hcp_f32x4 d4 = *(const hcp_f32x4*)(sL + KVT + qt * 16 + 4 * fg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = qt * 16 + 4 * fg + r;
-                    float pr = kok ? expf(sc[t][qt][r] * p.scale - sL[q]) : 0.f;
+                    float pr = kok ? hcp_exp2(sc[t][qt][r] * c2 - l4[r]) : 0.f;      // lse2 = +inf for q >= Nq -> 0
                     sc[t][qt][r] = pr;
-                    dp[t][qt][r] = pr * (dp[t][qt][r] - sL[KVT + q]) * p.scale;
+                    dp[t][qt][r] = pr * (dp[t][qt][r] - d4[r]) * p.scale;
                 }
+            }
             pf[t][0] = pack8(sc[t][0], sc[t][1]); pf[t][1] = pack8(sc[t][2], sc[t][3]);
             df[t][0] = pack8(dp[t][0], dp[t][1]); df[t][1] = pack8(dp[t][2], dp[t][3]);
         }
@@ -390,7 +492,14 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
                     dk[t][d] = hcp_mfma16(qa, df[t][s2], dk[t][d]);   // dK^T[dcol][key] += Q^T dS
                 }
             }
-        HCP_SYNC();
+        if (NB == 2) {
+            if (it + 1 < nt) store_all(lds + ((it + 1) & 1) * BUF);
+            HCP_SYNC();
+        } else {
+            HCP_SYNC();
+            if (it + 1 < nt) store_all(lds);
+            HCP_SYNC();
+        }
     }
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
@@ -412,10 +521,12 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     }
 }
 
+int g_attn_cfg = -1;   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32; -1 = heuristic
+
 template <int D, int QT>
 int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
     using G = AttnGeom<D>;
-    size_t smem = (size_t)(KVT * G::RS + G::DV * TS) * sizeof(hcp_bf16);
+    size_t smem = (size_t)2 * (G::RM_ELEMS + G::TR_ELEMS) * sizeof(hcp_bf16);
     HCP_LAUNCH((attn_fwd_kernel<D, QT>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), smem, stream, p);
     HCP_LAUNCH_CHECK("attn_fwd");
 }
@@ -429,24 +540,40 @@ int launch_delta(AttnParams& p, int B, hipStream_t stream) {
 template <int D, int QT>
 int launch_dq(AttnParams& p, int B, hipStream_t stream) {
     using G = AttnGeom<D>;
-    size_t s1 = (size_t)(2 * KVT * G::RS + G::DV * TS) * sizeof(hcp_bf16);
+    size_t s1 = (size_t)2 * (2 * G::RM_ELEMS + G::TR_ELEMS) * sizeof(hcp_bf16);
     HCP_LAUNCH((attn_bwd_dq_kernel<D, QT>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), s1, stream, p);
     HCP_LAUNCH_CHECK("attn_bwd_dq");
 }
 template <int D, int KT>
 int launch_dkv(AttnParams& p, int B, hipStream_t stream) {
     using G = AttnGeom<D>;
-    size_t s2 = (size_t)(2 * KVT * G::RS + 2 * G::DV * TS) * sizeof(hcp_bf16) + 2 * KVT * sizeof(float);
+    size_t s2 = (size_t)(2 * G::RM_ELEMS + 2 * G::TR_ELEMS + 4 * KVT) * sizeof(hcp_bf16);
+    if (2 * s2 <= 160 * 1024) s2 *= 2;
     HCP_LAUNCH((attn_bwd_dkv_kernel<D, KT>), dim3(hcp_cdiv(p.Nk, 64 * KT), p.H, B), dim3(256), s2, stream, p);
     HCP_LAUNCH_CHECK("attn_bwd_dkv");
 }
-template <int D, int QTMAX, int KTMAX>
-int launch_bwd(AttnParams& p, int B, hipStream_t stream) {
+
+// rows per wave: 32 only where the grid still fills the chip twice over AND registers allow >= 2 waves/SIMD
+template <int D> constexpr bool kWide = D <= 64;
+
+template <int D>
+int run_fwd(AttnParams& p, int B, hipStream_t stream) {
+    bool wide = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512;
+    if (g_attn_cfg >= 0) wide = kWide<D> && (g_attn_cfg & 1);
+    if constexpr (kWide<D>) { if (wide) return launch_fwd<D, 2>(p, B, stream); }
+    return launch_fwd<D, 1>(p, B, stream);
+}
+template <int D>
+int run_bwd(AttnParams& p, int B, hipStream_t stream) {
     if (int e = launch_delta<D>(p, B, stream)) return e;
-    const bool small_q = QTMAX == 1 || (long)B * p.H * hcp_cdiv(p.Nq, 128) < 256;
-    const bool small_k = KTMAX == 1 || (long)B * p.H * hcp_cdiv(p.Nk, 128) < 256;
-    if (int e = small_q ? launch_dq<D, 1>(p, B, stream) : launch_dq<D, QTMAX>(p, B, stream)) return e;
-    return small_k ? launch_dkv<D, 1>(p, B, stream) : launch_dkv<D, KTMAX>(p, B, stream);
+    bool wq = false, wk = false;
+    if (g_attn_cfg >= 0) { wq = kWide<D> && (g_attn_cfg & 2); wk = kWide<D> && (g_attn_cfg & 4); }
+    int e;
+    if constexpr (kWide<D>) { e = wq ? launch_dq<D, 2>(p, B, stream) : launch_dq<D, 1>(p, B, stream); }
+    else e = launch_dq<D, 1>(p, B, stream);
+    if (e) return e;
+    if constexpr (kWide<D>) { return wk ? launch_dkv<D, 2>(p, B, stream) : launch_dkv<D, 1>(p, B, stream); }
+    return launch_dkv<D, 1>(p, B, stream);
 }
 
 int attn_check(const AttnParams& p, int B, int D) {
@@ -459,6 +586,9 @@ int attn_check(const AttnParams& p, int B, int D) {
 
 }  // namespace
 
+// TOOLS ONLY: bit0 forward / bit1 dQ / bit2 dK,dV use 32 rows per wave; -1 restores the heuristic.
+HCP_API int hcp_debug_set_attention_config(int cfg) { g_attn_cfg = cfg; return 0; }
+
 // O[b,q,h,:] = softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,:];  lse[b,h,q] = logsumexp of the scaled scores.
 // All tensors bf16, token-major: element (b, n, h, c) at  base + b*bs + n*rs + h*D + c.
 HCP_API int hcp_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int Nq, int Nk,
@@ -470,12 +600,11 @@ HCP_API int hcp_attention_fwd(const void* Q, const void* K, const void* V, void*
     p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
     HCP_REQUIRE(Q && K && V && O && lse, "hcp_attention_fwd: null pointer");
     if (int e = attn_check(p, B, D)) return e;
-    const bool small = (long)B * H * hcp_cdiv(Nq, 128) < 256;   // too few workgroups: use 64-row query blocks
     switch (D) {
-        case 40: return small ? launch_fwd<40, 1>(p, B, stream) : launch_fwd<40, 2>(p, B, stream);
-        case 64: return small ? launch_fwd<64, 1>(p, B, stream) : launch_fwd<64, 2>(p, B, stream);
-        case 80: return small ? launch_fwd<80, 1>(p, B, stream) : launch_fwd<80, 2>(p, B, stream);
-        default: return launch_fwd<160, 1>(p, B, stream);
+        case 40: return run_fwd<40>(p, B, stream);
+        case 64: return run_fwd<64>(p, B, stream);
+        case 80: return run_fwd<80>(p, B, stream);
+        default: return run_fwd<160>(p, B, stream);
     }
 }
 
@@ -493,9 +622,9 @@ HCP_API int hcp_attention_bwd(const void* Q, const void* K, const void* V, const
     HCP_REQUIRE(Q && K && V && O && dO && lse && delta && dQ && dK && dV, "hcp_attention_bwd: null pointer");
     if (int e = attn_check(p, B, D)) return e;
     switch (D) {
-        case 40: return launch_bwd<40, 2, 2>(p, B, stream);
-        case 64: return launch_bwd<64, 2, 2>(p, B, stream);
-        case 80: return launch_bwd<80, 2, 1>(p, B, stream);
-        default: return launch_bwd<160, 1, 1>(p, B, stream);
+        case 40: return run_bwd<40>(p, B, stream);
+        case 64: return run_bwd<64>(p, B, stream);
+        case 80: return run_bwd<80>(p, B, stream);
+        default: return run_bwd<160>(p, B, stream);
     }
 }

@@ -5,16 +5,21 @@
 //
 // * A, B are K-contiguous bf16.  The optional (A2,B2) pair extends the reduction: it is the
 //   LoRA low-rank side path  y = x W^T + (x A^T)(alpha B)^T  (replaces the reference's
-//   per-forward weight merge W + alpha*B@A, lora_base_patch.py:61-74) and, on the conv path,
-//   nothing else is needed for the concat-free skip connection (two source tensors).
+//   per-forward weight merge W + alpha*B@A, lora_base_patch.py:61-74).
 // * MODE 1/2 replace the A operand by an on-the-fly im2col gather of an NHWC tensor:
 //   3x3 forward (stride 1/2, fused nearest-2x upsample, two-pointer channel concat) and
 //   3x3 data-gradient (transposed gather, stride 1/2).  Replaces F.conv2d reached through
 //   diffusers ResnetBlock2D/Downsample2D/Upsample2D.
-// * 256 threads = 4 waves, BK=64, LDS double buffer (row stride 72 bf16 = conflict-free
+//   FAST variants (channel count a multiple of 64, no upsample / strided dgrad) hoist all
+//   per-row address math out of the K loop: one base offset + a 9-bit tap-validity mask per row,
+//   a wave-uniform (tap, channel) cursor advanced per K tile.
+// * 64*WGM*WGN threads, BK=64, LDS double buffer (row stride 72 bf16 = conflict-free
 //   ds_read_b128), register-staged prefetch of the next K tile, one barrier per K tile.
 //   MFMA is issued with swapped operands so each lane owns 4 consecutive N of one row:
 //   8-byte bf16x4 stores and float4 bias loads in the epilogue.
+// * Tile shapes are chosen per problem so the grid fills 256 CUs: BN=160 divides every
+//   Cout of the SD UNet (320/640/1280/2560/5120/10240); small-M (16x16, 8x8 latent) layers
+//   use split-K into fp32 slabs + a fused reduce/epilogue kernel.
 #include "hcp_common.h"
 
 namespace {
@@ -40,78 +45,138 @@ struct GemmParams {
     const hcp_bf16* residual; int ldr;
     float alpha;
     int tiles_m;
+    int nsplit; int kt_per_split;   // split-K over the primary K tiles (grid.y)
+    float* slabs;                   // [nsplit][M][N] fp32 partials when nsplit > 1
     ConvDesc cv;
 };
 
 constexpr int BK = 64;
 constexpr int LDS_STRIDE = BK + 8;  // bf16 elements per LDS row
 
-template <int BM, int BN, int MODE>
-HCP_KERNEL(256) gemm_kernel(GemmParams p) {
-    constexpr int WTM = BM / 2, WTN = BN / 2;     // 2x2 waves
-    constexpr int TM = WTM / 16, TN = WTN / 16;   // MFMA tiles per wave
-    constexpr int A_IT = BM / 32, B_IT = BN / 32; // 16-byte chunks per thread per K tile
+HCP_DEVICE void epilogue_store(const GemmParams& p, int m, int n, hcp_f32x4 v) {
+    v = v * p.alpha;
+    if (p.bias) v += *(const hcp_f32x4*)(p.bias + n);
+    if (p.rowbias) v += *(const hcp_f32x4*)(p.rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld + n);
+    if (p.residual) {
+        hcp_bf16x4 r = *(const hcp_bf16x4*)(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)r[q]);
+    }
+    if (p.out_f32) {
+        *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
+    } else {
+        hcp_bf16x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(v[q]);
+        *(hcp_bf16x4*)((hcp_bf16*)p.D + (size_t)m * p.ldd + n) = o;
+    }
+}
+
+// MODE: 0 plain A, 1 conv forward gather, 2 conv data-gradient gather.  FAST: hoisted im2col addressing.
+template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST>
+HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int RPP = NT / 8;                       // rows staged per pass (8 chunks of 8 bf16 per row)
+    constexpr int A_IT = (BM + RPP - 1) / RPP, B_IT = (BN + RPP - 1) / RPP;
+    constexpr bool A_EXACT = BM % RPP == 0, B_EXACT = BN % RPP == 0;
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA tile");
     HCP_DYN_SMEM(smem);
     hcp_bf16* lds = (hcp_bf16*)smem;
     constexpr int A_ELEMS = BM * LDS_STRIDE, B_ELEMS = BN * LDS_STRIDE;
-    // layout: [buf0: A | B][buf1: A | B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
 
-    const int kc = tid & 7;        // which 8-element chunk of the 64-wide K tile
-    const int lrow = tid >> 3;     // 0..31
+    const int kc = tid & 7;
+    const int lrow = tid >> 3;
 
     const int nk1 = (p.K + BK - 1) / BK;
-    const int nk2 = (p.K2 + BK - 1) / BK;
-    const int nk = nk1 + nk2;
+    const int kt_begin = split * p.kt_per_split;
+    int kt_end = kt_begin + p.kt_per_split; if (kt_end > nk1) kt_end = nk1;
+    const bool last_split = split == p.nsplit - 1;
+    const int nk2 = last_split ? (p.K2 + BK - 1) / BK : 0;
+    const int nk = (kt_end - kt_begin) + nk2;          // tiles this block walks; tile index t -> primary kt_begin+t or ext
 
     // ---- per-thread row descriptors for the A operand
-    int a_pix[A_IT];          // MODE 0: unused; conv: packed (b<<20 | py<<10 | px), or -1 if row >= M
+    int a_pix[A_IT];     // slow conv path: packed (b<<20 | py<<10 | px) or -1;  fast path: element offset of the row base
+    int a_msk[A_IT];     // fast path: 9-bit tap validity (bit ky*3+kx), 0 for rows >= M
+    const int Ctot = p.cv.C1 + p.cv.C2;
     if (MODE != 0) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            int m = m0 + lrow + 32 * i;
-            if (m < p.M) {
+            int m = m0 + lrow + RPP * i;
+            a_pix[i] = -1; a_msk[i] = 0;
+            if ((A_EXACT || lrow + RPP * i < BM) && m < p.M) {
                 int hw = p.cv.Ho * p.cv.Wo;
                 int b = m / hw; int rem = m - b * hw;
                 int py = rem / p.cv.Wo; int px = rem - py * p.cv.Wo;
-                a_pix[i] = (b << 20) | (py << 10) | px;
-            } else a_pix[i] = -1;
+                if (!FAST) {
+                    a_pix[i] = (b << 20) | (py << 10) | px;
+                } else {
+                    // source pixel of tap (ky,kx):  fwd: (py*s + ky - 1, px*s + kx - 1);  dgrad (s=1): (py + 1 - ky, px + 1 - kx)
+                    const int s = MODE == 1 ? p.cv.stride : 1;
+                    a_pix[i] = (b * p.cv.Hs + py * s) * p.cv.Ws + px * s;          // pixel index of the centre tap
+                    int msk = 0;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            int sy = MODE == 1 ? py * s + ky - 1 : py + 1 - ky;
+                            int sx = MODE == 1 ? px * s + kx - 1 : px + 1 - kx;
+                            if (sy >= 0 && sy < p.cv.Hs && sx >= 0 && sx < p.cv.Ws) msk |= 1 << (ky * 3 + kx);
+                        }
+                    a_msk[i] = msk;
+                }
+            }
         }
     }
-    const int Ctot = p.cv.C1 + p.cv.C2;
 
     hcp_bf16x8 ra[A_IT], rb[B_IT];
 
-    auto load_tile = [&](int kt) {
-        const bool ext = kt >= nk1;
-        const int k = (ext ? (kt - nk1) : kt) * BK + kc * 8;
+    auto load_tile = [&](int t) {
+        const bool ext = t >= (kt_end - kt_begin);
+        const int kt = ext ? t - (kt_end - kt_begin) : kt_begin + t;
+        const int k = kt * BK + kc * 8;
         const int klim = ext ? p.K2 : p.K;
-        // ---- B operand (always plain row-major [N, K])
         {
             const hcp_bf16* Bp = ext ? p.B2 : p.B; const int ld = ext ? p.ldb2 : p.ldb;
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
-                int n = n0 + lrow + 32 * i;
-                if (n < p.N && k < klim) rb[i] = *(const hcp_bf16x8*)(Bp + (size_t)n * ld + k);
+                int r = lrow + RPP * i; int n = n0 + r;
+                if ((B_EXACT || r < BN) && n < p.N && k < klim) rb[i] = *(const hcp_bf16x8*)(Bp + (size_t)n * ld + k);
                 else rb[i] = hcp_zero8();
             }
         }
-        // ---- A operand
         if (MODE == 0 || ext) {
             const hcp_bf16* Ap = ext ? p.A2 : p.A; const int ld = ext ? p.lda2 : p.lda;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                int m = m0 + lrow + 32 * i;
-                if (m < p.M && k < klim) ra[i] = *(const hcp_bf16x8*)(Ap + (size_t)m * ld + k);
+                int r = lrow + RPP * i; int m = m0 + r;
+                if ((A_EXACT || r < BM) && m < p.M && k < klim) ra[i] = *(const hcp_bf16x8*)(Ap + (size_t)m * ld + k);
                 else ra[i] = hcp_zero8();
             }
+        } else if (FAST) {
+            // Ctot % 64 == 0: the whole K tile lies in one tap; (tap, c0) are wave-uniform
+            const int k0 = kt * BK;
+            const int tap = k0 / Ctot; const int c0 = k0 - tap * Ctot + kc * 8;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int doff = MODE == 1 ? (ky - 1) * p.cv.Ws + (kx - 1) : (1 - ky) * p.cv.Ws + (1 - kx);
+            const hcp_bf16* src; int cs, c;
+            if (c0 < p.cv.C1) { src = p.cv.X1; cs = p.cv.C1; c = c0; }
+            else { src = p.cv.X2; cs = p.cv.C2; c = c0 - p.cv.C1; }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                hcp_bf16x8 v = hcp_zero8();
+                if ((a_msk[i] >> tap) & 1) v = *(const hcp_bf16x8*)(src + (size_t)(a_pix[i] + doff) * cs + c);
+                ra[i] = v;
+            }
         } else {
-            // im2col: k = tap * Ctot + ci, tap = ky*3 + kx
             int tap = k / Ctot; int ci = k - tap * Ctot;
             int ky = tap / 3, kx = tap - ky * 3;
             const hcp_bf16* src; int cs, c;
@@ -124,12 +189,12 @@ HCP_KERNEL(256) gemm_kernel(GemmParams p) {
                 if (pix >= 0 && k < klim) {
                     int b = pix >> 20, py = (pix >> 10) & 1023, px = pix & 1023;
                     int sy, sx; bool ok;
-                    if (MODE == 1) {       // forward gather
+                    if (MODE == 1) {
                         sy = py * p.cv.stride + ky - 1; sx = px * p.cv.stride + kx - 1;
                         int He = p.cv.Hs << p.cv.up, We = p.cv.Ws << p.cv.up;
                         ok = sy >= 0 && sy < He && sx >= 0 && sx < We;
                         sy >>= p.cv.up; sx >>= p.cv.up;
-                    } else {               // data-gradient gather: source pixel o with o*stride + k - 1 == p
+                    } else {
                         int ty = py + 1 - ky, tx = px + 1 - kx;
                         ok = ty >= 0 && tx >= 0;
                         if (p.cv.stride == 2) { ok = ok && ((ty | tx) & 1) == 0; ty >>= 1; tx >>= 1; }
@@ -146,9 +211,11 @@ HCP_KERNEL(256) gemm_kernel(GemmParams p) {
         hcp_bf16* la = lds + buf * (A_ELEMS + B_ELEMS);
         hcp_bf16* lb = la + A_ELEMS;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) *(hcp_bf16x8*)(la + (lrow + 32 * i) * LDS_STRIDE + kc * 8) = ra[i];
+        for (int i = 0; i < A_IT; ++i)
+            if (A_EXACT || lrow + RPP * i < BM) *(hcp_bf16x8*)(la + (lrow + RPP * i) * LDS_STRIDE + kc * 8) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *(hcp_bf16x8*)(lb + (lrow + 32 * i) * LDS_STRIDE + kc * 8) = rb[i];
+        for (int i = 0; i < B_IT; ++i)
+            if (B_EXACT || lrow + RPP * i < BN) *(hcp_bf16x8*)(lb + (lrow + RPP * i) * LDS_STRIDE + kc * 8) = rb[i];
     };
 
     hcp_f32x4 acc[TM][TN];
@@ -157,14 +224,16 @@ HCP_KERNEL(256) gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
 
-    load_tile(0);
-    store_tile(0);
+    if (nk > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
     HCP_SYNC();
 
     const int fr = lane & 15, fg = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) load_tile(t + 1);
         const hcp_bf16* la = lds + cur * (A_ELEMS + B_ELEMS);
         const hcp_bf16* lb = la + A_ELEMS;
 #pragma unroll
@@ -182,7 +251,7 @@ HCP_KERNEL(256) gemm_kernel(GemmParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = hcp_mfma16(fb[j], fa[i], acc[i][j]);   // swapped: lane owns 4 consecutive n
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (t + 1 < nk) store_tile(cur ^ 1);
         HCP_SYNC();
     }
 
@@ -191,48 +260,107 @@ HCP_KERNEL(256) gemm_kernel(GemmParams p) {
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * 16 + fr;
         if (m >= p.M) continue;
-        const float* rbp = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WTN + j * 16 + 4 * fg;
             if (n >= p.N) continue;
-            hcp_f32x4 v = acc[i][j] * p.alpha;
-            if (p.bias) v += *(const hcp_f32x4*)(p.bias + n);
-            if (rbp) v += *(const hcp_f32x4*)(rbp + n);
-            if (p.residual) {
-                hcp_bf16x4 r = *(const hcp_bf16x4*)(p.residual + (size_t)m * p.ldr + n);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)r[q]);
-            }
-            if (p.out_f32) {
-                *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
-            } else {
-                hcp_bf16x4 o;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(v[q]);
-                *(hcp_bf16x4*)((hcp_bf16*)p.D + (size_t)m * p.ldd + n) = o;
-            }
+            if (p.nsplit > 1) *(hcp_f32x4*)(p.slabs + ((size_t)split * p.M + m) * p.N + n) = acc[i][j];
+            else epilogue_store(p, m, n, acc[i][j]);
         }
     }
 }
 
-template <int BM, int BN, int MODE>
-int launch_gemm(GemmParams& p, hipStream_t stream) {
+// sum the split-K slabs and apply the epilogue
+HCP_KERNEL(256) splitk_reduce_kernel(GemmParams p) {
+    const int nv = p.N / 4;
+    const long total = (long)p.M * nv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nv), n = (int)(i - (long)m * nv) * 4;
+        hcp_f32x4 v = *(const hcp_f32x4*)(p.slabs + (size_t)m * p.N + n);
+        for (int s = 1; s < p.nsplit; ++s) v += *(const hcp_f32x4*)(p.slabs + ((size_t)s * p.M + m) * p.N + n);
+        epilogue_store(p, m, n, v);
+    }
+}
+
+int g_force_cfg = -1;   // tools/tune: force a tile configuration (see hcp_debug_set_gemm_config)
+
+template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST>
+int launch_cfg(GemmParams& p, hipStream_t stream) {
     p.tiles_m = hcp_cdiv(p.M, BM);
     const int tiles_n = hcp_cdiv(p.N, BN);
     const size_t smem = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(hcp_bf16);
-    HCP_LAUNCH((gemm_kernel<BM, BN, MODE>), dim3(p.tiles_m * tiles_n), dim3(256), smem, stream, p);
+    HCP_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, MODE, FAST>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN), smem,
+               stream, p);
+    if (p.nsplit > 1) {
+        long nv = (long)p.M * (p.N / 4);
+        int g = (int)((nv + 255) / 256); if (g > 2048) g = 2048;
+        HCP_LAUNCH(splitk_reduce_kernel, dim3(g), dim3(256), 0, stream, p);
+    }
     HCP_LAUNCH_CHECK("gemm_kernel");
 }
 
-template <int MODE>
-int dispatch_gemm(GemmParams& p, hipStream_t stream) {
-    // Tile choice: fill >= 256 CUs where the problem allows it.
-    const long t128 = (long)hcp_cdiv(p.M, 128) * hcp_cdiv(p.N, 128);
-    const long t12864 = (long)hcp_cdiv(p.M, 128) * hcp_cdiv(p.N, 64);
-    if (p.N > 64 && t128 >= 256 && (p.N % 128 == 0 || p.N >= 1024)) return launch_gemm<128, 128, MODE>(p, stream);
-    if (t12864 >= 256) return launch_gemm<128, 64, MODE>(p, stream);
-    return launch_gemm<64, 64, MODE>(p, stream);
+struct TileCfg { int bm, bn; };
+constexpr TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}, {256, 128}, {256, 160}, {128, 320}};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+template <int MODE, bool FAST>
+int launch_by_id(int id, GemmParams& p, hipStream_t stream) {
+    switch (id) {
+        case 0: return launch_cfg<128, 128, 2, 2, MODE, FAST>(p, stream);
+        case 1: return launch_cfg<128, 64, 2, 2, MODE, FAST>(p, stream);
+        case 2: return launch_cfg<64, 64, 2, 2, MODE, FAST>(p, stream);
+        case 3: return launch_cfg<128, 160, 2, 2, MODE, FAST>(p, stream);
+        case 4: return launch_cfg<64, 160, 2, 2, MODE, FAST>(p, stream);
+        case 5: return launch_cfg<256, 128, 4, 2, MODE, FAST>(p, stream);
+        case 6: return launch_cfg<256, 160, 4, 2, MODE, FAST>(p, stream);
+        default: return launch_cfg<128, 320, 2, 4, MODE, FAST>(p, stream);
+    }
+}
+
+// Fallback for shapes outside the measured table (gemm_tuned.inc).  The sweep shows the kernel is latency-bound per
+// workgroup, so: narrow-M tiles (64x160, BN | every Cout) unless the problem is large, and split K until ~1024
+// workgroups are in flight.
+int choose_cfg(const GemmParams& p, int* nsplit_out) {
+    const int nk1 = hcp_cdiv(p.K, BK);
+    int id;
+    if (p.N <= 64) id = 2;
+    else if (p.N % 160 == 0) id = ((long)p.M * p.N >= (long)4096 * 2560) ? 6 : 4;
+    else id = ((long)p.M * p.N >= (long)4096 * 2048) ? 0 : 2;
+    const long tiles = (long)hcp_cdiv(p.M, kCfgs[id].bm) * hcp_cdiv(p.N, kCfgs[id].bn);
+    int s = 1;
+    while (s < 16 && tiles * s < 1024 && nk1 / (s * 2) >= 4) s *= 2;
+    *nsplit_out = s;
+    return id;
+}
+
+struct TunedEntry { int mode, M, N, K, has_k2, stride, up, cfg, split; };
+const TunedEntry kTuned[] = {
+#include "gemm_tuned.inc"
+};
+
+bool lookup_tuned(const GemmParams& p, int mode, int* cfg, int* split) {
+    for (const TunedEntry& e : kTuned) {
+        if (e.mode == mode && e.M == p.M && e.N == p.N && e.K == p.K && e.has_k2 == (p.K2 > 0) &&
+            (mode == 0 || (e.stride == p.cv.stride && e.up == p.cv.up))) {
+            *cfg = e.cfg; *split = e.split; return true;
+        }
+    }
+    return false;
+}
+
+template <int MODE, bool FAST>
+int dispatch_gemm(GemmParams& p, float* ws, size_t ws_bytes, hipStream_t stream) {
+    int nsplit = 1;
+    int id = 0;
+    if (!lookup_tuned(p, MODE, &id, &nsplit)) id = choose_cfg(p, &nsplit);
+    if (g_force_cfg >= 0) { id = g_force_cfg % 16; nsplit = g_force_cfg / 16 > 0 ? g_force_cfg / 16 : 1; }
+    if (nsplit > 1 && (size_t)nsplit * p.M * p.N * sizeof(float) > ws_bytes) nsplit = 1;
+    const int nk1 = hcp_cdiv(p.K, BK);
+    p.nsplit = nsplit;
+    p.kt_per_split = hcp_cdiv(nk1, nsplit);
+    p.nsplit = hcp_cdiv(nk1, p.kt_per_split);
+    p.slabs = ws;
+    return launch_by_id<MODE, FAST>(id, p, stream);
 }
 
 int check_common(const GemmParams& p) {
@@ -248,12 +376,19 @@ int check_common(const GemmParams& p) {
 
 }  // namespace
 
+// TOOLS ONLY (tools/tune_gemm.py): cfg = tile id + 16 * nsplit; -1 restores the heuristic.
+HCP_API int hcp_debug_set_gemm_config(int cfg) { g_force_cfg = cfg; return 0; }
+
+// Bytes of fp32 split-K workspace that lets every launch of this shape use its preferred decomposition.
+HCP_API size_t hcp_gemm_workspace_bytes(int M, int N) { return (size_t)16 * M * N * sizeof(float); }
+
 // Replaces: torch.mm(x2d, (W_host + dW)^T) + bias  (reference lora_layers_patch.py:50-57),
 // nn.Linear / 1x1 nn.Conv2d forward and their input-gradient (dX = dY W) in diffusers' UNet.
+// workspace may be null (then no split-K is used).
 HCP_API int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int ldd, int M, int N, int K,
                           const void* A2, int lda2, const void* B2, int ldb2, int K2, const float* bias,
                           const float* rowbias, int rowbias_ld, int rows_per_group, const void* residual, int ldr,
-                          float alpha, int out_f32, hipStream_t stream) {
+                          float alpha, int out_f32, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     GemmParams p = {};
     p.A = (const hcp_bf16*)A; p.lda = lda; p.B = (const hcp_bf16*)B; p.ldb = ldb;
     p.A2 = (const hcp_bf16*)A2; p.lda2 = lda2; p.B2 = (const hcp_bf16*)B2; p.ldb2 = ldb2; p.K2 = K2;
@@ -263,7 +398,7 @@ HCP_API int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* 
     HCP_REQUIRE(A && B && D, "hcp_gemm_bf16: null operand");
     HCP_REQUIRE(lda % 8 == 0, "hcp_gemm_bf16: lda (%d) must be a multiple of 8", lda);
     if (int e = check_common(p)) return e;
-    return dispatch_gemm<0>(p, stream);
+    return dispatch_gemm<0, false>(p, (float*)workspace, workspace ? workspace_bytes : 0, stream);
 }
 
 // Replaces F.conv2d(x, W[Cout,Cin,3,3], stride, padding=1) on NHWC bf16 activations:
@@ -274,13 +409,14 @@ HCP_API int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* 
 HCP_API int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int Bn, int Hs, int Ws, int Ho, int Wo,
                              int mode, int stride, int upsample, const void* Wp, int Cout, void* D, int ldd,
                              const float* bias, const float* rowbias, int rowbias_ld, const void* residual, int ldr,
-                             int out_f32, hipStream_t stream) {
+                             int out_f32, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     GemmParams p = {};
     HCP_REQUIRE(X1 && Wp && D, "hcp_conv3x3_bf16: null operand");
     HCP_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && (C2 == 0 || X2), "hcp_conv3x3_bf16: channels must be multiples of 8");
     HCP_REQUIRE(stride == 1 || stride == 2, "hcp_conv3x3_bf16: stride must be 1 or 2");
     HCP_REQUIRE(mode == 0 || (mode == 1 && upsample == 0 && C2 == 0), "hcp_conv3x3_bf16: bad mode/options");
     HCP_REQUIRE(Ho < 1024 && Wo < 1024 && Bn < 2048, "hcp_conv3x3_bf16: dims too large for packed pixel ids");
+    HCP_REQUIRE((long)Bn * Hs * Ws * (C1 > C2 ? C1 : C2) < (1L << 31), "hcp_conv3x3_bf16: source tensor too large for 32-bit offsets");
     p.cv.X1 = (const hcp_bf16*)X1; p.cv.C1 = C1; p.cv.X2 = (const hcp_bf16*)X2; p.cv.C2 = C2;
     p.cv.Hs = Hs; p.cv.Ws = Ws; p.cv.Ho = Ho; p.cv.Wo = Wo; p.cv.stride = stride; p.cv.up = upsample ? 1 : 0;
     p.M = Bn * Ho * Wo; p.N = Cout; p.K = 9 * (C1 + C2);
@@ -289,5 +425,9 @@ HCP_API int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int
     p.rowbias = rowbias; p.rowbias_ld = rowbias_ld; p.rows_per_group = Ho * Wo;
     p.residual = (const hcp_bf16*)residual; p.ldr = ldr; p.alpha = 1.0f;
     if (int e = check_common(p)) return e;
-    return mode == 0 ? dispatch_gemm<1>(p, stream) : dispatch_gemm<2>(p, stream);
+    float* ws = (float*)workspace; size_t wb = workspace ? workspace_bytes : 0;
+    // FAST needs: every 64-wide K tile inside one tap and one source tensor, linear source addressing
+    const bool fast = (C1 % 64 == 0) && (C2 % 64 == 0) && !upsample && !(mode == 1 && stride == 2);
+    if (mode == 0) return fast ? dispatch_gemm<1, true>(p, ws, wb, stream) : dispatch_gemm<1, false>(p, ws, wb, stream);
+    return fast ? dispatch_gemm<2, true>(p, ws, wb, stream) : dispatch_gemm<2, false>(p, ws, wb, stream);
 }

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #define HCP_DEVICE __device__ __forceinline__
+#define HCP_MEMBER __device__ __forceinline__
 #define HCP_KERNEL(maxthreads) __global__ void __launch_bounds__(maxthreads)
 // all LDS is dynamic and 16-byte aligned (guide §6 G17)
 #define HCP_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -51,6 +52,7 @@ HCP_DEVICE float hcp_shfl(float v, int src) { return __shfl(v, src, 64); }
 HCP_DEVICE int hcp_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
 HCP_DEVICE void hcp_atomic_add(float* p, float v) { atomicAdd(p, v); }
 HCP_DEVICE int hcp_lane() { return threadIdx.x & 63; }
+HCP_DEVICE float hcp_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 #endif  // HCP_EMU
 
 // ---------------------------------------------------------------- bf16 helpers (bit-exact RNE)

@@ -49,6 +49,19 @@ def _bf16_2d(t, name):
 
 BF16 = torch.bfloat16
 
+_WS = {}
+_WS_BYTES = 128 << 20
+
+
+def _workspace(t):
+    """One persistent split-K scratch buffer per device (kernels on one stream run in order, so it is reused)."""
+    key = (t.device.type, t.device.index)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.empty(_WS_BYTES if t.is_cuda else (4 << 20), dtype=torch.uint8, device=t.device)
+        _WS[key] = ws
+    return ws
+
 
 def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, residual=None, alpha=1.0,
          out_f32=False, out=None):
@@ -71,11 +84,12 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, r
         assert rowbias.dtype == torch.float32 and rowbias.shape[1] == N and rowbias.stride(1) == 1
     if residual is not None:
         _bf16_2d(residual, "residual"); assert residual.shape == (M, N)
+    ws = _workspace(a)
     _chk(lib().hcp_gemm_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K,
                              _p(a2), a2.stride(0) if a2 is not None else 0, _p(b2), b2.stride(0) if b2 is not None else 0,
                              K2, _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, rows_per_group,
                              _p(residual), residual.stride(0) if residual is not None else 0, float(alpha),
-                             1 if out.dtype == torch.float32 else 0, _stream(a)), "hcp_gemm_bf16")
+                             1 if out.dtype == torch.float32 else 0, _p(ws), ws.numel(), _stream(a)), "hcp_gemm_bf16")
     return out
 
 
@@ -103,9 +117,10 @@ def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=N
         assert rowbias.dtype == torch.float32 and rowbias.shape == (B, cout) and rowbias.stride(1) == 1
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == cout and bias.is_contiguous()
+    ws = _workspace(x1)
     _chk(lib().hcp_conv3x3_bf16(_p(x1), C1, _p(x2), C2, B, Hs, Ws, Ho, Wo, mode, stride, 1 if upsample else 0, _p(wp),
                                 cout, _p(out), cout, _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
-                                _p(residual), cout, 1 if out_f32 else 0, _stream(x1)), "hcp_conv3x3_bf16")
+                                _p(residual), cout, 1 if out_f32 else 0, _p(ws), ws.numel(), _stream(x1)), "hcp_conv3x3_bf16")
     return out
 
 

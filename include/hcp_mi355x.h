@@ -32,7 +32,11 @@ int hcp_abi_version(void);
  * (A2,B2) is the rank-r side path (x W_down^T, alpha*W_up) appended to the reduction. */
 int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int ldd, int M, int N, int K, const void* A2,
                   int lda2, const void* B2, int ldb2, int K2, const float* bias, const float* rowbias, int rowbias_ld,
-                  int rows_per_group, const void* residual, int ldr, float alpha, int out_f32, hcpStream_t stream);
+                  int rows_per_group, const void* residual, int ldr, float alpha, int out_f32, void* workspace,
+                  size_t workspace_bytes, hcpStream_t stream);
+/* fp32 split-K scratch (optional: workspace may be NULL, then small-M problems run unsplit). */
+size_t hcp_gemm_workspace_bytes(int M, int N);
+int hcp_debug_set_gemm_config(int cfg); /* tools/tune_gemm.py only: force tile id + 16*nsplit, -1 = heuristic */
 
 /* 3x3 / pad 1 convolution over NHWC bf16 as an implicit GEMM.  mode 0: forward, Wp = [Cout][3][3][C1+C2];
  * mode 1: data gradient, X1 = dY, Wp = [Cin][3][3][Cout].  Options: stride 1|2, nearest-2x upsampled source,
@@ -40,7 +44,8 @@ int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int l
  * Replaces F.conv2d in diffusers ResnetBlock2D / Downsample2D / Upsample2D (reference cfgs/unet_struct.txt:92-114,390-393). */
 int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int B, int Hs, int Ws, int Ho, int Wo, int mode,
                      int stride, int upsample, const void* Wp, int Cout, void* D, int ldd, const float* bias,
-                     const float* rowbias, int rowbias_ld, const void* residual, int ldr, int out_f32, hcpStream_t stream);
+                     const float* rowbias, int rowbias_ld, const void* residual, int ldr, int out_f32, void* workspace,
+                     size_t workspace_bytes, hcpStream_t stream);
 
 /* Fused attention, element (b,n,h,c) at base + b*bs + n*rs + h*D + c; lse[B,H,Nq] = logsumexp(scale*QK^T).
  * Replaces diffusers CrossAttention/AttnProcessor2_0 (SDPA) or xformers (reference train_ac.py:258-260). D in {40,64,80,160}. */
@@ -51,6 +56,8 @@ int hcp_attention_bwd(const void* Q, const void* K, const void* V, const void* O
                       float* delta_ws /* [B,H,Nq] */, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int D,
                       long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
                       hcpStream_t stream);
+
+int hcp_debug_set_attention_config(int cfg); /* tools only: bit0/1/2 = 32 rows per wave in fwd / dQ / dK,dV; -1 = heuristic */
 
 /* GroupNorm (+SiLU) over NHWC; stats[B,G,2] = (mean, rstd).  Replaces F.group_norm + SiLU
  * (unet_struct.txt:13,93,97,929).  Backward returns dx only (affine parameters frozen). */

@@ -48,6 +48,7 @@ typedef void* hipStream_t;
 #define gridDim (hcp_emu::g_gdim)
 
 #define HCP_DEVICE static inline
+#define HCP_MEMBER inline
 #define HCP_KERNEL(maxthreads) static void
 #define HCP_DYN_SMEM(name) unsigned char* name = hcp_emu::g_smem
 #define HCP_SYNC() hcp_emu::yield_barrier()
@@ -88,3 +89,4 @@ HCP_DEVICE int hcp_shfl_xor_i(int v, int mask) {
 }
 HCP_DEVICE void hcp_atomic_add(float* p, float v) { *p += v; }
 HCP_DEVICE int hcp_lane() { return hcp_emu::g_cur->lane; }
+HCP_DEVICE float hcp_exp2(float x) { return exp2f(x); }

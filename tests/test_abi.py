@@ -41,7 +41,7 @@ def test_product_path_fails_loudly_without_gpu_tensors():
 
 def test_argument_validation_returns_error_codes():
     lib = _lib.load()
-    rc = lib.hcp_gemm_bf16(None, 8, None, 8, None, 8, 8, 8, 8, None, 0, None, 0, 0, None, None, 0, 1, None, 0, 1.0, 0, None)
+    rc = lib.hcp_gemm_bf16(None, 8, None, 8, None, 8, 8, 8, 8, None, 0, None, 0, 0, None, None, 0, 1, None, 0, 1.0, 0, None, 0, None)
     assert rc < 0 and b"null" in lib.hcp_last_error()
     rc = lib.hcp_layernorm_fwd(None, None, None, None, None, 4, 7, 1e-5, None)
     assert rc < 0 and b"bad shape" in lib.hcp_last_error()

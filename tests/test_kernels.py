@@ -143,6 +143,24 @@ def test_attention_fwd_bwd(backend, case):
     assert relerr(dq, dq_ref) < 2e-2 and relerr(dk, dk_ref) < 2e-2 and relerr(dv, dv_ref) < 2e-2
 
 
+@pytest.mark.parametrize("cfg", [0, 7])
+def test_attention_rows_per_wave_variants(backend, cfg):
+    """16- and 32-rows-per-wave instantiations of forward / dQ / dK,dV agree with the reference (forced via the tools hook)."""
+    B, H, Nq, Nk, D = (1, 2, 150, 200, 40) if not backend.is_gpu else (2, 4, 1000, 1100, 64)
+    torch.manual_seed(cfg)
+    q, k, v, do = rnd(B, Nq, H * D), rnd(B, Nk, H * D), rnd(B, Nk, H * D), rnd(B, Nq, H * D)
+    o_ref, lse_ref, dq_ref, dk_ref, dv_ref = attn_ref(q, k, v, H, do)
+    to = backend.to
+    K.lib().hcp_debug_set_attention_config(cfg)
+    try:
+        o, lse = K.attention_fwd(to(q), to(k), to(v), H)
+        dq, dk, dv = K.attention_bwd(to(q), to(k), to(v), o, to(do), lse, H)
+    finally:
+        K.lib().hcp_debug_set_attention_config(-1)
+    assert relerr(o, o_ref) < 1e-2 and (lse.cpu() - lse_ref).abs().max().item() < 2e-2
+    assert relerr(dq, dq_ref) < 2e-2 and relerr(dk, dk_ref) < 2e-2 and relerr(dv, dv_ref) < 2e-2
+
+
 def test_attention_strided_qkv(backend):
     """q/k/v as column slices of one fused [B,N,3C] projection (non-contiguous rows)."""
     torch.manual_seed(3)
@@ -308,3 +326,24 @@ def test_adamw_clip(backend):
         K.adamw_clip_fused(p, g, m, v, lr, step, weight_decay=1e-3, sumsq_t=ss, grad_scale=0.5, max_norm=1.0)
         assert g.abs().max().item() == 0
     assert relerr(p, pr.detach()) < 1e-5 and step.item() == 3
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 2 + 16 * 2, 3 + 16 * 4, 1 + 16 * 3])
+def test_gemm_every_tile_config_and_splitk(backend, cfg):
+    """Each tile shape / split-K decomposition the dispatcher can pick gives the same answer (forced via the tuning hook)."""
+    torch.manual_seed(cfg)
+    M, N, Kd, K2 = (200, 328, 512, 32) if not backend.is_gpu else (1000, 1288, 2304, 32)
+    a, b, a2, b2 = rnd(M, Kd), rnd(N, Kd), rnd(M, K2), rnd(N, K2)
+    bias = torch.randn(N); res = rnd(M, N)
+    ref = a.float() @ b.float().T + a2.float() @ b2.float().T + bias + res.float()
+    to = backend.to
+    K.lib().hcp_debug_set_gemm_config(cfg)
+    try:
+        out = K.gemm(to(a), to(b), a2=to(a2), b2=to(b2), bias=to(bias), residual=to(res), out_f32=True)
+        x = rnd(1, 64, 9, 7).permute(0, 2, 3, 1).contiguous()          # conv through the same config (FAST gather)
+        w = rnd(24, 64, 3, 3, scale=0.05)
+        y = K.conv3x3(to(x), to(w.permute(0, 2, 3, 1).contiguous()), 24, out_f32=True)
+    finally:
+        K.lib().hcp_debug_set_gemm_config(-1)
+    assert relerr(out, ref) < 2e-5
+    assert relerr(y.permute(0, 3, 1, 2), F.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), None, 1, 1)) < 2e-5
