@@ -51,6 +51,8 @@ _PROTOTYPES = {
     "hcp_mse_masked_mean": (I, [P, P, P, I, P, P, I, I, I, F, P]),
     # L, ldl, R, ldr, out, ldo, M, P, Q, scale, transpose_out, stream
     "hcp_lora_wgrad": (I, [P, I, P, I, P, I, I, I, I, F, I, P]),
+    # U, x, ldx, K, grad_down, T, dY, ldy, N, grad_up, M, r, scale, stream
+    "hcp_lora_wgrad_pair": (I, [P, P, I, I, P, P, P, I, I, P, I, I, F, P]),
     "hcp_lora_pack": (I, [P, I, P]),
     "hcp_lora_pack_desc_bytes": (I, []),
     "hcp_sumsq_f32": (I, [P, L, P, P]),

@@ -18,8 +18,13 @@ constexpr int WG_LS = 32 + 2;     // LDS row stride of the L tile
 
 // out[p, q] (+)= scale * sum_m L[m, p] * R[m, q]      p < P (<= 32), q < Q
 // transpose_out: element (p,q) lives at out[q * ldo + p] instead of out[p * ldo + q]
-HCP_KERNEL(256) lora_wgrad_kernel(const hcp_bf16* L, int ldl, const hcp_bf16* R, int ldr, float* out, int ldo, int M, int P,
-                                  int Q, float scale, int transpose_out, int rows_per_split) {
+struct WgradProb { const hcp_bf16* L; int ldl; const hcp_bf16* R; int ldr; float* out; int ldo; int Q; int transpose_out; };
+
+HCP_KERNEL(256) lora_wgrad_kernel(WgradProb pr0, WgradProb pr1, int M, int P, float scale, int rows_per_split) {
+    const WgradProb pr = blockIdx.z == 0 ? pr0 : pr1;
+    const hcp_bf16* L = pr.L; const int ldl = pr.ldl; const hcp_bf16* R = pr.R; const int ldr = pr.ldr;
+    float* out = pr.out; const int ldo = pr.ldo; const int Q = pr.Q; const int transpose_out = pr.transpose_out;
+    if ((int)blockIdx.x * WG_BQ >= Q) return;          // the pair shares one grid sized for the wider problem
     HCP_DYN_SMEM(smem);
     hcp_bf16* sL = (hcp_bf16*)smem;              // [WG_BM][WG_LS]
     hcp_bf16* sR = sL + WG_BM * WG_LS;           // [WG_BM][WG_RS]
@@ -104,21 +109,44 @@ struct LoraPackDesc {
 
 HCP_KERNEL(256) lora_pack_kernel(const LoraPackDesc* descs) {
     const LoraPackDesc d = descs[blockIdx.x];
-    for (int i = threadIdx.x; i < 32 * d.K; i += blockDim.x) {
-        int p = i / d.K, k = i - p * d.K;
-        float w = p < d.r ? d.w_down[(size_t)p * d.K + k] : 0.f;
-        d.ad[i] = hcp_f2bf(w);
-        d.adt[(size_t)k * 32 + p] = hcp_f2bf(w * d.alpha);
+    const int nchunk = gridDim.y, chunk = blockIdx.y;
+    // [32, K] / [K, 32] images of W_down: this block handles a slice of k
+    const int kper = (d.K + nchunk - 1) / nchunk, k0 = chunk * kper;
+    int k1 = k0 + kper; if (k1 > d.K) k1 = d.K;
+    for (int i = threadIdx.x; i < 32 * (k1 - k0); i += blockDim.x) {
+        // consecutive threads -> consecutive p for the [K,32] image (coalesced 64-byte rows), k-major overall
+        int kk = i >> 5, pp = i & 31;
+        int k = k0 + kk;
+        float w = pp < d.r ? d.w_down[(size_t)pp * d.K + k] : 0.f;
+        d.adt[(size_t)k * 32 + pp] = hcp_f2bf(w * d.alpha);
+        d.ad[(size_t)pp * d.K + k] = hcp_f2bf(w);
     }
-    for (int i = threadIdx.x; i < 32 * d.N; i += blockDim.x) {
-        int n = i >> 5, p = i & 31;
-        float w = p < d.r ? d.w_up[(size_t)n * d.r + p] : 0.f;
-        d.bu[i] = hcp_f2bf(w * d.alpha);
-        d.but[(size_t)p * d.N + n] = hcp_f2bf(w);
+    const int nper = (d.N + nchunk - 1) / nchunk, n0 = chunk * nper;
+    int n1 = n0 + nper; if (n1 > d.N) n1 = d.N;
+    for (int i = threadIdx.x; i < 32 * (n1 - n0); i += blockDim.x) {
+        int nn = i >> 5, pp = i & 31;
+        int n = n0 + nn;
+        float w = pp < d.r ? d.w_up[(size_t)n * d.r + pp] : 0.f;
+        d.bu[(size_t)n * 32 + pp] = hcp_f2bf(w * d.alpha);
+        d.but[(size_t)pp * d.N + n] = hcp_f2bf(w);
     }
 }
 
 }  // namespace
+
+static int wgrad_launch(const WgradProb& a, const WgradProb& b, int nprob, int M, int P, float scale, hipStream_t stream) {
+    const int qmax = nprob == 2 && b.Q > a.Q ? b.Q : a.Q;
+    const int qt = hcp_cdiv(qmax, WG_BQ);
+    int splits = hcp_cdiv(1024, qt * nprob);
+    int maxs = hcp_cdiv(M, 2 * WG_BM);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    int rows = hcp_cdiv(hcp_cdiv(M, splits), WG_BM) * WG_BM;
+    splits = hcp_cdiv(M, rows);
+    size_t smem = (size_t)(WG_BM * WG_LS + WG_BM * WG_RS) * sizeof(hcp_bf16);
+    HCP_LAUNCH(lora_wgrad_kernel, dim3(qt, splits, nprob), dim3(256), smem, stream, a, b, M, P, scale, rows);
+    HCP_LAUNCH_CHECK("lora_wgrad");
+}
 
 // out (fp32, accumulated atomically; caller zeroes the bucket once per step)
 //   [p, q] += scale * sum_m L[m,p] R[m,q],  L:[M,32] bf16 (ldl), R:[M,Q] bf16 (ldr), p < P <= 32.
@@ -128,17 +156,20 @@ HCP_API int hcp_lora_wgrad(const void* L, int ldl, const void* R, int ldr, float
                            float scale, int transpose_out, hipStream_t stream) {
     HCP_REQUIRE(L && R && out && M > 0 && Q > 0, "hcp_lora_wgrad: bad arguments");
     HCP_REQUIRE(P > 0 && P <= 32 && ldl % 8 == 0 && ldl >= 32 && ldr % 8 == 0 && Q % 8 == 0, "hcp_lora_wgrad: P<=32, ldl>=32, 8-aligned leading dims required");
-    const int qt = hcp_cdiv(Q, WG_BQ);
-    int splits = hcp_cdiv(1024, qt);
-    int maxs = hcp_cdiv(M, 2 * WG_BM);
-    if (splits > maxs) splits = maxs;
-    if (splits < 1) splits = 1;
-    int rows = hcp_cdiv(hcp_cdiv(M, splits), WG_BM) * WG_BM;
-    splits = hcp_cdiv(M, rows);
-    size_t smem = (size_t)(WG_BM * WG_LS + WG_BM * WG_RS) * sizeof(hcp_bf16);
-    HCP_LAUNCH(lora_wgrad_kernel, dim3(qt, splits), dim3(256), smem, stream, (const hcp_bf16*)L, ldl, (const hcp_bf16*)R, ldr,
-               out, ldo, M, P, Q, scale, transpose_out, rows);
-    HCP_LAUNCH_CHECK("lora_wgrad");
+    WgradProb a = {(const hcp_bf16*)L, ldl, (const hcp_bf16*)R, ldr, out, ldo, Q, transpose_out};
+    return wgrad_launch(a, a, 1, M, P, scale, stream);
+}
+
+// Both LoRA weight gradients of one layer in ONE launch:
+//   grad_down[r,K] += scale * U^T x   (U = dY W_up [M,32], x [M,K])
+//   grad_up  [N,r] += scale * dY^T T  (T = x W_down^T [M,32], dY [M,N])
+HCP_API int hcp_lora_wgrad_pair(const void* U, const void* x, int ldx, int K, float* grad_down, const void* T, const void* dY,
+                                int ldy, int N, float* grad_up, int M, int r, float scale, hipStream_t stream) {
+    HCP_REQUIRE(U && x && grad_down && T && dY && grad_up && M > 0 && K > 0 && N > 0, "hcp_lora_wgrad_pair: bad arguments");
+    HCP_REQUIRE(r > 0 && r <= 32 && ldx % 8 == 0 && ldy % 8 == 0 && K % 8 == 0 && N % 8 == 0, "hcp_lora_wgrad_pair: r<=32, 8-aligned dims required");
+    WgradProb a = {(const hcp_bf16*)U, 32, (const hcp_bf16*)x, ldx, grad_down, K, K, 0};
+    WgradProb b = {(const hcp_bf16*)T, 32, (const hcp_bf16*)dY, ldy, grad_up, r, N, 1};
+    return wgrad_launch(a, b, 2, M, r, scale, stream);
 }
 
 // One launch converts the fp32 master LoRA factors of `count` layers into the four bf16 operand
@@ -146,7 +177,7 @@ HCP_API int hcp_lora_wgrad(const void* L, int ldl, const void* R, int ldr, float
 //   { const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r; float alpha; }
 HCP_API int hcp_lora_pack(const void* descs, int count, hipStream_t stream) {
     HCP_REQUIRE(descs && count > 0, "hcp_lora_pack: bad arguments");
-    HCP_LAUNCH(lora_pack_kernel, dim3(count), dim3(256), 0, stream, (const LoraPackDesc*)descs);
+    HCP_LAUNCH(lora_pack_kernel, dim3(count, 16), dim3(256), 0, stream, (const LoraPackDesc*)descs);
     HCP_LAUNCH_CHECK("lora_pack");
 }
 HCP_API int hcp_lora_pack_desc_bytes(void) { return (int)sizeof(LoraPackDesc); }

@@ -9,19 +9,16 @@
 
 namespace {
 
-constexpr int GN_MAX_CHUNKS = 128;
-
 struct GNGeom { int TX, R, threads, nchunk, rows_per_chunk; };
 
+// Thread (cx, ry) owns channels [8cx, 8cx+8) and rows ry, ry+R, ...; a chunk is 4R rows, so every thread has 4
+// independent 16-byte loads in flight and the grid has HW/(4R) x B workgroups (hundreds to thousands).
 GNGeom gn_geom(int HW, int C) {
     GNGeom g;
     g.TX = C / 8;
     g.R = 256 / g.TX; if (g.R < 1) g.R = 1;
     g.threads = g.TX * g.R;
-    long elems = (long)HW * C;
-    long n = elems / 16384; if (n < 1) n = 1; if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
-    if (n > HW) n = HW;
-    g.rows_per_chunk = (int)((HW + n - 1) / n);
+    g.rows_per_chunk = 4 * g.R;
     g.nchunk = (HW + g.rows_per_chunk - 1) / g.rows_per_chunk;
     return g;
 }
@@ -49,53 +46,74 @@ HCP_KERNEL(1024) gn_fwd_partial(const hcp_bf16* x, float* ws, int HW, int C, int
     for (int i = 0; i < 8; ++i) { s_sum[ry * C + cx * 8 + i] = s[i]; s_sq[ry * C + cx * 8 + i] = q[i]; }
     HCP_SYNC();
     const int Cg = C / G;
-    if (tid < G) {
-        float a = 0.f, bq = 0.f;
-        for (int rr = 0; rr < R; ++rr)
-            for (int c = 0; c < Cg; ++c) { a += s_sum[rr * C + tid * Cg + c]; bq += s_sq[rr * C + tid * Cg + c]; }
+    // 4 lanes per group sum the R x Cg per-channel partials, then combine with two xor-shuffles
+    float a = 0.f, bq = 0.f;
+    {
+        const int g = tid >> 2, sub = tid & 3;
+        if (g < G)
+            for (int j = sub; j < R * Cg; j += 4) {
+                int rr = j / Cg, c = j - rr * Cg;
+                a += s_sum[rr * C + g * Cg + c]; bq += s_sq[rr * C + g * Cg + c];
+            }
+        a += hcp_shfl_xor(a, 1); a += hcp_shfl_xor(a, 2);
+        bq += hcp_shfl_xor(bq, 1); bq += hcp_shfl_xor(bq, 2);
+    }
+    if ((tid & 3) == 0 && (tid >> 2) < G) {
+        const int gidx = tid >> 2;
         float n = (float)(r1 - r0) * Cg;
         float mean = a / n;
         float m2 = bq - a * mean; if (m2 < 0.f) m2 = 0.f;
-        float* o = ws + (((size_t)b * gridDim.x + chunk) * G + tid) * 2;
+        float* o = ws + (((size_t)b * gridDim.x + chunk) * G + gidx) * 2;
         o[0] = mean; o[1] = m2;
     }
 }
 
-HCP_KERNEL(1024) gn_fwd_apply(const hcp_bf16* x, const float* gamma, const float* beta, const float* ws, hcp_bf16* y,
-                              float* stats, int HW, int C, int G, int TX, int R, int rows_per_chunk, float eps, int silu) {
-    HCP_DYN_SMEM(smem);
-    float* s_a = (float*)smem;      // [C] scale
-    float* s_b = s_a + C;           // [C] shift
-    float* s_g = s_b + C;           // [G][2] mean, rstd
+// One wave per (b, g): merge the chunk partials.  mode 0: Chan-merge (mean, M2) -> stats (mean, rstd);
+// mode 1: plain sums (S1, S2) -> (S1/n, S2/n).
+HCP_KERNEL(256) gn_finalize(const float* ws, float* out, int BG, int G, int nchunk, int rows_per_chunk, int HW, int Cg, float eps,
+                            int mode) {
+    const int lane = threadIdx.x & 63;
+    const int bg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = bg < BG;
+    const int b = live ? bg / G : 0, g = live ? bg % G : 0;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+        const float* o = ws + (((size_t)b * nchunk + c) * G + g) * 2;
+        if (mode == 0) {
+            int r0 = c * rows_per_chunk; int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
+            float nb = (float)(r1 - r0) * Cg, nn = n + nb, d = o[0] - mean;
+            mean += d * nb / nn; m2 += o[1] + d * d * n * nb / nn; n = nn;
+        } else { mean += o[0]; m2 += o[1]; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float n2 = hcp_shfl_xor(n, off), mean2 = hcp_shfl_xor(mean, off), m22 = hcp_shfl_xor(m2, off);
+        if (mode == 0) {
+            float nn = n + n2;
+            if (nn > 0.f) { float d = mean2 - mean; mean += d * n2 / nn; m2 += m22 + d * d * n * n2 / nn; n = nn; }
+        } else { mean += mean2; m2 += m22; }
+    }
+    if (live && lane == 0) {
+        if (mode == 0) { out[(size_t)bg * 2] = mean; out[(size_t)bg * 2 + 1] = 1.0f / sqrtf(m2 / n + eps); }
+        else { float cnt = (float)HW * Cg; out[(size_t)bg * 2] = mean / cnt; out[(size_t)bg * 2 + 1] = m2 / cnt; }
+    }
+}
+
+HCP_KERNEL(1024) gn_fwd_apply(const hcp_bf16* x, const float* gamma, const float* beta, const float* stats, hcp_bf16* y,
+                              int HW, int C, int G, int TX, int R, int rows_per_chunk, int silu) {
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, b = blockIdx.y;
-    const int nchunk = gridDim.x;
     const int Cg = C / G;
-    if (tid < G) {
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-        for (int c = 0; c < nchunk; ++c) {
-            int r0 = c * rows_per_chunk; int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
-            float nb = (float)(r1 - r0) * Cg;
-            const float* o = ws + (((size_t)b * nchunk + c) * G + tid) * 2;
-            float d = o[0] - mean; float nn = n + nb;
-            mean += d * nb / nn; m2 += o[1] + d * d * n * nb / nn; n = nn;
-        }
-        float rstd = 1.0f / sqrtf(m2 / n + eps);
-        s_g[tid * 2] = mean; s_g[tid * 2 + 1] = rstd;
-        if (chunk == 0) { stats[((size_t)b * G + tid) * 2] = mean; stats[((size_t)b * G + tid) * 2 + 1] = rstd; }
-    }
-    HCP_SYNC();
-    for (int c = tid; c < C; c += blockDim.x) {
-        int g = c / Cg; float a = s_g[g * 2 + 1] * gamma[c];
-        s_a[c] = a; s_b[c] = beta[c] - s_g[g * 2] * a;
-    }
-    HCP_SYNC();
     const int cx = tid % TX, ry = tid / TX;
     const int r0 = chunk * rows_per_chunk;
     int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
     float a8[8], b8[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { a8[i] = s_a[cx * 8 + i]; b8[i] = s_b[cx * 8 + i]; }
+    for (int i = 0; i < 8; ++i) {
+        int c = cx * 8 + i; int g = c / Cg;
+        float a = stats[((size_t)b * G + g) * 2 + 1] * gamma[c];
+        a8[i] = a; b8[i] = beta[c] - stats[((size_t)b * G + g) * 2] * a;
+    }
     const size_t base = (size_t)b * HW * C + cx * 8;
     for (int r = r0 + ry; r < r1; r += R) {
         hcp_bf16x8 v = *(const hcp_bf16x8*)(x + base + (size_t)r * C);
@@ -145,34 +163,29 @@ HCP_KERNEL(1024) gn_bwd_partial(const hcp_bf16* x, const hcp_bf16* dy, const flo
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s_1[ry * C + cx * 8 + i] = s1[i]; s_2[ry * C + cx * 8 + i] = s2[i]; }
     HCP_SYNC();
-    if (tid < G) {
-        float a = 0.f, bq = 0.f;
-        for (int rr = 0; rr < R; ++rr)
-            for (int c = 0; c < Cg; ++c) { a += s_1[rr * C + tid * Cg + c]; bq += s_2[rr * C + tid * Cg + c]; }
-        float* o = ws + (((size_t)b * gridDim.x + chunk) * G + tid) * 2;
+    float a = 0.f, bq = 0.f;
+    {
+        const int g = tid >> 2, sub = tid & 3;
+        if (g < G)
+            for (int j = sub; j < R * Cg; j += 4) {
+                int rr = j / Cg, c = j - rr * Cg;
+                a += s_1[rr * C + g * Cg + c]; bq += s_2[rr * C + g * Cg + c];
+            }
+        a += hcp_shfl_xor(a, 1); a += hcp_shfl_xor(a, 2);
+        bq += hcp_shfl_xor(bq, 1); bq += hcp_shfl_xor(bq, 2);
+    }
+    if ((tid & 3) == 0 && (tid >> 2) < G) {
+        float* o = ws + (((size_t)b * gridDim.x + chunk) * G + (tid >> 2)) * 2;
         o[0] = a; o[1] = bq;
     }
 }
 
 HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float* gamma, const float* beta,
-                              const float* stats, const float* ws, hcp_bf16* dx, int HW, int C, int G, int TX, int R,
+                              const float* stats, const float* c12, hcp_bf16* dx, int HW, int C, int G, int TX, int R,
                               int rows_per_chunk, int silu) {
-    HCP_DYN_SMEM(smem);
-    float* s_c = (float*)smem;      // [G][2] c1, c2
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, b = blockIdx.y;
-    const int nchunk = gridDim.x;
     const int Cg = C / G;
-    if (tid < G) {
-        float a = 0.f, bq = 0.f;
-        for (int c = 0; c < nchunk; ++c) {
-            const float* o = ws + (((size_t)b * nchunk + c) * G + tid) * 2;
-            a += o[0]; bq += o[1];
-        }
-        float n = (float)HW * Cg;
-        s_c[tid * 2] = a / n; s_c[tid * 2 + 1] = bq / n;
-    }
-    HCP_SYNC();
     const int cx = tid % TX, ry = tid / TX;
     const int r0 = chunk * rows_per_chunk;
     int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
@@ -181,7 +194,7 @@ HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float
     for (int i = 0; i < 8; ++i) {
         int c = cx * 8 + i; int g = c / Cg;
         mean8[i] = stats[((size_t)b * G + g) * 2]; rstd8[i] = stats[((size_t)b * G + g) * 2 + 1];
-        g8[i] = gamma[c]; be8[i] = beta[c]; c1[i] = s_c[g * 2]; c2[i] = s_c[g * 2 + 1];
+        g8[i] = gamma[c]; be8[i] = beta[c]; c1[i] = c12[((size_t)b * G + g) * 2]; c2[i] = c12[((size_t)b * G + g) * 2 + 1];
     }
     const size_t base = (size_t)b * HW * C + cx * 8;
     for (int r = r0 + ry; r < r1; r += R) {
@@ -276,20 +289,22 @@ HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float
 
 int gn_check(int B, int HW, int C, int G) {
     HCP_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0, "groupnorm: empty problem");
-    HCP_REQUIRE(C % 8 == 0 && C % G == 0 && C <= 8192 && G <= 64, "groupnorm: C=%d G=%d unsupported", C, G);
+    HCP_REQUIRE(C % 8 == 0 && C % G == 0 && C <= 8192 && G <= 32, "groupnorm: C=%d G=%d unsupported", C, G);
+    HCP_REQUIRE(gn_geom(HW, C).threads >= 4 * G, "groupnorm: C=%d too small for G=%d", C, G);
     return 0;
 }
 
 }  // namespace
 
-// Workspace (bytes) both GroupNorm entry points need: [B][nchunk][G][2] fp32 partials.
+// Workspace (bytes) both GroupNorm entry points need: [B][nchunk][G][2] fp32 partials + [B][G][2] merged sums.
 HCP_API size_t hcp_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
     if (B <= 0 || HW <= 0 || C <= 0 || C % 8) return 0;
     GNGeom g = gn_geom(HW, C);
-    return (size_t)B * g.nchunk * G * 2 * sizeof(float);
+    return ((size_t)B * g.nchunk * G * 2 + (size_t)B * G * 2) * sizeof(float);
 }
 
 // y = [silu](group_norm(x; gamma, beta, eps)); stats[B,G,2] = (mean, rstd) saved for backward.
+// Three launches: per-chunk (mean, M2) partials -> wave-parallel Chan merge -> elementwise apply.
 HCP_API int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                    void* workspace, int B, int HW, int C, int G, float eps, int silu, hipStream_t stream) {
     if (int e = gn_check(B, HW, C, G)) return e;
@@ -298,9 +313,10 @@ HCP_API int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const floa
     size_t sm1 = (size_t)2 * g.R * C * sizeof(float);
     HCP_LAUNCH(gn_fwd_partial, dim3(g.nchunk, B), dim3(g.threads), sm1, stream, (const hcp_bf16*)x, (float*)workspace, HW, C,
                G, g.TX, g.R, g.rows_per_chunk);
-    size_t sm2 = (size_t)(2 * C + 2 * G) * sizeof(float);
-    HCP_LAUNCH(gn_fwd_apply, dim3(g.nchunk, B), dim3(g.threads), sm2, stream, (const hcp_bf16*)x, gamma, beta,
-               (const float*)workspace, (hcp_bf16*)y, stats, HW, C, G, g.TX, g.R, g.rows_per_chunk, eps, silu);
+    HCP_LAUNCH(gn_finalize, dim3(hcp_cdiv(B * G, 4)), dim3(256), 0, stream, (const float*)workspace, stats, B * G, G, g.nchunk,
+               g.rows_per_chunk, HW, C / G, eps, 0);
+    HCP_LAUNCH(gn_fwd_apply, dim3(g.nchunk, B), dim3(g.threads), 0, stream, (const hcp_bf16*)x, gamma, beta, (const float*)stats,
+               (hcp_bf16*)y, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu);
     HCP_LAUNCH_CHECK("groupnorm_fwd");
 }
 
@@ -311,12 +327,14 @@ HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* g
     if (int e = gn_check(B, HW, C, G)) return e;
     HCP_REQUIRE(x && dy && gamma && beta && stats && dx && workspace, "hcp_groupnorm_silu_bwd: null pointer");
     GNGeom g = gn_geom(HW, C);
+    float* c12 = (float*)workspace + (size_t)B * g.nchunk * G * 2;
     size_t sm1 = (size_t)2 * g.R * C * sizeof(float);
     HCP_LAUNCH(gn_bwd_partial, dim3(g.nchunk, B), dim3(g.threads), sm1, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy,
                gamma, beta, stats, (float*)workspace, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu);
-    size_t sm2 = (size_t)2 * G * sizeof(float);
-    HCP_LAUNCH(gn_bwd_apply, dim3(g.nchunk, B), dim3(g.threads), sm2, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy,
-               gamma, beta, stats, (const float*)workspace, (hcp_bf16*)dx, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu);
+    HCP_LAUNCH(gn_finalize, dim3(hcp_cdiv(B * G, 4)), dim3(256), 0, stream, (const float*)workspace, c12, B * G, G, g.nchunk,
+               g.rows_per_chunk, HW, C / G, 0.f, 1);
+    HCP_LAUNCH(gn_bwd_apply, dim3(g.nchunk, B), dim3(g.threads), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy,
+               gamma, beta, stats, (const float*)c12, (hcp_bf16*)dx, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu);
     HCP_LAUNCH_CHECK("groupnorm_bwd");
 }
 

@@ -334,6 +334,16 @@ def lora_wgrad(L, R, out, P, scale, transpose_out):
                               1 if transpose_out else 0, _stream(L)), "hcp_lora_wgrad")
 
 
+def lora_wgrad_pair(U, x, grad_down, T, dy, grad_up, r, scale):
+    _bf16_2d(U, "U"); _bf16_2d(x, "x"); _bf16_2d(T, "T"); _bf16_2d(dy, "dy")
+    M, Kd = x.shape
+    N = dy.shape[1]
+    assert U.shape == (M, 32) and T.shape == (M, 32) and U.is_contiguous() and T.is_contiguous()
+    assert grad_down.shape == (r, Kd) and grad_up.shape == (N, r) and grad_down.is_contiguous() and grad_up.is_contiguous()
+    _chk(lib().hcp_lora_wgrad_pair(_p(U), _p(x), x.stride(0), Kd, _p(grad_down), _p(T), _p(dy), dy.stride(0), N, _p(grad_up), M, r,
+                                   float(scale), _stream(x)), "hcp_lora_wgrad_pair")
+
+
 def lora_pack(desc_tensor, count):
     _chk(lib().hcp_lora_pack(_p(desc_tensor), count, _stream(desc_tensor)), "hcp_lora_pack")
 

@@ -59,8 +59,7 @@ class _LinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = K.gemm(dy2, pk.wt, a2=U, b2=lp.adt)
             gd, gu = lora.grad_views()
-            K.lora_wgrad(U, x2, gd, lora.rank, lora.alpha_f, False)
-            K.lora_wgrad(T, dy2, gu, lora.rank, lora.alpha_f, True)
+            K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, lora.rank, lora.alpha_f)
         elif ctx.needs_input_grad[0]:
             dx = K.gemm(dy2, pk.wt)
         if dx is not None:

@@ -98,6 +98,9 @@ int hcp_mse_masked_mean(const float* pred, const float* target, const float* mas
  * dW_down = alpha (dY W_up)^T x, dW_up = alpha dY^T (x W_down^T) (autograd of lora_base_patch.py:61-74). */
 int hcp_lora_wgrad(const void* L, int ldl, const void* R, int ldr, float* out, int ldo, int M, int P, int Q, float scale,
                    int transpose_out, hcpStream_t stream);
+/* both gradients of one LoRA layer in one launch: grad_down[r,K] += s U^T x ; grad_up[N,r] += s dY^T T */
+int hcp_lora_wgrad_pair(const void* U, const void* x, int ldx, int K, float* grad_down, const void* T, const void* dY, int ldy,
+                        int N, float* grad_up, int M, int r, float scale, hcpStream_t stream);
 /* fp32 LoRA factors -> the four bf16 operand layouts, all layers in one launch (descs: device array, 64 B each:
  * {const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r; float alpha;}) */
 int hcp_lora_pack(const void* descs, int count, hcpStream_t stream);

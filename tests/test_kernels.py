@@ -305,6 +305,9 @@ def test_lora_wgrad_and_pack(backend, M, Kd, N, r):
     K.lora_wgrad(U, to(x), gd, r, alpha, False)
     K.lora_wgrad(T, to(dy), gu, r, alpha, True)
     assert relerr(gd, wdr.grad) < 2e-2 and relerr(gu, wur.grad) < 2e-2
+    gd2 = torch.zeros(r, Kd, device=dev); gu2 = torch.zeros(N, r, device=dev)
+    K.lora_wgrad_pair(U, to(x), gd2, T, to(dy), gu2, r, alpha)           # both gradients, one launch
+    assert relerr(gd2, wdr.grad) < 2e-2 and relerr(gu2, wur.grad) < 2e-2
 
 
 def test_adamw_clip(backend):
