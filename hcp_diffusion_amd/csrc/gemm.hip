@@ -47,6 +47,9 @@ struct GemmParams {
     int tiles_m;
     int nsplit; int kt_per_split;   // split-K over the primary K tiles (grid.y)
     float* slabs;                   // [nsplit][M][N] fp32 partials when nsplit > 1
+    // fused LoRA (LORA kernels): T = A L^T is accumulated next to the main tile from the same A tiles, rounded to
+    // bf16, then D += T E^T as one extra k-step.  L [32,K] (ldl = K), E [N,32], Tout [M,32] (optional, for wgrad).
+    const hcp_bf16* L; const hcp_bf16* E; hcp_bf16* Tout;
     ConvDesc cv;
 };
 
@@ -73,8 +76,9 @@ HCP_DEVICE void epilogue_store(const GemmParams& p, int m, int n, hcp_f32x4 v) {
 }
 
 // MODE: 0 plain A, 1 conv forward gather, 2 conv data-gradient gather.  FAST: hoisted im2col addressing.
-template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST>
+template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false>
 HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
+    static_assert(!LORA || (MODE == 0 && WGN == 2), "fused LoRA: plain GEMM, two waves across N");
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -85,6 +89,8 @@ HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
     HCP_DYN_SMEM(smem);
     hcp_bf16* lds = (hcp_bf16*)smem;
     constexpr int A_ELEMS = BM * LDS_STRIDE, B_ELEMS = BN * LDS_STRIDE;
+    constexpr int L_ELEMS = LORA ? 32 * LDS_STRIDE : 0;
+    constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS + L_ELEMS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -138,6 +144,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
     }
 
     hcp_bf16x8 ra[A_IT], rb[B_IT];
+    hcp_bf16x8 rl = hcp_zero8();
 
     auto load_tile = [&](int t) {
         const bool ext = t >= (kt_end - kt_begin);
@@ -153,6 +160,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
                 else rb[i] = hcp_zero8();
             }
         }
+        if (LORA && tid < 256) rl = k < klim ? *(const hcp_bf16x8*)(p.L + (size_t)lrow * p.K + k) : hcp_zero8();
         if (MODE == 0 || ext) {
             const hcp_bf16* Ap = ext ? p.A2 : p.A; const int ld = ext ? p.lda2 : p.lda;
 #pragma unroll
@@ -208,8 +216,9 @@ HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
         }
     };
     auto store_tile = [&](int buf) {
-        hcp_bf16* la = lds + buf * (A_ELEMS + B_ELEMS);
+        hcp_bf16* la = lds + buf * BUF_ELEMS;
         hcp_bf16* lb = la + A_ELEMS;
+        if (LORA && tid < 256) *(hcp_bf16x8*)(lb + B_ELEMS + lrow * LDS_STRIDE + kc * 8) = rl;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
             if (A_EXACT || lrow + RPP * i < BM) *(hcp_bf16x8*)(la + (lrow + RPP * i) * LDS_STRIDE + kc * 8) = ra[i];
@@ -219,10 +228,13 @@ HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
     };
 
     hcp_f32x4 acc[TM][TN];
+    hcp_f32x4 tacc[LORA ? TM : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+#pragma unroll
+    for (int i = 0; i < (LORA ? TM : 1); ++i) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; tacc[i] = z; }
 
     if (nk > 0) {
         load_tile(0);
@@ -234,7 +246,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) load_tile(t + 1);
-        const hcp_bf16* la = lds + cur * (A_ELEMS + B_ELEMS);
+        const hcp_bf16* la = lds + cur * BUF_ELEMS;
         const hcp_bf16* lb = la + A_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -250,9 +262,46 @@ HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = hcp_mfma16(fb[j], fa[i], acc[i][j]);   // swapped: lane owns 4 consecutive n
+            if (LORA) {   // T[m][p]: this wave owns rank columns [16 wn, 16 wn + 16)
+                hcp_bf16x8 fl = *(const hcp_bf16x8*)(lb + B_ELEMS + (wn * 16 + fr) * LDS_STRIDE + (ks * 4 + fg) * 8);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) tacc[i] = hcp_mfma16(fl, fa[i], tacc[i]);
+            }
         }
         if (t + 1 < nk) store_tile(cur ^ 1);
         HCP_SYNC();
+    }
+
+    if (LORA) {
+        // T tile (bf16) -> LDS [BM][40]; E tile [BN][32] -> LDS [BN][40]; one more k-step of 32: D += T E^T
+        constexpr int TS2 = 40;
+        hcp_bf16* lt = lds;                       // all waves are past the last barrier: both buffers are free
+        hcp_bf16* le = lds + BM * TS2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            hcp_bf16x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(tacc[i][q]);
+            const int ml = wm * WTM + i * 16 + fr;
+            *(hcp_bf16x4*)(lt + ml * TS2 + wn * 16 + 4 * fg) = o;
+            if (tile_n == 0 && p.Tout && m0 + ml < p.M) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * 32 + wn * 16 + 4 * fg) = o;
+        }
+        for (int c = tid; c < BN * 4; c += NT) {
+            const int r = c >> 2, q = c & 3;
+            hcp_bf16x8 v = hcp_zero8();
+            if (n0 + r < p.N) v = *(const hcp_bf16x8*)(p.E + (size_t)(n0 + r) * 32 + q * 8);
+            *(hcp_bf16x8*)(le + r * TS2 + q * 8) = v;
+        }
+        HCP_SYNC();
+        hcp_bf16x8 ft[TM], fe[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ft[i] = *(const hcp_bf16x8*)(lt + (wm * WTM + i * 16 + fr) * TS2 + fg * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fe[j] = *(const hcp_bf16x8*)(le + (wn * WTN + j * 16 + fr) * TS2 + fg * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
     }
 
     // ---- epilogue: lane holds D[m = .. + fr][n = .. + 4*fg + r]
@@ -284,12 +333,12 @@ HCP_KERNEL(256) splitk_reduce_kernel(GemmParams p) {
 
 int g_force_cfg = -1;   // tools/tune: force a tile configuration (see hcp_debug_set_gemm_config)
 
-template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST>
+template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false>
 int launch_cfg(GemmParams& p, hipStream_t stream) {
     p.tiles_m = hcp_cdiv(p.M, BM);
     const int tiles_n = hcp_cdiv(p.N, BN);
-    const size_t smem = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(hcp_bf16);
-    HCP_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, MODE, FAST>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN), smem,
+    const size_t smem = (size_t)2 * (BM + BN + (LORA ? 32 : 0)) * LDS_STRIDE * sizeof(hcp_bf16);
+    HCP_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, MODE, FAST, LORA>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN), smem,
                stream, p);
     if (p.nsplit > 1) {
         long nv = (long)p.M * (p.N / 4);
@@ -314,6 +363,18 @@ int launch_by_id(int id, GemmParams& p, hipStream_t stream) {
         case 5: return launch_cfg<256, 128, 4, 2, MODE, FAST>(p, stream);
         case 6: return launch_cfg<256, 160, 4, 2, MODE, FAST>(p, stream);
         default: return launch_cfg<128, 320, 2, 4, MODE, FAST>(p, stream);
+    }
+}
+
+int launch_lora_by_id(int id, GemmParams& p, hipStream_t stream) {
+    switch (id) {
+        case 0: return launch_cfg<128, 128, 2, 2, 0, false, true>(p, stream);
+        case 1: return launch_cfg<128, 64, 2, 2, 0, false, true>(p, stream);
+        case 2: return launch_cfg<64, 64, 2, 2, 0, false, true>(p, stream);
+        case 3: return launch_cfg<128, 160, 2, 2, 0, false, true>(p, stream);
+        case 5: return launch_cfg<256, 128, 4, 2, 0, false, true>(p, stream);
+        case 6: return launch_cfg<256, 160, 4, 2, 0, false, true>(p, stream);
+        default: return launch_cfg<64, 160, 2, 2, 0, false, true>(p, stream);
     }
 }
 
@@ -430,4 +491,29 @@ HCP_API int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int
     const bool fast = (C1 % 64 == 0) && (C2 % 64 == 0) && !upsample && !(mode == 1 && stride == 2);
     if (mode == 0) return fast ? dispatch_gemm<1, true>(p, ws, wb, stream) : dispatch_gemm<1, false>(p, ws, wb, stream);
     return fast ? dispatch_gemm<2, true>(p, ws, wb, stream) : dispatch_gemm<2, false>(p, ws, wb, stream);
+}
+
+// Fused LoRA linear (forward AND input-gradient use the same entry point):
+//   T[M,32] = A[M,K] L[32,K]^T  (bf16-rounded, written to Tout if non-null)
+//   D[M,N]  = A B[N,K]^T + T E[N,32]^T + bias + residual
+// forward : A = x,  B = W,   L = W_down (rank-padded), E = alpha*W_up   -> y,  T = x W_down^T   (for dW_up)
+// backward: A = dY, B = W^T, L = W_up^T,               E = alpha*W_down^T -> dX, T = dY W_up    (for dW_down)
+// One launch replaces LoraPatchContainer.forward's weight merge + mm (reference lora_base_patch.py:20-35,61-74).
+HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, void* D,
+                               int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, hipStream_t stream) {
+    GemmParams p = {};
+    p.A = (const hcp_bf16*)A; p.lda = lda; p.B = (const hcp_bf16*)B; p.ldb = ldb;
+    p.M = M; p.N = N; p.K = K; p.D = D; p.ldd = ldd; p.out_f32 = 0;
+    p.bias = bias; p.residual = (const hcp_bf16*)residual; p.ldr = ldr; p.alpha = 1.0f;
+    p.L = (const hcp_bf16*)L; p.E = (const hcp_bf16*)E; p.Tout = (hcp_bf16*)Tout;
+    HCP_REQUIRE(A && B && D && L && E, "hcp_gemm_lora_bf16: null operand");
+    HCP_REQUIRE(lda % 8 == 0, "hcp_gemm_lora_bf16: lda (%d) must be a multiple of 8", lda);
+    if (int e = check_common(p)) return e;
+    int id = 4, nsplit = 1;
+    GemmParams q = p; q.K2 = 32;                 // reuse the measured table of the K-extension form for the tile choice
+    if (!lookup_tuned(q, 0, &id, &nsplit)) id = choose_cfg(p, &nsplit);
+    if (g_force_cfg >= 0) id = g_force_cfg % 16;
+    if (id == 7) id = 6;
+    p.nsplit = 1; p.kt_per_split = hcp_cdiv(p.K, BK); p.slabs = nullptr;
+    return launch_lora_by_id(id, p, stream);
 }

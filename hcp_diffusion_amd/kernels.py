@@ -93,6 +93,23 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, r
     return out
 
 
+def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True):
+    """(D, T): T[M,32] = a @ l[32,K]^T (bf16);  D[M,N] = a @ b[N,K]^T + T @ e[N,32]^T + bias + residual — one launch."""
+    _bf16_2d(a, "a"); _bf16_2d(b, "b"); _bf16_2d(l, "l"); _bf16_2d(e, "e")
+    M, Kd = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == Kd and l.shape == (32, Kd) and e.shape == (N, 32) and l.is_contiguous() and e.is_contiguous()
+    out = torch.empty((M, N), dtype=BF16, device=a.device)
+    t = torch.empty((M, 32), dtype=BF16, device=a.device) if want_t else None
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    if residual is not None:
+        _bf16_2d(residual, "residual"); assert residual.shape == (M, N)
+    _chk(lib().hcp_gemm_lora_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(l), _p(e), _p(t), _p(out), N, M, N, Kd, _p(bias),
+                                  _p(residual), residual.stride(0) if residual is not None else 0, _stream(a)), "hcp_gemm_lora_bf16")
+    return out, t
+
+
 def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=None, bias=None, rowbias=None,
             residual=None, out_f32=False):
     """3x3 / pad 1 convolution on NHWC bf16. mode 0: forward (wp = [cout][3][3][C1+C2]); mode 1: data gradient

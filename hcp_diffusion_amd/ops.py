@@ -34,8 +34,7 @@ class _LinearFn(torch.autograd.Function):
         T = None
         if lora is not None:
             lp = lora.packed()
-            T = K.gemm(x2, lp.ad)
-            y = K.gemm(x2, pk.w, a2=T, b2=lp.bu, bias=pk.bias, residual=res2)
+            y, T = K.gemm_lora(x2, pk.w, lp.ad, lp.bu, bias=pk.bias, residual=res2)
         else:
             y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2, out_f32=out_f32)
         ctx.host, ctx.lora = host, lora
@@ -55,9 +54,10 @@ class _LinearFn(torch.autograd.Function):
         dx = None
         if lora is not None:
             lp = lora.packed()
-            U = K.gemm(dy2, lp.but)
             if ctx.needs_input_grad[0]:
-                dx = K.gemm(dy2, pk.wt, a2=U, b2=lp.adt)
+                dx, U = K.gemm_lora(dy2, pk.wt, lp.but, lp.adt)
+            else:
+                U = K.gemm(dy2, lp.but)
             gd, gu = lora.grad_views()
             K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, lora.rank, lora.alpha_f)
         elif ctx.needs_input_grad[0]:

@@ -301,6 +301,11 @@ def test_lora_wgrad_and_pack(backend, M, Kd, N, r):
     U = K.gemm(to(dy), but)
     dx = K.gemm(to(dy), to(w.T.contiguous()), a2=U, b2=adt, out_f32=True)
     assert relerr(dx, xr.grad) < 1e-2
+    # fused form: the block computes its own T / U tile (one launch for forward, one for the input gradient)
+    y2, T2 = K.gemm_lora(to(x), to(w), ad, bu)
+    assert relerr(y2, yr) < 1e-2 and relerr(T2, T) < 1e-2
+    dx2, U2 = K.gemm_lora(to(dy), to(w.T.contiguous()), but, adt)
+    assert relerr(dx2, xr.grad) < 1e-2 and relerr(U2, U) < 1e-2
     gd = torch.zeros(r, Kd, device=dev); gu = torch.zeros(N, r, device=dev)
     K.lora_wgrad(U, to(x), gd, r, alpha, False)
     K.lora_wgrad(T, to(dy), gu, r, alpha, True)
@@ -343,6 +348,12 @@ def test_gemm_every_tile_config_and_splitk(backend, cfg):
     K.lib().hcp_debug_set_gemm_config(cfg)
     try:
         out = K.gemm(to(a), to(b), a2=to(a2), b2=to(b2), bias=to(bias), residual=to(res), out_f32=True)
+        if cfg < 7:
+            l, e = rnd(32, Kd), rnd(N, 32)                                  # fused-LoRA instantiation of the same tile
+            yl, tl = K.gemm_lora(to(a), to(b), to(l), to(e), bias=to(bias), residual=to(res))
+            t_ref = (a.float() @ l.float().T).to(BF).float()
+            assert relerr(tl, t_ref) < 1e-2
+            assert relerr(yl, a.float() @ b.float().T + t_ref @ e.float().T + bias + res.float()) < 1e-2
         x = rnd(1, 64, 9, 7).permute(0, 2, 3, 1).contiguous()          # conv through the same config (FAST gather)
         w = rnd(24, 64, 3, 3, scale=0.05)
         y = K.conv3x3(to(x), to(w.permute(0, 2, 3, 1).contiguous()), 24, out_f32=True)
