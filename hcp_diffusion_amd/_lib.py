@@ -20,8 +20,8 @@ _PROTOTYPES = {
     # A, lda, B, ldb, D, ldd, M, N, K, A2, lda2, B2, ldb2, K2, bias, rowbias, rowbias_ld, rows_per_group,
     # residual, ldr, alpha, out_f32, workspace, workspace_bytes, stream
     "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, F, I, P, c_size_t, P]),
-    # A, lda, B, ldb, L, E, Tout, D, ldd, M, N, K, bias, residual, ldr, stream
-    "hcp_gemm_lora_bf16": (I, [P, I, P, I, P, P, P, P, I, I, I, I, P, P, I, P]),
+    # A, lda, B, ldb, L, E, Tout, D, ldd, M, N, K, bias, residual, ldr, workspace, workspace_bytes, stream
+    "hcp_gemm_lora_bf16": (I, [P, I, P, I, P, P, P, P, I, I, I, I, P, P, I, P, c_size_t, P]),
     "hcp_gemm_workspace_bytes": (c_size_t, [I, I]),
     "hcp_debug_set_gemm_config": (I, [I]),
     # X1, C1, X2, C2, B, Hs, Ws, Ho, Wo, mode, stride, upsample, Wp, Cout, D, ldd, bias, rowbias, rowbias_ld,

@@ -500,7 +500,8 @@ HCP_API int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int
 // backward: A = dY, B = W^T, L = W_up^T,               E = alpha*W_down^T -> dX, T = dY W_up    (for dW_down)
 // One launch replaces LoraPatchContainer.forward's weight merge + mm (reference lora_base_patch.py:20-35,61-74).
 HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, void* D,
-                               int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, hipStream_t stream) {
+                               int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream) {
     GemmParams p = {};
     p.A = (const hcp_bf16*)A; p.lda = lda; p.B = (const hcp_bf16*)B; p.ldb = ldb;
     p.M = M; p.N = N; p.K = K; p.D = D; p.ldd = ldd; p.out_f32 = 0;
@@ -510,10 +511,26 @@ HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, c
     HCP_REQUIRE(lda % 8 == 0, "hcp_gemm_lora_bf16: lda (%d) must be a multiple of 8", lda);
     if (int e = check_common(p)) return e;
     int id = 4, nsplit = 1;
-    GemmParams q = p; q.K2 = 32;                 // reuse the measured table of the K-extension form for the tile choice
-    if (!lookup_tuned(q, 0, &id, &nsplit)) id = choose_cfg(p, &nsplit);
+    GemmParams q = p; q.K2 = 32;
+    if (!lookup_tuned(q, 3, &id, &nsplit)) {
+        // unseen shape: deep-K / small-M problems want split-K (two launches); otherwise fuse with a narrow-M tile
+        if (p.K >= 4096 && p.M <= 4096) id = -1;
+        else if ((long)p.M * p.N >= (long)4096 * 2560 && p.N % 160 == 0) id = 6;
+        else if (p.N % 160 == 0 && (long)p.M * p.N >= (long)4096 * 640) id = 4;
+        else id = 2;
+    }
     if (g_force_cfg >= 0) id = g_force_cfg % 16;
     if (id == 7) id = 6;
+    if (id < 0) {
+        // two-launch form: T = A L^T, then D = A B^T + T E^T with the measured tile / split-K choice
+        HCP_REQUIRE(Tout, "hcp_gemm_lora_bf16: this shape runs as two launches and needs the T buffer");
+        GemmParams t = {};
+        t.A = p.A; t.lda = p.lda; t.B = p.L; t.ldb = p.K; t.M = p.M; t.N = 32; t.K = p.K; t.D = Tout; t.ldd = 32; t.alpha = 1.0f;
+        if (int e2 = dispatch_gemm<0, false>(t, (float*)workspace, workspace ? workspace_bytes : 0, stream)) return e2;
+        p.A2 = (const hcp_bf16*)Tout; p.lda2 = 32; p.B2 = p.E; p.ldb2 = 32; p.K2 = 32;
+        p.L = nullptr; p.E = nullptr; p.Tout = nullptr;
+        return dispatch_gemm<0, false>(p, (float*)workspace, workspace ? workspace_bytes : 0, stream);
+    }
     p.nsplit = 1; p.kt_per_split = hcp_cdiv(p.K, BK); p.slabs = nullptr;
     return launch_lora_by_id(id, p, stream);
 }

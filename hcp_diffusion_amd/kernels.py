@@ -105,8 +105,10 @@ def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True):
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     if residual is not None:
         _bf16_2d(residual, "residual"); assert residual.shape == (M, N)
+    ws = _workspace(a)
     _chk(lib().hcp_gemm_lora_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(l), _p(e), _p(t), _p(out), N, M, N, Kd, _p(bias),
-                                  _p(residual), residual.stride(0) if residual is not None else 0, _stream(a)), "hcp_gemm_lora_bf16")
+                                  _p(residual), residual.stride(0) if residual is not None else 0, _p(ws), ws.numel(), _stream(a)),
+         "hcp_gemm_lora_bf16")
     return out, t
 
 

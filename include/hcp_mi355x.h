@@ -35,10 +35,12 @@ int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int l
                   int rows_per_group, const void* residual, int ldr, float alpha, int out_f32, void* workspace,
                   size_t workspace_bytes, hcpStream_t stream);
 /* Fused LoRA linear, forward and input-gradient: T = A L^T (rank slot 32, written to Tout if non-NULL),
- * D = A B^T + T E^T + bias + residual in ONE launch (the block accumulates its T tile from the A tiles it streams).
+ * D = A B^T + T E^T + bias + residual in ONE launch (the block accumulates its T tile from the A tiles it streams);
+ * deep-K / small-M shapes run as two launches (T GEMM, then split-K K-extension GEMM) and then require Tout.
  * Replaces LoraPatchContainer.forward's weight merge + mm (lora_base_patch.py:20-35,61-74). */
 int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, void* D,
-                       int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, hcpStream_t stream);
+                       int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, void* workspace,
+                       size_t workspace_bytes, hcpStream_t stream);
 /* fp32 split-K scratch (optional: workspace may be NULL, then small-M problems run unsplit). */
 size_t hcp_gemm_workspace_bytes(int M, int N);
 int hcp_debug_set_gemm_config(int cfg); /* tools/tune_gemm.py only: force tile id + 16*nsplit, -1 = heuristic */
