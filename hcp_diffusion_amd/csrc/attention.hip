@@ -10,7 +10,7 @@
 //    column (lane&15) and 16 keys of the 64-key tile: row max / sum are in-lane + two cross-lane xor steps;
 //  * P^T never leaves registers: MFMA sums over its 32 k-slots in any order as long as A and B agree, so the
 //    lane's own 8 exponentiated scores ARE its B fragment for O^T = V^T P^T, and the matching A fragment is
-//    two 8-byte reads of a transposed V copy in LDS;
+//    two ds_read_b64_tr_b16 (LDS transpose reads) of the ROW-major V tile — no transposed copy is ever staged;
 //  * K/V (or Q/dO) tiles are double-buffered in LDS; the next tile's global loads are issued into registers
 //    before the current tile's MFMAs and written to the other buffer after them: one barrier per tile;
 //  * softmax runs in the exp2 domain with scale*log2(e) folded into one multiply; fully valid tiles skip masking;
@@ -47,6 +47,14 @@ HCP_DEVICE hcp_bf16x8 join8(hcp_bf16x4 a, hcp_bf16x4 b) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { r[i] = a[i]; r[4 + i] = b[i]; }
     return r;
+}
+
+// A-operand fragment for O^T / dQ^T / dK^T / dV^T products: row-major tile [64][RS] (rows = keys or queries),
+// output columns c0..c0+15, k-slots = rows {(2 s2) 16 + 4 fg + j} U {(2 s2 + 1) 16 + 4 fg + j}  (j = 0..3) — the same
+// row set the lane's score registers hold, so P / dS never leave registers.  Two LDS transpose reads.
+HCP_DEVICE hcp_bf16x8 tr_frag(const hcp_bf16* tile, int RSv, int c0, int s2, int fr, int fg) {
+    const hcp_bf16* a = tile + ((2 * s2) * 16 + 4 * fg + (fr >> 2)) * RSv + c0 + 4 * (fr & 3);
+    return join8(hcp_lds_read_tr4(a), hcp_lds_read_tr4(a + 16 * RSv));
 }
 
 template <int D> struct AttnGeom {
@@ -104,8 +112,8 @@ template <int D, int QT>
 HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
-    hcp_bf16* lds = (hcp_bf16*)smem;                // 2 x { K [64][RS] | Vt [DV][TS] }
-    constexpr int BUF = G::RM_ELEMS + G::TR_ELEMS;
+    hcp_bf16* lds = (hcp_bf16*)smem;                // 2 x { K [64][RS] | V [64][RS] }   (both row-major)
+    constexpr int BUF = 2 * G::RM_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -138,14 +146,14 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
         for (int d = 0; d < G::NDV; ++d) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; o[t][d] = z; }
     }
     HCP_SYNC();                                      // zero fill complete
-    sk.store_rm(lds, G::RS, tid); sv.store_tr(lds + G::RM_ELEMS, tid);
+    sk.store_rm(lds, G::RS, tid); sv.store_rm(lds + G::RM_ELEMS, G::RS, tid);
     HCP_SYNC();
 
     for (int it = 0; it < nt; ++it) {
         const int kv0 = it * KVT;
         const int nvalid = p.Nk - kv0 < KVT ? p.Nk - kv0 : KVT;
         const hcp_bf16* sK = lds + (it & 1) * BUF;
-        const hcp_bf16* sVt = sK + G::RM_ELEMS;
+        const hcp_bf16* sV = sK + G::RM_ELEMS;
         if (it + 1 < nt) {
             const int nv = p.Nk - kv0 - KVT < KVT ? p.Nk - kv0 - KVT : KVT;
             sk.load(Kb + (size_t)(kv0 + KVT) * p.k_rs, p.k_rs, nv, tid);
@@ -202,14 +210,13 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
         for (int d = 0; d < G::NDV; ++d)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const hcp_bf16* row = sVt + (d * 16 + fr) * TS + 4 * fg;
-                hcp_bf16x8 vf = join8(*(const hcp_bf16x4*)(row + (2 * s2) * 16), *(const hcp_bf16x4*)(row + (2 * s2 + 1) * 16));
+                hcp_bf16x8 vf = tr_frag(sV, G::RS, d * 16, s2, fr, fg);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) o[t][d] = hcp_mfma16(vf, pf[t][s2], o[t][d]);
             }
         if (it + 1 < nt) {
             hcp_bf16* nK = lds + ((it + 1) & 1) * BUF;
-            sk.store_rm(nK, G::RS, tid); sv.store_tr(nK + G::RM_ELEMS, tid);
+            sk.store_rm(nK, G::RS, tid); sv.store_rm(nK + G::RM_ELEMS, G::RS, tid);
         }
         HCP_SYNC();
     }
@@ -258,8 +265,8 @@ template <int D, int QT>
 HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
-    hcp_bf16* lds = (hcp_bf16*)smem;                // 2 x { K [64][RS] | V [64][RS] | Kt [DV][TS] }
-    constexpr int BUF = 2 * G::RM_ELEMS + G::TR_ELEMS;
+    hcp_bf16* lds = (hcp_bf16*)smem;                // 2 x { K [64][RS] | V [64][RS] }
+    constexpr int BUF = 2 * G::RM_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -295,7 +302,7 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
         for (int d = 0; d < G::NDV; ++d) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; dq[t][d] = z; }
     }
     HCP_SYNC();
-    sk.store_rm(lds, G::RS, tid); sk.store_tr(lds + 2 * G::RM_ELEMS, tid); sv.store_rm(lds + G::RM_ELEMS, G::RS, tid);
+    sk.store_rm(lds, G::RS, tid); sv.store_rm(lds + G::RM_ELEMS, G::RS, tid);
     HCP_SYNC();
 
     for (int it = 0; it < nt; ++it) {
@@ -303,7 +310,6 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
         const int nvalid = p.Nk - kv0 < KVT ? p.Nk - kv0 : KVT;
         const hcp_bf16* sK = lds + (it & 1) * BUF;
         const hcp_bf16* sV = sK + G::RM_ELEMS;
-        const hcp_bf16* sKt = sV + G::RM_ELEMS;
         if (it + 1 < nt) {
             const int nv = p.Nk - kv0 - KVT < KVT ? p.Nk - kv0 - KVT : KVT;
             sk.load(Kb + (size_t)(kv0 + KVT) * p.k_rs, p.k_rs, nv, tid);
@@ -344,14 +350,13 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
         for (int d = 0; d < G::NDV; ++d)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const hcp_bf16* row = sKt + (d * 16 + fr) * TS + 4 * fg;
-                hcp_bf16x8 kf = join8(*(const hcp_bf16x4*)(row + (2 * s2) * 16), *(const hcp_bf16x4*)(row + (2 * s2 + 1) * 16));
+                hcp_bf16x8 kf = tr_frag(sK, G::RS, d * 16, s2, fr, fg);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) dq[t][d] = hcp_mfma16(kf, df[t][s2], dq[t][d]);
             }
         if (it + 1 < nt) {
             hcp_bf16* nb = lds + ((it + 1) & 1) * BUF;
-            sk.store_rm(nb, G::RS, tid); sk.store_tr(nb + 2 * G::RM_ELEMS, tid); sv.store_rm(nb + G::RM_ELEMS, G::RS, tid);
+            sk.store_rm(nb, G::RS, tid); sv.store_rm(nb + G::RM_ELEMS, G::RS, tid);
         }
         HCP_SYNC();
     }
@@ -378,8 +383,8 @@ template <int D, int KT>
 HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
-    hcp_bf16* lds = (hcp_bf16*)smem;     // 2 x { Q [64][RS] | dO [64][RS] | Qt [DV][TS] | dOt [DV][TS] | lse2[64], delta[64] (fp32) }
-    constexpr int BUF = 2 * G::RM_ELEMS + 2 * G::TR_ELEMS + 4 * KVT;   // 2*64 floats = 4*64 bf16 slots
+    hcp_bf16* lds = (hcp_bf16*)smem;     // 2 x { Q [64][RS] | dO [64][RS] | lse2[64], delta[64] (fp32) }
+    constexpr int BUF = 2 * G::RM_ELEMS + 4 * KVT;   // 2*64 floats = 4*64 bf16 slots
     constexpr int NB = (2 * BUF * 2 <= 160 * 1024) ? 2 : 1;            // head_dim 160: one buffer, two barriers per tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -422,8 +427,7 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     }
     auto store_all = [&](hcp_bf16* base) {
         sq.store_rm(base, G::RS, tid); sg.store_rm(base + G::RM_ELEMS, G::RS, tid);
-        sq.store_tr(base + 2 * G::RM_ELEMS, tid); sg.store_tr(base + 2 * G::RM_ELEMS + G::TR_ELEMS, tid);
-        float* sl = (float*)(base + 2 * G::RM_ELEMS + 2 * G::TR_ELEMS);
+        float* sl = (float*)(base + 2 * G::RM_ELEMS);
         if (tid < 2 * KVT) sl[tid] = rl;
     };
     HCP_SYNC();
@@ -434,9 +438,7 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
         const int q0 = it * KVT;
         const hcp_bf16* sQ = lds + (NB == 2 ? (it & 1) : 0) * BUF;
         const hcp_bf16* sG = sQ + G::RM_ELEMS;
-        const hcp_bf16* sQt = sG + G::RM_ELEMS;
-        const hcp_bf16* sGt = sQt + G::TR_ELEMS;
-        const float* sL = (const float*)(sGt + G::TR_ELEMS);
+        const float* sL = (const float*)(sG + G::RM_ELEMS);
         if (it + 1 < nt) {
             const int nv = p.Nq - q0 - KVT < KVT ? p.Nq - q0 - KVT : KVT;
             sq.load(Qb + (size_t)(q0 + KVT) * p.q_rs, p.q_rs, nv, tid);
@@ -482,10 +484,8 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
         for (int d = 0; d < G::NDV; ++d)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const hcp_bf16* rq = sQt + (d * 16 + fr) * TS + 4 * fg;
-                const hcp_bf16* rg = sGt + (d * 16 + fr) * TS + 4 * fg;
-                hcp_bf16x8 qa = join8(*(const hcp_bf16x4*)(rq + (2 * s2) * 16), *(const hcp_bf16x4*)(rq + (2 * s2 + 1) * 16));
-                hcp_bf16x8 ga = join8(*(const hcp_bf16x4*)(rg + (2 * s2) * 16), *(const hcp_bf16x4*)(rg + (2 * s2 + 1) * 16));
+                hcp_bf16x8 qa = tr_frag(sQ, G::RS, d * 16, s2, fr, fg);
+                hcp_bf16x8 ga = tr_frag(sG, G::RS, d * 16, s2, fr, fg);
 #pragma unroll
                 for (int t = 0; t < KT; ++t) {
                     dv[t][d] = hcp_mfma16(ga, pf[t][s2], dv[t][d]);   // dV^T[dcol][key] += dO^T P
@@ -526,7 +526,7 @@ int g_attn_cfg = -1;   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bi
 template <int D, int QT>
 int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
     using G = AttnGeom<D>;
-    size_t smem = (size_t)2 * (G::RM_ELEMS + G::TR_ELEMS) * sizeof(hcp_bf16);
+    size_t smem = (size_t)2 * (2 * G::RM_ELEMS) * sizeof(hcp_bf16);
     HCP_LAUNCH((attn_fwd_kernel<D, QT>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), smem, stream, p);
     HCP_LAUNCH_CHECK("attn_fwd");
 }
@@ -540,14 +540,14 @@ int launch_delta(AttnParams& p, int B, hipStream_t stream) {
 template <int D, int QT>
 int launch_dq(AttnParams& p, int B, hipStream_t stream) {
     using G = AttnGeom<D>;
-    size_t s1 = (size_t)2 * (2 * G::RM_ELEMS + G::TR_ELEMS) * sizeof(hcp_bf16);
+    size_t s1 = (size_t)2 * (2 * G::RM_ELEMS) * sizeof(hcp_bf16);
     HCP_LAUNCH((attn_bwd_dq_kernel<D, QT>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), s1, stream, p);
     HCP_LAUNCH_CHECK("attn_bwd_dq");
 }
 template <int D, int KT>
 int launch_dkv(AttnParams& p, int B, hipStream_t stream) {
     using G = AttnGeom<D>;
-    size_t s2 = (size_t)(2 * G::RM_ELEMS + 2 * G::TR_ELEMS + 4 * KVT) * sizeof(hcp_bf16);
+    size_t s2 = (size_t)(2 * G::RM_ELEMS + 4 * KVT) * sizeof(hcp_bf16);
     if (2 * s2 <= 160 * 1024) s2 *= 2;
     HCP_LAUNCH((attn_bwd_dkv_kernel<D, KT>), dim3(hcp_cdiv(p.Nk, 64 * KT), p.H, B), dim3(256), s2, stream, p);
     HCP_LAUNCH_CHECK("attn_bwd_dkv");

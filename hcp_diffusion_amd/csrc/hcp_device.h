@@ -53,6 +53,14 @@ HCP_DEVICE int hcp_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64);
 HCP_DEVICE void hcp_atomic_add(float* p, float v) { atomicAdd(p, v); }
 HCP_DEVICE int hcp_lane() { return threadIdx.x & 63; }
 HCP_DEVICE float hcp_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read), semantics measured with tools/probes/tr_read_probe.hip:
+// within each 16-lane group, lane p supplies the address of 4 contiguous bf16 M[p][0..3]; lane i receives
+// { M[4j + (i>>2)][i&3] : j = 0..3 }.  With lane p -> &tile[r0 + (p>>2)][c0 + 4*(p&3)] of a ROW-major tile, lane i
+// gets tile[r0 + j][c0 + i], j = 0..3: four consecutive rows of column i — an MFMA operand whose k-slots run down
+// the rows, read straight from the row-major image (no transposed copy in LDS).
+HCP_DEVICE hcp_bf16x4 hcp_lds_read_tr4(const unsigned short* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hcp_bf16x4*)p);
+}
 #endif  // HCP_EMU
 
 // ---------------------------------------------------------------- bf16 helpers (bit-exact RNE)

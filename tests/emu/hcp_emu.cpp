@@ -82,6 +82,19 @@ static void resolve_wave(std::vector<Fiber>& fb, int w0, int w1) {
     if (op == OP_SHFL) {
         for (int i = w0; i < w1; ++i)
             if (fb[i].state == ST_WAVE) fb[i].out[0] = in(fb[i].src_lane, 0);
+    } else if (op == OP_TR16) {
+        // lane i of a 16-lane group receives { M[4j + (i>>2)][i&3] : j }, M[p] = the 4 bf16 lane p pointed at
+        for (int l = 0; l < 64 && w0 + l < w1; ++l) {
+            if (fb[w0 + l].state != ST_WAVE) continue;
+            const int base = l & ~15, i = l & 15;
+            uint16_t o[4];
+            for (int j = 0; j < 4; ++j) {
+                const int src = base + 4 * j + (i >> 2), e = i & 3;
+                uint32_t w = in(src, e >> 1);
+                o[j] = (uint16_t)((e & 1) ? (w >> 16) : (w & 0xffff));
+            }
+            memcpy(fb[w0 + l].out, o, 8);
+        }
     } else if (op == OP_MFMA16) {
         // A[i][k]: lane = i + 16*(k/8), elem k%8 ; B[k][j]: lane = j + 16*(k/8), elem k%8
         // D[i][j]: lane = j + 16*(i/4), reg i%4

@@ -19,7 +19,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 enum { ST_RUN = 0, ST_BARRIER = 1, ST_WAVE = 2, ST_DONE = 3 };
-enum { OP_SHFL = 1, OP_MFMA16 = 2, OP_MFMA32 = 3 };
+enum { OP_SHFL = 1, OP_MFMA16 = 2, OP_MFMA32 = 3, OP_TR16 = 4 };
 struct Fiber {
     void* sp;
     uint3_t tid;
@@ -90,3 +90,11 @@ HCP_DEVICE int hcp_shfl_xor_i(int v, int mask) {
 HCP_DEVICE void hcp_atomic_add(float* p, float v) { *p += v; }
 HCP_DEVICE int hcp_lane() { return hcp_emu::g_cur->lane; }
 HCP_DEVICE float hcp_exp2(float x) { return exp2f(x); }
+// LDS transpose read (ds_read_b64_tr_b16), semantics as measured on gfx950 (tools/probes/tr_read_probe.hip)
+HCP_DEVICE hcp_bf16x4 hcp_lds_read_tr4(const unsigned short* p) {
+    hcp_emu::Fiber* f = hcp_emu::g_cur;
+    f->op = hcp_emu::OP_TR16;
+    memcpy(&f->in[0], p, 8);
+    hcp_emu::wave_collective();
+    hcp_bf16x4 d; memcpy(&d, hcp_emu::g_cur->out, 8); return d;
+}
