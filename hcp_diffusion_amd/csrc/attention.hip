@@ -566,7 +566,7 @@ int run_fwd(AttnParams& p, int B, hipStream_t stream) {
 template <int D>
 int run_bwd(AttnParams& p, int B, hipStream_t stream) {
     if (int e = launch_delta<D>(p, B, stream)) return e;
-    bool wq = false, wk = false;
+    bool wq = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512, wk = false;   // measured: dQ likes 32 rows/wave, dK/dV 16
     if (g_attn_cfg >= 0) { wq = kWide<D> && (g_attn_cfg & 2); wk = kWide<D> && (g_attn_cfg & 4); }
     int e;
     if constexpr (kWide<D>) { e = wq ? launch_dq<D, 2>(p, B, stream) : launch_dq<D, 1>(p, B, stream); }

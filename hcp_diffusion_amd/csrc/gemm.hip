@@ -319,6 +319,262 @@ HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
     }
 }
 
+// 16 zero bytes in device memory: the source of every masked lane of an LDS-DMA load (out-of-range rows / columns,
+// the zero padding of the convolution, K tails).
+HCP_DEVICE_GLOBAL __attribute__((aligned(16))) unsigned char g_zero_page[16];
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA main loop.  Same tiling, fragment mapping, epilogues and fused-LoRA tail as gemm_kernel, but the K tiles
+// travel global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write: the register-staged loop is bound
+// by the ~79 B/clk ds_write_b128 port, not by MFMA).  DMA destinations are lane-linear, so the LDS image is unpadded
+// [rows][64] and bank conflicts are removed by an XOR swizzle applied to the SOURCE chunk index and to the reads:
+// position (r, c) holds global chunk c ^ ((r >> 1) & 7), which makes the 16-lane ds_read_b128 groups of this
+// fragment mapping conflict-free (even/odd rows fall in different bank halves of the 256-byte bank row).
+template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false>
+HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
+    static_assert(!LORA || (MODE == 0 && WGN == 2), "fused LoRA: plain GEMM, two waves across N");
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int RPP = NT / 8;
+    constexpr int A_IT = (BM + RPP - 1) / RPP, B_IT = (BN + RPP - 1) / RPP;
+    static_assert(BM % 8 == 0 && BN % 8 == 0, "a wave stages 8 whole rows per DMA instruction");
+    HCP_DYN_SMEM(smem);
+    hcp_bf16* lds = (hcp_bf16*)smem;
+    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, L_ELEMS = LORA ? 32 * BK : 0;
+    constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS + L_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int kc = tid & 7, lrow = tid >> 3;
+
+    const int nk1 = (p.K + BK - 1) / BK;
+    const int kt_begin = split * p.kt_per_split;
+    int kt_end = kt_begin + p.kt_per_split; if (kt_end > nk1) kt_end = nk1;
+    const bool last_split = split == p.nsplit - 1;
+    const int nk2 = last_split ? (p.K2 + BK - 1) / BK : 0;
+    const int nprim = kt_end - kt_begin;
+    const int nk = nprim + nk2;
+
+    int a_pix[A_IT], a_msk[A_IT];
+    const int Ctot = p.cv.C1 + p.cv.C2;
+    if (MODE != 0) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int m = m0 + lrow + RPP * i;
+            a_pix[i] = -1; a_msk[i] = 0;
+            if (lrow + RPP * i < BM && m < p.M) {
+                int hw = p.cv.Ho * p.cv.Wo;
+                int b = m / hw; int rem = m - b * hw;
+                int py = rem / p.cv.Wo; int px = rem - py * p.cv.Wo;
+                if (!FAST) {
+                    a_pix[i] = (b << 20) | (py << 10) | px;
+                } else {
+                    const int s = MODE == 1 ? p.cv.stride : 1;
+                    a_pix[i] = (b * p.cv.Hs + py * s) * p.cv.Ws + px * s;
+                    int msk = 0;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            int sy = MODE == 1 ? py * s + ky - 1 : py + 1 - ky;
+                            int sx = MODE == 1 ? px * s + kx - 1 : px + 1 - kx;
+                            if (sy >= 0 && sy < p.cv.Hs && sx >= 0 && sx < p.cv.Ws) msk |= 1 << (ky * 3 + kx);
+                        }
+                    a_msk[i] = msk;
+                }
+            }
+        }
+    }
+    const hcp_bf16* zero = (const hcp_bf16*)g_zero_page;
+
+    auto issue_tile = [&](int t, int buf) {
+        hcp_bf16* la = lds + buf * BUF_ELEMS;
+        hcp_bf16* lb = la + A_ELEMS;
+        const bool ext = t >= nprim;
+        const int kt = ext ? t - nprim : kt_begin + t;
+        const int klim = ext ? p.K2 : p.K;
+        // ---- B rows
+        {
+            const hcp_bf16* Bp = ext ? p.B2 : p.B; const int ld = ext ? p.ldb2 : p.ldb;
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int r = lrow + RPP * i;
+                if (wave * 8 + RPP * i < BN) {                       // wave-uniform: this wave's 8 rows exist in the tile
+                    const int k = kt * BK + ((kc ^ ((r >> 1) & 7)) << 3);
+                    const int n = n0 + r;
+                    const hcp_bf16* src = (n < p.N && k < klim) ? Bp + (size_t)n * ld + k : zero;
+                    hcp_glds16(src, lb + (wave * 8 + RPP * i) * BK);
+                }
+            }
+        }
+        if (LORA && wave < 4) {
+            const int r = lrow;                                      // 32 rows of L, one DMA instruction per wave 0..3
+            const int k = kt * BK + ((kc ^ ((r >> 1) & 7)) << 3);
+            const hcp_bf16* src = k < klim ? p.L + (size_t)r * p.K + k : zero;
+            hcp_glds16(src, lb + B_ELEMS + (wave * 8) * BK);
+        }
+        // ---- A rows
+        if (MODE == 0 || ext) {
+            const hcp_bf16* Ap = ext ? p.A2 : p.A; const int ld = ext ? p.lda2 : p.lda;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int r = lrow + RPP * i;
+                if (wave * 8 + RPP * i < BM) {
+                    const int k = kt * BK + ((kc ^ ((r >> 1) & 7)) << 3);
+                    const int m = m0 + r;
+                    const hcp_bf16* src = (m < p.M && k < klim) ? Ap + (size_t)m * ld + k : zero;
+                    hcp_glds16(src, la + (wave * 8 + RPP * i) * BK);
+                }
+            }
+        } else if (FAST) {
+            const int k0 = kt * BK;
+            const int tap = k0 / Ctot; const int cb = k0 - tap * Ctot;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int doff = MODE == 1 ? (ky - 1) * p.cv.Ws + (kx - 1) : (1 - ky) * p.cv.Ws + (1 - kx);
+            const hcp_bf16* srcb; int cs, cbase;
+            if (cb < p.cv.C1) { srcb = p.cv.X1; cs = p.cv.C1; cbase = cb; }
+            else { srcb = p.cv.X2; cs = p.cv.C2; cbase = cb - p.cv.C1; }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int r = lrow + RPP * i;
+                if (wave * 8 + RPP * i < BM) {
+                    const int c = cbase + ((kc ^ ((r >> 1) & 7)) << 3);
+                    const hcp_bf16* src = ((a_msk[i] >> tap) & 1) ? srcb + (size_t)(a_pix[i] + doff) * cs + c : zero;
+                    hcp_glds16(src, la + (wave * 8 + RPP * i) * BK);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int r = lrow + RPP * i;
+                if (wave * 8 + RPP * i < BM) {
+                    const int k = kt * BK + ((kc ^ ((r >> 1) & 7)) << 3);
+                    int tap = k / Ctot; int ci = k - tap * Ctot;
+                    int ky = tap / 3, kx = tap - ky * 3;
+                    const hcp_bf16* srcb; int cs, c;
+                    if (ci < p.cv.C1) { srcb = p.cv.X1; cs = p.cv.C1; c = ci; }
+                    else { srcb = p.cv.X2; cs = p.cv.C2; c = ci - p.cv.C1; }
+                    const hcp_bf16* src = zero;
+                    int pix = a_pix[i];
+                    if (pix >= 0 && k < klim) {
+                        int b = pix >> 20, py = (pix >> 10) & 1023, px = pix & 1023;
+                        int sy, sx; bool ok;
+                        if (MODE == 1) {
+                            sy = py * p.cv.stride + ky - 1; sx = px * p.cv.stride + kx - 1;
+                            int He = p.cv.Hs << p.cv.up, We = p.cv.Ws << p.cv.up;
+                            ok = sy >= 0 && sy < He && sx >= 0 && sx < We;
+                            sy >>= p.cv.up; sx >>= p.cv.up;
+                        } else {
+                            int ty = py + 1 - ky, tx = px + 1 - kx;
+                            ok = ty >= 0 && tx >= 0;
+                            if (p.cv.stride == 2) { ok = ok && ((ty | tx) & 1) == 0; ty >>= 1; tx >>= 1; }
+                            ok = ok && ty < p.cv.Hs && tx < p.cv.Ws;
+                            sy = ty; sx = tx;
+                        }
+                        if (ok) src = srcb + ((size_t)(b * p.cv.Hs + sy) * p.cv.Ws + sx) * cs + c;
+                    }
+                    hcp_glds16(src, la + (wave * 8 + RPP * i) * BK);
+                }
+            }
+        }
+    };
+
+    hcp_f32x4 acc[TM][TN];
+    hcp_f32x4 tacc[LORA ? TM : 1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+#pragma unroll
+    for (int i = 0; i < (LORA ? TM : 1); ++i) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; tacc[i] = z; }
+
+    if (nk > 0) issue_tile(0, 0);
+    HCP_SYNC();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) issue_tile(t + 1, cur ^ 1);
+        const hcp_bf16* la = lds + cur * BUF_ELEMS;
+        const hcp_bf16* lb = la + A_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int q = ks * 4 + fg;
+            hcp_bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int R = wm * WTM + i * 16 + fr;
+                fa[i] = *(const hcp_bf16x8*)(la + R * BK + ((q ^ ((R >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int R = wn * WTN + j * 16 + fr;
+                fb[j] = *(const hcp_bf16x8*)(lb + R * BK + ((q ^ ((R >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fb[j], fa[i], acc[i][j]);
+            if (LORA) {
+                const int R = wn * 16 + fr;
+                hcp_bf16x8 fl = *(const hcp_bf16x8*)(lb + B_ELEMS + R * BK + ((q ^ ((R >> 1) & 7)) << 3));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) tacc[i] = hcp_mfma16(fl, fa[i], tacc[i]);
+            }
+        }
+        HCP_SYNC();
+    }
+
+    if (LORA) {
+        constexpr int TS2 = 40;
+        hcp_bf16* lt = lds;
+        hcp_bf16* le = lds + BM * TS2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            hcp_bf16x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(tacc[i][q]);
+            const int ml = wm * WTM + i * 16 + fr;
+            *(hcp_bf16x4*)(lt + ml * TS2 + wn * 16 + 4 * fg) = o;
+            if (tile_n == 0 && p.Tout && m0 + ml < p.M) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * 32 + wn * 16 + 4 * fg) = o;
+        }
+        for (int c = tid; c < BN * 4; c += NT) {
+            const int r = c >> 2, q = c & 3;
+            hcp_bf16x8 v = hcp_zero8();
+            if (n0 + r < p.N) v = *(const hcp_bf16x8*)(p.E + (size_t)(n0 + r) * 32 + q * 8);
+            *(hcp_bf16x8*)(le + r * TS2 + q * 8) = v;
+        }
+        HCP_SYNC();
+        hcp_bf16x8 ft[TM], fe[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ft[i] = *(const hcp_bf16x8*)(lt + (wm * WTM + i * 16 + fr) * TS2 + fg * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fe[j] = *(const hcp_bf16x8*)(le + (wn * WTN + j * 16 + fr) * TS2 + fg * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + 4 * fg;
+            if (n >= p.N) continue;
+            if (p.nsplit > 1) *(hcp_f32x4*)(p.slabs + ((size_t)split * p.M + m) * p.N + n) = acc[i][j];
+            else epilogue_store(p, m, n, acc[i][j]);
+        }
+    }
+}
+
 // sum the split-K slabs and apply the epilogue
 HCP_KERNEL(256) splitk_reduce_kernel(GemmParams p) {
     const int nv = p.N / 4;
@@ -332,14 +588,23 @@ HCP_KERNEL(256) splitk_reduce_kernel(GemmParams p) {
 }
 
 int g_force_cfg = -1;   // tools/tune: force a tile configuration (see hcp_debug_set_gemm_config)
+int g_use_glds = 1;     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
 
 template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false>
 int launch_cfg(GemmParams& p, hipStream_t stream) {
     p.tiles_m = hcp_cdiv(p.M, BM);
     const int tiles_n = hcp_cdiv(p.N, BN);
-    const size_t smem = (size_t)2 * (BM + BN + (LORA ? 32 : 0)) * LDS_STRIDE * sizeof(hcp_bf16);
-    HCP_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, MODE, FAST, LORA>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN), smem,
-               stream, p);
+    if (g_use_glds) {
+        size_t smem = (size_t)2 * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
+        const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);      // fused-LoRA tail images
+        if (LORA && smem < tail) smem = tail;
+        HCP_LAUNCH((gemm_glds_kernel<BM, BN, WGM, WGN, MODE, FAST, LORA>), dim3(p.tiles_m * tiles_n, p.nsplit),
+                   dim3(64 * WGM * WGN), smem, stream, p);
+    } else {
+        const size_t smem = (size_t)2 * (BM + BN + (LORA ? 32 : 0)) * LDS_STRIDE * sizeof(hcp_bf16);
+        HCP_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, MODE, FAST, LORA>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN),
+                   smem, stream, p);
+    }
     if (p.nsplit > 1) {
         long nv = (long)p.M * (p.N / 4);
         int g = (int)((nv + 255) / 256); if (g > 2048) g = 2048;
@@ -439,6 +704,8 @@ int check_common(const GemmParams& p) {
 
 // TOOLS ONLY (tools/tune_gemm.py): cfg = tile id + 16 * nsplit; -1 restores the heuristic.
 HCP_API int hcp_debug_set_gemm_config(int cfg) { g_force_cfg = cfg; return 0; }
+// TOOLS ONLY: 1 = LDS-DMA main loop (default), 0 = register-staged main loop.
+HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = on; return 0; }
 
 // Bytes of fp32 split-K workspace that lets every launch of this shape use its preferred decomposition.
 HCP_API size_t hcp_gemm_workspace_bytes(int M, int N) { return (size_t)16 * M * N * sizeof(float); }

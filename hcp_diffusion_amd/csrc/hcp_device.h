@@ -61,6 +61,14 @@ HCP_DEVICE float hcp_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_
 HCP_DEVICE hcp_bf16x4 hcp_lds_read_tr4(const unsigned short* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hcp_bf16x4*)p);
 }
+// global_load_lds_dwordx4: asynchronous 16-byte/lane copy global -> LDS without passing through VGPRs or the
+// ds_write port.  The LDS destination is wave-uniform base + lane*16 (lane-linear); the global source is per lane.
+// Completion: the issuing wave's vmcnt, made visible to other waves by the following workgroup barrier.
+HCP_DEVICE void hcp_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#define HCP_DEVICE_GLOBAL __device__
 #endif  // HCP_EMU
 
 // ---------------------------------------------------------------- bf16 helpers (bit-exact RNE)

@@ -98,3 +98,8 @@ HCP_DEVICE hcp_bf16x4 hcp_lds_read_tr4(const unsigned short* p) {
     hcp_emu::wave_collective();
     hcp_bf16x4 d; memcpy(&d, hcp_emu::g_cur->out, 8); return d;
 }
+// LDS-DMA (global_load_lds_dwordx4): lane l's 16 bytes land at wave_base + 16*l; the interpreter copies immediately.
+HCP_DEVICE void hcp_glds16(const void* gsrc, void* lds_wave_base) {
+    memcpy((unsigned char*)lds_wave_base + 16 * hcp_emu::g_cur->lane, gsrc, 16);
+}
+#define HCP_DEVICE_GLOBAL static
