@@ -29,7 +29,7 @@ def _stale(out: Path, deps):
 
 def build_product(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
-    headers = sorted(CSRC.glob("*.h"))
+    headers = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc"))
     objs = []
     bdir = CSRC / "build"
     bdir.mkdir(exist_ok=True)

@@ -24,7 +24,7 @@ def build_emu(force=False):
     sys.path.insert(0, str(HERE.parent.parent))
     from hcp_diffusion_amd.build import SOURCES
     srcs = [CSRC / s for s in SOURCES] + [HERE / "hcp_emu.cpp"]
-    deps = srcs + list(CSRC.glob("*.h")) + [HERE / "hcp_emu.h"]
+    deps = srcs + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [HERE / "hcp_emu.h"]
     if not force and LIB.exists() and all(d.stat().st_mtime <= LIB.stat().st_mtime for d in deps):
         return LIB
     bdir = HERE / "build"
@@ -33,7 +33,7 @@ def build_emu(force=False):
     for s in srcs:
         obj = bdir / (s.stem + ".o")
         objs.append(obj)
-        if force or not obj.exists() or any(d.stat().st_mtime > obj.stat().st_mtime for d in [s] + list(CSRC.glob("*.h")) + [HERE / "hcp_emu.h"]):
+        if force or not obj.exists() or any(d.stat().st_mtime > obj.stat().st_mtime for d in [s] + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [HERE / "hcp_emu.h"]):
             cmd = [_cxx(), "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DHCP_EMU", "-ffp-contract=off",
                    "-fvisibility=hidden", "-Wno-unused-function", "-Wno-unknown-attributes",
                    f"-I{HERE}", f"-I{CSRC}", "-c", str(s), "-o", str(obj)]
