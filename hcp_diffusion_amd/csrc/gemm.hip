@@ -330,9 +330,10 @@ HCP_DEVICE_GLOBAL __attribute__((aligned(16))) unsigned char g_zero_page[16];
 // [rows][64] and bank conflicts are removed by an XOR swizzle applied to the SOURCE chunk index and to the reads:
 // position (r, c) holds global chunk c ^ ((r >> 1) & 7), which makes the 16-lane ds_read_b128 groups of this
 // fragment mapping conflict-free (even/odd rows fall in different bank halves of the 256-byte bank row).
-template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false>
+template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false, int NSTAGE = 2>
 HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
     static_assert(!LORA || (MODE == 0 && WGN == 2), "fused LoRA: plain GEMM, two waves across N");
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "2-stage (barrier drains the DMA) or 3-stage (counted vmcnt) pipeline");
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -493,14 +494,17 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < (LORA ? TM : 1); ++i) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; tacc[i] = z; }
 
-    if (nk > 0) issue_tile(0, 0);
-    HCP_SYNC();
+    // DMA instructions this wave issues per K tile (wave-uniform): the count the 3-stage pipeline leaves in flight
+    int dma_per_tile = 0;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) dma_per_tile += (wave * 8 + RPP * i < BN) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) dma_per_tile += (wave * 8 + RPP * i < BM) ? 1 : 0;
+    if (LORA && wave < 4) dma_per_tile += 1;
 
     const int fr = lane & 15, fg = lane >> 4;
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) issue_tile(t + 1, cur ^ 1);
-        const hcp_bf16* la = lds + cur * BUF_ELEMS;
+    auto compute_tile = [&](int stage) {
+        const hcp_bf16* la = lds + stage * BUF_ELEMS;
         const hcp_bf16* lb = la + A_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -527,7 +531,32 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
                 for (int i = 0; i < TM; ++i) tacc[i] = hcp_mfma16(fl, fa[i], tacc[i]);
             }
         }
+    };
+
+    if (NSTAGE == 2) {
+        if (nk > 0) issue_tile(0, 0);
         HCP_SYNC();
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nk) issue_tile(t + 1, cur ^ 1);
+            compute_tile(cur);
+            HCP_SYNC();                                  // drains the DMA of tile t+1 (vmcnt(0)) and fences the LDS reads
+        }
+    } else {
+        // tile t+2 is in flight while tile t is multiplied; a barrier never waits for more than tile t+1
+        if (nk > 0) issue_tile(0, 0);
+        if (nk > 1) issue_tile(1, 1);
+        hcp_wait_vmcnt(nk > 1 ? dma_per_tile : 0);
+        hcp_barrier_keep_dma();
+        int st = 0;
+        for (int t = 0; t < nk; ++t) {
+            const bool more = t + 2 < nk;
+            if (more) issue_tile(t + 2, st == 0 ? 2 : st - 1);     // stage (t+2) % 3
+            compute_tile(st);
+            hcp_wait_vmcnt(more ? dma_per_tile : 0);                // own share of tile t+1 has landed
+            hcp_barrier_keep_dma();                                 // ... everyone's has; stage t%3 is free again
+            st = st == 2 ? 0 : st + 1;
+        }
     }
 
     if (LORA) {
@@ -590,15 +619,15 @@ HCP_KERNEL(256) splitk_reduce_kernel(GemmParams p) {
 int g_force_cfg = -1;   // tools/tune: force a tile configuration (see hcp_debug_set_gemm_config)
 int g_use_glds = 1;     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
 
-template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false>
+template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false, int NSTAGE = 2>
 int launch_cfg(GemmParams& p, hipStream_t stream) {
     p.tiles_m = hcp_cdiv(p.M, BM);
     const int tiles_n = hcp_cdiv(p.N, BN);
-    if (g_use_glds) {
-        size_t smem = (size_t)2 * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
+    if (g_use_glds || NSTAGE == 3) {
+        size_t smem = (size_t)NSTAGE * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
         const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);      // fused-LoRA tail images
         if (LORA && smem < tail) smem = tail;
-        HCP_LAUNCH((gemm_glds_kernel<BM, BN, WGM, WGN, MODE, FAST, LORA>), dim3(p.tiles_m * tiles_n, p.nsplit),
+        HCP_LAUNCH((gemm_glds_kernel<BM, BN, WGM, WGN, MODE, FAST, LORA, NSTAGE>), dim3(p.tiles_m * tiles_n, p.nsplit),
                    dim3(64 * WGM * WGN), smem, stream, p);
     } else {
         const size_t smem = (size_t)2 * (BM + BN + (LORA ? 32 : 0)) * LDS_STRIDE * sizeof(hcp_bf16);
@@ -614,7 +643,8 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
 }
 
 struct TileCfg { int bm, bn; };
-constexpr TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}, {256, 128}, {256, 160}, {128, 320}};
+constexpr TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}, {256, 128}, {256, 160}, {128, 320},
+                             {128, 160}, {128, 160}, {256, 160}};   // 8: 8 waves x 3 stages, 9: 4 waves x 3 stages, 10: 8 waves x 3 stages
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 template <int MODE, bool FAST>
@@ -627,6 +657,9 @@ int launch_by_id(int id, GemmParams& p, hipStream_t stream) {
         case 4: return launch_cfg<64, 160, 2, 2, MODE, FAST>(p, stream);
         case 5: return launch_cfg<256, 128, 4, 2, MODE, FAST>(p, stream);
         case 6: return launch_cfg<256, 160, 4, 2, MODE, FAST>(p, stream);
+        case 8: return launch_cfg<128, 160, 4, 2, MODE, FAST, false, 3>(p, stream);
+        case 9: return launch_cfg<128, 160, 2, 2, MODE, FAST, false, 3>(p, stream);
+        case 10: return launch_cfg<256, 160, 4, 2, MODE, FAST, false, 3>(p, stream);
         default: return launch_cfg<128, 320, 2, 4, MODE, FAST>(p, stream);
     }
 }
@@ -639,6 +672,8 @@ int launch_lora_by_id(int id, GemmParams& p, hipStream_t stream) {
         case 3: return launch_cfg<128, 160, 2, 2, 0, false, true>(p, stream);
         case 5: return launch_cfg<256, 128, 4, 2, 0, false, true>(p, stream);
         case 6: return launch_cfg<256, 160, 4, 2, 0, false, true>(p, stream);
+        case 8: return launch_cfg<128, 160, 4, 2, 0, false, true, 3>(p, stream);
+        case 9: return launch_cfg<128, 160, 2, 2, 0, false, true, 3>(p, stream);
         default: return launch_cfg<64, 160, 2, 2, 0, false, true>(p, stream);
     }
 }
@@ -787,7 +822,7 @@ HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, c
         else id = 2;
     }
     if (g_force_cfg >= 0) id = g_force_cfg % 16;
-    if (id == 7) id = 6;
+    if (id == 7 || id == 10) id = 6;
     if (id < 0) {
         // two-launch form: T = A L^T, then D = A B^T + T E^T with the measured tile / split-K choice
         HCP_REQUIRE(Tout, "hcp_gemm_lora_bf16: this shape runs as two launches and needs the T buffer");

@@ -69,6 +69,33 @@ HCP_DEVICE void hcp_glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 #define HCP_DEVICE_GLOBAL __device__
+// Counted wait on the vector-memory counter (LDS-DMA loads are VM operations): returns when at most n of this wave's
+// loads are still in flight.  Immediate operand => switch over the small set of values the kernels use.
+HCP_DEVICE void hcp_wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+// Workgroup barrier WITHOUT the vmcnt(0) drain __syncthreads() implies while LDS-DMA is in flight: own LDS reads are
+// retired (lgkmcnt(0)), DMA completion is the caller's counted hcp_wait_vmcnt.
+HCP_DEVICE void hcp_barrier_keep_dma() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 #endif  // HCP_EMU
 
 // ---------------------------------------------------------------- bf16 helpers (bit-exact RNE)

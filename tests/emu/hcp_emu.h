@@ -103,3 +103,5 @@ HCP_DEVICE void hcp_glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((unsigned char*)lds_wave_base + 16 * hcp_emu::g_cur->lane, gsrc, 16);
 }
 #define HCP_DEVICE_GLOBAL static
+HCP_DEVICE void hcp_wait_vmcnt(int) {}                       // DMA is synchronous in the interpreter
+HCP_DEVICE void hcp_barrier_keep_dma() { hcp_emu::yield_barrier(); }

@@ -11,7 +11,7 @@ from hcp_diffusion_amd import kernels as K
 
 BF = torch.bfloat16
 dev = torch.device("cuda:0")
-CFG_NAMES = ["128x128", "128x64", "64x64", "128x160", "64x160", "256x128", "256x160", "128x320"]
+CFG_NAMES = ["128x128", "128x64", "64x64", "128x160", "64x160", "256x128", "256x160", "128x320", "128x160w8s3", "128x160w4s3", "256x160w8s3"]
 
 
 def timeit(fn, iters=10, warm=2):
@@ -33,7 +33,7 @@ def rnd(*s):
 
 def sweep(name, fn, flops, nk1, allow_split=True):
     res = {}
-    for cid in range(8):
+    for cid in range(len(CFG_NAMES)):
         for s in (1, 2, 4, 8, 16):
             if s > 1 and (not allow_split or nk1 // s < 4):
                 continue
