@@ -36,10 +36,10 @@ _PROTOTYPES = {
     "hcp_groupnorm_workspace_bytes": (c_size_t, [I, I, I, I]),
     # x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream
     "hcp_groupnorm_silu_fwd": (I, [P, P, P, P, P, P, I, I, I, I, F, I, P]),
-    # x, dy, gamma, beta, stats, dx, ws, B, HW, C, G, silu, stream
-    "hcp_groupnorm_silu_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    # x, dy, gamma, beta, stats, addend, dx, ws, B, HW, C, G, silu, stream
+    "hcp_groupnorm_silu_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "hcp_layernorm_fwd": (I, [P, P, P, P, P, I, I, F, P]),
-    "hcp_layernorm_bwd": (I, [P, P, P, P, P, I, I, P]),
+    "hcp_layernorm_bwd": (I, [P, P, P, P, P, P, I, I, P]),
     "hcp_geglu_fwd": (I, [P, P, L, I, P]),
     "hcp_geglu_bwd": (I, [P, P, P, L, I, P]),
     "hcp_add_bf16": (I, [P, P, P, L, P]),

@@ -181,8 +181,8 @@ HCP_KERNEL(1024) gn_bwd_partial(const hcp_bf16* x, const hcp_bf16* dy, const flo
 }
 
 HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float* gamma, const float* beta,
-                              const float* stats, const float* c12, hcp_bf16* dx, int HW, int C, int G, int TX, int R,
-                              int rows_per_chunk, int silu) {
+                              const float* stats, const float* c12, const hcp_bf16* addend, hcp_bf16* dx, int HW, int C, int G,
+                              int TX, int R, int rows_per_chunk, int silu) {
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int Cg = C / G;
@@ -200,6 +200,7 @@ HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float
     for (int r = r0 + ry; r < r1; r += R) {
         hcp_bf16x8 v = *(const hcp_bf16x8*)(x + base + (size_t)r * C);
         hcp_bf16x8 d = *(const hcp_bf16x8*)(dy + base + (size_t)r * C);
+        hcp_bf16x8 ad = addend ? *(const hcp_bf16x8*)(addend + base + (size_t)r * C) : hcp_zero8();
         hcp_bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -207,7 +208,7 @@ HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float
             float dz = hcp_bf2f((unsigned short)d[i]);
             if (silu) { float z = xh * g8[i] + be8[i]; float sg = hcp_sigmoid(z); dz *= sg * (1.f + z * (1.f - sg)); }
             float dxh = dz * g8[i];
-            o[i] = (short)hcp_f2bf(rstd8[i] * (dxh - c1[i] - xh * c2[i]));
+            o[i] = (short)hcp_f2bf(rstd8[i] * (dxh - c1[i] - xh * c2[i]) + (addend ? hcp_bf2f((unsigned short)ad[i]) : 0.f));
         }
         *(hcp_bf16x8*)(dx + base + (size_t)r * C) = o;
     }
@@ -253,7 +254,7 @@ HCP_KERNEL(256) ln_fwd_kernel(const hcp_bf16* x, const float* gamma, const float
 }
 
 HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float* gamma, const float* stats,
-                              hcp_bf16* dx, int M, int C) {
+                              const hcp_bf16* addend, hcp_bf16* dx, int M, int C) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool live = row < M;
@@ -276,12 +277,13 @@ HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float
     for (int j = lane; j < nch; j += 64) {
         hcp_bf16x8 v = *(const hcp_bf16x8*)(x + off + j * 8);
         hcp_bf16x8 d = *(const hcp_bf16x8*)(dy + off + j * 8);
+        hcp_bf16x8 ad = addend ? *(const hcp_bf16x8*)(addend + off + j * 8) : hcp_zero8();
         hcp_bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float xh = (hcp_bf2f((unsigned short)v[i]) - mean) * rstd;
             float dxh = hcp_bf2f((unsigned short)d[i]) * gamma[j * 8 + i];
-            o[i] = (short)hcp_f2bf(rstd * (dxh - c1 - xh * c2));
+            o[i] = (short)hcp_f2bf(rstd * (dxh - c1 - xh * c2) + (addend ? hcp_bf2f((unsigned short)ad[i]) : 0.f));
         }
         *(hcp_bf16x8*)(dx + off + j * 8) = o;
     }
@@ -321,9 +323,10 @@ HCP_API int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const floa
 }
 
 // dx for y = [silu](group_norm(x)); gamma/beta frozen (their gradients are not produced here).
+// (optional addend: gradient arriving on the residual path that forks off before the norm; added in the same pass)
 HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
-                                   const float* stats, void* dx, void* workspace, int B, int HW, int C, int G, int silu,
-                                   hipStream_t stream) {
+                                   const float* stats, const void* addend, void* dx, void* workspace, int B, int HW, int C,
+                                   int G, int silu, hipStream_t stream) {
     if (int e = gn_check(B, HW, C, G)) return e;
     HCP_REQUIRE(x && dy && gamma && beta && stats && dx && workspace, "hcp_groupnorm_silu_bwd: null pointer");
     GNGeom g = gn_geom(HW, C);
@@ -334,7 +337,8 @@ HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* g
     HCP_LAUNCH(gn_finalize, dim3(hcp_cdiv(B * G, 4)), dim3(256), 0, stream, (const float*)workspace, c12, B * G, G, g.nchunk,
                g.rows_per_chunk, HW, C / G, 0.f, 1);
     HCP_LAUNCH(gn_bwd_apply, dim3(g.nchunk, B), dim3(g.threads), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy,
-               gamma, beta, stats, (const float*)c12, (hcp_bf16*)dx, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu);
+               gamma, beta, stats, (const float*)c12, (const hcp_bf16*)addend, (hcp_bf16*)dx, HW, C, G, g.TX, g.R,
+               g.rows_per_chunk, silu);
     HCP_LAUNCH_CHECK("groupnorm_bwd");
 }
 
@@ -347,11 +351,12 @@ HCP_API int hcp_layernorm_fwd(const void* x, const float* gamma, const float* be
     HCP_LAUNCH_CHECK("layernorm_fwd");
 }
 
-HCP_API int hcp_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, void* dx, int M,
-                              int C, hipStream_t stream) {
+// dx = layer_norm_backward(dy) [+ addend]   (addend: gradient arriving on the residual path of a pre-norm block)
+HCP_API int hcp_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, const void* addend,
+                              void* dx, int M, int C, hipStream_t stream) {
     HCP_REQUIRE(M > 0 && C > 0 && C % 8 == 0, "hcp_layernorm_bwd: bad shape M=%d C=%d", M, C);
     HCP_REQUIRE(x && dy && gamma && stats && dx, "hcp_layernorm_bwd: null pointer");
     HCP_LAUNCH(ln_bwd_kernel, dim3(hcp_cdiv(M, 4)), dim3(256), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy, gamma,
-               stats, (hcp_bf16*)dx, M, C);
+               stats, (const hcp_bf16*)addend, (hcp_bf16*)dx, M, C);
     HCP_LAUNCH_CHECK("layernorm_bwd");
 }

@@ -195,13 +195,14 @@ def groupnorm_fwd(x, gamma, beta, groups, eps, silu):
     return y, stats
 
 
-def groupnorm_bwd(x, dy, gamma, beta, stats, groups, silu):
+def groupnorm_bwd(x, dy, gamma, beta, stats, groups, silu, addend=None):
     assert x.dtype == BF16 and x.is_contiguous() and dy.dtype == BF16 and dy.is_contiguous()
+    assert addend is None or (addend.dtype == BF16 and addend.is_contiguous() and addend.numel() == x.numel())
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     dx = torch.empty_like(x)
     ws = _gn_ws(x, B, HW, C, groups)
-    _chk(lib().hcp_groupnorm_silu_bwd(_p(x), _p(dy), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws), B, HW, C, groups,
+    _chk(lib().hcp_groupnorm_silu_bwd(_p(x), _p(dy), _p(gamma), _p(beta), _p(stats), _p(addend), _p(dx), _p(ws), B, HW, C, groups,
                                       1 if silu else 0, _stream(x)), "hcp_groupnorm_silu_bwd")
     return dx
 
@@ -215,11 +216,12 @@ def layernorm_fwd(x, gamma, beta, eps):
     return y, stats
 
 
-def layernorm_bwd(x, dy, gamma, stats):
+def layernorm_bwd(x, dy, gamma, stats, addend=None):
     assert x.is_contiguous() and dy.is_contiguous() and dy.dtype == BF16
+    assert addend is None or (addend.dtype == BF16 and addend.is_contiguous() and addend.numel() == x.numel())
     C = x.shape[-1]; M = x.numel() // C
     dx = torch.empty_like(x)
-    _chk(lib().hcp_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(stats), _p(dx), M, C, _stream(x)), "hcp_layernorm_bwd")
+    _chk(lib().hcp_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(stats), _p(addend), _p(dx), M, C, _stream(x)), "hcp_layernorm_bwd")
     return dx
 
 

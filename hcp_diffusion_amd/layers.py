@@ -94,10 +94,11 @@ class _F32Affine:
 
 
 class HipGroupNorm(_F32Affine, nn.GroupNorm):
-    def forward(self, x, silu=False):
-        return ops.groupnorm(x, self, silu)
+    def forward(self, x, silu=False, fork=False):
+        """fork=True returns (norm(x), x): use the second value as the residual so backward fuses the gradient add."""
+        return ops.groupnorm_fork(x, self, silu) if fork else ops.groupnorm(x, self, silu)
 
 
 class HipLayerNorm(_F32Affine, nn.LayerNorm):
-    def forward(self, x):
-        return ops.layernorm(x, self)
+    def forward(self, x, fork=False):
+        return ops.layernorm_fork(x, self) if fork else ops.layernorm(x, self)

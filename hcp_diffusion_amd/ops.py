@@ -134,6 +134,33 @@ def groupnorm(x, gn, silu):
     return _GroupNormFn.apply(x, gn, silu)
 
 
+class _GroupNormForkFn(torch.autograd.Function):
+    """(norm(x), x): the block input forks into the normalised branch and the residual path.  Backward receives both
+    gradients at once and adds the residual-path one inside the norm-backward kernel (no separate accumulation)."""
+
+    @staticmethod
+    def forward(ctx, x, gn, silu):
+        g, b = gn.f32_params()
+        y, stats = K.groupnorm_fwd(x, g, b, gn.num_groups, gn.eps, silu)
+        ctx.save_for_backward(x, stats)
+        ctx.gn, ctx.silu = gn, silu
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, stats = ctx.saved_tensors
+        g, b = ctx.gn.f32_params()
+        if dy is None:
+            return dskip, None, None
+        return K.groupnorm_bwd(x, dy.contiguous(), g, b, stats, ctx.gn.num_groups, ctx.silu,
+                               dskip.contiguous() if dskip is not None else None), None, None
+
+
+def groupnorm_fork(x, gn, silu):
+    _no_host_grad(gn.weight, gn.bias)
+    return _GroupNormForkFn.apply(x, gn, silu)
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln):
@@ -153,6 +180,31 @@ class _LayerNormFn(torch.autograd.Function):
 def layernorm(x, ln):
     _no_host_grad(ln.weight, ln.bias)
     return _LayerNormFn.apply(x, ln)
+
+
+class _LayerNormForkFn(torch.autograd.Function):
+    """(layer_norm(x), x) for pre-norm residual blocks; see _GroupNormForkFn."""
+
+    @staticmethod
+    def forward(ctx, x, ln):
+        g, b = ln.f32_params()
+        y, stats = K.layernorm_fwd(x, g, b, ln.eps)
+        ctx.save_for_backward(x, stats)
+        ctx.ln = ln
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, stats = ctx.saved_tensors
+        g, _ = ctx.ln.f32_params()
+        if dy is None:
+            return dskip, None
+        return K.layernorm_bwd(x, dy.contiguous(), g, stats, dskip.contiguous() if dskip is not None else None), None
+
+
+def layernorm_fork(x, ln):
+    _no_host_grad(ln.weight, ln.bias)
+    return _LayerNormForkFn.apply(x, ln)
 
 
 class _GegluFn(torch.autograd.Function):

@@ -75,7 +75,10 @@ class ResnetBlock2D(nn.Module):
         """x [B,H,W,C] (+ optional skip tensor = the up-path concat, never materialised); temb_act = SiLU(temb)."""
         if skip is not None:
             x = ops.concat_channels(x, skip)          # GroupNorm needs the joint tensor once; convs read it back
-        h = self.norm1(x, silu=True)
+        if hasattr(self, "conv_shortcut"):
+            h = self.norm1(x, silu=True)
+        else:
+            h, x = self.norm1(x, silu=True, fork=True)       # x continues as the identity residual
         if isinstance(self.time_emb_proj, HipLinear):  # [B, Cout] fp32 row bias fused into conv1's epilogue
             tb = self.time_emb_proj(temb_act, out_f32=True)
         else:
@@ -132,9 +135,12 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = HipLayerNorm(dim)
 
     def forward(self, x, context):
-        x = self.attn1(self.norm1(x), residual=x)
-        x = self.attn2(self.norm2(x), context, residual=x)
-        return self.ff(self.norm3(x), residual=x)
+        h, x = self.norm1(x, fork=True)                        # (LN(x), x): the fork fuses the residual-gradient add
+        x = self.attn1(h, residual=x)
+        h, x = self.norm2(x, fork=True)
+        x = self.attn2(h, context, residual=x)
+        h, x = self.norm3(x, fork=True)
+        return self.ff(h, residual=x)
 
 
 class Transformer2DModel(nn.Module):
@@ -148,7 +154,8 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, context):
         B, H, W, C = x.shape
-        h = self.proj_in(self.norm(x, silu=False)).view(B, H * W, C)
+        h, x = self.norm(x, silu=False, fork=True)
+        h = self.proj_in(h).view(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
         return _call_res(self.proj_out, h.view(B, H, W, C), x)

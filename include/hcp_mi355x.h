@@ -73,13 +73,14 @@ size_t hcp_groupnorm_workspace_bytes(int B, int HW, int C, int G);
 int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, void* workspace,
                            int B, int HW, int C, int G, float eps, int silu, hcpStream_t stream);
 int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats,
-                           void* dx, void* workspace, int B, int HW, int C, int G, int silu, hcpStream_t stream);
+                           const void* addend /* optional residual-path gradient, added in the same pass */, void* dx,
+                           void* workspace, int B, int HW, int C, int G, int silu, hcpStream_t stream);
 
 /* LayerNorm over the last dim; stats[M,2] = (mean, rstd).  Replaces F.layer_norm (unet_struct.txt:44-46). */
 int hcp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int C, float eps,
                       hcpStream_t stream);
-int hcp_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, void* dx, int M, int C,
-                      hcpStream_t stream);
+int hcp_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, const void* addend, void* dx,
+                      int M, int C, hcpStream_t stream);
 
 /* y[M,F] = h[:, :F] * gelu(h[:, F:])   (diffusers GEGLU, unet_struct.txt:28-30) */
 int hcp_geglu_fwd(const void* h, void* y, long M, int F, hcpStream_t stream);

@@ -198,6 +198,9 @@ def test_groupnorm_silu(backend, case):
     assert (stats[..., 0].cpu() - mean_ref).abs().max().item() < 1e-4
     dx = K.groupnorm_bwd(to(nhwc(x)), to(nhwc(dy)), to(gamma), to(beta), stats, 32, silu)
     assert relerr(dx.permute(0, 3, 1, 2), xr.grad) < 1e-2
+    skip = rnd(B, C, H, W)                                   # fused residual-path gradient
+    dx2 = K.groupnorm_bwd(to(nhwc(x)), to(nhwc(dy)), to(gamma), to(beta), stats, 32, silu, addend=to(nhwc(skip)))
+    assert relerr(dx2.permute(0, 3, 1, 2), xr.grad + skip.float()) < 1e-2
 
 
 @pytest.mark.parametrize("M,C", [(10, 320), (7, 640), (5, 1280), (16384, 320), (1024, 1280)])
@@ -214,6 +217,8 @@ def test_layernorm(backend, M, C):
     assert relerr(y, yr) < 1e-2
     dx = K.layernorm_bwd(to(x), to(dy), to(gamma), stats)
     assert relerr(dx, xr.grad) < 1e-2
+    skip = rnd(M, C)
+    assert relerr(K.layernorm_bwd(to(x), to(dy), to(gamma), stats, addend=to(skip)), xr.grad + skip.float()) < 1e-2
 
 
 @pytest.mark.parametrize("M,Fd", [(9, 64), (33, 1280), (16384, 1280)])
