@@ -123,6 +123,10 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
     const hcp_bf16* Vb = p.V + (size_t)b * p.v_bs + h * D;
     const float c2 = p.scale * LOG2E;
 
+    // Row sums ride on the PV MFMA when V's column padding has room: column D of the V image is 1.0, so output row D
+    // of O^T accumulates sum_k P[k][q] (and is rescaled with O) — no VALU adds / cross-lane sums per tile.
+    constexpr bool ONES_COL = G::DV > D;
+    constexpr float RESCALE_LOG2 = 6.0f;
     zero_lds(lds, 2 * BUF, tid);
     TileStage<D> sk, sv;
     const int nt = (p.Nk + KVT - 1) / KVT;
@@ -146,6 +150,7 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
         for (int d = 0; d < G::NDV; ++d) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; o[t][d] = z; }
     }
     HCP_SYNC();                                      // zero fill complete
+    if (ONES_COL && tid < 2 * KVT) lds[(tid >> 6) * BUF + G::RM_ELEMS + (tid & 63) * G::RS + D] = 0x3F80;   // bf16 1.0
     sk.store_rm(lds, G::RS, tid); sv.store_rm(lds + G::RM_ELEMS, G::RS, tid);
     HCP_SYNC();
 
@@ -175,34 +180,42 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
         hcp_bf16x8 pf[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
+            // running max m_i is kept on the RAW scores; p = exp2(s*c2 - m*c2) is one FMA + v_exp_f32
             float mx = -INFINITY;
-            if (nvalid == KVT) {
+            if (nvalid != KVT) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { float v = sc[t][kt][r] * c2; sc[t][kt][r] = v; mx = v > mx ? v : mx; }
-            } else {
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = (kt * 16 + 4 * fg + r) < nvalid ? sc[t][kt][r] * c2 : -INFINITY;
-                        sc[t][kt][r] = v; mx = v > mx ? v : mx;
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if ((kt * 16 + 4 * fg + r) >= nvalid) sc[t][kt][r] = -INFINITY;
             }
-            float o1 = hcp_shfl_xor(mx, 16); mx = o1 > mx ? o1 : mx;
-            o1 = hcp_shfl_xor(mx, 32); mx = o1 > mx ? o1 : mx;
-            const float m_new = mx > m_i[t] ? mx : m_i[t];
-            const float alpha = hcp_exp2(m_i[t] - m_new);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][kt][r]);
+            mx = fmaxf(mx, hcp_shfl_xor(mx, 16));
+            mx = fmaxf(mx, hcp_shfl_xor(mx, 32));
+            // lazy rescale: keep the old reference max while the new one is < 2^RESCALE_LOG2 above it (p stays bounded);
+            // the accumulator / row-sum rescale then runs on few tiles only.  Wave-uniform decision.
+            if (!hcp_all((mx - m_i[t]) * c2 <= RESCALE_LOG2)) {
+                const float m_new = fmaxf(mx, m_i[t]);
+                const float alpha = hcp_exp2((m_i[t] - m_new) * c2);      // m_i = -inf on the first tile -> 0
+                m_i[t] = m_new;
+                l_i[t] *= alpha;
+#pragma unroll
+                for (int d = 0; d < G::NDV; ++d) o[t][d] *= alpha;
+            }
+            const float mc = m_i[t] * c2;
             float rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { float e = hcp_exp2(sc[t][kt][r] - m_new); sc[t][kt][r] = e; rs += e; }
-            rs += hcp_shfl_xor(rs, 16); rs += hcp_shfl_xor(rs, 32);
-            l_i[t] = l_i[t] * alpha + rs; m_i[t] = m_new;
-#pragma unroll
-            for (int d = 0; d < G::NDV; ++d) o[t][d] *= alpha;
+                for (int r = 0; r < 4; ++r) {
+                    float e = hcp_exp2(fmaf(sc[t][kt][r], c2, -mc));
+                    sc[t][kt][r] = e;
+                    if (!ONES_COL) rs += e;
+                }
+            if (!ONES_COL) { rs += hcp_shfl_xor(rs, 16); rs += hcp_shfl_xor(rs, 32); l_i[t] += rs; }
             pf[t][0] = pack8(sc[t][0], sc[t][1]);
             pf[t][1] = pack8(sc[t][2], sc[t][3]);
         }
@@ -224,8 +237,10 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int row = q_base + t * 16 + fr;
+        float lsum = l_i[t];
+        if (ONES_COL) lsum = hcp_shfl(o[t][D / 16][D % 16 % 4], ((D % 16) / 4) * 16 + fr);   // O^T row D lives in lane group (D%16)/4
         if (row >= p.Nq) continue;
-        const float inv = 1.0f / l_i[t];
+        const float inv = 1.0f / lsum;
         hcp_bf16* orow = p.Out + (size_t)b * p.o_bs + (size_t)row * p.o_rs + h * D;
 #pragma unroll
         for (int d = 0; d < G::NDV; ++d) {
@@ -237,7 +252,7 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
                 *(hcp_bf16x4*)(orow + col) = w;
             }
         }
-        if (fg == 0) p.lse[((size_t)b * p.H + h) * p.Nq + row] = (m_i[t] + log2f(l_i[t])) * LN2;
+        if (fg == 0) p.lse[((size_t)b * p.H + h) * p.Nq + row] = (m_i[t] * c2 + log2f(lsum)) * LN2;
     }
 }
 
@@ -339,9 +354,9 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pr = hcp_exp2(sc[t][kt][r] * c2 - lse2[t]);
+                    float pr = hcp_exp2(fmaf(sc[t][kt][r], c2, -lse2[t]));
                     if (nvalid != KVT && (kt * 16 + 4 * fg + r) >= nvalid) pr = 0.f;
-                    sc[t][kt][r] = pr * (dp[t][kt][r] - del_i[t]) * p.scale;
+                    sc[t][kt][r] = pr * (dp[t][kt][r] - del_i[t]);          // softmax scale applied once, at the store
                 }
             df[t][0] = pack8(sc[t][0], sc[t][1]);
             df[t][1] = pack8(sc[t][2], sc[t][3]);
@@ -371,7 +386,7 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
             if (col < D) {
                 hcp_bf16x4 w;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = (short)hcp_f2bf(dq[t][d][r]);
+                for (int r = 0; r < 4; ++r) w[r] = (short)hcp_f2bf(dq[t][d][r] * p.scale);
                 *(hcp_bf16x4*)(orow + col) = w;
             }
         }
@@ -472,9 +487,9 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
                 const hcp_f32x4 d4 = *(const hcp_f32x4*)(sL + KVT + qt * 16 + 4 * fg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pr = kok ? hcp_exp2(sc[t][qt][r] * c2 - l4[r]) : 0.f;      // lse2 = +inf for q >= Nq -> 0
+                    float pr = kok ? hcp_exp2(fmaf(sc[t][qt][r], c2, -l4[r])) : 0.f;      // lse2 = +inf for q >= Nq -> 0
                     sc[t][qt][r] = pr;
-                    dp[t][qt][r] = pr * (dp[t][qt][r] - d4[r]) * p.scale;
+                    dp[t][qt][r] = pr * (dp[t][qt][r] - d4[r]);              // softmax scale applied once, at the store
                 }
             }
             pf[t][0] = pack8(sc[t][0], sc[t][1]); pf[t][1] = pack8(sc[t][2], sc[t][3]);
@@ -513,7 +528,7 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
             if (col < D) {
                 hcp_bf16x4 wk, wv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { wk[r] = (short)hcp_f2bf(dk[t][d][r]); wv[r] = (short)hcp_f2bf(dv[t][d][r]); }
+                for (int r = 0; r < 4; ++r) { wk[r] = (short)hcp_f2bf(dk[t][d][r] * p.scale); wv[r] = (short)hcp_f2bf(dv[t][d][r]); }
                 *(hcp_bf16x4*)(krow + col) = wk;
                 *(hcp_bf16x4*)(vrow + col) = wv;
             }

@@ -69,6 +69,7 @@ HCP_DEVICE void hcp_glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 #define HCP_DEVICE_GLOBAL __device__
+HCP_DEVICE bool hcp_all(bool pred) { return __all(pred); }   // wave-uniform vote
 // Counted wait on the vector-memory counter (LDS-DMA loads are VM operations): returns when at most n of this wave's
 // loads are still in flight.  Immediate operand => switch over the small set of values the kernels use.
 HCP_DEVICE void hcp_wait_vmcnt(int n) {
