@@ -29,6 +29,9 @@ struct AttnParams {
     int q_rs, k_rs, v_rs, o_rs;    // token-row strides (elements); head h starts at column h*D
     int H, Nq, Nk;
     float scale;
+    // dK/dV kernel: the query loop may be split over gridDim.x / nkv workgroups that accumulate into fp32 buffers
+    int qsplit;           // number of query-range splits (1 = none)
+    float* dk32; float* dv32;   // [B, Nk, H*D] fp32 accumulators when qsplit > 1
 };
 
 constexpr int KVT = 64;            // keys (or queries, in the dK/dV kernel) per tile
@@ -404,7 +407,8 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int k_base = blockIdx.x * (64 * KT) + wave * (16 * KT);
+    const int kblk = blockIdx.x / p.qsplit, qs = blockIdx.x - kblk * p.qsplit;
+    const int k_base = kblk * (64 * KT) + wave * (16 * KT);
     const hcp_bf16* Qb = p.Q + (size_t)b * p.q_bs + h * D;
     const hcp_bf16* Kb = p.K + (size_t)b * p.k_bs + h * D;
     const hcp_bf16* Vb = p.V + (size_t)b * p.v_bs + h * D;
@@ -416,14 +420,21 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     zero_lds(lds, NB * BUF, tid);
     TileStage<D> sq, sg;
     float rl = 0.f;                                  // staged lse2 (tid < 64) / delta (64 <= tid < 128)
-    const int nt = (p.Nq + KVT - 1) / KVT;
+    const int nt_all = (p.Nq + KVT - 1) / KVT;
+    const int per = (nt_all + p.qsplit - 1) / p.qsplit;
+    const int it0 = qs * per;
+    const int nt = it0 + per < nt_all ? it0 + per : nt_all;      // this workgroup walks query tiles [it0, nt)
     auto load_stats = [&](int q0) {
         if (tid < KVT) rl = q0 + tid < p.Nq ? lse_b[q0 + tid] * LOG2E : INFINITY;
         else if (tid < 2 * KVT) rl = q0 + tid - KVT < p.Nq ? del_b[q0 + tid - KVT] : 0.f;
     };
-    sq.load(Qb, p.q_rs, p.Nq < KVT ? p.Nq : KVT, tid);
-    sg.load(dOb, p.o_rs, p.Nq < KVT ? p.Nq : KVT, tid);
-    load_stats(0);
+    {
+        const int q0 = it0 * KVT;
+        const int nv0 = p.Nq - q0 < KVT ? (p.Nq - q0 > 0 ? p.Nq - q0 : 0) : KVT;
+        sq.load(Qb + (size_t)q0 * p.q_rs, p.q_rs, nv0, tid);
+        sg.load(dOb + (size_t)q0 * p.o_rs, p.o_rs, nv0, tid);
+        load_stats(q0);
+    }
 
     hcp_bf16x8 kf[KT][G::NQK], vf[KT][G::NQK];
     hcp_f32x4 dk[KT][G::NDV], dv[KT][G::NDV];
@@ -449,9 +460,9 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     store_all(lds);
     HCP_SYNC();
 
-    for (int it = 0; it < nt; ++it) {
+    for (int it = it0; it < nt; ++it) {
         const int q0 = it * KVT;
-        const hcp_bf16* sQ = lds + (NB == 2 ? (it & 1) : 0) * BUF;
+        const hcp_bf16* sQ = lds + (NB == 2 ? ((it - it0) & 1) : 0) * BUF;
         const hcp_bf16* sG = sQ + G::RM_ELEMS;
         const float* sL = (const float*)(sG + G::RM_ELEMS);
         if (it + 1 < nt) {
@@ -508,7 +519,7 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
                 }
             }
         if (NB == 2) {
-            if (it + 1 < nt) store_all(lds + ((it + 1) & 1) * BUF);
+            if (it + 1 < nt) store_all(lds + ((it + 1 - it0) & 1) * BUF);
             HCP_SYNC();
         } else {
             HCP_SYNC();
@@ -520,6 +531,19 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     for (int t = 0; t < KT; ++t) {
         const int row = k_base + t * 16 + fr;
         if (row >= p.Nk) continue;
+        if (p.qsplit > 1) {
+            float* k32 = p.dk32 + ((size_t)b * p.Nk + row) * (p.H * D) + h * D;
+            float* v32 = p.dv32 + ((size_t)b * p.Nk + row) * (p.H * D) + h * D;
+#pragma unroll
+            for (int d = 0; d < G::NDV; ++d) {
+                const int col = d * 16 + 4 * fg;
+                if (col < D) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { hcp_atomic_add(k32 + col + r, dk[t][d][r] * p.scale); hcp_atomic_add(v32 + col + r, dv[t][d][r]); }
+                }
+            }
+            continue;
+        }
         hcp_bf16* krow = p.dK + (size_t)b * p.k_bs + (size_t)row * p.k_rs + h * D;
         hcp_bf16* vrow = p.dV + (size_t)b * p.v_bs + (size_t)row * p.v_rs + h * D;
 #pragma unroll
@@ -533,6 +557,22 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
                 *(hcp_bf16x4*)(vrow + col) = wv;
             }
         }
+    }
+}
+
+// fp32 accumulators of the query-split dK/dV pass -> bf16 outputs (token-major, strided)
+HCP_KERNEL(256) attn_dkv_convert_kernel(AttnParams p, int B, int C) {
+    const int cv = C / 4;
+    const long total = (long)B * p.Nk * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 4; long r = i / cv; const int n = (int)(r % p.Nk); const int b = (int)(r / p.Nk);
+        const hcp_f32x4 k4 = *(const hcp_f32x4*)(p.dk32 + ((size_t)b * p.Nk + n) * C + c);
+        const hcp_f32x4 v4 = *(const hcp_f32x4*)(p.dv32 + ((size_t)b * p.Nk + n) * C + c);
+        hcp_bf16x4 wk, wv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { wk[q] = (short)hcp_f2bf(k4[q]); wv[q] = (short)hcp_f2bf(v4[q]); }
+        *(hcp_bf16x4*)(p.dK + (size_t)b * p.k_bs + (size_t)n * p.k_rs + c) = wk;
+        *(hcp_bf16x4*)(p.dV + (size_t)b * p.v_bs + (size_t)n * p.v_rs + c) = wv;
     }
 }
 
@@ -560,11 +600,32 @@ int launch_dq(AttnParams& p, int B, hipStream_t stream) {
     HCP_LAUNCH_CHECK("attn_bwd_dq");
 }
 template <int D, int KT>
-int launch_dkv(AttnParams& p, int B, hipStream_t stream) {
+int launch_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t stream) {
     using G = AttnGeom<D>;
     size_t s2 = (size_t)(2 * G::RM_ELEMS + 4 * KVT) * sizeof(hcp_bf16);
     if (2 * s2 <= 160 * 1024) s2 *= 2;
-    HCP_LAUNCH((attn_bwd_dkv_kernel<D, KT>), dim3(hcp_cdiv(p.Nk, 64 * KT), p.H, B), dim3(256), s2, stream, p);
+    const int nkv = hcp_cdiv(p.Nk, 64 * KT);
+    // few key tiles (cross-attention: 77 keys): split the query loop so the grid still fills the chip
+    const int nqt = hcp_cdiv(p.Nq, KVT);
+    int qsplit = 1;
+    const long base = (long)nkv * p.H * B;
+    const size_t need = (size_t)2 * B * p.Nk * p.H * D * sizeof(float);
+    if (base < 256 && nqt >= 8 && ws && ws_bytes >= need) {
+        qsplit = (int)((512 + base - 1) / base);
+        if (qsplit > nqt / 2) qsplit = nqt / 2;
+        if (qsplit < 1) qsplit = 1;
+    }
+    p.qsplit = qsplit;
+    if (qsplit > 1) {
+        p.dk32 = ws; p.dv32 = ws + (size_t)B * p.Nk * p.H * D;
+        if (hcp_memset_async(ws, 0, need, stream)) return hcp_set_error("attention_bwd: memset failed");
+    }
+    HCP_LAUNCH((attn_bwd_dkv_kernel<D, KT>), dim3(nkv * qsplit, p.H, B), dim3(256), s2, stream, p);
+    if (qsplit > 1) {
+        long tot = (long)B * p.Nk * (p.H * D / 4);
+        int g = (int)((tot + 255) / 256); if (g > 2048) g = 2048;
+        HCP_LAUNCH(attn_dkv_convert_kernel, dim3(g), dim3(256), 0, stream, p, B, p.H * D);
+    }
     HCP_LAUNCH_CHECK("attn_bwd_dkv");
 }
 
@@ -579,16 +640,17 @@ int run_fwd(AttnParams& p, int B, hipStream_t stream) {
     return launch_fwd<D, 1>(p, B, stream);
 }
 template <int D>
-int run_bwd(AttnParams& p, int B, hipStream_t stream) {
+int run_bwd(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t stream) {
     if (int e = launch_delta<D>(p, B, stream)) return e;
-    bool wq = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512, wk = false;   // measured: dQ likes 32 rows/wave, dK/dV 16
+    // measured on MI355X: 32 rows per wave pay off once the grid has >= 512 such workgroups
+    bool wq = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512, wk = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nk, 128) >= 512;
     if (g_attn_cfg >= 0) { wq = kWide<D> && (g_attn_cfg & 2); wk = kWide<D> && (g_attn_cfg & 4); }
     int e;
     if constexpr (kWide<D>) { e = wq ? launch_dq<D, 2>(p, B, stream) : launch_dq<D, 1>(p, B, stream); }
     else e = launch_dq<D, 1>(p, B, stream);
     if (e) return e;
-    if constexpr (kWide<D>) { return wk ? launch_dkv<D, 2>(p, B, stream) : launch_dkv<D, 1>(p, B, stream); }
-    return launch_dkv<D, 1>(p, B, stream);
+    if constexpr (kWide<D>) { return wk ? launch_dkv<D, 2>(p, B, ws, ws_bytes, stream) : launch_dkv<D, 1>(p, B, ws, ws_bytes, stream); }
+    return launch_dkv<D, 1>(p, B, ws, ws_bytes, stream);
 }
 
 int attn_check(const AttnParams& p, int B, int D) {
@@ -612,7 +674,7 @@ HCP_API int hcp_attention_fwd(const void* Q, const void* K, const void* V, void*
     AttnParams p = {};
     p.Q = (const hcp_bf16*)Q; p.K = (const hcp_bf16*)K; p.V = (const hcp_bf16*)V; p.Out = (hcp_bf16*)O; p.lse = lse;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
-    p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
+    p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = 1;
     HCP_REQUIRE(Q && K && V && O && lse, "hcp_attention_fwd: null pointer");
     if (int e = attn_check(p, B, D)) return e;
     switch (D) {
@@ -623,23 +685,25 @@ HCP_API int hcp_attention_fwd(const void* Q, const void* K, const void* V, void*
     }
 }
 
-// Gradients of hcp_attention_fwd.  delta is a [B,H,Nq] fp32 scratch buffer (caller-provided workspace).
+// Gradients of hcp_attention_fwd.  delta is a [B,H,Nq] fp32 scratch buffer; workspace (optional, 2*B*Nk*H*D floats)
+// lets short-key problems (cross-attention) split the query loop of the dK/dV pass across workgroups.
 HCP_API int hcp_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                               float* delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int D, long q_bs,
                               int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
-                              hipStream_t stream) {
+                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
     AttnParams p = {};
     p.Q = (const hcp_bf16*)Q; p.K = (const hcp_bf16*)K; p.V = (const hcp_bf16*)V; p.O = (const hcp_bf16*)O;
     p.dO = (const hcp_bf16*)dO; p.lse = (float*)lse; p.delta = delta;
     p.dQ = (hcp_bf16*)dQ; p.dK = (hcp_bf16*)dK; p.dV = (hcp_bf16*)dV;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
-    p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
+    p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = 1;
     HCP_REQUIRE(Q && K && V && O && dO && lse && delta && dQ && dK && dV, "hcp_attention_bwd: null pointer");
     if (int e = attn_check(p, B, D)) return e;
+    float* ws = (float*)workspace; const size_t wb = workspace ? workspace_bytes : 0;
     switch (D) {
-        case 40: return run_bwd<40>(p, B, stream);
-        case 64: return run_bwd<64>(p, B, stream);
-        case 80: return run_bwd<80>(p, B, stream);
-        default: return run_bwd<160>(p, B, stream);
+        case 40: return run_bwd<40>(p, B, ws, wb, stream);
+        case 64: return run_bwd<64>(p, B, ws, wb, stream);
+        case 80: return run_bwd<80>(p, B, ws, wb, stream);
+        default: return run_bwd<160>(p, B, ws, wb, stream);
     }
 }

@@ -172,8 +172,10 @@ def attention_bwd(q, k, v, o, do, lse, heads, scale=None):
     dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
     delta = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
     qb, qr = _attn_strides(q); kb, kr = _attn_strides(k); vb, vr = _attn_strides(v); ob, orr = _attn_strides(o)
+    ws = _workspace(q)
     _chk(lib().hcp_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, heads,
-                                 Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr, float(scale), _stream(q)), "hcp_attention_bwd")
+                                 Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr, float(scale), _p(ws), ws.numel(), _stream(q)),
+         "hcp_attention_bwd")
     return dq, dk, dv
 
 

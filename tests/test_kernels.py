@@ -105,7 +105,8 @@ def test_conv3x3_dgrad(backend, case):
 
 
 ATTN_CASES_EMU = [  # B, H, Nq, Nk, D
-    (1, 2, 64, 64, 40), (1, 1, 100, 77, 40), (2, 1, 32, 150, 80), (1, 1, 70, 70, 160), (1, 2, 16, 77, 64)]
+    (1, 2, 64, 64, 40), (1, 1, 100, 77, 40), (2, 1, 32, 150, 80), (1, 1, 70, 70, 160), (1, 2, 16, 77, 64),
+    (1, 1, 520, 77, 40)]      # last: long query / short key -> query-split dK/dV accumulation
 ATTN_CASES_GPU = ATTN_CASES_EMU + [(4, 8, 4096, 4096, 40), (4, 8, 4096, 77, 40), (4, 8, 1024, 1024, 80), (4, 8, 1024, 77, 80),
                                    (4, 8, 256, 256, 160), (4, 8, 256, 77, 160), (4, 8, 64, 64, 160), (2, 10, 4096, 4096, 64)]
 
