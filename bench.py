@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--rank-lora", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="keep the LoRA wgrad kernels on the main stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,7 +118,7 @@ def main():
             else:
                 p.zero_()
     tr = NativeTrainer(unet, [dict(layers=LORA_PATTERNS, rank=args.rank_lora, lr=1e-4)], lr=1e-4, weight_decay=1e-3,
-                       scale_lr_factor=args.batch * world, use_graph=not args.no_graph)
+                       scale_lr_factor=args.batch * world, use_graph=not args.no_graph, overlap_wgrad=not args.no_overlap)
     torch.manual_seed(114514 + rank)               # set_seed(seed + local_rank), train_ac.py:128
     with torch.no_grad():                          # non-zero W_up so every LoRA path carries signal
         for blk in tr.bucket.blocks:

@@ -612,8 +612,8 @@ int launch_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t str
     const size_t need = (size_t)2 * B * p.Nk * p.H * D * sizeof(float);
     if (base < 256 && nqt >= 8 && ws && ws_bytes >= need) {
         qsplit = (int)((512 + base - 1) / base);
-        if (qsplit > nqt / 2) qsplit = nqt / 2;
-        if (qsplit < 1) qsplit = 1;
+        if (qsplit > nqt / 8) qsplit = nqt / 8;       // >= 8 query tiles per workgroup, else memset + convert dominate
+        if (qsplit < 2) qsplit = 1;
     }
     p.qsplit = qsplit;
     if (qsplit > 1) {

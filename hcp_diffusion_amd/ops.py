@@ -10,6 +10,38 @@ from . import kernels as K
 
 BF16 = torch.bfloat16
 
+# ---- side stream for the LoRA weight-gradient kernels -------------------------------------------------------------
+# dW_down / dW_up are leaves of the backward graph (only the optimizer reads them), while the dX chain is a long
+# sequence of small, latency-bound kernels.  When enabled (NativeTrainer does), each layer's wgrad launch goes to a
+# second HIP stream, ordered after the dX kernel that produced U by an event, and joins the main stream once, after
+# the backward pass.  Under hipGraph capture this becomes a parallel branch of the graph.
+_side = {"enabled": False, "stream": None, "keep": []}
+
+
+def enable_wgrad_side_stream(flag=True):
+    _side["enabled"] = bool(flag)
+
+
+def join_side_stream():
+    """Make the current stream wait for every wgrad launched on the side stream; release the tensors kept alive for it."""
+    if _side["stream"] is not None and _side["keep"]:
+        torch.cuda.current_stream().wait_stream(_side["stream"])
+    _side["keep"].clear()
+
+
+def _wgrad(U, x2, gd, T, dy2, gu, rank, alpha):
+    if not (_side["enabled"] and x2.is_cuda):
+        K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
+        return
+    if _side["stream"] is None:
+        _side["stream"] = torch.cuda.Stream(device=x2.device)
+    ev = torch.cuda.Event()
+    ev.record()                                   # after the dX kernel (U is complete)
+    _side["stream"].wait_event(ev)
+    with torch.cuda.stream(_side["stream"]):
+        K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
+    _side["keep"].append((U, x2, T, dy2))         # the allocator must not recycle these before the side kernel ran
+
 
 def _no_host_grad(*params):
     if not torch.is_grad_enabled():
@@ -59,7 +91,7 @@ class _LinearFn(torch.autograd.Function):
             else:
                 U = K.gemm(dy2, lp.but)
             gd, gu = lora.grad_views()
-            K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, lora.rank, lora.alpha_f)
+            _wgrad(U, x2, gd, T, dy2, gu, lora.rank, lora.alpha_f)
         elif ctx.needs_input_grad[0]:
             dx = K.gemm(dy2, pk.wt)
         if dx is not None:

@@ -17,6 +17,7 @@ per-step ``loss.item()`` sync (train_ac.py:504) is deferred to whenever the call
 import torch
 
 from . import kernels as K
+from . import ops
 from .lora import make_lora
 
 
@@ -29,7 +30,8 @@ def ddpm_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0
 
 class NativeTrainer:
     def __init__(self, unet, lora_cfg, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
-                 scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000):
+                 scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000,
+                 overlap_wgrad=True):
         self.unet = unet
         self.device = next(unet.parameters()).device
         unet.requires_grad_(False)            # config_model(): freeze host, eval (train_ac.py:264-268)
@@ -50,6 +52,7 @@ class NativeTrainer:
         self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or
                                                                           torch.distributed.is_initialized()) else 1
         self.use_graph = use_graph
+        self.overlap_wgrad = overlap_wgrad and self.device.type == "cuda"
         self._graphs = None
         self._static = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -64,7 +67,12 @@ class NativeTrainer:
         noisy, noise, t = self.make_noise(latents)
         pred = self.unet(noisy, t, encoder_hidden_states).sample          # wrapper.py:29
         loss, grad = K.mse_masked_mean(pred.detach(), noise, mask, weight=self.loss_weight)    # loss.type == 'eps'
-        torch.autograd.backward(pred, grad)
+        ops.enable_wgrad_side_stream(self.overlap_wgrad)
+        try:
+            torch.autograd.backward(pred, grad)
+        finally:
+            ops.join_side_stream()               # LoRA wgrads ran on a parallel stream / graph branch
+            ops.enable_wgrad_side_stream(False)
         return loss
 
     def all_reduce(self):
