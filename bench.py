@@ -88,7 +88,8 @@ def main():
     ap.add_argument("--rank-lora", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="keep the LoRA wgrad kernels on the main stream")
+    ap.add_argument("--overlap", action="store_true", help="LoRA wgrad kernels on a side stream (measured slower)")
+    ap.add_argument("--no-grouped-wgrad", action="store_true", help="one wgrad launch per layer instead of one grouped launch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,7 +119,8 @@ def main():
             else:
                 p.zero_()
     tr = NativeTrainer(unet, [dict(layers=LORA_PATTERNS, rank=args.rank_lora, lr=1e-4)], lr=1e-4, weight_decay=1e-3,
-                       scale_lr_factor=args.batch * world, use_graph=not args.no_graph, overlap_wgrad=not args.no_overlap)
+                       scale_lr_factor=args.batch * world, use_graph=not args.no_graph, overlap_wgrad=args.overlap,
+                       grouped_wgrad=not args.no_grouped_wgrad)
     torch.manual_seed(114514 + rank)               # set_seed(seed + local_rank), train_ac.py:128
     with torch.no_grad():                          # non-zero W_up so every LoRA path carries signal
         for blk in tr.bucket.blocks:

@@ -56,6 +56,9 @@ _PROTOTYPES = {
     "hcp_lora_wgrad": (I, [P, I, P, I, P, I, I, I, I, F, I, P]),
     # U, x, ldx, K, grad_down, T, dY, ldy, N, grad_up, M, r, scale, stream
     "hcp_lora_wgrad_pair": (I, [P, P, I, I, P, P, P, I, I, P, I, I, F, P]),
+    "hcp_lora_wgrad_group_geometry": (I, [I, I, I, P, P, P]),
+    "hcp_lora_wgrad_group_desc_bytes": (I, []),
+    "hcp_lora_wgrad_grouped": (I, [P, I, I, P]),
     "hcp_lora_pack": (I, [P, I, P]),
     "hcp_lora_pack_desc_bytes": (I, []),
     "hcp_sumsq_f32": (I, [P, L, P, P]),

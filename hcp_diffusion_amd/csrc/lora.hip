@@ -20,17 +20,16 @@ constexpr int WG_LS = 32 + 2;     // LDS row stride of the L tile
 // transpose_out: element (p,q) lives at out[q * ldo + p] instead of out[p * ldo + q]
 struct WgradProb { const hcp_bf16* L; int ldl; const hcp_bf16* R; int ldr; float* out; int ldo; int Q; int transpose_out; };
 
-HCP_KERNEL(256) lora_wgrad_kernel(WgradProb pr0, WgradProb pr1, int M, int P, float scale, int rows_per_split) {
-    const WgradProb pr = blockIdx.z == 0 ? pr0 : pr1;
+HCP_DEVICE void wgrad_block(const WgradProb& pr, int M, int P, float scale, int rows_per_split, int qtile, int split) {
     const hcp_bf16* L = pr.L; const int ldl = pr.ldl; const hcp_bf16* R = pr.R; const int ldr = pr.ldr;
     float* out = pr.out; const int ldo = pr.ldo; const int Q = pr.Q; const int transpose_out = pr.transpose_out;
-    if ((int)blockIdx.x * WG_BQ >= Q) return;          // the pair shares one grid sized for the wider problem
+    if (qtile * WG_BQ >= Q) return;          // the pair shares one grid sized for the wider problem
     HCP_DYN_SMEM(smem);
     hcp_bf16* sL = (hcp_bf16*)smem;              // [WG_BM][WG_LS]
     hcp_bf16* sR = sL + WG_BM * WG_LS;           // [WG_BM][WG_RS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * WG_BQ;
-    const int mb = blockIdx.y * rows_per_split;
+    const int q0 = qtile * WG_BQ;
+    const int mb = split * rows_per_split;
     int me = mb + rows_per_split; if (me > M) me = M;
     const int fr = lane & 15, fg = lane >> 4;
 
@@ -94,6 +93,37 @@ HCP_KERNEL(256) lora_wgrad_kernel(WgradProb pr0, WgradProb pr1, int M, int P, fl
                 hcp_atomic_add(dst, acc[i][j][r] * scale);
             }
         }
+}
+
+HCP_KERNEL(256) lora_wgrad_kernel(WgradProb pr0, WgradProb pr1, int M, int P, float scale, int rows_per_split) {
+    wgrad_block(blockIdx.z == 0 ? pr0 : pr1, M, P, scale, rows_per_split, blockIdx.x, blockIdx.y);
+}
+
+// One launch for the weight gradients of MANY LoRA layers (all 160 of an SD1.5 step): workgroup -> (layer, problem,
+// column tile, token split) through a prefix table.  144-byte descriptors, device array:
+struct WgradGroupDesc {
+    WgradProb down;        // grad_down[r,K] += s U^T x
+    WgradProb up;          // grad_up[N,r]  += s dY^T T
+    int M, P; float scale; int rows_per_split;
+    int qt, splits;        // grid shape of this layer: qt column tiles x splits token ranges x 2 problems
+    int block_begin;       // first workgroup index of this layer in the grouped grid
+    int pad;
+};
+
+HCP_KERNEL(256) lora_wgrad_grouped_kernel(const WgradGroupDesc* descs, int count) {
+    // binary search the layer whose block range contains blockIdx.x (wave-uniform)
+    int lo = 0, hi = count - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_begin <= bid) lo = mid; else hi = mid - 1;
+    }
+    const WgradGroupDesc d = descs[lo];
+    int local = bid - d.block_begin;
+    const int per_prob = d.qt * d.splits;
+    const int z = local / per_prob; local -= z * per_prob;
+    const int split = local / d.qt, qtile = local - split * d.qt;
+    wgrad_block(z == 0 ? d.down : d.up, d.M, d.P, d.scale, d.rows_per_split, qtile, split);
 }
 
 struct LoraPackDesc {
@@ -170,6 +200,30 @@ HCP_API int hcp_lora_wgrad_pair(const void* U, const void* x, int ldx, int K, fl
     WgradProb a = {(const hcp_bf16*)U, 32, (const hcp_bf16*)x, ldx, grad_down, K, K, 0};
     WgradProb b = {(const hcp_bf16*)T, 32, (const hcp_bf16*)dY, ldy, grad_up, r, N, 1};
     return wgrad_launch(a, b, 2, M, r, scale, stream);
+}
+
+// Geometry the grouped launch uses for one layer: returns workgroups needed, fills qt / splits / rows_per_split.
+HCP_API int hcp_lora_wgrad_group_geometry(int M, int K, int N, int* qt, int* splits, int* rows_per_split) {
+    const int qmax = K > N ? K : N;
+    const int t = hcp_cdiv(qmax, WG_BQ);
+    int s = hcp_cdiv(256, t * 2);                 // grouped: many layers share the grid, fewer splits per layer
+    int maxs = hcp_cdiv(M, 4 * WG_BM);
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    int rows = hcp_cdiv(hcp_cdiv(M, s), WG_BM) * WG_BM;
+    s = hcp_cdiv(M, rows);
+    *qt = t; *splits = s; *rows_per_split = rows;
+    return t * s * 2;
+}
+HCP_API int hcp_lora_wgrad_group_desc_bytes(void) { return (int)sizeof(WgradGroupDesc); }
+
+// All layers' LoRA weight gradients in ONE launch.  descs: device array of `count` descriptors (layout: struct
+// WgradGroupDesc above; host builders: hcp_diffusion_amd/ops.py), total_blocks = sum of the per-layer workgroup counts.
+HCP_API int hcp_lora_wgrad_grouped(const void* descs, int count, int total_blocks, hipStream_t stream) {
+    HCP_REQUIRE(descs && count > 0 && total_blocks > 0, "hcp_lora_wgrad_grouped: bad arguments");
+    size_t smem = (size_t)(WG_BM * WG_LS + WG_BM * WG_RS) * sizeof(hcp_bf16);
+    HCP_LAUNCH(lora_wgrad_grouped_kernel, dim3(total_blocks), dim3(256), smem, stream, (const WgradGroupDesc*)descs, count);
+    HCP_LAUNCH_CHECK("lora_wgrad_grouped");
 }
 
 // One launch converts the fp32 master LoRA factors of `count` layers into the four bf16 operand

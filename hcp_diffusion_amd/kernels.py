@@ -367,6 +367,34 @@ def lora_wgrad_pair(U, x, grad_down, T, dy, grad_up, r, scale):
                                    float(scale), _stream(x)), "hcp_lora_wgrad_pair")
 
 
+def lora_wgrad_grouped(items):
+    """items: list of (U, x, grad_down, T, dy, grad_up, r, scale) — every layer's LoRA weight gradients, ONE launch."""
+    import struct
+    L = lib()
+    assert L.hcp_lora_wgrad_group_desc_bytes() == 144
+    qt, sp, rows = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    buf = bytearray()
+    begin = 0
+    for (U, x, gd, T, dy, gu, r, scale) in items:
+        M, Kd = x.shape
+        N = dy.shape[1]
+        nb = L.hcp_lora_wgrad_group_geometry(M, Kd, N, ctypes.byref(qt), ctypes.byref(sp), ctypes.byref(rows))
+        buf += struct.pack("<Qi4xQi4xQiii4x", U.data_ptr(), 32, x.data_ptr(), x.stride(0), gd.data_ptr(), Kd, Kd, 0)
+        buf += struct.pack("<Qi4xQi4xQiii4x", T.data_ptr(), 32, dy.data_ptr(), dy.stride(0), gu.data_ptr(), r, N, 1)
+        buf += struct.pack("<iifiiiii", M, r, float(scale), rows.value, qt.value, sp.value, begin, 0)
+        begin += nb
+    dev = items[0][1].device
+    host = torch.frombuffer(buf, dtype=torch.uint8)
+    if dev.type == "cuda":
+        host = host.pin_memory()
+        table = torch.empty(len(buf), dtype=torch.uint8, device=dev)
+        table.copy_(host, non_blocking=True)
+    else:
+        table = host.clone()
+    _chk(L.hcp_lora_wgrad_grouped(_p(table), len(items), begin, _stream(table)), "hcp_lora_wgrad_grouped")
+    return host, table       # the caller keeps these alive until the stream has consumed them (graph replays re-read them)
+
+
 def lora_pack(desc_tensor, count):
     _chk(lib().hcp_lora_pack(_p(desc_tensor), count, _stream(desc_tensor)), "hcp_lora_pack")
 

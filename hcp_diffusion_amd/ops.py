@@ -29,7 +29,27 @@ def join_side_stream():
     _side["keep"].clear()
 
 
+# ---- grouped LoRA weight gradients -------------------------------------------------------------------------------
+# dW_down / dW_up are leaves of the backward graph: instead of one small launch per layer inside the latency-bound
+# dX chain, the trainer collects (U, x, T, dY) of every layer and computes all 160 pairs in ONE launch at the end.
+_group = {"enabled": False, "items": [], "keep": []}
+
+
+def enable_grouped_wgrad(flag=True):
+    _group["enabled"] = bool(flag)
+
+
+def flush_grouped_wgrad():
+    if _group["items"]:
+        keep = K.lora_wgrad_grouped(_group["items"])
+        _group["keep"] = [keep, _group["items"]]      # descriptor table + operand tensors stay alive (hipGraph replays)
+        _group["items"] = []
+
+
 def _wgrad(U, x2, gd, T, dy2, gu, rank, alpha):
+    if _group["enabled"]:
+        _group["items"].append((U, x2, gd, T, dy2, gu, rank, alpha))
+        return
     if not (_side["enabled"] and x2.is_cuda):
         K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
         return

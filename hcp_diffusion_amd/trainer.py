@@ -31,7 +31,7 @@ def ddpm_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0
 class NativeTrainer:
     def __init__(self, unet, lora_cfg, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000,
-                 overlap_wgrad=True):
+                 overlap_wgrad=False, grouped_wgrad=True):
         self.unet = unet
         self.device = next(unet.parameters()).device
         unet.requires_grad_(False)            # config_model(): freeze host, eval (train_ac.py:264-268)
@@ -52,7 +52,10 @@ class NativeTrainer:
         self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or
                                                                           torch.distributed.is_initialized()) else 1
         self.use_graph = use_graph
+        # measured on MI355X / ROCm 7.2: the side-stream (parallel graph branch) form is SLOWER (32.6 vs 30.0 ms/step:
+        # every fork/join edge of the hipGraph costs more than the overlap buys); one grouped launch at the end wins.
         self.overlap_wgrad = overlap_wgrad and self.device.type == "cuda"
+        self.grouped_wgrad = grouped_wgrad
         self._graphs = None
         self._static = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -68,11 +71,14 @@ class NativeTrainer:
         pred = self.unet(noisy, t, encoder_hidden_states).sample          # wrapper.py:29
         loss, grad = K.mse_masked_mean(pred.detach(), noise, mask, weight=self.loss_weight)    # loss.type == 'eps'
         ops.enable_wgrad_side_stream(self.overlap_wgrad)
+        ops.enable_grouped_wgrad(self.grouped_wgrad)
         try:
             torch.autograd.backward(pred, grad)
+            ops.flush_grouped_wgrad()            # all layers' LoRA weight gradients: one grouped launch
         finally:
-            ops.join_side_stream()               # LoRA wgrads ran on a parallel stream / graph branch
+            ops.join_side_stream()
             ops.enable_wgrad_side_stream(False)
+            ops.enable_grouped_wgrad(False)
         return loss
 
     def all_reduce(self):

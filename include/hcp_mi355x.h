@@ -110,6 +110,10 @@ int hcp_lora_wgrad(const void* L, int ldl, const void* R, int ldr, float* out, i
 /* both gradients of one LoRA layer in one launch: grad_down[r,K] += s U^T x ; grad_up[N,r] += s dY^T T */
 int hcp_lora_wgrad_pair(const void* U, const void* x, int ldx, int K, float* grad_down, const void* T, const void* dY, int ldy,
                         int N, float* grad_up, int M, int r, float scale, hcpStream_t stream);
+/* the weight gradients of MANY LoRA layers in one launch (descriptor layout: csrc/lora.hip WgradGroupDesc, 144 B) */
+int hcp_lora_wgrad_group_geometry(int M, int K, int N, int* qt, int* splits, int* rows_per_split);
+int hcp_lora_wgrad_group_desc_bytes(void);
+int hcp_lora_wgrad_grouped(const void* descs, int count, int total_blocks, hcpStream_t stream);
 /* fp32 LoRA factors -> the four bf16 operand layouts, all layers in one launch (descs: device array, 64 B each:
  * {const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r; float alpha;}) */
 int hcp_lora_pack(const void* descs, int count, hcpStream_t stream);

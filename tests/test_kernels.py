@@ -367,3 +367,20 @@ def test_gemm_every_tile_config_and_splitk(backend, cfg):
         K.lib().hcp_debug_set_gemm_config(-1)
     assert relerr(out, ref) < 2e-5
     assert relerr(y.permute(0, 3, 1, 2), F.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), None, 1, 1)) < 2e-5
+
+
+def test_lora_wgrad_grouped(backend):
+    """Several layers' weight gradients in one grouped launch == the per-layer launches."""
+    torch.manual_seed(11)
+    to = backend.to
+    dev = backend.device
+    items, refs = [], []
+    for (M, Kd, N, r) in [(200, 64, 72, 4), (130, 320, 40, 8), (64, 40, 328, 8)]:
+        U, T, x, dy = rnd(M, 32), rnd(M, 32), rnd(M, Kd), rnd(M, N)
+        gd = torch.zeros(r, Kd, device=dev); gu = torch.zeros(N, r, device=dev)
+        items.append((to(U), to(x), gd, to(T), to(dy), gu, r, 0.5))
+        refs.append((0.5 * U.float()[:, :r].T @ x.float(), 0.5 * dy.float().T @ T.float()[:, :r]))
+    keep = K.lora_wgrad_grouped(items)
+    for it, (rd, ru) in zip(items, refs):
+        assert relerr(it[2], rd) < 2e-2 and relerr(it[5], ru) < 2e-2
+    del keep
