@@ -50,6 +50,7 @@ def _bf16_2d(t, name):
 BF16 = torch.bfloat16
 
 _WS = {}
+_WGTAB = {}
 _WS_BYTES = 128 << 20
 
 
@@ -384,15 +385,27 @@ def lora_wgrad_grouped(items):
         buf += struct.pack("<iifiiiii", M, r, float(scale), rows.value, qt.value, sp.value, begin, 0)
         begin += nb
     dev = items[0][1].device
-    host = torch.frombuffer(buf, dtype=torch.uint8)
+    src = torch.frombuffer(buf, dtype=torch.uint8)
     if dev.type == "cuda":
-        host = host.pin_memory()
-        table = torch.empty(len(buf), dtype=torch.uint8, device=dev)
-        table.copy_(host, non_blocking=True)
+        # persistent pinned staging buffer + device table (no allocation while a hipGraph is being captured)
+        key = (dev.index, len(buf))
+        slot = _WGTAB.get(key)
+        if slot is None:
+            slot = {"host": torch.empty(len(buf), dtype=torch.uint8).pin_memory(),
+                    "table": torch.empty(len(buf), dtype=torch.uint8, device=dev), "event": None}
+            _WGTAB[key] = slot
+        capturing = torch.cuda.is_current_stream_capturing()
+        if slot["event"] is not None and not capturing:
+            slot["event"].synchronize()           # the previous step's H2D copy has consumed the staging buffer
+        slot["host"].copy_(src)
+        slot["table"].copy_(slot["host"], non_blocking=True)
+        if not capturing:
+            slot["event"] = torch.cuda.Event(); slot["event"].record()
+        host, table = slot["host"], slot["table"]
     else:
-        table = host.clone()
+        host, table = src, src.clone()
     _chk(L.hcp_lora_wgrad_grouped(_p(table), len(items), begin, _stream(table)), "hcp_lora_wgrad_grouped")
-    return host, table       # the caller keeps these alive until the stream has consumed them (graph replays re-read them)
+    return host, table
 
 
 def lora_pack(desc_tensor, count):
