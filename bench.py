@@ -74,7 +74,7 @@ def dominant_kernel_roofline(dev):
     dt = e0.elapsed_time(e1) * 1e-3 / n
     flops = 2.0 * B * H * H * C * 9 * C
     ach = flops / dt / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<128,64,MODE=1> conv3x3 C320 64x64 B4", "achieved": round(ach, 1),
+    return {"bound": "mfma", "kernel": "gemm_glds_kernel<MODE=1,FAST> implicit-GEMM conv3x3 C320->320 @64x64, B=4 (+ split-K reduce when chosen)", "achieved": round(ach, 1),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4), "traffic": None,
             "avg_launch_us": round(dt * 1e6, 1)}
 
