@@ -18,11 +18,12 @@ constexpr int WG_LS = 32 + 2;     // LDS row stride of the L tile
 
 // out[p, q] (+)= scale * sum_m L[m, p] * R[m, q]      p < P (<= 32), q < Q
 // transpose_out: element (p,q) lives at out[q * ldo + p] instead of out[p * ldo + q]
-struct WgradProb { const hcp_bf16* L; int ldl; const hcp_bf16* R; int ldr; float* out; int ldo; int Q; int transpose_out; };
+struct WgradProb { const hcp_bf16* L; int ldl; const hcp_bf16* R; int ldr; float* out; int ldo; int Q; int transpose_out; int pcol0; };
 
 HCP_DEVICE void wgrad_block(const WgradProb& pr, int M, int P, float scale, int rows_per_split, int qtile, int split) {
     const hcp_bf16* L = pr.L; const int ldl = pr.ldl; const hcp_bf16* R = pr.R; const int ldr = pr.ldr;
     float* out = pr.out; const int ldo = pr.ldo; const int Q = pr.Q; const int transpose_out = pr.transpose_out;
+    const int pcol0 = pr.pcol0;                // this layer's rank slots are columns [pcol0, pcol0 + P) of L
     if (qtile * WG_BQ >= Q) return;          // the pair shares one grid sized for the wider problem
     HCP_DYN_SMEM(smem);
     hcp_bf16* sL = (hcp_bf16*)smem;              // [WG_BM][WG_LS]
@@ -87,8 +88,8 @@ HCP_DEVICE void wgrad_block(const WgradProb& pr, int M, int P, float scale, int 
             if (q >= Q) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int p = i * 16 + 4 * fg + r;
-                if (p >= P) continue;
+                const int p = i * 16 + 4 * fg + r - pcol0;
+                if (p < 0 || p >= P) continue;
                 float* dst = transpose_out ? out + (size_t)q * ldo + p : out + (size_t)p * ldo + q;
                 hcp_atomic_add(dst, acc[i][j][r] * scale);
             }
@@ -102,7 +103,7 @@ HCP_KERNEL(256) lora_wgrad_kernel(WgradProb pr0, WgradProb pr1, int M, int P, fl
 // One launch for the weight gradients of MANY LoRA layers (all 160 of an SD1.5 step): workgroup -> (layer, problem,
 // column tile, token split) through a prefix table.  144-byte descriptors, device array:
 struct WgradGroupDesc {
-    WgradProb down;        // grad_down[r,K] += s U^T x
+    WgradProb down;        // grad_down[r,K] += s U^T x      (56 bytes each)
     WgradProb up;          // grad_up[N,r]  += s dY^T T
     int M, P; float scale; int rows_per_split;
     int qt, splits;        // grid shape of this layer: qt column tiles x splits token ranges x 2 problems
@@ -129,36 +130,35 @@ HCP_KERNEL(256) lora_wgrad_grouped_kernel(const WgradGroupDesc* descs, int count
 struct LoraPackDesc {
     const float* w_down;   // [r, K]  fp32 master
     const float* w_up;     // [N, r]
-    hcp_bf16* ad;          // [32, K]   W_down, rows >= r zero         (B operand of T = x Ad^T)
-    hcp_bf16* adt;         // [K, 32]   alpha * W_down^T               (K-extension operand of dX)
-    hcp_bf16* bu;          // [N, 32]   alpha * W_up                   (K-extension operand of y)
-    hcp_bf16* but;         // [32, N]   W_up^T                         (B operand of U = dY Bu)
+    hcp_bf16* ad;          // [32, K]       rows slot0.. : W_down                         (B operand of T = x Ad^T)
+    hcp_bf16* adt;         // [K, 32]       cols slot0.. : alpha * W_down^T               (side-path operand of dX)
+    hcp_bf16* bu;          // [Ntot, 32]    rows n0.., cols slot0.. : alpha * W_up        (side-path operand of y)
+    hcp_bf16* but;         // [32, Ntot]    rows slot0.., cols n0.. : W_up^T              (B operand of U = dY Bu)
     int K, N, r;
     float alpha;
+    int slot0, n0, Ntot, pad;   // placement inside a (possibly shared) operand image; images are zero-initialised once
 };
 
 HCP_KERNEL(256) lora_pack_kernel(const LoraPackDesc* descs) {
     const LoraPackDesc d = descs[blockIdx.x];
     const int nchunk = gridDim.y, chunk = blockIdx.y;
-    // [32, K] / [K, 32] images of W_down: this block handles a slice of k
     const int kper = (d.K + nchunk - 1) / nchunk, k0 = chunk * kper;
     int k1 = k0 + kper; if (k1 > d.K) k1 = d.K;
-    for (int i = threadIdx.x; i < 32 * (k1 - k0); i += blockDim.x) {
-        // consecutive threads -> consecutive p for the [K,32] image (coalesced 64-byte rows), k-major overall
-        int kk = i >> 5, pp = i & 31;
+    for (int i = threadIdx.x; i < d.r * (k1 - k0); i += blockDim.x) {
+        int kk = i / d.r, pp = i - kk * d.r;
         int k = k0 + kk;
-        float w = pp < d.r ? d.w_down[(size_t)pp * d.K + k] : 0.f;
-        d.adt[(size_t)k * 32 + pp] = hcp_f2bf(w * d.alpha);
-        d.ad[(size_t)pp * d.K + k] = hcp_f2bf(w);
+        float w = d.w_down[(size_t)pp * d.K + k];
+        d.adt[(size_t)k * 32 + d.slot0 + pp] = hcp_f2bf(w * d.alpha);
+        d.ad[(size_t)(d.slot0 + pp) * d.K + k] = hcp_f2bf(w);
     }
     const int nper = (d.N + nchunk - 1) / nchunk, n0 = chunk * nper;
     int n1 = n0 + nper; if (n1 > d.N) n1 = d.N;
-    for (int i = threadIdx.x; i < 32 * (n1 - n0); i += blockDim.x) {
-        int nn = i >> 5, pp = i & 31;
+    for (int i = threadIdx.x; i < d.r * (n1 - n0); i += blockDim.x) {
+        int nn = i / d.r, pp = i - nn * d.r;
         int n = n0 + nn;
-        float w = pp < d.r ? d.w_up[(size_t)n * d.r + pp] : 0.f;
-        d.bu[(size_t)n * 32 + pp] = hcp_f2bf(w * d.alpha);
-        d.but[(size_t)pp * d.N + n] = hcp_f2bf(w);
+        float w = d.w_up[(size_t)n * d.r + pp];
+        d.bu[(size_t)(d.n0 + n) * 32 + d.slot0 + pp] = hcp_f2bf(w * d.alpha);
+        d.but[(size_t)(d.slot0 + pp) * d.Ntot + d.n0 + n] = hcp_f2bf(w);
     }
 }
 
@@ -186,7 +186,7 @@ HCP_API int hcp_lora_wgrad(const void* L, int ldl, const void* R, int ldr, float
                            float scale, int transpose_out, hipStream_t stream) {
     HCP_REQUIRE(L && R && out && M > 0 && Q > 0, "hcp_lora_wgrad: bad arguments");
     HCP_REQUIRE(P > 0 && P <= 32 && ldl % 8 == 0 && ldl >= 32 && ldr % 8 == 0 && Q % 8 == 0, "hcp_lora_wgrad: P<=32, ldl>=32, 8-aligned leading dims required");
-    WgradProb a = {(const hcp_bf16*)L, ldl, (const hcp_bf16*)R, ldr, out, ldo, Q, transpose_out};
+    WgradProb a = {(const hcp_bf16*)L, ldl, (const hcp_bf16*)R, ldr, out, ldo, Q, transpose_out, 0};
     return wgrad_launch(a, a, 1, M, P, scale, stream);
 }
 
@@ -197,8 +197,8 @@ HCP_API int hcp_lora_wgrad_pair(const void* U, const void* x, int ldx, int K, fl
                                 int ldy, int N, float* grad_up, int M, int r, float scale, hipStream_t stream) {
     HCP_REQUIRE(U && x && grad_down && T && dY && grad_up && M > 0 && K > 0 && N > 0, "hcp_lora_wgrad_pair: bad arguments");
     HCP_REQUIRE(r > 0 && r <= 32 && ldx % 8 == 0 && ldy % 8 == 0 && K % 8 == 0 && N % 8 == 0, "hcp_lora_wgrad_pair: r<=32, 8-aligned dims required");
-    WgradProb a = {(const hcp_bf16*)U, 32, (const hcp_bf16*)x, ldx, grad_down, K, K, 0};
-    WgradProb b = {(const hcp_bf16*)T, 32, (const hcp_bf16*)dY, ldy, grad_up, r, N, 1};
+    WgradProb a = {(const hcp_bf16*)U, 32, (const hcp_bf16*)x, ldx, grad_down, K, K, 0, 0};
+    WgradProb b = {(const hcp_bf16*)T, 32, (const hcp_bf16*)dY, ldy, grad_up, r, N, 1, 0};
     return wgrad_launch(a, b, 2, M, r, scale, stream);
 }
 
@@ -228,7 +228,8 @@ HCP_API int hcp_lora_wgrad_grouped(const void* descs, int count, int total_block
 
 // One launch converts the fp32 master LoRA factors of `count` layers into the four bf16 operand
 // layouts the GEMMs consume. `descs` is a DEVICE array of 64-byte descriptors:
-//   { const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r; float alpha; }
+//   { const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r; float alpha;
+//     int slot0; int n0; int Ntot; int pad; }   (80 bytes; the operand images must be zero-initialised once by the caller)
 HCP_API int hcp_lora_pack(const void* descs, int count, hipStream_t stream) {
     HCP_REQUIRE(descs && count > 0, "hcp_lora_pack: bad arguments");
     HCP_LAUNCH(lora_pack_kernel, dim3(count, 16), dim3(256), 0, stream, (const LoraPackDesc*)descs);

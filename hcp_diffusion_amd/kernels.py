@@ -163,14 +163,20 @@ def attention_fwd(q, k, v, heads, scale=None):
     return o, lse
 
 
-def attention_bwd(q, k, v, o, do, lse, heads, scale=None):
+def attention_bwd(q, k, v, o, do, lse, heads, scale=None, out=None):
+    """Gradients (dq, dk, dv).  q/k/v may be column-slice views of a fused projection buffer; `out` = preallocated
+    (dq, dk, dv) with the SAME strides as (q, k, v) (e.g. slices of one [B,N,3C] gradient buffer)."""
     B, Nq, C = q.shape
     Nk = k.shape[1]
     D = C // heads
     scale = scale if scale is not None else 1.0 / math.sqrt(D)
-    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and o.is_contiguous() and do.is_contiguous(), \
-        "attention_bwd: contiguous q/k/v/o/do required (gradients are written with the same strides)"
-    dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
+    assert o.is_contiguous() and do.is_contiguous()
+    if out is None:
+        assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous(), "strided q/k/v need matching `out` buffers"
+        dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
+    else:
+        dq, dk, dv = out
+        assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
     delta = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
     qb, qr = _attn_strides(q); kb, kr = _attn_strides(k); vb, vr = _attn_strides(v); ob, orr = _attn_strides(o)
     ws = _workspace(q)
@@ -369,19 +375,22 @@ def lora_wgrad_pair(U, x, grad_down, T, dy, grad_up, r, scale):
 
 
 def lora_wgrad_grouped(items):
-    """items: list of (U, x, grad_down, T, dy, grad_up, r, scale) — every layer's LoRA weight gradients, ONE launch."""
+    """items: list of (U, x, grad_down, T, dy, grad_up, r, scale[, slot0]) — every layer's LoRA weight gradients, ONE launch.
+    dy may be a column-slice view (row stride = its stride(0)); slot0 = first rank column of the layer in U / T."""
     import struct
     L = lib()
     assert L.hcp_lora_wgrad_group_desc_bytes() == 144
     qt, sp, rows = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     buf = bytearray()
     begin = 0
-    for (U, x, gd, T, dy, gu, r, scale) in items:
+    for item in items:
+        (U, x, gd, T, dy, gu, r, scale) = item[:8]
+        slot0 = item[8] if len(item) > 8 else 0          # first rank column of this layer inside U / T (fused groups)
         M, Kd = x.shape
         N = dy.shape[1]
         nb = L.hcp_lora_wgrad_group_geometry(M, Kd, N, ctypes.byref(qt), ctypes.byref(sp), ctypes.byref(rows))
-        buf += struct.pack("<Qi4xQi4xQiii4x", U.data_ptr(), 32, x.data_ptr(), x.stride(0), gd.data_ptr(), Kd, Kd, 0)
-        buf += struct.pack("<Qi4xQi4xQiii4x", T.data_ptr(), 32, dy.data_ptr(), dy.stride(0), gu.data_ptr(), r, N, 1)
+        buf += struct.pack("<Qi4xQi4xQiiii", U.data_ptr(), 32, x.data_ptr(), x.stride(0), gd.data_ptr(), Kd, Kd, 0, slot0)
+        buf += struct.pack("<Qi4xQi4xQiiii", T.data_ptr(), 32, dy.data_ptr(), dy.stride(0), gu.data_ptr(), r, N, 1, slot0)
         buf += struct.pack("<iifiiiii", M, r, float(scale), rows.value, qt.value, sp.value, begin, 0)
         begin += nb
     dev = items[0][1].device

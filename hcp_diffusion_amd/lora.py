@@ -126,31 +126,60 @@ class _LoraOperands:
     pass
 
 
+class FusedLoraGroup:
+    """Several LoRA'd Linear layers that read the SAME input and are evaluated as ONE fused-LoRA GEMM
+    (q/k/v of self-attention; k/v of cross-attention): outputs concatenated along N, the layers' rank slots packed
+    side by side in one 32-wide slot group.  `blocks[i]` may be None for a host without LoRA."""
+
+    def __init__(self, hosts, blocks):
+        self.hosts, self.blocks = list(hosts), list(blocks)
+        self.n_off, n = [], 0
+        for h in self.hosts:
+            self.n_off.append(n); n += h.weight.shape[0]
+        self.n_total = n
+        self.k = self.hosts[0].weight.shape[1]
+        self.slot_off, sl = [], 0
+        for b in self.blocks:
+            self.slot_off.append(sl); sl += 8 * ((b.rank + 7) // 8) if b is not None else 0
+        self.slots = sl
+        self.has_lora = any(b is not None for b in self.blocks)
+        self._pk = None
+        self.ops = None         # _LoraOperands with the fused images (set by LoraBucket.add_group)
+
+    def packed_host(self):
+        """bf16 [Ntot, K] (forward B operand) and [K, Ntot] (dX B operand) of the concatenated frozen host weights."""
+        key = tuple((h.weight._version, h.weight.data_ptr()) for h in self.hosts)
+        if self._pk is None or self._pk[0] != key:
+            w = torch.cat([h.weight.detach().reshape(h.weight.shape[0], -1) for h in self.hosts], 0).to(BF16).contiguous()
+            self._pk = (key, w, w.t().contiguous())
+        return self._pk[1], self._pk[2]
+
+
 class LoraBucket:
     """All LoRA factors of a model in ONE flat fp32 parameter buffer + ONE flat gradient buffer.
 
     * W_down/W_up become views into `params`; their `.grad` are views into `grads` (so torch optimizers, the
       reference's clip_grad_norm_ and checkpointing still see ordinary parameters);
-    * `pack()` refreshes the bf16 operand copies of every layer with one kernel launch (call once per step,
-      after the optimizer update);
+    * `pack()` refreshes the bf16 operand copies of every layer (and of every fused group) with one kernel launch
+      (call once per step, after the optimizer update);
     * the data-parallel exchange is one all-reduce of `grads` (dist.py), the optimizer one fused launch (optim.py).
     """
 
     def __init__(self, blocks):
         self.blocks = list(blocks)
         dev = self.blocks[0].layer.W_down.device
+        self.device = dev
         n = sum(b.layer.W_down.numel() + b.layer.W_up.numel() for b in self.blocks)
         self.params = torch.empty(n, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
-        nb = sum(2 * RANK_SLOT * (b.layer.W_down.shape[1] + b.layer.W_up.shape[0]) for b in self.blocks)
-        self.operands = torch.zeros(nb, dtype=BF16, device=dev)
-        off, ooff = 0, 0
-        descs = bytearray()
+        off = 0
         self._ops = {}
         self._gviews = {}
+        self._desc_bytes = bytearray()
+        self._desc_count = 0
+        self._images = []          # zero-initialised operand images (kept alive)
+        self.groups = []
         for b in self.blocks:
-            r, k = b.layer.W_down.shape
-            n_out = b.layer.W_up.shape[0]
             views = []
             for p in (b.layer.W_down, b.layer.W_up):
                 v = self.params[off:off + p.numel()].view_as(p)
@@ -161,28 +190,62 @@ class LoraBucket:
                 views.append(g)
                 off += p.numel()
             self._gviews[id(b)] = tuple(views)
-            o = _LoraOperands()
-            o.ad = self.operands[ooff:ooff + RANK_SLOT * k].view(RANK_SLOT, k); ooff += RANK_SLOT * k
-            o.adt = self.operands[ooff:ooff + RANK_SLOT * k].view(k, RANK_SLOT); ooff += RANK_SLOT * k
-            o.bu = self.operands[ooff:ooff + RANK_SLOT * n_out].view(n_out, RANK_SLOT); ooff += RANK_SLOT * n_out
-            o.but = self.operands[ooff:ooff + RANK_SLOT * n_out].view(RANK_SLOT, n_out); ooff += RANK_SLOT * n_out
-            self._ops[id(b)] = o
-            descs += struct.pack("<6Q3if", b.layer.W_down.data_ptr(), b.layer.W_up.data_ptr(), o.ad.data_ptr(), o.adt.data_ptr(),
-                                 o.bu.data_ptr(), o.but.data_ptr(), k, n_out, r, b.alpha_f)
+            r, k = b.layer.W_down.shape
+            n_out = b.layer.W_up.shape[0]
+            self._ops[id(b)] = self._new_images(k, n_out)
+            self._add_desc(b, self._ops[id(b)], 0, 0, n_out)
             b._bucket = self
-        assert K.lib().hcp_lora_pack_desc_bytes() == 64
-        self.descs = torch.frombuffer(descs, dtype=torch.uint8).to(dev)
+        assert K.lib().hcp_lora_pack_desc_bytes() == 80
+        self._upload_descs()
         self._packed_version = None
         self.pack()
 
+    def _new_images(self, k, n_total):
+        o = _LoraOperands()
+        img = torch.zeros(2 * RANK_SLOT * (k + n_total), dtype=BF16, device=self.device)   # padding stays zero forever
+        self._images.append(img)
+        a = RANK_SLOT * k; c = RANK_SLOT * n_total
+        o.ad = img[0:a].view(RANK_SLOT, k); o.adt = img[a:2 * a].view(k, RANK_SLOT)
+        o.bu = img[2 * a:2 * a + c].view(n_total, RANK_SLOT); o.but = img[2 * a + c:2 * a + 2 * c].view(RANK_SLOT, n_total)
+        return o
+
+    def _add_desc(self, b, o, slot0, n0, n_total):
+        r, k = b.layer.W_down.shape
+        n_out = b.layer.W_up.shape[0]
+        self._desc_bytes += struct.pack("<6Q3if4i", b.layer.W_down.data_ptr(), b.layer.W_up.data_ptr(), o.ad.data_ptr(), o.adt.data_ptr(),
+                                        o.bu.data_ptr(), o.but.data_ptr(), k, n_out, r, b.alpha_f, slot0, n0, n_total, 0)
+        self._desc_count += 1
+
+    def _upload_descs(self):
+        self.descs = torch.frombuffer(bytearray(self._desc_bytes), dtype=torch.uint8).to(self.device)
+
+    def add_group(self, group):
+        """Register a FusedLoraGroup: allocate its shared operand images and pack descriptors (one per member block)."""
+        if group.slots > RANK_SLOT:
+            raise ValueError("fused LoRA group needs more than 32 rank slots")
+        group.ops = self._new_images(group.k, group.n_total)
+        for b, n0, s0 in zip(group.blocks, group.n_off, group.slot_off):
+            if b is not None:
+                assert b._bucket is self
+                self._add_desc(b, group.ops, s0, n0, group.n_total)
+        self._upload_descs()
+        self.groups.append(group)
+        self.pack()
+        return group
+
     def pack(self):
-        K.lora_pack(self.descs, len(self.blocks))
+        K.lora_pack(self.descs, self._desc_count)
         self._packed_version = self.params._version
 
     def packed_for(self, blk):
         if self._packed_version != self.params._version:
             self.pack()
         return self._ops[id(blk)]
+
+    def packed_group(self, group):
+        if self._packed_version != self.params._version:
+            self.pack()
+        return group.ops
 
     def grad_views_for(self, blk):
         gd, gu = self._gviews[id(blk)]

@@ -46,9 +46,12 @@ def flush_grouped_wgrad():
         _group["items"] = []
 
 
-def _wgrad(U, x2, gd, T, dy2, gu, rank, alpha):
+def _wgrad(U, x2, gd, T, dy2, gu, rank, alpha, slot0=0):
     if _group["enabled"]:
-        _group["items"].append((U, x2, gd, T, dy2, gu, rank, alpha))
+        _group["items"].append((U, x2, gd, T, dy2, gu, rank, alpha, slot0))
+        return
+    if slot0 != 0 or not dy2.is_contiguous():     # member of a fused group: the grouped entry point handles slots / strides
+        _group["keep"] = [K.lora_wgrad_grouped([(U, x2, gd, T, dy2, gu, rank, alpha, slot0)])]
         return
     if not (_side["enabled"] and x2.is_cuda):
         K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
@@ -126,6 +129,59 @@ def linear(x, host, lora=None, residual=None, out_f32=False):
     if out_f32 and (lora is not None or x.requires_grad):
         raise NotImplementedError("hcp_diffusion_amd: fp32 linear output is only provided for the gradient-free time-embedding path")
     return _LinearFn.apply(x, residual, wd, wu, host, lora, out_f32)
+
+
+class _LinearGroupFn(torch.autograd.Function):
+    """Several frozen Linear layers (+ their LoRA blocks) reading the same input, as ONE fused-LoRA GEMM:
+    y = x [W_0; W_1; ...]^T + T E^T with every block's rank slots packed side by side (lora.FusedLoraGroup)."""
+
+    @staticmethod
+    def forward(ctx, x, group, *lora_params):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        w, _ = group.packed_host()
+        T = None
+        if group.has_lora:
+            o = group.bucket.packed_group(group)
+            y, T = K.gemm_lora(x2, w, o.ad, o.bu)
+        else:
+            y = K.gemm(x2, w)
+        ctx.group = group
+        ctx.save_for_backward(x2 if group.has_lora else None, T)
+        ctx.xshape = shp
+        return y.view(*shp[:-1], group.n_total)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, T = ctx.saved_tensors
+        g = ctx.group
+        dy2 = dy.reshape(-1, g.n_total)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        _, wt = g.packed_host()
+        dx = None
+        if g.has_lora:
+            o = g.bucket.packed_group(g)
+            if ctx.needs_input_grad[0]:
+                dx, U = K.gemm_lora(dy2, wt, o.but, o.adt)
+            else:
+                U = K.gemm(dy2, o.but)
+            for blk, n0, s0, host in zip(g.blocks, g.n_off, g.slot_off, g.hosts):
+                if blk is not None:
+                    gd, gu = blk.grad_views()
+                    _wgrad(U, x2, gd, T, dy2[:, n0:n0 + host.weight.shape[0]], gu, blk.rank, blk.alpha_f, s0)
+        elif ctx.needs_input_grad[0]:
+            dx = K.gemm(dy2, wt)
+        if dx is not None:
+            dx = dx.view(ctx.xshape)
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def linear_group(x, group):
+    for h in group.hosts:
+        _no_host_grad(h.weight, h.bias)
+    params = [p for b in group.blocks if b is not None for p in (b.layer.W_down, b.layer.W_up)]
+    return _LinearGroupFn.apply(x, group, *params)
 
 
 class _Conv3x3Fn(torch.autograd.Function):
@@ -291,6 +347,42 @@ class _AttentionFn(torch.autograd.Function):
 
 def attention(q, k, v, heads):
     return _AttentionFn.apply(q, k, v, heads)
+
+
+class _AttentionPackedFn(torch.autograd.Function):
+    """Attention on fused projection buffers: `a` = [B,N,3C] (q|k|v, self-attention) or `a` = q [B,N,C] with
+    `kv` = [B,Nk,2C] (k|v, cross-attention).  The kernels read the column slices in place and write the gradients
+    into ONE buffer per input — no slice/concat nodes in the autograd graph."""
+
+    @staticmethod
+    def forward(ctx, a, kv, heads):
+        if kv is None:
+            C = a.shape[-1] // 3
+            q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
+        else:
+            C = a.shape[-1]
+            q, k, v = a, kv[..., :C], kv[..., C:]
+        o, lse = K.attention_fwd(q, k, v, heads)
+        ctx.save_for_backward(a, kv, o, lse)
+        ctx.heads, ctx.C = heads, C
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        a, kv, o, lse = ctx.saved_tensors
+        C = ctx.C
+        if kv is None:
+            da = torch.empty_like(a)
+            q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
+            K.attention_bwd(q, k, v, o, do.contiguous(), lse, ctx.heads, out=(da[..., :C], da[..., C:2 * C], da[..., 2 * C:]))
+            return da, None, None
+        da = torch.empty_like(a); dkv = torch.empty_like(kv)
+        K.attention_bwd(a, kv[..., :C], kv[..., C:], o, do.contiguous(), lse, ctx.heads, out=(da, dkv[..., :C], dkv[..., C:]))
+        return da, dkv, None
+
+
+def attention_packed(a, kv, heads):
+    return _AttentionPackedFn.apply(a, kv, heads)
 
 
 class _AddFn(torch.autograd.Function):

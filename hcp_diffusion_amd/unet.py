@@ -89,6 +89,22 @@ class ResnetBlock2D(nn.Module):
         return self.conv2(h, residual=sc)
 
 
+def _fusable_linear(m):
+    """(host, lora block or None) if `m` is a native bias-free Linear — bare or in a single-block native LoRA
+    container — with no hooks attached (a hooked module must be called through __call__); else None."""
+    from .lora import LoraHipContainer
+    host, blk = m, None
+    if isinstance(m, LoraHipContainer):
+        if len(m.plugin_names) != 1:
+            return None
+        host, blk = m._host, m[m.plugin_names[0]]
+        if m._forward_hooks or m._forward_pre_hooks:
+            return None
+    if type(host) is not HipLinear or host.bias is not None or host._forward_hooks or host._forward_pre_hooks:
+        return None
+    return host, blk
+
+
 class CrossAttention(nn.Module):
     def __init__(self, dim, ctx_dim, heads):
         super().__init__()
@@ -97,11 +113,44 @@ class CrossAttention(nn.Module):
         self.to_k = HipLinear(ctx_dim, dim, bias=False)
         self.to_v = HipLinear(ctx_dim, dim, bias=False)
         self.to_out = nn.ModuleList([HipLinear(dim, dim), nn.Dropout(0.0)])
+        self._groups = {}
+
+    def _group(self, mods):
+        """FusedLoraGroup for projections that share an input, or None when any of them must stay a separate call."""
+        from .lora import FusedLoraGroup
+        key = tuple(id(m) for m in mods)
+        hit = self._groups.get(key)
+        if hit is not None:
+            return hit[0]
+        pairs = [_fusable_linear(m) for m in mods]
+        group = None
+        if all(p is not None for p in pairs):
+            blocks = [p[1] for p in pairs]
+            buckets = {id(b._bucket) for b in blocks if b is not None}
+            ok = len(buckets) <= 1 and all(b is None or b._bucket is not None for b in blocks)
+            if ok and sum(8 * ((b.rank + 7) // 8) for b in blocks if b is not None) <= 32:
+                group = FusedLoraGroup([p[0] for p in pairs], blocks)
+                lb = next((b for b in blocks if b is not None), None)
+                group.bucket = lb._bucket if lb is not None else None
+                if lb is not None:
+                    group.bucket.add_group(group)
+        self._groups = {key: (group, mods)}          # keeps the modules alive so the ids stay unique
+        return group
 
     def forward(self, x, context=None, residual=None):
-        ctx = x if context is None else context
-        q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
-        o = ops.attention(q, k, v, self.heads)
+        if context is None:
+            g = self._group((self.to_q, self.to_k, self.to_v))
+            if g is not None:                          # q|k|v in one fused-LoRA GEMM, attention reads the slices in place
+                o = ops.attention_packed(ops.linear_group(x, g), None, self.heads)
+            else:
+                o = ops.attention(self.to_q(x), self.to_k(x), self.to_v(x), self.heads)
+        else:
+            q = self.to_q(x)
+            g = self._group((self.to_k, self.to_v))
+            if g is not None:
+                o = ops.attention_packed(q, ops.linear_group(context, g), self.heads)
+            else:
+                o = ops.attention(q, self.to_k(context), self.to_v(context), self.heads)
         return _call_res(self.to_out[0], o, residual) if residual is not None else self.to_out[0](o)
 
 

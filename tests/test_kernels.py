@@ -288,10 +288,11 @@ def test_lora_wgrad_and_pack(backend, M, Kd, N, r):
     dev = backend.device
     wd = torch.randn(r, Kd) * 0.1; wu = torch.randn(N, r) * 0.1; alpha = 1.0 / r
     wd_d, wu_d = to(wd), to(wu)
-    ad = torch.empty(32, Kd, dtype=BF, device=dev); adt = torch.empty(Kd, 32, dtype=BF, device=dev)
-    bu = torch.empty(N, 32, dtype=BF, device=dev); but = torch.empty(32, N, dtype=BF, device=dev)
-    assert K.lib().hcp_lora_pack_desc_bytes() == 64
-    desc = struct.pack("<6Q3if", wd_d.data_ptr(), wu_d.data_ptr(), ad.data_ptr(), adt.data_ptr(), bu.data_ptr(), but.data_ptr(), Kd, N, r, alpha)
+    ad = torch.zeros(32, Kd, dtype=BF, device=dev); adt = torch.zeros(Kd, 32, dtype=BF, device=dev)      # zero-initialised images
+    bu = torch.zeros(N, 32, dtype=BF, device=dev); but = torch.zeros(32, N, dtype=BF, device=dev)
+    assert K.lib().hcp_lora_pack_desc_bytes() == 80
+    desc = struct.pack("<6Q3if4i", wd_d.data_ptr(), wu_d.data_ptr(), ad.data_ptr(), adt.data_ptr(), bu.data_ptr(), but.data_ptr(), Kd, N, r, alpha,
+                       0, 0, N, 0)
     dt = torch.frombuffer(bytearray(desc), dtype=torch.uint8).to(dev)
     K.lora_pack(dt, 1)
     assert relerr(ad[:r], wd) < 1e-2 and ad[r:].abs().max().item() == 0
