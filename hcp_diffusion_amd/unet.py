@@ -32,6 +32,12 @@ def _call_res(mod, x, residual):
     return ops.add(mod(x), residual)     # e.g. the reference's own LoraPatchContainer swallows extra kwargs
 
 
+def _tb(temb_act, resnet):
+    """This resnet's slice of the batched time-embedding projection, if the UNet attached one to `temb_act`."""
+    table = getattr(temb_act, "_hcp_tb", None)
+    return table.get(id(resnet)) if table is not None else None
+
+
 class Timesteps(nn.Module):
     def __init__(self, dim):
         super().__init__()
@@ -71,15 +77,18 @@ class ResnetBlock2D(nn.Module):
             self.conv_shortcut = HipConv2d(cin, cout, 1)
         self.gradient_checkpointing = False
 
-    def forward(self, x, temb_act, skip=None):
-        """x [B,H,W,C] (+ optional skip tensor = the up-path concat, never materialised); temb_act = SiLU(temb)."""
+    def forward(self, x, temb_act, skip=None, temb_bias=None):
+        """x [B,H,W,C] (+ optional skip tensor = the up-path concat); temb_act = SiLU(temb); temb_bias = this block's
+        slice of the batched time-embedding projection (fp32 [B,Cout]) when the UNet precomputed it."""
         if skip is not None:
             x = ops.concat_channels(x, skip)          # GroupNorm needs the joint tensor once; convs read it back
         if hasattr(self, "conv_shortcut"):
             h = self.norm1(x, silu=True)
         else:
             h, x = self.norm1(x, silu=True, fork=True)       # x continues as the identity residual
-        if isinstance(self.time_emb_proj, HipLinear):  # [B, Cout] fp32 row bias fused into conv1's epilogue
+        if temb_bias is not None:
+            tb = temb_bias
+        elif isinstance(self.time_emb_proj, HipLinear):  # [B, Cout] fp32 row bias fused into conv1's epilogue
             tb = self.time_emb_proj(temb_act, out_f32=True)
         else:
             tb = self.time_emb_proj(temb_act).float()
@@ -244,7 +253,7 @@ class _DownBlock(nn.Module):
     def forward(self, h, temb_act, context):
         skips = ()
         for i, res in enumerate(self.resnets):
-            h = res(h, temb_act)
+            h = res(h, temb_act, temb_bias=_tb(temb_act, res))
             if self.has_attn:
                 h = self.attentions[i](h, context)
             skips += (h,)
@@ -271,9 +280,9 @@ class UNetMidBlock2DCrossAttn(nn.Module):
         self.gradient_checkpointing = False
 
     def forward(self, h, temb_act, context):
-        h = self.resnets[0](h, temb_act)
+        h = self.resnets[0](h, temb_act, temb_bias=_tb(temb_act, self.resnets[0]))
         h = self.attentions[0](h, context)
-        return self.resnets[1](h, temb_act)
+        return self.resnets[1](h, temb_act, temb_bias=_tb(temb_act, self.resnets[1]))
 
 
 class _UpBlock(nn.Module):
@@ -296,7 +305,7 @@ class _UpBlock(nn.Module):
 
     def forward(self, h, skips, temb_act, context):
         for i, res in enumerate(self.resnets):
-            h = res(h, temb_act, skip=skips[-1])
+            h = res(h, temb_act, skip=skips[-1], temb_bias=_tb(temb_act, res))
             skips = skips[:-1]
             if self.has_attn:
                 h = self.attentions[i](h, context)
@@ -390,6 +399,27 @@ class NativeUNet2DConditionModel(nn.Module):
         raise NotImplementedError("hcp_diffusion_amd: gradient checkpointing is not implemented (288 GB HBM holds all SD1.5/SDXL "
                                   "activations at the benchmark batch sizes); set model.gradient_checkpointing: False")
 
+    def _batched_time_proj(self, temb_act):
+        """All ResnetBlock2D.time_emb_proj layers read the same SiLU(temb): evaluate them as ONE GEMM against the
+        concatenated (frozen) weights and hand each block its fp32 column slice (22 tiny launches -> 1)."""
+        res = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        ok = (not temb_act.requires_grad) and all(
+            type(r.time_emb_proj) is HipLinear and not r.time_emb_proj.weight.requires_grad and not r.time_emb_proj._forward_hooks
+            and not r.time_emb_proj._forward_pre_hooks for r in res)
+        if not ok:
+            return
+        key = tuple((r.time_emb_proj.weight._version, r.time_emb_proj.weight.data_ptr()) for r in res)
+        if getattr(self, "_tb_cache", None) is None or self._tb_cache[0] != key:
+            w = torch.cat([r.time_emb_proj.weight.detach() for r in res], 0).to(BF16).contiguous()
+            b = torch.cat([r.time_emb_proj.bias.detach().float() for r in res], 0).contiguous()
+            offs, o = [], 0
+            for r in res:
+                offs.append(o); o += r.time_emb_proj.weight.shape[0]
+            self._tb_cache = (key, w, b, offs)
+        _, w, b, offs = self._tb_cache
+        allp = K.gemm(temb_act.reshape(-1, temb_act.shape[-1]), w, bias=b, out_f32=True)        # [B, sum Cout] fp32
+        temb_act._hcp_tb = {id(r): allp[:, o:o + r.time_emb_proj.weight.shape[0]] for r, o in zip(res, offs)}
+
     def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, added_cond_kwargs=None,
                 cross_attention_kwargs=None, **kwargs):
         if encoder_attention_mask is not None:
@@ -402,6 +432,7 @@ class NativeUNet2DConditionModel(nn.Module):
         timestep = timestep.to(torch.int64).reshape(-1).expand(B).contiguous()
         temb = self.time_embedding(self.time_proj(timestep))
         temb_act = ops.silu(temb)                      # every ResnetBlock applies SiLU(temb): do it once
+        self._batched_time_proj(temb_act)
         ctx = encoder_hidden_states
         if ctx.dtype != BF16:
             ctx = ctx.to(BF16)

@@ -12,7 +12,10 @@ from tune_gemm_common import timeit, rnd, CFG_NAMES
 SHAPES = [(16384, 320, 320), (16384, 2560, 320), (16384, 320, 1280), (16384, 320, 2560), (16384, 1280, 320),
           (4096, 640, 640), (4096, 5120, 640), (4096, 640, 2560), (4096, 640, 5120), (4096, 2560, 640),
           (1024, 1280, 1280), (1024, 10240, 1280), (1024, 1280, 5120), (1024, 1280, 10240), (1024, 5120, 1280),
-          (256, 1280, 1280), (256, 10240, 1280), (256, 1280, 5120), (308, 320, 768), (308, 640, 768), (308, 1280, 768)]
+          (256, 1280, 1280), (256, 10240, 1280), (256, 1280, 5120), (308, 320, 768), (308, 640, 768), (308, 1280, 768),
+          # fused q|k|v and k|v projection groups (forward N = 3C / 2C, input-gradient K = 3C)
+          (16384, 960, 320), (16384, 320, 960), (4096, 1920, 640), (4096, 640, 1920), (1024, 3840, 1280), (1024, 1280, 3840),
+          (256, 3840, 1280), (256, 1280, 3840), (308, 2560, 768)]
 out = []
 for (M, N, Kd) in SHAPES:
     a, b, l, e = rnd(M, Kd), rnd(N, Kd), rnd(32, Kd), rnd(N, 32)
