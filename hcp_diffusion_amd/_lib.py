@@ -25,6 +25,7 @@ _PROTOTYPES = {
     "hcp_gemm_workspace_bytes": (c_size_t, [I, I]),
     "hcp_debug_set_gemm_config": (I, [I]),
     "hcp_debug_set_gemm_glds": (I, [I]),
+    "hcp_debug_set_gemm_ablation": (I, [I]),
     # X1, C1, X2, C2, B, Hs, Ws, Ho, Wo, mode, stride, upsample, Wp, Cout, D, ldd, bias, rowbias, rowbias_ld,
     # residual, ldr, out_f32, workspace, workspace_bytes, stream
     "hcp_conv3x3_bf16": (I, [P, I, P, I, I, I, I, I, I, I, I, I, P, I, P, I, P, P, I, P, I, I, P, c_size_t, P]),

@@ -50,6 +50,7 @@ struct GemmParams {
     // fused LoRA (LORA kernels): T = A L^T is accumulated next to the main tile from the same A tiles, rounded to
     // bf16, then D += T E^T as one extra k-step.  L [32,K] (ldl = K), E [N,32], Tout [M,32] (optional, for wgrad).
     const hcp_bf16* L; const hcp_bf16* E; hcp_bf16* Tout;
+    int dbg;                        // tools/ablate_gemm.py: 1 = skip the DMA after the first tile, 2 = skip the MFMAs, 4 = skip LDS reads + MFMAs
     ConvDesc cv;
 };
 
@@ -506,6 +507,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
     auto compute_tile = [&](int stage) {
         const hcp_bf16* la = lds + stage * BUF_ELEMS;
         const hcp_bf16* lb = la + A_ELEMS;
+        // (issuing both k-steps' LDS reads ahead of the MFMAs was measured: no gain, +40 VGPRs)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int q = ks * 4 + fg;
@@ -520,10 +522,17 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
                 const int R = wn * WTN + j * 16 + fr;
                 fb[j] = *(const hcp_bf16x8*)(lb + R * BK + ((q ^ ((R >> 1) & 7)) << 3));
             }
+            if (p.dbg & 2) {                              // ablation: keep the LDS reads alive, drop the matrix work
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) acc[i][0][0] += (float)fa[i][0];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fb[j], fa[i], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[0][j][1] += (float)fb[j][0];
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fb[j], fa[i], acc[i][j]);
+            }
             if (LORA) {
                 const int R = wn * 16 + fr;
                 hcp_bf16x8 fl = *(const hcp_bf16x8*)(lb + B_ELEMS + R * BK + ((q ^ ((R >> 1) & 7)) << 3));
@@ -538,8 +547,8 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
         HCP_SYNC();
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
-            if (t + 1 < nk) issue_tile(t + 1, cur ^ 1);
-            compute_tile(cur);
+            if (t + 1 < nk && !(p.dbg & 1)) issue_tile(t + 1, cur ^ 1);
+            if (!(p.dbg & 4)) compute_tile(cur);
             HCP_SYNC();                                  // drains the DMA of tile t+1 (vmcnt(0)) and fences the LDS reads
         }
     } else {
@@ -617,12 +626,14 @@ HCP_KERNEL(256) splitk_reduce_kernel(GemmParams p) {
 }
 
 int g_force_cfg = -1;   // tools/tune: force a tile configuration (see hcp_debug_set_gemm_config)
+int g_dbg_ablate = 0;   // tools only, see GemmParams::dbg
 int g_use_glds = 1;     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
 
 template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false, int NSTAGE = 2>
 int launch_cfg(GemmParams& p, hipStream_t stream) {
     p.tiles_m = hcp_cdiv(p.M, BM);
     const int tiles_n = hcp_cdiv(p.N, BN);
+    p.dbg = g_dbg_ablate;
     if (g_use_glds || NSTAGE == 3) {
         size_t smem = (size_t)NSTAGE * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
         const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);      // fused-LoRA tail images
@@ -741,6 +752,8 @@ int check_common(const GemmParams& p) {
 HCP_API int hcp_debug_set_gemm_config(int cfg) { g_force_cfg = cfg; return 0; }
 // TOOLS ONLY: 1 = LDS-DMA main loop (default), 0 = register-staged main loop.
 HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = on; return 0; }
+// TOOLS ONLY: ablation of the 2-stage LDS-DMA loop (results are wrong when != 0): 1 no DMA after tile 0, 2 no MFMA, 4 no LDS reads.
+HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; return 0; }
 
 // Bytes of fp32 split-K workspace that lets every launch of this shape use its preferred decomposition.
 HCP_API size_t hcp_gemm_workspace_bytes(int M, int N) { return (size_t)16 * M * N * sizeof(float); }
