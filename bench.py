@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_IMAGE_LORA_NOCKPT = 1.61e12      # BASELINE.md §2 (fwd 803.3 G + dX backward 803.3 G + LoRA side paths)
+FLOP_PER_IMAGE_SDXL_LORA_NOCKPT = 13.5e12 # SDXL fwd ~6.76 TFLOP/img @1024px, x2 (fwd + dX backward)
 MFMA_BF16_PEAK = 2.5e15                   # MI355X_MICROARCH.md: dense bf16 MFMA
 LORA_PATTERNS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]      # cfgs/train/examples/lora_conventional.yaml:10-12
 
@@ -84,8 +85,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--rank-lora", type=int, default=8)
+    ap.add_argument("--workload", choices=["sd15", "sdxl"], default="sd15",
+                    help="sd15 = the headline metric (BASELINE.json configs[1]); sdxl = configs[3] (SDXL LoRA r16 1024px bs2), "
+                         "a secondary line, not the headline")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--rank-lora", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="LoRA wgrad kernels on a side stream (measured slower)")
@@ -104,11 +108,14 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from hcp_diffusion_amd.trainer import NativeTrainer
-    from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
+    from hcp_diffusion_amd.unet import SDXL_CONFIG, NativeUNet2DConditionModel
 
+    sdxl = args.workload == "sdxl"
+    args.batch = args.batch or (2 if sdxl else 4)
+    args.rank_lora = args.rank_lora or (16 if sdxl else 8)
     torch.manual_seed(114514)                      # same weights on every rank (train_base.yaml:5)
     with torch.device("meta"):
-        unet = NativeUNet2DConditionModel()
+        unet = NativeUNet2DConditionModel(**SDXL_CONFIG) if sdxl else NativeUNet2DConditionModel()
     unet = unet.to_empty(device=dev)
     with torch.no_grad():                          # random-init weights of the SD1.5 architecture, generated on the GPU
         for name, p in unet.named_parameters():
@@ -129,8 +136,15 @@ def main():
         torch.distributed.broadcast(tr.bucket.params, 0)
     tr.bucket.pack()
     B = args.batch
-    latents = torch.randn(B, 4, 64, 64, device=dev)
-    ehs = torch.randn(B, 77, 768, device=dev).to(torch.bfloat16)
+    added = None
+    if sdxl:                                       # [2,4,128,128], ctx [2,77,2048], pooled [2,1280], crop_info [2,6]
+        latents = torch.randn(B, 4, 128, 128, device=dev)
+        ehs = torch.randn(B, 77, 2048, device=dev).to(torch.bfloat16)
+        added = dict(text_embeds=torch.randn(B, 1280, device=dev),
+                     time_ids=torch.tensor([[1024.0, 1024.0, 0.0, 0.0, 1024.0, 1024.0]] * B, device=dev))
+    else:
+        latents = torch.randn(B, 4, 64, 64, device=dev)
+        ehs = torch.randn(B, 77, 768, device=dev).to(torch.bfloat16)
 
     def sync():
         if world > 1:
@@ -138,11 +152,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        tr.train_one_step(latents, ehs)
+        tr.train_one_step(latents, ehs, None, added)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tr.train_one_step(latents, ehs)
+        loss = tr.train_one_step(latents, ehs, None, added)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev)
@@ -153,17 +167,21 @@ def main():
     if rank == 0:
         ips = world * B * args.steps / dt
         out = {
-            "metric": "training images/sec (whole node), SD1.5 LoRA 512px bs=4/GPU", "value": round(ips, 2), "unit": "images/sec",
+            "metric": ("training images/sec (whole node), SDXL LoRA 1024px bs=%d/GPU" % B) if sdxl else
+                      "training images/sec (whole node), SD1.5 LoRA 512px bs=4/GPU", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "SD1.5 UNet LoRA rank=%d bf16, bs=%d/GPU, 512x512 (64x64 latents), 77-token context, "
-                                   "random-init weights, cached latents, grad-ckpt off" % (args.rank_lora, B),
+            "config": {"workload": ("SDXL-base UNet LoRA rank=%d bf16, bs=%d/GPU, 1024x1024 (128x128 latents), 77x2048 context + text_time "
+                                    "cond, random-init weights, cached latents, grad-ckpt off" if sdxl else
+                                    "SD1.5 UNet LoRA rank=%d bf16, bs=%d/GPU, 512x512 (64x64 latents), 77-token context, "
+                                    "random-init weights, cached latents, grad-ckpt off") % (args.rank_lora, B),
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
             "final_loss": round(loss_v, 5),
-            "step_mfma_frac": round(ips / world * FLOP_PER_IMAGE_LORA_NOCKPT / MFMA_BF16_PEAK, 4),
+            "step_mfma_frac": round(ips / world * (FLOP_PER_IMAGE_SDXL_LORA_NOCKPT if sdxl else FLOP_PER_IMAGE_LORA_NOCKPT)
+                                    / MFMA_BF16_PEAK, 4),
         }
         out["roofline"] = dominant_kernel_roofline(dev)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not sdxl:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

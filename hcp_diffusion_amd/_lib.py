@@ -51,6 +51,7 @@ _PROTOTYPES = {
     "hcp_nhwc_to_nchw_f32": (I, [P, P, I, I, I, I, P]),
     "hcp_upsample2x_bwd": (I, [P, P, I, I, I, I, P]),
     "hcp_timestep_embedding": (I, [P, P, I, I, F, P]),
+    "hcp_timestep_embedding_f32": (I, [P, P, I, I, F, P]),
     "hcp_add_noise": (I, [P, P, P, P, P, I, L, P]),
     "hcp_mse_masked_mean": (I, [P, P, P, I, P, P, I, I, I, F, P]),
     # L, ldl, R, ldr, out, ldo, M, P, Q, scale, transpose_out, stream

@@ -132,13 +132,14 @@ HCP_KERNEL(256) upsample2x_bwd_kernel(const hcp_bf16* dup, hcp_bf16* dx, int B, 
 }
 
 // emb[b, 0:half] = cos(t * f_i), emb[b, half:] = sin(t * f_i), f_i = exp(-ln(max_period) * i / half)
-HCP_KERNEL(256) timestep_embedding_kernel(const long long* t, hcp_bf16* emb, int B, int dim, float max_period) {
+// t is int64 (scheduler timesteps) or, when tf != nullptr, fp32 (SDXL micro-conditioning scalars).
+HCP_KERNEL(256) timestep_embedding_kernel(const long long* t, const float* tf, hcp_bf16* emb, int B, int dim, float max_period) {
     const int half = dim / 2;
     const int total = B * half;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int b = i / half, k = i - b * half;
         float f = expf(-logf(max_period) * (float)k / (float)half);
-        float a = (float)t[b] * f;
+        float a = (tf ? tf[b] : (float)t[b]) * f;
         emb[(size_t)b * dim + k] = hcp_f2bf(cosf(a));
         emb[(size_t)b * dim + half + k] = hcp_f2bf(sinf(a));
     }
@@ -237,8 +238,14 @@ HCP_API int hcp_timestep_embedding(const long long* timesteps, void* emb, int B,
                                    hipStream_t stream) {
     HCP_REQUIRE(timesteps && emb && B > 0 && dim > 0 && dim % 2 == 0, "hcp_timestep_embedding: bad arguments");
     HCP_LAUNCH(timestep_embedding_kernel, dim3(pw_grid((long)B * dim / 2)), dim3(PW_THREADS), 0, stream, timesteps,
-               (hcp_bf16*)emb, B, dim, max_period);
+               (const float*)nullptr, (hcp_bf16*)emb, B, dim, max_period);
     HCP_LAUNCH_CHECK("timestep_embedding");
+}
+HCP_API int hcp_timestep_embedding_f32(const float* values, void* emb, int B, int dim, float max_period, hipStream_t stream) {
+    HCP_REQUIRE(values && emb && B > 0 && dim > 0 && dim % 2 == 0, "hcp_timestep_embedding_f32: bad arguments");
+    HCP_LAUNCH(timestep_embedding_kernel, dim3(pw_grid((long)B * dim / 2)), dim3(PW_THREADS), 0, stream,
+               (const long long*)nullptr, values, (hcp_bf16*)emb, B, dim, max_period);
+    HCP_LAUNCH_CHECK("timestep_embedding_f32");
 }
 HCP_API int hcp_add_noise(const float* x0, const float* noise, const long long* timesteps, const float* alphas_cumprod,
                           float* xt, int B, long per_sample, hipStream_t stream) {

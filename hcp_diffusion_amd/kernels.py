@@ -323,9 +323,13 @@ def upsample2x_bwd(dup):
 
 
 def timestep_embedding(t, dim, max_period=10000.0):
-    assert t.dtype == torch.int64 and t.is_contiguous()
+    assert t.dtype in (torch.int64, torch.float32) and t.is_contiguous()
     emb = torch.empty((t.numel(), dim), dtype=BF16, device=t.device)
-    _chk(lib().hcp_timestep_embedding(_p(t), _p(emb), t.numel(), dim, float(max_period), _stream(t)), "hcp_timestep_embedding")
+    if t.dtype == torch.int64:
+        _chk(lib().hcp_timestep_embedding(_p(t), _p(emb), t.numel(), dim, float(max_period), _stream(t)), "hcp_timestep_embedding")
+    else:
+        _chk(lib().hcp_timestep_embedding_f32(_p(t), _p(emb), t.numel(), dim, float(max_period), _stream(t)),
+             "hcp_timestep_embedding_f32")
     return emb
 
 

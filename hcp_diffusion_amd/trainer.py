@@ -66,9 +66,12 @@ class NativeTrainer:
         t = torch.randint(0, self.num_train_timesteps, (latents.shape[0],), device=latents.device).long()
         return K.add_noise(latents, noise, t, self.acp), noise, t
 
-    def forward_backward(self, latents, encoder_hidden_states, mask=None):
+    def forward_backward(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None):
         noisy, noise, t = self.make_noise(latents)
-        pred = self.unet(noisy, t, encoder_hidden_states).sample          # wrapper.py:29
+        if added_cond_kwargs:                                             # SDXL: wrapper.py:66-73
+            pred = self.unet(noisy, t, encoder_hidden_states, added_cond_kwargs=added_cond_kwargs).sample
+        else:
+            pred = self.unet(noisy, t, encoder_hidden_states).sample      # wrapper.py:29
         loss, grad = K.mse_masked_mean(pred.detach(), noise, mask, weight=self.loss_weight)    # loss.type == 'eps'
         ops.enable_wgrad_side_stream(self.overlap_wgrad)
         ops.enable_grouped_wgrad(self.grouped_wgrad)
@@ -97,43 +100,46 @@ class NativeTrainer:
         self.lr.fill_(lr)
 
     # ---- one optimisation step
-    def train_one_step(self, latents, encoder_hidden_states, mask=None):
-        """latents [B,4,h,w] fp32 (cached VAE latents), encoder_hidden_states [B,L,D]. Returns the loss as a device
-        tensor (no host sync)."""
+    def train_one_step(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None):
+        """latents [B,4,h,w] fp32 (cached VAE latents), encoder_hidden_states [B,L,D]; SDXL adds
+        added_cond_kwargs={"text_embeds" [B,1280], "time_ids" [B,6]}. Returns the loss as a device tensor (no host sync)."""
         if not self.use_graph:
-            self.loss = self.forward_backward(latents.float().contiguous(), encoder_hidden_states, mask)
+            self.loss = self.forward_backward(latents.float().contiguous(), encoder_hidden_states, mask, added_cond_kwargs)
             self.all_reduce()
             self.optimizer_step()
             return self.loss
         if self._graphs is None:
-            self._capture(latents, encoder_hidden_states, mask)
+            self._capture(latents, encoder_hidden_states, mask, added_cond_kwargs)
         s = self._static
         s["latents"].copy_(latents)
         s["ehs"].copy_(encoder_hidden_states)
         if mask is not None:
             s["mask"].copy_(mask)
+        for k, v in (added_cond_kwargs or {}).items():
+            s["added"][k].copy_(v)
         g1, g2 = self._graphs
         g1.replay()
         self.all_reduce()
         g2.replay()
         return self.loss
 
-    def _capture(self, latents, ehs, mask):
-        s = {"latents": latents.float().contiguous().clone(), "ehs": ehs.clone(), "mask": mask.clone() if mask is not None else None}
+    def _capture(self, latents, ehs, mask, added=None):
+        s = {"latents": latents.float().contiguous().clone(), "ehs": ehs.clone(), "mask": mask.clone() if mask is not None else None,
+             "added": {k: v.clone() for k, v in added.items()} if added else None}
         self._static = s
         # warm-up on a side stream (allocator + lazy weight packing must not happen inside the capture)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                self.forward_backward(s["latents"], s["ehs"], s["mask"])
+                self.forward_backward(s["latents"], s["ehs"], s["mask"], s["added"])
                 self.all_reduce()
                 self.optimizer_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
-            loss = self.forward_backward(s["latents"], s["ehs"], s["mask"])
+            loss = self.forward_backward(s["latents"], s["ehs"], s["mask"], s["added"])
         self.loss = loss
         with torch.cuda.graph(g2, pool=g1.pool()):
             self.optimizer_step()

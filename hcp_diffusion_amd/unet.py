@@ -22,7 +22,23 @@ SD15_CONFIG = dict(
     in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
     down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
     up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
-    num_attention_heads=8, cross_attention_dim=768, norm_num_groups=32, num_train_timesteps=1000)
+    num_attention_heads=8, cross_attention_dim=768, norm_num_groups=32, num_train_timesteps=1000,
+    transformer_layers_per_block=1, use_linear_projection=False, addition_embed_type=None, addition_time_embed_dim=None,
+    projection_class_embeddings_input_dim=None)
+
+# SDXL-base (BASELINE.json configs[3]); the reference fixes only the call contract (models/wrapper.py:57-74) and the
+# block-index map (tools/lora_convert.py:116-186) — the numbers are the public SDXL config.json.
+SDXL_CONFIG = dict(
+    in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280), layers_per_block=2,
+    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+    up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+    num_attention_heads=(5, 10, 20), cross_attention_dim=2048, norm_num_groups=32, num_train_timesteps=1000,
+    transformer_layers_per_block=(1, 2, 10), use_linear_projection=True, addition_embed_type="text_time",
+    addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816)
+
+
+def _per_block(v, i):
+    return v[i] if isinstance(v, (tuple, list)) else v
 
 
 def _call_res(mod, x, residual):
@@ -202,21 +218,30 @@ class BasicTransformerBlock(nn.Module):
 
 
 class Transformer2DModel(nn.Module):
-    def __init__(self, dim, ctx_dim, heads, groups):
+    def __init__(self, dim, ctx_dim, heads, groups, depth=1, linear_proj=False):
         super().__init__()
         self.norm = HipGroupNorm(groups, dim, eps=1e-6)
-        self.proj_in = HipConv2d(dim, dim, 1)
-        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, ctx_dim, heads)])
-        self.proj_out = HipConv2d(dim, dim, 1)
+        # use_linear_projection (SDXL): an nn.Linear on tokens — the same GEMM on channels-last memory, but the leaf class
+        # (and so the weight shape [C,C] vs [C,C,1,1] and what a LoRA regex over nn.Linear matches) follows diffusers.
+        self.proj_in = HipLinear(dim, dim) if linear_proj else HipConv2d(dim, dim, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, ctx_dim, heads) for _ in range(depth)])
+        self.proj_out = HipLinear(dim, dim) if linear_proj else HipConv2d(dim, dim, 1)
         self.gradient_checkpointing = False
 
     def forward(self, x, context):
         B, H, W, C = x.shape
         h, x = self.norm(x, silu=False, fork=True)
-        h = self.proj_in(h).view(B, H * W, C)
+        h = self.proj_in(h.view(B, H * W, C)) if isinstance(self.proj_in, nn.Linear) else self.proj_in(h).view(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
+        if isinstance(self.proj_out, nn.Linear):
+            return _call_res(self.proj_out, h, x.view(B, H * W, C)).view(B, H, W, C)
         return _call_res(self.proj_out, h.view(B, H, W, C), x)
+
+
+def _transformer(c, cfg, level):
+    return Transformer2DModel(c, cfg["cross_attention_dim"], _per_block(cfg["num_attention_heads"], level), cfg["norm_num_groups"],
+                              _per_block(cfg["transformer_layers_per_block"], level), cfg["use_linear_projection"])
 
 
 class Downsample2D(nn.Module):
@@ -238,12 +263,11 @@ class Upsample2D(nn.Module):
 
 
 class _DownBlock(nn.Module):
-    def __init__(self, cin, cout, temb_dim, n_layers, cfg, has_attn, add_down):
+    def __init__(self, cin, cout, temb_dim, n_layers, cfg, has_attn, add_down, level=0):
         super().__init__()
         g = cfg["norm_num_groups"]
         if has_attn:
-            self.attentions = nn.ModuleList([Transformer2DModel(cout, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)
-                                             for _ in range(n_layers)])
+            self.attentions = nn.ModuleList([_transformer(cout, cfg, level) for _ in range(n_layers)])
         self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_dim, g) for i in range(n_layers)])
         if add_down:
             self.downsamplers = nn.ModuleList([Downsample2D(cout)])
@@ -275,7 +299,7 @@ class UNetMidBlock2DCrossAttn(nn.Module):
     def __init__(self, c, temb_dim, cfg):
         super().__init__()
         g = cfg["norm_num_groups"]
-        self.attentions = nn.ModuleList([Transformer2DModel(c, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)])
+        self.attentions = nn.ModuleList([_transformer(c, cfg, len(cfg["block_out_channels"]) - 1)])
         self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb_dim, g), ResnetBlock2D(c, c, temb_dim, g)])
         self.gradient_checkpointing = False
 
@@ -286,12 +310,11 @@ class UNetMidBlock2DCrossAttn(nn.Module):
 
 
 class _UpBlock(nn.Module):
-    def __init__(self, cin, cout, prev, temb_dim, n_layers, cfg, has_attn, add_up):
+    def __init__(self, cin, cout, prev, temb_dim, n_layers, cfg, has_attn, add_up, level=0):
         super().__init__()
         g = cfg["norm_num_groups"]
         if has_attn:
-            self.attentions = nn.ModuleList([Transformer2DModel(cout, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)
-                                             for _ in range(n_layers)])
+            self.attentions = nn.ModuleList([_transformer(cout, cfg, level) for _ in range(n_layers)])
         res = []
         for i in range(n_layers):
             skip_c = cin if i == n_layers - 1 else cout
@@ -346,7 +369,7 @@ class NativeUNet2DConditionModel(nn.Module):
         for i, t in enumerate(cfg["down_block_types"]):
             in_c, out_c = out_c, boc[i]
             cls = CrossAttnDownBlock2D if t.startswith("CrossAttn") else DownBlock2D
-            downs.append(cls(in_c, out_c, temb_dim, n, cfg, t.startswith("CrossAttn"), i != len(boc) - 1))
+            downs.append(cls(in_c, out_c, temb_dim, n, cfg, t.startswith("CrossAttn"), i != len(boc) - 1, level=i))
         self.down_blocks = nn.ModuleList(downs)
         ups, rev = [], list(reversed(boc))
         out_c = rev[0]
@@ -354,13 +377,19 @@ class NativeUNet2DConditionModel(nn.Module):
             prev, out_c = out_c, rev[i]
             in_c = rev[min(i + 1, len(boc) - 1)]
             cls = CrossAttnUpBlock2D if t.startswith("CrossAttn") else UpBlock2D
-            ups.append(cls(in_c, out_c, prev, temb_dim, n + 1, cfg, t.startswith("CrossAttn"), i != len(boc) - 1))
+            ups.append(cls(in_c, out_c, prev, temb_dim, n + 1, cfg, t.startswith("CrossAttn"), i != len(boc) - 1,
+                           level=len(boc) - 1 - i))
         self.up_blocks = nn.ModuleList(ups)
         self.mid_block = UNetMidBlock2DCrossAttn(boc[-1], temb_dim, cfg)
         self.conv_norm_out = HipGroupNorm(cfg["norm_num_groups"], boc[0], eps=1e-5)
         self.conv_act = SiLU()
         self.conv_out = HipConv2d(boc[0], cfg["out_channels"], 3, 1, 1)
         self.class_embedding = None
+        if cfg["addition_embed_type"] == "text_time":
+            self.add_time_proj = Timesteps(cfg["addition_time_embed_dim"])
+            self.add_embedding = TimestepEmbedding(cfg["projection_class_embeddings_input_dim"], temb_dim)
+        elif cfg["addition_embed_type"] is not None:
+            raise NotImplementedError(f"hcp_diffusion_amd: addition_embed_type={cfg['addition_embed_type']!r}")
 
     # ---- reference-facing conveniences (train_ac.py:257-278, wrapper.py:39-49)
     @classmethod
@@ -374,12 +403,16 @@ class NativeUNet2DConditionModel(nn.Module):
         import os
         root = os.path.join(path, subfolder) if subfolder else path
         cfg = json.load(open(os.path.join(root, "config.json")))
-        heads = cfg.get("attention_head_dim", 8)
+        heads = cfg.get("num_attention_heads") or cfg.get("attention_head_dim", 8)    # diffusers' historical mis-naming
+        tl = cfg.get("transformer_layers_per_block", 1)
         model = cls(in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
                     block_out_channels=tuple(cfg["block_out_channels"]), layers_per_block=cfg["layers_per_block"],
                     down_block_types=tuple(cfg["down_block_types"]), up_block_types=tuple(cfg["up_block_types"]),
-                    num_attention_heads=heads if isinstance(heads, int) else heads[0], cross_attention_dim=cfg["cross_attention_dim"],
-                    norm_num_groups=cfg["norm_num_groups"])
+                    num_attention_heads=heads if isinstance(heads, int) else tuple(heads), cross_attention_dim=cfg["cross_attention_dim"],
+                    norm_num_groups=cfg["norm_num_groups"], transformer_layers_per_block=tl if isinstance(tl, int) else tuple(tl),
+                    use_linear_projection=bool(cfg.get("use_linear_projection", False)),
+                    addition_embed_type=cfg.get("addition_embed_type"), addition_time_embed_dim=cfg.get("addition_time_embed_dim"),
+                    projection_class_embeddings_input_dim=cfg.get("projection_class_embeddings_input_dim"))
         from safetensors.torch import load_file
         model.load_state_dict(load_file(os.path.join(root, "diffusion_pytorch_model.safetensors")))
         return model
@@ -424,13 +457,20 @@ class NativeUNet2DConditionModel(nn.Module):
                 cross_attention_kwargs=None, **kwargs):
         if encoder_attention_mask is not None:
             raise NotImplementedError("hcp_diffusion_amd: encoder_attention_mask (additive key mask) is not implemented yet")
-        if added_cond_kwargs:
-            raise NotImplementedError("hcp_diffusion_amd: SDXL added_cond_kwargs are a later SURVEY §8 row")
+        text_time = self.config["addition_embed_type"] == "text_time"
+        if bool(added_cond_kwargs) != text_time:
+            raise ValueError("hcp_diffusion_amd: added_cond_kwargs={text_embeds,time_ids} is required by (and only by) a UNet with "
+                             "addition_embed_type='text_time' (SDXL; reference models/wrapper.py:66-73)")
         B = sample.shape[0]
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], dtype=torch.int64, device=sample.device)
         timestep = timestep.to(torch.int64).reshape(-1).expand(B).contiguous()
         temb = self.time_embedding(self.time_proj(timestep))
+        if text_time:                                  # SDXL micro-conditioning: sinusoid(6 scalars) | pooled text -> MLP -> +temb
+            text_embeds, time_ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+            te = self.add_time_proj(time_ids.reshape(-1).float()).view(B, -1)
+            add = ops.concat_channels(text_embeds.to(BF16).contiguous(), te)
+            temb = ops.add(temb, self.add_embedding(add))
         temb_act = ops.silu(temb)                      # every ResnetBlock applies SiLU(temb): do it once
         self._batched_time_proj(temb_act)
         ctx = encoder_hidden_states

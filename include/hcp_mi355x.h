@@ -97,6 +97,8 @@ int hcp_upsample2x_bwd(const void* dup, void* dx, int B, int H, int W, int C, hc
 
 /* Timesteps(flip_sin_to_cos=True, freq_shift=0) (unet_struct.txt:3): emb[b] = [cos(t f_i) | sin(t f_i)] */
 int hcp_timestep_embedding(const long long* timesteps, void* emb, int B, int dim, float max_period, hcpStream_t stream);
+/* same for fp32 inputs: SDXL's add_time_proj over added_cond_kwargs["time_ids"] (= crop_info, models/wrapper.py:66) */
+int hcp_timestep_embedding_f32(const float* values, void* emb, int B, int dim, float max_period, hcpStream_t stream);
 /* DDPMScheduler.add_noise as called by train_ac.py:447 */
 int hcp_add_noise(const float* x0, const float* noise, const long long* timesteps, const float* alphas_cumprod, float* xt,
                   int B, long per_sample, hcpStream_t stream);

@@ -175,7 +175,41 @@ def sd15_full_vectors():
     return dict(pred=pred.detach(), loss=float(loss), n_lora=len(wr), fingerprint=grad_fingerprint([(n, p.grad) for n, p in lora_named]))
 
 
+def sdxl_full_inputs():
+    """SDXL-base shapes at batch 1 / 512 px (64x64 latents keep the CPU oracle to minutes; every layer shape except the
+    token count equals BASELINE.json configs[3])."""
+    g2 = torch.Generator().manual_seed(43)
+    x0 = torch.randn(1, 4, 64, 64, generator=g2); ehs = torch.randn(1, 77, 2048, generator=g2)
+    noise = torch.randn(1, 4, 64, 64, generator=g2); t = torch.tensor([611])
+    added = dict(text_embeds=torch.randn(1, 1280, generator=g2), time_ids=torch.tensor([[512.0, 512.0, 0.0, 0.0, 512.0, 512.0]]))
+    return x0, ehs, noise, t, added
+
+
+def sdxl_full_vectors():
+    """Full SDXL-base architecture (2.567 B params, seeded init), LoRA rank 16 on attn/ff blocks."""
+    import torch.nn.functional as F
+    from oracle.lora_ref import wrap_lora
+    from oracle.unet_sd15 import OracleUNet2DConditionModel, SDXL_CONFIG, add_noise, ddpm_alphas_cumprod, seeded_init_
+    with torch.device("meta"):
+        m = OracleUNet2DConditionModel(**SDXL_CONFIG)
+    m = seeded_init_(m.to_empty(device="cpu"), 1)
+    m.requires_grad_(False)
+    wr = wrap_lora(m, [r"re:.*\.attn.?$", r"re:.*\.ff$"], rank=16)
+    lora_named = [(n, p) for n, p in m.named_parameters() if "lora_block_" in n]
+    sd15_lora_init_(lora_named)
+    x0, ehs, noise, t, added = sdxl_full_inputs()
+    pred = m(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ehs, added_cond_kwargs=added).sample
+    loss = F.mse_loss(pred, noise)
+    loss.backward()
+    return dict(pred=pred.detach(), loss=float(loss), n_lora=len(wr), n_lora_params=sum(p.numel() for _, p in lora_named),
+                fingerprint=grad_fingerprint([(n, p.grad) for n, p in lora_named]))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sdxl":
+        torch.save(sdxl_full_vectors(), os.path.join(GOLD, "sdxl_full_oracle.pt"))
+        print("sdxl_full_oracle.pt", os.path.getsize(os.path.join(GOLD, "sdxl_full_oracle.pt")))
+        sys.exit(0)
     os.makedirs(GOLD, exist_ok=True)
     ref = os.environ.get("HCP_REFERENCE_ROOT", "/root/reference")
     shapes = parse_unet_struct(os.path.join(ref, "cfgs", "unet_struct.txt"))

@@ -24,7 +24,33 @@ SD15_CONFIG = dict(
     in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
     down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
     up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
-    num_attention_heads=8, cross_attention_dim=768, norm_num_groups=32, num_train_timesteps=1000)
+    num_attention_heads=8, cross_attention_dim=768, norm_num_groups=32, num_train_timesteps=1000,
+    transformer_layers_per_block=1, use_linear_projection=False, addition_embed_type=None, addition_time_embed_dim=None,
+    projection_class_embeddings_input_dim=None)
+
+# SDXL-base UNet (BASELINE.json configs[3]).  NOT present anywhere in the reference: restated from the
+# public SDXL config.json [ext]: 3 levels, transformer depth 1/2/10, head_dim 64 (diffusers' mis-named
+# ``attention_head_dim`` = heads per level 5/10/20), cross dim 2048, linear proj_in/out, "text_time" additional embedding
+# (6 micro-conditioning scalars x 256 sinusoid + 1280 pooled text = 2816 -> 1280).  The reference only fixes the CALL:
+# ``unet(..., added_cond_kwargs={"text_embeds", "time_ids"})`` (hcpdiff/models/wrapper.py:66-73) and the block-index map
+# (hcpdiff/tools/lora_convert.py:116-186: attentions at down_blocks.1-2, mid, up_blocks.0-1).
+SDXL_CONFIG = dict(
+    in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280), layers_per_block=2,
+    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+    up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+    num_attention_heads=(5, 10, 20), cross_attention_dim=2048, norm_num_groups=32, num_train_timesteps=1000,
+    transformer_layers_per_block=(1, 2, 10), use_linear_projection=True, addition_embed_type="text_time",
+    addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816)
+
+# Miniature with the SDXL structure (head_dim 64; pooled text 64 + 6 x 32 = 256 additional-embedding input).
+TINY_SDXL_CONFIG = dict(SDXL_CONFIG, block_out_channels=(64, 128, 256), layers_per_block=1, num_attention_heads=(1, 2, 4),
+                        cross_attention_dim=64, norm_num_groups=8, transformer_layers_per_block=(1, 1, 2),
+                        addition_time_embed_dim=32, projection_class_embeddings_input_dim=256)
+
+
+def per_block(v, i):
+    """diffusers accepts an int or a per-down-block tuple for heads / transformer depth."""
+    return v[i] if isinstance(v, (tuple, list)) else v
 
 # A structurally identical miniature (same block types; channel counts chosen so head_dim is 40 / 80 as in SD1.5).
 TINY_CONFIG = dict(SD15_CONFIG, block_out_channels=(80, 160, 160, 160), layers_per_block=1, num_attention_heads=2,
@@ -141,20 +167,31 @@ class BasicTransformerBlock(nn.Module):  # unet_struct.txt:16-47 (module order a
 
 
 class Transformer2DModel(nn.Module):  # unet_struct.txt:12-50
-    def __init__(self, dim, ctx_dim, heads, groups):
+    def __init__(self, dim, ctx_dim, heads, groups, depth=1, linear_proj=False):
         super().__init__()
         self.norm = nn.GroupNorm(groups, dim, eps=1e-6)
-        self.proj_in = nn.Conv2d(dim, dim, 1)
-        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, ctx_dim, heads)])
-        self.proj_out = nn.Conv2d(dim, dim, 1)
+        self.proj_in = nn.Linear(dim, dim) if linear_proj else nn.Conv2d(dim, dim, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, ctx_dim, heads) for _ in range(depth)])
+        self.proj_out = nn.Linear(dim, dim) if linear_proj else nn.Conv2d(dim, dim, 1)
+        self.linear_proj = linear_proj
 
     def forward(self, x, context):
         B, C, H, W = x.shape
-        h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        if self.linear_proj:                       # use_linear_projection [ext]: tokens first, then nn.Linear
+            h = self.proj_in(self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C))
+        else:
+            h = self.proj_in(self.norm(x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
+        if self.linear_proj:
+            return self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2) + x
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
         return self.proj_out(h) + x
+
+
+def _transformer(c, cfg, level):
+    return Transformer2DModel(c, cfg["cross_attention_dim"], per_block(cfg["num_attention_heads"], level), cfg["norm_num_groups"],
+                              per_block(cfg["transformer_layers_per_block"], level), cfg["use_linear_projection"])
 
 
 class Downsample2D(nn.Module):  # unet_struct.txt:111-114
@@ -178,12 +215,11 @@ class Upsample2D(nn.Module):  # unet_struct.txt:390-393; nearest 2x then conv [e
 class DownBlock(nn.Module):
     """CrossAttnDownBlock2D / DownBlock2D. Returns (hidden, skip tuple) — reference controlnet.py:149-171."""
 
-    def __init__(self, cin, cout, temb_dim, n_layers, cfg, has_attn, add_down):
+    def __init__(self, cin, cout, temb_dim, n_layers, cfg, has_attn, add_down, level=0):
         super().__init__()
         g = cfg["norm_num_groups"]
         if has_attn:
-            self.attentions = nn.ModuleList([Transformer2DModel(cout, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)
-                                             for _ in range(n_layers)])
+            self.attentions = nn.ModuleList([_transformer(cout, cfg, level) for _ in range(n_layers)])
         self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_dim, g) for i in range(n_layers)])
         if add_down:
             self.downsamplers = nn.ModuleList([Downsample2D(cout)])
@@ -206,7 +242,7 @@ class MidBlock(nn.Module):  # unet_struct.txt:866-928
     def __init__(self, c, temb_dim, cfg):
         super().__init__()
         g = cfg["norm_num_groups"]
-        self.attentions = nn.ModuleList([Transformer2DModel(c, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)])
+        self.attentions = nn.ModuleList([_transformer(c, cfg, len(cfg["block_out_channels"]) - 1)])
         self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb_dim, g), ResnetBlock2D(c, c, temb_dim, g)])
 
     def forward(self, h, temb, context):
@@ -218,12 +254,11 @@ class MidBlock(nn.Module):  # unet_struct.txt:866-928
 class UpBlock(nn.Module):
     """UpBlock2D / CrossAttnUpBlock2D: concat order is [hidden, skip] (reference controlnet.py:73-75)."""
 
-    def __init__(self, cin, cout, prev, temb_dim, n_layers, cfg, has_attn, add_up):
+    def __init__(self, cin, cout, prev, temb_dim, n_layers, cfg, has_attn, add_up, level=0):
         super().__init__()
         g = cfg["norm_num_groups"]
         if has_attn:
-            self.attentions = nn.ModuleList([Transformer2DModel(cout, cfg["cross_attention_dim"], cfg["num_attention_heads"], g)
-                                             for _ in range(n_layers)])
+            self.attentions = nn.ModuleList([_transformer(cout, cfg, level) for _ in range(n_layers)])
         res = []
         for i in range(n_layers):
             skip_c = cin if i == n_layers - 1 else cout
@@ -267,23 +302,34 @@ class OracleUNet2DConditionModel(nn.Module):
         downs, out_c = [], boc[0]
         for i, t in enumerate(cfg["down_block_types"]):
             in_c, out_c = out_c, boc[i]
-            downs.append(DownBlock(in_c, out_c, temb_dim, n, cfg, t.startswith("CrossAttn"), i != len(boc) - 1))
+            downs.append(DownBlock(in_c, out_c, temb_dim, n, cfg, t.startswith("CrossAttn"), i != len(boc) - 1, level=i))
         self.down_blocks = nn.ModuleList(downs)
         ups, rev = [], list(reversed(boc))
         out_c = rev[0]
         for i, t in enumerate(cfg["up_block_types"]):
             prev, out_c = out_c, rev[i]
             in_c = rev[min(i + 1, len(boc) - 1)]
-            ups.append(UpBlock(in_c, out_c, prev, temb_dim, n + 1, cfg, t.startswith("CrossAttn"), i != len(boc) - 1))
+            ups.append(UpBlock(in_c, out_c, prev, temb_dim, n + 1, cfg, t.startswith("CrossAttn"), i != len(boc) - 1,
+                               level=len(boc) - 1 - i))          # reversed heads / transformer depth [ext]
         self.up_blocks = nn.ModuleList(ups)
         self.mid_block = MidBlock(boc[-1], temb_dim, cfg)
         self.conv_norm_out = nn.GroupNorm(cfg["norm_num_groups"], boc[0], eps=1e-5)
         self.conv_act = nn.SiLU()
         self.conv_out = nn.Conv2d(boc[0], cfg["out_channels"], 3, 1, 1)
+        if cfg["addition_embed_type"] == "text_time":            # SDXL micro-conditioning [ext]
+            self.add_time_proj = Timesteps(cfg["addition_time_embed_dim"])
+            self.add_embedding = TimestepEmbedding(cfg["projection_class_embeddings_input_dim"], temb_dim)
+        else:
+            assert cfg["addition_embed_type"] is None
 
-    def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, **kwargs):
+    def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, added_cond_kwargs=None, **kwargs):
         assert encoder_attention_mask is None, "oracle: additive key mask not restated"
         temb = self.time_embedding(self.time_proj(timestep).to(sample.dtype))
+        if self.config["addition_embed_type"] == "text_time":    # call contract: reference wrapper.py:66,73
+            text_embeds, time_ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+            time_embeds = self.add_time_proj(time_ids.flatten()).reshape(text_embeds.shape[0], -1)
+            add_embeds = torch.cat([text_embeds, time_embeds], dim=-1).to(temb.dtype)
+            temb = temb + self.add_embedding(add_embeds)
         h = self.conv_in(sample)
         skips = (h,)
         for blk in self.down_blocks:

@@ -16,7 +16,8 @@ from hcp_diffusion_amd.lora import LoraHipLayer, make_lora
 from hcp_diffusion_amd.trainer import NativeTrainer
 from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
 from oracle.lora_ref import wrap_lora
-from oracle.unet_sd15 import OracleUNet2DConditionModel, SD15_CONFIG, TINY_CONFIG, add_noise, ddpm_alphas_cumprod, seeded_init_
+from oracle.unet_sd15 import (OracleUNet2DConditionModel, SD15_CONFIG, SDXL_CONFIG, TINY_CONFIG, TINY_SDXL_CONFIG, add_noise,
+                              ddpm_alphas_cumprod, seeded_init_)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
@@ -53,7 +54,7 @@ def test_tiny_forward_vs_oracle_and_golden(backend):
     assert ((yn - yo).norm() / yo.norm()).item() < 2e-2
 
 
-def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42):
+def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42, pooled_dim=None):
     dev = backend.device
     ora, nat = _pair(cfg, dev)
     ora.requires_grad_(False)
@@ -70,11 +71,15 @@ def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42):
     g2 = torch.Generator().manual_seed(seed)
     x0 = torch.randn(*shape, generator=g2); ehs = torch.randn(shape[0], ctx_len, ctx_dim, generator=g2)
     noise = torch.randn(*shape, generator=g2); t = torch.randint(0, 1000, (shape[0],), generator=g2).long()
-    pred = ora(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ehs).sample
+    added = None
+    if pooled_dim:                                   # SDXL call contract (reference models/wrapper.py:66)
+        added = dict(text_embeds=torch.randn(shape[0], pooled_dim, generator=g2),
+                     time_ids=torch.tensor([[shape[2] * 8.0, shape[3] * 8.0, 0.0, 16.0, shape[2] * 8.0, shape[3] * 8.0]] * shape[0]))
+    pred = ora(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ehs, added_cond_kwargs=added).sample
     loss_o = F.mse_loss(pred, noise)
     loss_o.backward()
     tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
-    loss_n = tr.forward_backward(x0.to(dev), ehs.to(dev))
+    loss_n = tr.forward_backward(x0.to(dev), ehs.to(dev), None, {k: v.to(dev) for k, v in added.items()} if added else None)
     go = torch.cat([p.grad.flatten() for w in wr.values() for p in (w.lora_block_0.layer.W_down, w.lora_block_0.layer.W_up)])
     return loss_o.item(), loss_n.item(), go, tr, wr
 
@@ -94,6 +99,32 @@ def test_tiny_lora_train_step_vs_oracle(backend):
     po = torch.cat([p.detach().flatten() for p in params])
     assert ((po - tr.bucket.params.cpu()).abs().max() / po.abs().max()).item() < 1e-5
     assert tr.bucket.grads.abs().max().item() == 0.0
+
+
+def test_sdxl_structure_matches_public_config():
+    """SDXL-base: 2.567 B parameters in 1680 tensors; attentions at down_blocks.1-2 / mid / up_blocks.0-1 (the layout the
+    reference's converters assume, hcpdiff/tools/lora_convert.py:116-186); linear proj_in/out; same names as the oracle."""
+    with torch.device("meta"):
+        nat = NativeUNet2DConditionModel(**SDXL_CONFIG)
+        ora = OracleUNet2DConditionModel(**SDXL_CONFIG)
+    sn = {k: tuple(v.shape) for k, v in nat.state_dict().items()}
+    assert sn == {k: tuple(v.shape) for k, v in ora.state_dict().items()}
+    assert len(sn) == 1680 and sum(torch.Size(v).numel() for v in sn.values()) == 2_567_463_684
+    assert sn["add_embedding.linear_1.weight"] == (1280, 2816) and sn["down_blocks.1.attentions.0.proj_in.weight"] == (640, 640)
+    assert not hasattr(nat.down_blocks[0], "attentions") and not hasattr(nat.up_blocks[2], "attentions")
+    assert [len(a.transformer_blocks) for a in nat.up_blocks[0].attentions] == [10, 10, 10]
+    assert len(nat.mid_block.attentions[0].transformer_blocks) == 10 and len(nat.down_blocks[1].attentions[0].transformer_blocks) == 2
+    assert nat.down_blocks[2].attentions[0].transformer_blocks[0].attn1.heads == 20
+    with pytest.raises(ValueError):
+        NativeUNet2DConditionModel(**TINY_SDXL_CONFIG)(torch.zeros(1, 4, 8, 8), torch.zeros(1).long(), torch.zeros(1, 77, 64))
+
+
+def test_tiny_sdxl_lora_train_step_vs_oracle(backend):
+    """SDXL-structured miniature (3 levels, DownBlock2D first, transformer depth 1/1/2, head_dim 64, linear projections,
+    text_time additional embedding, rank-16 LoRA as in BASELINE.json configs[3])."""
+    lo, ln, go, tr, wr = _train_step_pair(TINY_SDXL_CONFIG, backend, 16, (2, 4, 8, 8), 77, 64, pooled_dim=64)
+    assert abs(lo - ln) / abs(lo) < 2e-2
+    assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.995
 
 
 def test_lora_layer_api_surface(backend):
@@ -155,3 +186,39 @@ def test_sd15_full_size_forward_and_lora_grads_vs_golden():
     assert num / (da * db) > 0.99                                # projections agree in sign and size across 320 tensors
     bad = [n for n in fp if g["fingerprint"][n][0] > 1e-7 and abs(fp[n][0] - g["fingerprint"][n][0]) / g["fingerprint"][n][0] > 0.1]
     assert len(bad) <= 3, bad                                    # per-tensor gradient norms within 10% (bf16 pipeline)
+
+
+@pytest.mark.gpu
+def test_sdxl_full_size_forward_and_lora_grads_vs_golden():
+    """Full SDXL-base architecture (2.567 B params, seeded init), batch 1, 64x64 latents, 77x2048 context + text_time
+    conditioning, LoRA rank 16 (BASELINE.json configs[3] layer shapes).  Oracle values: oracle/make_golden.py sdxl ->
+    tests/golden/sdxl_full_oracle.pt (generated in the build container)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import math
+    from oracle.make_golden import grad_fingerprint, sd15_lora_init_, sdxl_full_inputs
+    K._set_backend_for_tests(None)
+    dev = torch.device("cuda:0")
+    g = torch.load(os.path.join(GOLD, "sdxl_full_oracle.pt"))
+    with torch.device("meta"):
+        nat = NativeUNet2DConditionModel(**SDXL_CONFIG)
+    nat = seeded_init_(nat.to_empty(device=dev), 1)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=16)], lr=1e-4)
+    assert len(tr.bucket.blocks) == g["n_lora"] and tr.bucket.numel == g["n_lora_params"]
+    lora_named = [(n, p) for n, p in nat.named_parameters() if "lora_block_" in n]
+    sd15_lora_init_(lora_named)
+    tr.bucket.pack()
+    x0, ehs, noise, t, added = sdxl_full_inputs()
+    added = {k: v.to(dev) for k, v in added.items()}
+    tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
+    with torch.no_grad():
+        pred = nat(K.add_noise(x0.to(dev), noise.to(dev), t.to(dev), tr.acp), t.to(dev), ehs.to(dev), added_cond_kwargs=added).sample.cpu()
+    assert ((pred - g["pred"]).norm() / g["pred"].norm()).item() < 3e-2         # 70 transformer blocks deep in bf16
+    loss = tr.forward_backward(x0.to(dev), ehs.to(dev), None, added).item()
+    assert abs(loss - g["loss"]) / g["loss"] < 2e-2
+    fp = grad_fingerprint([(n, p.grad) for n, p in lora_named])
+    num = sum(fp[n][1] * g["fingerprint"][n][1] for n in fp); da = math.sqrt(sum(v[1] ** 2 for v in fp.values()))
+    db = math.sqrt(sum(v[1] ** 2 for v in g["fingerprint"].values()))
+    assert num / (da * db) > 0.99
+    bad = [n for n in fp if g["fingerprint"][n][0] > 1e-7 and abs(fp[n][0] - g["fingerprint"][n][0]) / g["fingerprint"][n][0] > 0.1]
+    assert len(bad) <= len(fp) // 100, bad
