@@ -144,6 +144,43 @@ def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=N
     return out
 
 
+def wgrad_linear(dy, x, dw):
+    """dw [N,K] fp32 (any row stride) += dy[M,N]^T x[M,K]; dy / x bf16 2-D views with unit column stride."""
+    assert dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == torch.float32 and dy.dim() == 2 and x.dim() == 2
+    assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1 and dy.shape[0] == x.shape[0]
+    M, N = dy.shape
+    K = x.shape[1]
+    assert tuple(dw.shape) == (N, K)
+    _chk(lib().hcp_wgrad_linear_bf16(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), M, N, K, _stream(x)),
+         "hcp_wgrad_linear_bf16")
+
+
+def wgrad_conv3x3(dy, x1, dw, *, x2=None, stride=1, upsample=False, cout=None):
+    """dw [Cout][3][3][Cw] fp32 contiguous (the channels_last storage of a [Cout,Cw,3,3] weight) += dY^T im2col(x1|x2).
+    dy [B,Ho,Wo,ldy] bf16 (ldy >= Cout, padded columns zero), x1/x2 the forward's NHWC inputs."""
+    assert dy.dtype == BF16 and x1.dtype == BF16 and dw.dtype == torch.float32 and dy.is_contiguous() and x1.is_contiguous()
+    B, Hs, Ws, C1 = x1.shape
+    C2 = 0
+    if x2 is not None:
+        assert x2.dtype == BF16 and x2.is_contiguous() and x2.shape[:3] == x1.shape[:3]
+        C2 = x2.shape[3]
+    _, Ho, Wo, ldy = dy.shape
+    cout = cout or ldy
+    cw = dw.numel() // (cout * 9)
+    assert dw.numel() == cout * 9 * cw and cw <= C1 + C2
+    _chk(lib().hcp_wgrad_conv3x3_bf16(_p(dy), ldy, _p(x1), C1, _p(x2), C2, _p(dw), cw, B, Hs, Ws, Ho, Wo, cout, stride,
+                                      1 if upsample else 0, _stream(x1)), "hcp_wgrad_conv3x3_bf16")
+
+
+def colsum(y, out, rows_per_group=None):
+    """out[g, :N] (fp32) += column sums of the rows of group g of y [M, N] bf16 (rows_per_group=None: one group)."""
+    assert y.dtype == BF16 and y.dim() == 2 and y.stride(1) == 1 and out.dtype == torch.float32
+    M, N = y.shape
+    rpg = rows_per_group or M
+    ldo = out.stride(0) if out.dim() == 2 else N
+    _chk(lib().hcp_colsum_bf16(_p(y), y.stride(0), _p(out), ldo, M, N, rpg, _stream(y)), "hcp_colsum_bf16")
+
+
 def _attn_strides(t):
     assert t.dtype == BF16 and t.dim() == 3 and t.stride(2) == 1
     return t.stride(0), t.stride(1)

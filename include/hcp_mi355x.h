@@ -95,6 +95,19 @@ int hcp_nchw_to_nhwc_bf16(const void* src, int src_is_f32, void* dst, int B, int
 int hcp_nhwc_to_nchw_f32(const float* src, float* dst, int B, int C, int HW, int Csrc, hcpStream_t stream);
 int hcp_upsample2x_bwd(const void* dup, void* dx, int B, int H, int W, int C, hcpStream_t stream);
 
+/* ---- host-layer weight gradients (full fine-tuning: cfgs/train/examples/DreamBooth.yaml:6-10 trains every UNet
+ * parameter; autograd's dW of nn.Linear / nn.Conv2d [ext]).  fp32 `+=` into the gradient buffer (atomics). ---- */
+/* dW[N,K] += dY[M,N]^T X[M,K] */
+int hcp_wgrad_linear_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, int M, int N, int K,
+                          hcpStream_t stream);
+/* dW[Cout][3][3][Cw] += dY^T im2col(X1|X2): same gather as hcp_conv3x3_bf16 (stride, nearest-2x upsample, concat);
+ * layout = torch channels_last storage of the diffusers weight [Cout,Cin,3,3] */
+int hcp_wgrad_conv3x3_bf16(const void* dY, int ldy, const void* X1, int C1, const void* X2, int C2, float* dW, int Cw, int B,
+                           int Hs, int Ws, int Ho, int Wo, int Cout, int stride, int upsample, hcpStream_t stream);
+/* out[g][n] += sum of rows of group g of Y (bias gradients; per-sample time-embedding row-bias gradient) */
+int hcp_colsum_bf16(const void* Y, int ldy, float* out, int ldo, int M, int N, int rows_per_group, hcpStream_t stream);
+int hcp_debug_set_wgrad_tile(int wx);
+
 /* Timesteps(flip_sin_to_cos=True, freq_shift=0) (unet_struct.txt:3): emb[b] = [cos(t f_i) | sin(t f_i)] */
 int hcp_timestep_embedding(const long long* timesteps, void* emb, int B, int dim, float max_period, hcpStream_t stream);
 /* same for fp32 inputs: SDXL's add_time_proj over added_cond_kwargs["time_ids"] (= crop_info, models/wrapper.py:66) */

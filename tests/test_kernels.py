@@ -385,3 +385,76 @@ def test_lora_wgrad_grouped(backend):
     for it, (rd, ru) in zip(items, refs):
         assert relerr(it[2], rd) < 2e-2 and relerr(it[5], ru) < 2e-2
     del keep
+
+
+# ---- host-layer weight gradients (full fine-tuning): dW = dY^T X as TN GEMM with LDS transpose reads
+WGL_CASES_EMU = [(64, 16, 64), (100, 36, 72), (200, 130, 200), (70, 4, 520), (130, 8, 8)]      # M, N, K
+WGL_CASES_GPU = WGL_CASES_EMU + [(16384, 320, 320), (4096, 640, 2560), (308, 320, 768), (1024, 10240, 1280), (256, 1280, 1280), (4, 1280, 320)]
+
+
+@pytest.mark.parametrize("wx", [0, 64, 128])
+@pytest.mark.parametrize("case", range(len(WGL_CASES_GPU)))
+def test_wgrad_linear(backend, case, wx):
+    if not backend.is_gpu and case >= len(WGL_CASES_EMU):
+        pytest.skip("large shape: GPU only")
+    M, N, Kd = WGL_CASES_GPU[case]
+    torch.manual_seed(case)
+    ldy = (N + 7) // 8 * 8
+    dy = torch.zeros(M, ldy, dtype=BF); dy[:, :N] = rnd(M, N)
+    x = rnd(M, Kd)
+    dw0 = torch.randn(N, Kd)
+    ref = dw0 + dy[:, :N].float().T @ x.float()
+    to = backend.to
+    dw = to(dw0.clone())
+    K.lib().hcp_debug_set_wgrad_tile(wx)
+    try:
+        K.wgrad_linear(to(dy)[:, :N], to(x), dw)
+    finally:
+        K.lib().hcp_debug_set_wgrad_tile(0)
+    assert relerr(dw, ref) < 3e-5 * max(1.0, math.sqrt(M / 256))
+
+
+WGC_CASES_EMU = [  # B, C1, C2, H, W, Cout, stride, up, Cw
+    (2, 16, 0, 6, 5, 24, 1, 0, 16), (1, 8, 16, 8, 8, 16, 1, 0, 24), (2, 16, 0, 8, 6, 8, 2, 0, 16), (1, 16, 0, 4, 5, 16, 1, 1, 16),
+    (1, 8, 0, 7, 7, 4, 1, 0, 8), (1, 8, 0, 6, 6, 16, 1, 0, 4), (1, 64, 0, 5, 5, 16, 1, 0, 64)]
+WGC_CASES_GPU = WGC_CASES_EMU + [(4, 320, 0, 64, 64, 320, 1, 0, 320), (2, 640, 320, 32, 32, 320, 1, 0, 960), (2, 320, 0, 64, 64, 320, 2, 0, 320),
+                                 (2, 1280, 0, 16, 16, 1280, 1, 1, 1280), (4, 1280, 1280, 8, 8, 1280, 1, 0, 2560), (4, 8, 0, 64, 64, 320, 1, 0, 4),
+                                 (4, 320, 0, 64, 64, 4, 1, 0, 320)]
+
+
+@pytest.mark.parametrize("case", range(len(WGC_CASES_GPU)))
+def test_wgrad_conv3x3(backend, case):
+    if not backend.is_gpu and case >= len(WGC_CASES_EMU):
+        pytest.skip("large shape: GPU only")
+    B, C1, C2, H, W, Cout, stride, up, Cw = WGC_CASES_GPU[case]
+    torch.manual_seed(case)
+    x1 = rnd(B, C1, H, W); x2 = rnd(B, C2, H, W) if C2 else None
+    xin = torch.cat([x1, x2], 1).float() if C2 else x1.float()
+    xin = xin[:, :Cw]                                  # conv_in: staged channels beyond the weight's Cin are padding
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    w = torch.zeros(Cout, Cw, 3, 3, requires_grad=True)
+    y = F.conv2d(xin, w, None, stride, 1)
+    dy = rnd(*y.shape)
+    y.backward(dy.float())
+    ldy = (Cout + 7) // 8 * 8
+    dyp = torch.zeros(B, y.shape[2], y.shape[3], ldy, dtype=BF); dyp[..., :Cout] = nhwc(dy)
+    dw0 = torch.randn(Cout, 3, 3, Cw)
+    ref = dw0 + w.grad.permute(0, 2, 3, 1)
+    to = backend.to
+    dw = to(dw0.clone())
+    K.wgrad_conv3x3(to(dyp), to(nhwc(x1)), dw, x2=to(nhwc(x2)) if C2 else None, stride=stride, upsample=bool(up), cout=Cout)
+    assert relerr(dw, ref) < 3e-5 * max(1.0, math.sqrt(B * y.shape[2] * y.shape[3] / 256))
+
+
+@pytest.mark.parametrize("M,N,rpg", [(70, 8, None), (256, 72, 64), (1000, 320, None), (128, 16, 32)])
+def test_colsum(backend, M, N, rpg):
+    torch.manual_seed(M)
+    y = rnd(M, N)
+    g = M // (rpg or M)
+    out0 = torch.randn(g, N)
+    ref = out0 + y.float().view(g, -1, N).sum(1)
+    to = backend.to
+    out = to(out0.clone())
+    K.colsum(to(y), out, rpg)
+    assert relerr(out, ref) < 1e-5
