@@ -59,6 +59,10 @@ _PROTOTYPES = {
     # Y, ldy, out, ldo, M, N, rows_per_group, stream
     "hcp_colsum_bf16": (I, [P, I, P, I, I, I, I, P]),
     "hcp_debug_set_wgrad_tile": (I, [I]),
+    # x, dy, gamma, beta, stats, dgamma, dbeta, B, HW, C, G, silu, stream
+    "hcp_groupnorm_affine_grad": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    # x, dy, stats, dgamma, dbeta, M, C, stream
+    "hcp_layernorm_affine_grad": (I, [P, P, P, P, P, I, I, P]),
     "hcp_add_noise": (I, [P, P, P, P, P, I, L, P]),
     "hcp_mse_masked_mean": (I, [P, P, P, I, P, P, I, I, I, F, P]),
     # L, ldl, R, ldr, out, ldo, M, P, Q, scale, transpose_out, stream

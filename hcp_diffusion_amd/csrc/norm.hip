@@ -289,6 +289,70 @@ HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float
     }
 }
 
+// Affine-parameter gradients (full fine-tuning: every norm's weight/bias is trainable — DreamBooth.yaml:6-10):
+//   dgamma[c] += sum_rows dz * xhat ; dbeta[c] += sum_rows dz ;  dz = dy [* silu'(xhat gamma + beta)]
+// Thread (ch, rl) owns 8 channels x every 32nd row of its block's row range; LDS reduce over the 32 row lanes,
+// fp32 atomics into the gradient bucket.  GROUP=true: stats per (sample, group), grid.z = sample; false: per row.
+template <bool GROUP>
+HCP_KERNEL(256) norm_affine_grad_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float* gamma, const float* beta,
+                                        const float* stats, float* dgamma, float* dbeta, int rows, int C, int G, int silu,
+                                        int rows_per_block) {
+    HCP_DYN_SMEM(smem);
+    float (*red)[129] = (float (*)[129])smem;              // [32][64 dgamma | 64 dbeta]
+    const int tid = threadIdx.x;
+    const int ch = tid & 7, rl = tid >> 3;
+    const int c0 = blockIdx.x * 64 + ch * 8;
+    const int b = blockIdx.z;
+    const int mb = blockIdx.y * rows_per_block;
+    int me = mb + rows_per_block; if (me > rows) me = rows;
+    float sg[8], sb[8], mean8[8], rstd8[8], g8[8], be8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sg[i] = 0.f; sb[i] = 0.f; mean8[i] = 0.f; rstd8[i] = 1.f; g8[i] = 1.f; be8[i] = 0.f; }
+    if (c0 < C) {
+        if (GROUP) {
+            const int Cg = C / G;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int g = (c0 + i) / Cg;
+                mean8[i] = stats[((size_t)b * G + g) * 2]; rstd8[i] = stats[((size_t)b * G + g) * 2 + 1];
+                g8[i] = gamma[c0 + i]; be8[i] = beta[c0 + i];
+            }
+        }
+        const size_t base = (size_t)b * rows * C + c0;
+        for (int r = mb + rl; r < me; r += 32) {
+            hcp_bf16x8 v = *(const hcp_bf16x8*)(x + base + (size_t)r * C);
+            hcp_bf16x8 d = *(const hcp_bf16x8*)(dy + base + (size_t)r * C);
+            float mean = 0.f, rstd = 1.f;
+            if (!GROUP) { mean = stats[(size_t)r * 2]; rstd = stats[(size_t)r * 2 + 1]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (hcp_bf2f((unsigned short)v[i]) - (GROUP ? mean8[i] : mean)) * (GROUP ? rstd8[i] : rstd);
+                float dz = hcp_bf2f((unsigned short)d[i]);
+                if (GROUP && silu) { float z = xh * g8[i] + be8[i]; float s = hcp_sigmoid(z); dz *= s * (1.f + z * (1.f - s)); }
+                sg[i] += dz * xh; sb[i] += dz;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[rl][ch * 8 + i] = sg[i]; red[rl][64 + ch * 8 + i] = sb[i]; }
+    HCP_SYNC();
+    if (tid < 128) {
+        float t = 0.f;
+        for (int r = 0; r < 32; ++r) t += red[r][tid];
+        const int c = blockIdx.x * 64 + (tid & 63);
+        if (c < C && mb < me) hcp_atomic_add((tid < 64 ? dgamma : dbeta) + c, t);
+    }
+}
+
+int affine_grad_blocks(int rows, int col_tiles, int groups, int* rows_per_block) {
+    int splits = hcp_cdiv(1024, col_tiles * groups);
+    const int max_splits = hcp_cdiv(rows, 128);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    *rows_per_block = hcp_cdiv(hcp_cdiv(rows, splits), 32) * 32;
+    return hcp_cdiv(rows, *rows_per_block);
+}
+
 int gn_check(int B, int HW, int C, int G) {
     HCP_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0, "groupnorm: empty problem");
     HCP_REQUIRE(C % 8 == 0 && C % G == 0 && C <= 8192 && G <= 32, "groupnorm: C=%d G=%d unsupported", C, G);
@@ -359,4 +423,27 @@ HCP_API int hcp_layernorm_bwd(const void* x, const void* dy, const float* gamma,
     HCP_LAUNCH(ln_bwd_kernel, dim3(hcp_cdiv(M, 4)), dim3(256), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy, gamma,
                stats, (const hcp_bf16*)addend, (hcp_bf16*)dx, M, C);
     HCP_LAUNCH_CHECK("layernorm_bwd");
+}
+
+// dgamma[C] += sum_{b,hw} dz * xhat, dbeta[C] += sum dz for y = [silu](group_norm(x)); stats from the forward.
+HCP_API int hcp_groupnorm_affine_grad(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats,
+                                      float* dgamma, float* dbeta, int B, int HW, int C, int G, int silu, hipStream_t stream) {
+    HCP_REQUIRE(x && dy && gamma && beta && stats && dgamma && dbeta, "hcp_groupnorm_affine_grad: null argument");
+    HCP_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % 8 == 0 && C % G == 0, "hcp_groupnorm_affine_grad: C=%d G=%d unsupported", C, G);
+    const int ct = hcp_cdiv(C, 64);
+    int rpb; const int splits = affine_grad_blocks(HW, ct, B, &rpb);
+    HCP_LAUNCH((norm_affine_grad_kernel<true>), dim3(ct, splits, B), dim3(256), 32 * 129 * sizeof(float), stream,
+               (const hcp_bf16*)x, (const hcp_bf16*)dy, gamma, beta, stats, dgamma, dbeta, HW, C, G, silu, rpb);
+    HCP_LAUNCH_CHECK("groupnorm_affine_grad");
+}
+
+// dgamma[C] += sum_m dy * xhat, dbeta[C] += sum_m dy for y = layer_norm(x); stats[M,2] = (mean, rstd) from the forward.
+HCP_API int hcp_layernorm_affine_grad(const void* x, const void* dy, const float* stats, float* dgamma, float* dbeta, int M, int C,
+                                      hipStream_t stream) {
+    HCP_REQUIRE(x && dy && stats && dgamma && dbeta && M > 0 && C > 0 && C % 8 == 0, "hcp_layernorm_affine_grad: bad arguments");
+    const int ct = hcp_cdiv(C, 64);
+    int rpb; const int splits = affine_grad_blocks(M, ct, 1, &rpb);
+    HCP_LAUNCH((norm_affine_grad_kernel<false>), dim3(ct, splits, 1), dim3(256), 32 * 129 * sizeof(float), stream,
+               (const hcp_bf16*)x, (const hcp_bf16*)dy, (const float*)nullptr, (const float*)nullptr, stats, dgamma, dbeta, M, C, 1, 0, rpb);
+    HCP_LAUNCH_CHECK("layernorm_affine_grad");
 }

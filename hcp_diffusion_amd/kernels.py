@@ -253,6 +253,23 @@ def groupnorm_bwd(x, dy, gamma, beta, stats, groups, silu, addend=None):
     return dx
 
 
+def groupnorm_affine_grad(x, dy, gamma, beta, stats, groups, silu, dgamma, dbeta):
+    """dgamma / dbeta (fp32 [C], accumulated in place) for y = [silu](group_norm(x))."""
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    assert x.is_contiguous() and dy.is_contiguous() and dgamma.dtype == torch.float32 and dbeta.dtype == torch.float32
+    _chk(lib().hcp_groupnorm_affine_grad(_p(x), _p(dy), _p(gamma), _p(beta), _p(stats), _p(dgamma), _p(dbeta), B, HW, C, groups,
+                                         1 if silu else 0, _stream(x)), "hcp_groupnorm_affine_grad")
+
+
+def layernorm_affine_grad(x, dy, stats, dgamma, dbeta):
+    C = x.shape[-1]
+    M = x.numel() // C
+    assert x.is_contiguous() and dy.is_contiguous() and dgamma.dtype == torch.float32 and dbeta.dtype == torch.float32
+    _chk(lib().hcp_layernorm_affine_grad(_p(x), _p(dy), _p(stats), _p(dgamma), _p(dbeta), M, C, _stream(x)),
+         "hcp_layernorm_affine_grad")
+
+
 def layernorm_fwd(x, gamma, beta, eps):
     assert x.dtype == BF16 and x.is_contiguous()
     C = x.shape[-1]; M = x.numel() // C

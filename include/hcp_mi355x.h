@@ -107,6 +107,12 @@ int hcp_wgrad_conv3x3_bf16(const void* dY, int ldy, const void* X1, int C1, cons
 /* out[g][n] += sum of rows of group g of Y (bias gradients; per-sample time-embedding row-bias gradient) */
 int hcp_colsum_bf16(const void* Y, int ldy, float* out, int ldo, int M, int N, int rows_per_group, hcpStream_t stream);
 int hcp_debug_set_wgrad_tile(int wx);
+/* norm weight / bias gradients: dgamma[c] += sum dz * xhat, dbeta[c] += sum dz (dz includes the fused SiLU'), stats
+ * as saved by the forward entry points */
+int hcp_groupnorm_affine_grad(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats,
+                              float* dgamma, float* dbeta, int B, int HW, int C, int G, int silu, hcpStream_t stream);
+int hcp_layernorm_affine_grad(const void* x, const void* dy, const float* stats, float* dgamma, float* dbeta, int M, int C,
+                              hcpStream_t stream);
 
 /* Timesteps(flip_sin_to_cos=True, freq_shift=0) (unet_struct.txt:3): emb[b] = [cos(t f_i) | sin(t f_i)] */
 int hcp_timestep_embedding(const long long* timesteps, void* emb, int B, int dim, float max_period, hcpStream_t stream);

@@ -188,12 +188,19 @@ def test_groupnorm_silu(backend, case):
     x = (torch.randn(B, C, H, W) * 2 + 0.7).to(BF); gamma = torch.randn(C) * 0.5 + 1; beta = torch.randn(C) * 0.3
     dy = rnd(B, C, H, W)
     xr = x.float().requires_grad_(True)
+    gamma.requires_grad_(True); beta.requires_grad_(True)
     yr = F.group_norm(xr, 32, gamma, beta, eps)
     if silu:
         yr = F.silu(yr)
     yr.backward(dy.float())
+    dg_ref, db_ref = gamma.grad, beta.grad
+    gamma = gamma.detach(); beta = beta.detach()
     to = backend.to
     y, stats = K.groupnorm_fwd(to(nhwc(x)), to(gamma), to(beta), 32, eps, silu)
+    dg0, db0 = torch.randn(C), torch.randn(C)                # affine gradients accumulate into the bucket
+    dg, db = to(dg0.clone()), to(db0.clone())
+    K.groupnorm_affine_grad(to(nhwc(x)), to(nhwc(dy)), to(gamma), to(beta), stats, 32, silu, dg, db)
+    assert relerr(dg.cpu() - dg0, dg_ref) < 2e-3 and relerr(db.cpu() - db0, db_ref) < 2e-3
     assert relerr(y.permute(0, 3, 1, 2), yr) < 1e-2
     mean_ref = x.float().view(B, 32, -1).mean(-1)
     assert (stats[..., 0].cpu() - mean_ref).abs().max().item() < 1e-4
@@ -211,10 +218,16 @@ def test_layernorm(backend, M, C):
     torch.manual_seed(M)
     x = (torch.randn(M, C) * 3 + 1).to(BF); gamma = torch.randn(C) * 0.5 + 1; beta = torch.randn(C) * 0.2; dy = rnd(M, C)
     xr = x.float().requires_grad_(True)
+    gamma.requires_grad_(True); beta.requires_grad_(True)
     yr = F.layer_norm(xr, (C,), gamma, beta, 1e-5)
     yr.backward(dy.float())
+    dg_ref, db_ref = gamma.grad, beta.grad
+    gamma = gamma.detach(); beta = beta.detach()
     to = backend.to
     y, stats = K.layernorm_fwd(to(x), to(gamma), to(beta), 1e-5)
+    dg, db = to(torch.zeros(C)), to(torch.zeros(C))
+    K.layernorm_affine_grad(to(x), to(dy), stats, dg, db)
+    assert relerr(dg, dg_ref) < 2e-3 and relerr(db, db_ref) < 2e-3
     assert relerr(y, yr) < 1e-2
     dx = K.layernorm_bwd(to(x), to(dy), to(gamma), stats)
     assert relerr(dx, xr.grad) < 1e-2
