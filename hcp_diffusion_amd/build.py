@@ -10,7 +10,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(__file__).resolve().parent / "libhcp_mi355x.so"
-SOURCES = ["runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "pointwise.hip", "lora.hip", "optim.hip", "wgrad.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "pointwise.hip", "lora.hip", "optim.hip", "wgrad.hip", "pack.hip"]
 
 
 def _hipcc():

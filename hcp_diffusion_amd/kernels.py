@@ -479,6 +479,11 @@ def lora_pack(desc_tensor, count):
     _chk(lib().hcp_lora_pack(_p(desc_tensor), count, _stream(desc_tensor)), "hcp_lora_pack")
 
 
+def pack_weights(pieces, count, total_tiles):
+    assert pieces.dtype == torch.uint8 and pieces.is_contiguous() and pieces.numel() >= count * lib().hcp_pack_piece_bytes()
+    _chk(lib().hcp_pack_weights(_p(pieces), count, total_tiles, _stream(pieces)), "hcp_pack_weights")
+
+
 def sumsq(g, out):
     assert g.dtype == torch.float32 and g.is_contiguous()
     _chk(lib().hcp_sumsq_f32(_p(g), g.numel(), _p(out), _stream(g)), "hcp_sumsq_f32")

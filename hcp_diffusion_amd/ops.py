@@ -2,7 +2,9 @@
 
 Activations are bf16, token-major / NHWC.  Frozen-weight layers produce input gradients only; LoRA factors get
 their gradients accumulated by the wgrad kernel straight into the flat fp32 bucket (their ``.grad`` views).
-Full fine-tuning (weight gradients of the host layers) is not built yet and fails loudly.
+Host parameters with ``requires_grad`` (full fine-tuning, reference DreamBooth.yaml:6-10) get theirs from the TN-GEMM /
+column-sum / norm-affine kernels, accumulated in place into ``param.grad`` (fp32; 3x3 conv weights in channels_last
+storage = the kernels' [Cout][ky][kx][Cin]) — autograd sees ``None`` for them.
 """
 import torch
 
@@ -66,14 +68,29 @@ def _wgrad(U, x2, gd, T, dy2, gu, rank, alpha, slot0=0):
     _side["keep"].append((U, x2, T, dy2))         # the allocator must not recycle these before the side kernel ran
 
 
-def _no_host_grad(*params):
-    if not torch.is_grad_enabled():
-        return
-    for p in params:
-        if p is not None and p.requires_grad:
-            raise NotImplementedError(
-                "hcp_diffusion_amd: gradients for host (non-LoRA) weights are not implemented yet "
-                "(full fine-tune / DreamBooth is a later SURVEY §8 row); freeze the host or use LoRA")
+def _tr(p):
+    """The parameter itself when it is trainable (it then becomes an input of the autograd node so that backward runs
+    even if no activation input requires grad), else None."""
+    return p if (p is not None and p.requires_grad and torch.is_grad_enabled()) else None
+
+
+def grad_buffer(p, conv3x3=False):
+    """fp32 accumulation target for parameter `p`: its ``.grad`` (created zero-filled on first use).  For a 3x3 conv
+    weight [Cout,Cin,3,3] the buffer is channels_last and the returned tensor is its contiguous [Cout,3,3,Cin] view."""
+    g = p.grad
+    if g is None:
+        if conv3x3:
+            g = torch.zeros((p.shape[0], 3, 3, p.shape[1]), dtype=torch.float32, device=p.device).permute(0, 3, 1, 2)
+        else:
+            g = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+        p.grad = g
+    if g.dtype != torch.float32:
+        raise TypeError("hcp_diffusion_amd: host gradients accumulate in fp32 (fp32 master parameters expected)")
+    if conv3x3:
+        g = g.permute(0, 2, 3, 1)
+    if not g.is_contiguous():
+        raise RuntimeError("hcp_diffusion_amd: .grad of a trainable host parameter must be dense (3x3 conv weights: channels_last)")
+    return g
 
 
 class _LinearFn(torch.autograd.Function):
@@ -81,7 +98,7 @@ class _LinearFn(torch.autograd.Function):
     LoraPatchContainer.forward / LoraBlock.post_forward (lora_base_patch.py:20-35,68-74)."""
 
     @staticmethod
-    def forward(ctx, x, residual, w_down, w_up, host, lora, out_f32=False):
+    def forward(ctx, x, residual, w_down, w_up, host, lora, out_f32=False, hw=None, hb=None):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
@@ -93,7 +110,8 @@ class _LinearFn(torch.autograd.Function):
         else:
             y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2, out_f32=out_f32)
         ctx.host, ctx.lora = host, lora
-        ctx.save_for_backward(x2 if lora is not None else None, T)
+        ctx.train_w, ctx.train_b = hw is not None, hb is not None
+        ctx.save_for_backward(x2 if (lora is not None or hw is not None) else None, T)
         ctx.xshape = shp
         ctx.has_res = residual is not None
         return y.view(*shp[:-1], y.shape[-1])
@@ -117,18 +135,23 @@ class _LinearFn(torch.autograd.Function):
             _wgrad(U, x2, gd, T, dy2, gu, lora.rank, lora.alpha_f)
         elif ctx.needs_input_grad[0]:
             dx = K.gemm(dy2, pk.wt)
+        if ctx.train_w:                                # dW[N,K] += dY^T X (nn.Linear [N,K]; 1x1 conv [N,K,1,1] = same memory)
+            gw = grad_buffer(host.weight)
+            K.wgrad_linear(dy2, x2, gw.view(gw.shape[0], -1))
+        if ctx.train_b:
+            K.colsum(dy2, grad_buffer(host.bias))
         if dx is not None:
             dx = dx.view(ctx.xshape)
-        return dx, (dy if ctx.has_res else None), None, None, None, None, None
+        return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None
 
 
 def linear(x, host, lora=None, residual=None, out_f32=False):
-    _no_host_grad(host.weight, host.bias)
     wd = lora.layer.W_down if lora is not None else None
     wu = lora.layer.W_up if lora is not None else None
-    if out_f32 and (lora is not None or x.requires_grad):
+    hw, hb = _tr(host.weight), _tr(host.bias)
+    if out_f32 and (lora is not None or x.requires_grad or hw is not None or hb is not None):
         raise NotImplementedError("hcp_diffusion_amd: fp32 linear output is only provided for the gradient-free time-embedding path")
-    return _LinearFn.apply(x, residual, wd, wu, host, lora, out_f32)
+    return _LinearFn.apply(x, residual, wd, wu, host, lora, out_f32, hw, hb)
 
 
 class _LinearGroupFn(torch.autograd.Function):
@@ -178,8 +201,8 @@ class _LinearGroupFn(torch.autograd.Function):
 
 
 def linear_group(x, group):
-    for h in group.hosts:
-        _no_host_grad(h.weight, h.bias)
+    for h in group.hosts:                              # unet._fusable_linear never groups trainable hosts
+        assert _tr(h.weight) is None and _tr(h.bias) is None, "fused projection groups require frozen host weights"
     params = [p for b in group.blocks if b is not None for p in (b.layer.W_down, b.layer.W_up)]
     return _LinearGroupFn.apply(x, group, *params)
 
@@ -189,13 +212,16 @@ class _Conv3x3Fn(torch.autograd.Function):
     input (channel concat), stride 2, fused nearest-2x upsample."""
 
     @staticmethod
-    def forward(ctx, x1, x2, rowbias, residual, host, stride, upsample):
+    def forward(ctx, x1, x2, rowbias, residual, host, stride, upsample, hw=None, hb=None):
         pk = host.packed()
         y = K.conv3x3(x1, pk.w, pk.cout, x2=x2, stride=stride, upsample=upsample, bias=pk.bias, rowbias=rowbias, residual=residual)
         ctx.host, ctx.stride, ctx.upsample = host, stride, upsample
         ctx.in_shape = x1.shape
         ctx.c2 = x2.shape[-1] if x2 is not None else 0
         ctx.has_res = residual is not None
+        ctx.train_w, ctx.train_b = hw is not None, hb is not None
+        if hw is not None:
+            ctx.save_for_backward(x1, x2)
         return y
 
     @staticmethod
@@ -211,35 +237,56 @@ class _Conv3x3Fn(torch.autograd.Function):
                 dx1 = K.upsample2x_bwd(dx1)
         if ctx.c2 and ctx.needs_input_grad[1]:
             dx2 = K.conv3x3(dy, pk.wd[C1:], ctx.c2, mode=1, stride=ctx.stride, out_hw=hw)
-        if ctx.needs_input_grad[2]:
-            raise NotImplementedError("hcp_diffusion_amd: gradient w.r.t. the time-embedding bias is not implemented (frozen time MLP assumed)")
-        return dx1, dx2, None, (dy if ctx.has_res else None), None, None, None
+        drb = None
+        dy2 = dy.view(-1, dy.shape[-1])
+        if ctx.needs_input_grad[2]:                    # per-sample row bias (time embedding): sum over the sample's pixels
+            drb = torch.zeros((B, dy.shape[-1]), dtype=torch.float32, device=dy.device)
+            K.colsum(dy2, drb, dy.shape[1] * dy.shape[2])
+        if ctx.train_w:
+            x1, x2 = ctx.saved_tensors
+            K.wgrad_conv3x3(dy, x1, grad_buffer(ctx.host.weight, True), x2=x2, stride=ctx.stride, upsample=ctx.upsample)
+        if ctx.train_b:
+            K.colsum(dy2, grad_buffer(ctx.host.bias))
+        return dx1, dx2, drb, (dy if ctx.has_res else None), None, None, None, None, None
 
 
 def conv3x3(x1, host, *, x2=None, rowbias=None, residual=None, stride=1, upsample=False):
-    _no_host_grad(host.weight, host.bias)
-    return _Conv3x3Fn.apply(x1, x2, rowbias, residual, host, stride, upsample)
+    return _Conv3x3Fn.apply(x1, x2, rowbias, residual, host, stride, upsample, _tr(host.weight), _tr(host.bias))
+
+
+def _gn_affine(ctx, x, dy, g, b, stats):
+    if ctx.train:
+        K.groupnorm_affine_grad(x, dy, g, b, stats, ctx.gn.num_groups, ctx.silu, grad_buffer(ctx.gn.weight), grad_buffer(ctx.gn.bias))
+
+
+def _norm_tr(m):
+    w, b = _tr(m.weight), _tr(m.bias)
+    if (w is None) != (b is None):
+        raise NotImplementedError("hcp_diffusion_amd: a norm layer's weight and bias must be trainable together")
+    return w, b
 
 
 class _GroupNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gn, silu):
+    def forward(ctx, x, gn, silu, hw=None, hb=None):
         g, b = gn.f32_params()
         y, stats = K.groupnorm_fwd(x, g, b, gn.num_groups, gn.eps, silu)
         ctx.save_for_backward(x, stats)
-        ctx.gn, ctx.silu = gn, silu
+        ctx.gn, ctx.silu, ctx.train = gn, silu, hw is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, stats = ctx.saved_tensors
         g, b = ctx.gn.f32_params()
-        return K.groupnorm_bwd(x, dy.contiguous(), g, b, stats, ctx.gn.num_groups, ctx.silu), None, None
+        dy = dy.contiguous()
+        _gn_affine(ctx, x, dy, g, b, stats)
+        dx = K.groupnorm_bwd(x, dy, g, b, stats, ctx.gn.num_groups, ctx.silu) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None
 
 
 def groupnorm(x, gn, silu):
-    _no_host_grad(gn.weight, gn.bias)
-    return _GroupNormFn.apply(x, gn, silu)
+    return _GroupNormFn.apply(x, gn, silu, *_norm_tr(gn))
 
 
 class _GroupNormForkFn(torch.autograd.Function):
@@ -247,11 +294,11 @@ class _GroupNormForkFn(torch.autograd.Function):
     gradients at once and adds the residual-path one inside the norm-backward kernel (no separate accumulation)."""
 
     @staticmethod
-    def forward(ctx, x, gn, silu):
+    def forward(ctx, x, gn, silu, hw=None, hb=None):
         g, b = gn.f32_params()
         y, stats = K.groupnorm_fwd(x, g, b, gn.num_groups, gn.eps, silu)
         ctx.save_for_backward(x, stats)
-        ctx.gn, ctx.silu = gn, silu
+        ctx.gn, ctx.silu, ctx.train = gn, silu, hw is not None
         return y, x.view_as(x)
 
     @staticmethod
@@ -259,46 +306,49 @@ class _GroupNormForkFn(torch.autograd.Function):
         x, stats = ctx.saved_tensors
         g, b = ctx.gn.f32_params()
         if dy is None:
-            return dskip, None, None
-        return K.groupnorm_bwd(x, dy.contiguous(), g, b, stats, ctx.gn.num_groups, ctx.silu,
-                               dskip.contiguous() if dskip is not None else None), None, None
+            return dskip, None, None, None, None
+        dy = dy.contiguous()
+        _gn_affine(ctx, x, dy, g, b, stats)
+        return K.groupnorm_bwd(x, dy, g, b, stats, ctx.gn.num_groups, ctx.silu,
+                               dskip.contiguous() if dskip is not None else None), None, None, None, None
 
 
 def groupnorm_fork(x, gn, silu):
-    _no_host_grad(gn.weight, gn.bias)
-    return _GroupNormForkFn.apply(x, gn, silu)
+    return _GroupNormForkFn.apply(x, gn, silu, *_norm_tr(gn))
 
 
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ln):
+    def forward(ctx, x, ln, hw=None, hb=None):
         g, b = ln.f32_params()
         y, stats = K.layernorm_fwd(x, g, b, ln.eps)
         ctx.save_for_backward(x, stats)
-        ctx.ln = ln
+        ctx.ln, ctx.train = ln, hw is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, stats = ctx.saved_tensors
         g, _ = ctx.ln.f32_params()
-        return K.layernorm_bwd(x, dy.contiguous(), g, stats), None
+        dy = dy.contiguous()
+        if ctx.train:
+            K.layernorm_affine_grad(x, dy, stats, grad_buffer(ctx.ln.weight), grad_buffer(ctx.ln.bias))
+        return (K.layernorm_bwd(x, dy, g, stats) if ctx.needs_input_grad[0] else None), None, None, None
 
 
 def layernorm(x, ln):
-    _no_host_grad(ln.weight, ln.bias)
-    return _LayerNormFn.apply(x, ln)
+    return _LayerNormFn.apply(x, ln, *_norm_tr(ln))
 
 
 class _LayerNormForkFn(torch.autograd.Function):
     """(layer_norm(x), x) for pre-norm residual blocks; see _GroupNormForkFn."""
 
     @staticmethod
-    def forward(ctx, x, ln):
+    def forward(ctx, x, ln, hw=None, hb=None):
         g, b = ln.f32_params()
         y, stats = K.layernorm_fwd(x, g, b, ln.eps)
         ctx.save_for_backward(x, stats)
-        ctx.ln = ln
+        ctx.ln, ctx.train = ln, hw is not None
         return y, x.view_as(x)
 
     @staticmethod
@@ -306,13 +356,15 @@ class _LayerNormForkFn(torch.autograd.Function):
         x, stats = ctx.saved_tensors
         g, _ = ctx.ln.f32_params()
         if dy is None:
-            return dskip, None
-        return K.layernorm_bwd(x, dy.contiguous(), g, stats, dskip.contiguous() if dskip is not None else None), None
+            return dskip, None, None, None
+        dy = dy.contiguous()
+        if ctx.train:
+            K.layernorm_affine_grad(x, dy, stats, grad_buffer(ctx.ln.weight), grad_buffer(ctx.ln.bias))
+        return K.layernorm_bwd(x, dy, g, stats, dskip.contiguous() if dskip is not None else None), None, None, None
 
 
 def layernorm_fork(x, ln):
-    _no_host_grad(ln.weight, ln.bias)
-    return _LayerNormForkFn.apply(x, ln)
+    return _LayerNormForkFn.apply(x, ln, *_norm_tr(ln))
 
 
 class _GegluFn(torch.autograd.Function):
@@ -432,11 +484,14 @@ class _ConvOutFn(torch.autograd.Function):
     channel-padded NHWC bf16 -> data-gradient conv."""
 
     @staticmethod
-    def forward(ctx, x, host):
+    def forward(ctx, x, host, hw=None, hb=None):
         pk = host.packed()
         y = K.conv3x3(x, pk.w, pk.cout, bias=pk.bias, out_f32=True)
         ctx.host = host
         ctx.in_shape = x.shape
+        ctx.train_w, ctx.train_b = hw is not None, hb is not None
+        if hw is not None:
+            ctx.save_for_backward(x)
         return K.nhwc_to_nchw_f32(y, pk.cout)
 
     @staticmethod
@@ -444,19 +499,56 @@ class _ConvOutFn(torch.autograd.Function):
         pk = ctx.host.packed()
         B, H, W, C = ctx.in_shape
         g = K.nchw_to_nhwc(dy.contiguous(), pk.cout_pad)
-        return K.conv3x3(g, pk.wd, C, mode=1, stride=1, out_hw=(H, W)), None
+        _conv_param_grads(ctx, g, pk)
+        dx = K.conv3x3(g, pk.wd, C, mode=1, stride=1, out_hw=(H, W)) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None
+
+
+def _conv_param_grads(ctx, g, pk):
+    """Weight / bias gradients of a 3x3 conv whose output gradient `g` is channel-padded NHWC bf16."""
+    if ctx.train_w:
+        (x,) = ctx.saved_tensors
+        K.wgrad_conv3x3(g, x, grad_buffer(ctx.host.weight, True), cout=pk.cout)
+    if ctx.train_b:
+        gb = grad_buffer(ctx.host.bias)
+        if g.shape[-1] == pk.cout:
+            K.colsum(g.view(-1, pk.cout), gb)
+        else:                                          # conv_out: 4 real channels staged in 8
+            tmp = torch.zeros(g.shape[-1], dtype=torch.float32, device=g.device)
+            K.colsum(g.view(-1, g.shape[-1]), tmp)
+            gb += tmp[:pk.cout]
 
 
 def conv_out(x, host):
-    _no_host_grad(host.weight, host.bias)
-    return _ConvOutFn.apply(x, host)
+    return _ConvOutFn.apply(x, host, _tr(host.weight), _tr(host.bias))
+
+
+class _ConvInFn(torch.autograd.Function):
+    """conv_in with trainable parameters: the latents carry no gradient, so the parameters are the node's only
+    differentiable inputs."""
+
+    @staticmethod
+    def forward(ctx, x, host, hw, hb):
+        pk = host.packed()
+        ctx.host = host
+        ctx.train_w, ctx.train_b = hw is not None, hb is not None
+        if hw is not None:
+            ctx.save_for_backward(x)
+        return K.conv3x3(x, pk.w, pk.cout, bias=pk.bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        _conv_param_grads(ctx, dy.contiguous(), ctx.host.packed())
+        return None, None, None, None
 
 
 def conv_in(sample, host):
     """NCHW fp32/bf16 latents -> channel-padded NHWC bf16 -> 3x3 conv.  The latents never need a gradient."""
-    _no_host_grad(host.weight, host.bias)
     if sample.requires_grad:
         raise NotImplementedError("hcp_diffusion_amd: gradient w.r.t. the input latents is not implemented")
     pk = host.packed()
     x = K.nchw_to_nhwc(sample.contiguous(), pk.cin_pad)
-    return K.conv3x3(x, pk.w, pk.cout, bias=pk.bias)
+    hw, hb = _tr(host.weight), _tr(host.bias)
+    if hw is None and hb is None:
+        return K.conv3x3(x, pk.w, pk.cout, bias=pk.bias)
+    return _ConvInFn.apply(x, host, hw, hb)

@@ -18,7 +18,8 @@ import torch
 
 from . import kernels as K
 from . import ops
-from .lora import make_lora
+from .fullft import HostBucket
+from .lora import get_match_layers, make_lora
 
 
 def ddpm_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, device="cpu"):
@@ -28,22 +29,47 @@ def ddpm_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0
     return torch.cumprod(1.0 - betas, dim=0).to(device)
 
 
+class _OptState:
+    """AdamW state of one flat bucket: moments, device-resident lr / step counter / squared-norm scalar."""
+
+    def __init__(self, bucket, lr, device):
+        self.bucket = bucket
+        self.exp_avg = torch.zeros(bucket.numel, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(bucket.numel, dtype=torch.float32, device=device)
+        self.lr = torch.full((1,), lr, dtype=torch.float32, device=device)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+
+
 class NativeTrainer:
-    def __init__(self, unet, lora_cfg, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
+    def __init__(self, unet, lora_cfg=None, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000,
-                 overlap_wgrad=False, grouped_wgrad=True):
+                 overlap_wgrad=False, grouped_wgrad=True, train_cfg=None):
+        """lora_cfg: the reference's ``lora_unet`` list ({layers, rank, alpha, lr, ...}); train_cfg: its ``unet`` list
+        ({layers, lr}) of host modules to fine-tune in full (DreamBooth.yaml:6-10 uses ``layers: ['']`` = everything)."""
         self.unet = unet
         self.device = next(unet.parameters()).device
         unet.requires_grad_(False)            # config_model(): freeze host, eval (train_ac.py:264-268)
         unet.eval()
-        self.param_groups, self.lora_group, self.bucket = make_lora(unet, lora_cfg)
-        assert self.bucket is not None, "no LoRA layer matched"
-        n = self.bucket.numel
-        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.lr = torch.full((1,), lr * scale_lr_factor, dtype=torch.float32, device=self.device)
-        self.step_count = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.host_buckets = []
+        named = dict(unet.named_modules())
+        for item in (train_cfg or []):        # get_params_group (train_ac.py:280-296): matched modules' own parameters
+            seen, params = set(), []
+            for layer_name in get_match_layers(item["layers"], named):
+                for n_, p_ in named[layer_name].named_parameters():
+                    full = f"{layer_name}.{n_}" if layer_name else n_
+                    if id(p_) not in seen and "lora_block_" not in full:
+                        seen.add(id(p_)); params.append((full, p_))
+            hb = HostBucket(unet, params)
+            self.host_buckets.append(_OptState(hb, item.get("lr", lr) * scale_lr_factor, self.device))
+        self.param_groups, self.lora_group, self.bucket = make_lora(unet, lora_cfg) if lora_cfg else ([], None, None)
+        assert self.bucket is not None or self.host_buckets, "nothing to train: no LoRA layer matched and no host group given"
+        self._lora_state = _OptState(self.bucket, lr * scale_lr_factor, self.device) if self.bucket is not None else None
+        if self._lora_state is not None:      # historical attribute names (tests / tools read them)
+            st = self._lora_state
+            self.exp_avg, self.exp_avg_sq, self.lr, self.step_count, self.sumsq = st.exp_avg, st.exp_avg_sq, st.lr, st.step_count, st.sumsq
+        for st in self.host_buckets:
+            st.bucket.repack()
         self.weight_decay, self.betas, self.eps, self.max_grad_norm = weight_decay, betas, eps, max_grad_norm
         self.loss_weight = loss_weight
         self.acp = ddpm_alphas_cumprod(num_train_timesteps, device=self.device)
@@ -84,20 +110,34 @@ class NativeTrainer:
             ops.enable_grouped_wgrad(False)
         return loss
 
+    def _states(self):
+        return ([self._lora_state] if self._lora_state is not None else []) + self.host_buckets
+
     def all_reduce(self):
-        if self.world > 1:
-            torch.distributed.all_reduce(self.bucket.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        if self.world > 1:                     # one collective per flat bucket (LoRA: 12 MB; SD1.5 full FT: 3.4 GB)
+            for st in self._states():
+                torch.distributed.all_reduce(st.bucket.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def optimizer_step(self):
-        b = self.bucket
-        K.sumsq(b.grads, self.sumsq)
-        K.adamw_clip_fused(b.params, b.grads, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count, beta1=self.betas[0],
-                           beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, sumsq_t=self.sumsq,
-                           grad_scale=1.0 / self.world, max_norm=self.max_grad_norm)
-        b.pack()                               # refresh the bf16 LoRA operands for the next forward
+        states = self._states()
+        for st in states:
+            K.sumsq(st.bucket.grads, st.sumsq)
+        total = states[0].sumsq
+        if len(states) > 1:                    # clip_grad_norm_ over ALL trainable parameters (train_ac.py:485-489)
+            total = torch.stack([st.sumsq for st in states]).sum(0)
+        for st in states:
+            b = st.bucket
+            K.adamw_clip_fused(b.params, b.grads, st.exp_avg, st.exp_avg_sq, st.lr, st.step_count, beta1=self.betas[0],
+                               beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, sumsq_t=total,
+                               grad_scale=1.0 / self.world, max_norm=self.max_grad_norm)
+        if self.bucket is not None:
+            self.bucket.pack()                 # refresh the bf16 LoRA operands for the next forward
+        for st in self.host_buckets:
+            st.bucket.repack()                 # ... and the bf16 host operands (one grouped launch)
 
     def set_lr(self, lr):
-        self.lr.fill_(lr)
+        for st in self._states():
+            st.lr.fill_(lr)
 
     # ---- one optimisation step
     def train_one_step(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None):

@@ -104,7 +104,8 @@ class ResnetBlock2D(nn.Module):
             h, x = self.norm1(x, silu=True, fork=True)       # x continues as the identity residual
         if temb_bias is not None:
             tb = temb_bias
-        elif isinstance(self.time_emb_proj, HipLinear):  # [B, Cout] fp32 row bias fused into conv1's epilogue
+        elif (isinstance(self.time_emb_proj, HipLinear) and not temb_act.requires_grad
+              and not self.time_emb_proj.weight.requires_grad):  # [B, Cout] fp32 row bias fused into conv1's epilogue
             tb = self.time_emb_proj(temb_act, out_f32=True)
         else:
             tb = self.time_emb_proj(temb_act).float()
@@ -126,6 +127,8 @@ def _fusable_linear(m):
         if m._forward_hooks or m._forward_pre_hooks:
             return None
     if type(host) is not HipLinear or host.bias is not None or host._forward_hooks or host._forward_pre_hooks:
+        return None
+    if host.weight.requires_grad:                      # trainable host: the fused (concatenated) operand would go stale
         return None
     return host, blk
 

@@ -107,6 +107,11 @@ int hcp_wgrad_conv3x3_bf16(const void* dY, int ldy, const void* X1, int C1, cons
 /* out[g][n] += sum of rows of group g of Y (bias gradients; per-sample time-embedding row-bias gradient) */
 int hcp_colsum_bf16(const void* Y, int ldy, float* out, int ldo, int M, int N, int rows_per_group, hcpStream_t stream);
 int hcp_debug_set_wgrad_tile(int wx);
+/* After the optimizer step of a full fine-tune: refresh every layer's bf16 operand copies (row-major + transposed) from
+ * the fp32 masters in ONE grouped launch.  pieces = device array of 56-byte descriptors
+ * {const float* src; bf16* dst_rm; bf16* dst_tr; int rows, cols, src_ld, rm_ld, tr_ld, tile0, tiles_c, pad;} sorted by tile0. */
+int hcp_pack_piece_bytes(void);
+int hcp_pack_weights(const void* pieces, int count, int total_tiles, hcpStream_t stream);
 /* norm weight / bias gradients: dgamma[c] += sum dz * xhat, dbeta[c] += sum dz (dz includes the fused SiLU'), stats
  * as saved by the forward entry points */
 int hcp_groupnorm_affine_grad(const void* x, const void* dy, const float* gamma, const float* beta, const float* stats,

@@ -471,3 +471,36 @@ def test_colsum(backend, M, N, rpg):
     out = to(out0.clone())
     K.colsum(to(y), out, rpg)
     assert relerr(out, ref) < 1e-5
+
+
+def test_pack_weights_grouped(backend):
+    """fullft.HostBucket: flat fp32 masters -> every layer's bf16 operand layouts in one grouped launch (csrc/pack.hip)."""
+    from hcp_diffusion_amd.fullft import HostBucket
+    from hcp_diffusion_amd.layers import HipConv2d, HipLinear
+    torch.manual_seed(3)
+    m = torch.nn.Module()
+    m.a = HipLinear(72, 130); m.b = HipConv2d(4, 24, 3, 1, 1); m.c = HipConv2d(16, 4, 3, 1, 1); m.d = HipConv2d(40, 24, 1)
+    m.e = HipConv2d(72, 80, 3, 2, 1)
+    m.to(backend.device)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    hb = HostBucket(m, list(m.named_parameters()))
+    assert all(torch.equal(v.cpu(), sd[k]) for k, v in m.state_dict().items())          # re-homing keeps values / shapes
+    assert m.b.weight.permute(0, 2, 3, 1).is_contiguous() and m.b.weight.grad.shape == m.b.weight.shape
+    hb.repack()
+    with torch.no_grad():
+        hb.params.copy_(backend.to(torch.randn(hb.numel)))                               # "optimizer step" on the flat bucket
+    hb.repack()
+    for layer in (m.a, m.d):
+        w = layer.weight.detach().cpu().reshape(layer.weight.shape[0], -1)
+        pk = layer.packed()
+        assert torch.equal(pk.w.cpu(), w.to(BF)) and torch.equal(pk.wt.cpu(), w.t().to(BF))
+    for layer in (m.b, m.c, m.e):
+        w = layer.weight.detach().cpu()
+        pk = layer.packed()
+        co, ci = w.shape[:2]
+        assert torch.equal(pk.w.cpu()[..., :ci], w.permute(0, 2, 3, 1).to(BF))
+        assert torch.equal(pk.wd.cpu()[..., :co], w.permute(1, 2, 3, 0).to(BF))
+        if co % 8:
+            assert pk.wd.cpu()[..., co:].abs().max().item() == 0.0
+        if ci % 8:
+            assert pk.w.cpu()[..., ci:].abs().max().item() == 0.0

@@ -127,6 +127,68 @@ def test_tiny_sdxl_lora_train_step_vs_oracle(backend):
     assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.995
 
 
+def _full_ft_pair(cfg, backend, shape, ctx_len, ctx_dim, pooled_dim=None, seed=11):
+    dev = backend.device
+    ora, nat = _pair(cfg, dev)
+    tr = NativeTrainer(nat, None, lr=1e-3, train_cfg=[dict(layers=[""], lr=1e-3)])          # DreamBooth.yaml:6-10
+    g2 = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(*shape, generator=g2); ehs = torch.randn(shape[0], ctx_len, ctx_dim, generator=g2)
+    noise = torch.randn(*shape, generator=g2); t = torch.randint(0, 1000, (shape[0],), generator=g2).long()
+    added = None
+    if pooled_dim:
+        added = dict(text_embeds=torch.randn(shape[0], pooled_dim, generator=g2),
+                     time_ids=torch.tensor([[shape[2] * 8.0, shape[3] * 8.0, 0.0, 16.0, shape[2] * 8.0, shape[3] * 8.0]] * shape[0]))
+    pred = ora(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ehs, added_cond_kwargs=added).sample
+    loss_o = F.mse_loss(pred, noise)
+    loss_o.backward()
+    tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
+    batch = (x0.to(dev), ehs.to(dev), None, {k: v.to(dev) for k, v in added.items()} if added else None)
+    loss_n = tr.forward_backward(*batch)
+    return ora, nat, tr, loss_o.item(), loss_n.item(), batch
+
+
+@pytest.mark.parametrize("cfg_name", ["sd15", "sdxl"])
+def test_tiny_full_finetune_step_vs_oracle(backend, cfg_name):
+    """Every UNet parameter trainable (reference cfgs/train/examples/DreamBooth.yaml:6-10): weight / bias / norm-affine
+    gradients of all layers vs fp32 autograd of the oracle, then clip + AdamW + bf16 operand refresh."""
+    cfg, extra = (TINY_CONFIG, {}) if cfg_name == "sd15" else (TINY_SDXL_CONFIG, dict(pooled_dim=64))
+    ora, nat, tr, lo, ln, batch = _full_ft_pair(cfg, backend, (2, 4, 8, 8), 77, 64, **extra)
+    assert abs(lo - ln) / abs(lo) < 2e-2
+    po = dict(ora.named_parameters())
+    hb = tr.host_buckets[0].bucket
+    assert len(hb.named) == len(po) and hb.numel >= sum(p.numel() for p in po.values())
+    num = den_a = den_b = 0.0
+    bad = []
+    for name, p in nat.named_parameters():
+        go, gn = po[name].grad, p.grad.cpu()
+        assert gn.shape == go.shape
+        num += (go * gn).sum().item(); den_a += go.norm().item() ** 2; den_b += gn.norm().item() ** 2
+        cos = F.cosine_similarity(go.flatten(), gn.flatten(), dim=0).item()
+        if go.norm().item() > 1e-6 and cos < 0.97:
+            bad.append((name, round(cos, 4)))
+    assert num / (den_a * den_b) ** 0.5 > 0.995          # all gradients, flat
+    assert not bad, bad                                   # and each tensor on its own (bf16 pipeline vs fp32 oracle)
+    # optimizer: torch clip + AdamW on the oracle with the NATIVE gradients, vs the fused kernel; then the refreshed
+    # bf16 operands must reproduce the updated model's forward
+    params = list(po.values())
+    for name, p in nat.named_parameters():
+        po[name].grad = p.grad.cpu().contiguous().clone()
+    torch.nn.utils.clip_grad_norm_(params, 1.0)
+    torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-3).step()
+    tr.all_reduce(); tr.optimizer_step()
+    for name, p in nat.named_parameters():
+        assert ((po[name].detach() - p.detach().cpu()).abs().max() / po[name].abs().max().clamp_min(1e-6)).item() < 1e-5, name
+    assert hb.grads.abs().max().item() == 0.0
+    x0, ehs, _, added = batch
+    noise_t = tr.make_noise(x0)
+    with torch.no_grad():
+        kw = dict(added_cond_kwargs=added) if added else {}
+        yn = nat(noise_t[0], noise_t[2], ehs, **kw).sample.cpu()
+        kwo = dict(added_cond_kwargs={k: v.cpu() for k, v in added.items()}) if added else {}
+        yo = ora(noise_t[0].cpu(), noise_t[2].cpu(), ehs.cpu(), **kwo).sample
+    assert ((yn - yo).norm() / yo.norm()).item() < 2e-2
+
+
 def test_lora_layer_api_surface(backend):
     """The reference-facing surface of seam 2: wrap_model returns {path: block}, container replaces the host in its
     parent, state keys, remove(), reparameterization_to_host()."""
