@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_IMAGE_LORA_NOCKPT = 1.61e12      # BASELINE.md §2 (fwd 803.3 G + dX backward 803.3 G + LoRA side paths)
 FLOP_PER_IMAGE_SDXL_LORA_NOCKPT = 13.5e12 # SDXL fwd ~6.76 TFLOP/img @1024px, x2 (fwd + dX backward)
+FLOP_PER_IMAGE_FULLFT_NOCKPT = 2.41e12    # full fine-tune, ckpt off (fwd + dX + dW)
 MFMA_BF16_PEAK = 2.5e15                   # MI355X_MICROARCH.md: dense bf16 MFMA
 LORA_PATTERNS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]      # cfgs/train/examples/lora_conventional.yaml:10-12
 
@@ -85,9 +86,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["sd15", "sdxl"], default="sd15",
-                    help="sd15 = the headline metric (BASELINE.json configs[1]); sdxl = configs[3] (SDXL LoRA r16 1024px bs2), "
-                         "a secondary line, not the headline")
+    ap.add_argument("--workload", choices=["sd15", "sdxl", "dreambooth"], default="sd15",
+                    help="sd15 = the headline metric (BASELINE.json configs[1]); sdxl = configs[3] (SDXL LoRA r16 1024px bs2); "
+                         "dreambooth = configs[2] (SD1.5 full fine-tune, all 859.5 M parameters, bs2) — secondary lines")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--rank-lora", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true")
@@ -111,7 +112,8 @@ def main():
     from hcp_diffusion_amd.unet import SDXL_CONFIG, NativeUNet2DConditionModel
 
     sdxl = args.workload == "sdxl"
-    args.batch = args.batch or (2 if sdxl else 4)
+    fullft = args.workload == "dreambooth"
+    args.batch = args.batch or (2 if (sdxl or fullft) else 4)
     args.rank_lora = args.rank_lora or (16 if sdxl else 8)
     torch.manual_seed(114514)                      # same weights on every rank (train_base.yaml:5)
     with torch.device("meta"):
@@ -125,16 +127,21 @@ def main():
                 p.fill_(1.0)
             else:
                 p.zero_()
-    tr = NativeTrainer(unet, [dict(layers=LORA_PATTERNS, rank=args.rank_lora, lr=1e-4)], lr=1e-4, weight_decay=1e-3,
-                       scale_lr_factor=args.batch * world, use_graph=not args.no_graph, overlap_wgrad=args.overlap,
-                       grouped_wgrad=not args.no_grouped_wgrad)
-    torch.manual_seed(114514 + rank)               # set_seed(seed + local_rank), train_ac.py:128
-    with torch.no_grad():                          # non-zero W_up so every LoRA path carries signal
-        for blk in tr.bucket.blocks:
-            blk.layer.W_up.normal_(0, 0.02)
-    if world > 1:                                  # identical LoRA init on every rank (DDP broadcasts rank 0's)
-        torch.distributed.broadcast(tr.bucket.params, 0)
-    tr.bucket.pack()
+    if fullft:                                     # cfgs/train/examples/DreamBooth.yaml:6-10: unet: [{lr: 1e-6, layers: ['']}]
+        tr = NativeTrainer(unet, None, lr=1e-6, weight_decay=1e-3, scale_lr_factor=args.batch * world, use_graph=not args.no_graph,
+                           train_cfg=[dict(layers=[""], lr=1e-6)])
+        torch.manual_seed(114514 + rank)
+    else:
+        tr = NativeTrainer(unet, [dict(layers=LORA_PATTERNS, rank=args.rank_lora, lr=1e-4)], lr=1e-4, weight_decay=1e-3,
+                           scale_lr_factor=args.batch * world, use_graph=not args.no_graph, overlap_wgrad=args.overlap,
+                           grouped_wgrad=not args.no_grouped_wgrad)
+        torch.manual_seed(114514 + rank)           # set_seed(seed + local_rank), train_ac.py:128
+        with torch.no_grad():                      # non-zero W_up so every LoRA path carries signal
+            for blk in tr.bucket.blocks:
+                blk.layer.W_up.normal_(0, 0.02)
+        if world > 1:                              # identical LoRA init on every rank (DDP broadcasts rank 0's)
+            torch.distributed.broadcast(tr.bucket.params, 0)
+        tr.bucket.pack()
     B = args.batch
     added = None
     if sdxl:                                       # [2,4,128,128], ctx [2,77,2048], pooled [2,1280], crop_info [2,6]
@@ -168,20 +175,23 @@ def main():
         ips = world * B * args.steps / dt
         out = {
             "metric": ("training images/sec (whole node), SDXL LoRA 1024px bs=%d/GPU" % B) if sdxl else
+                      ("training images/sec (whole node), SD1.5 full fine-tune (DreamBooth) 512px bs=%d/GPU" % B) if fullft else
                       "training images/sec (whole node), SD1.5 LoRA 512px bs=4/GPU", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("SDXL-base UNet LoRA rank=%d bf16, bs=%d/GPU, 1024x1024 (128x128 latents), 77x2048 context + text_time "
-                                    "cond, random-init weights, cached latents, grad-ckpt off" if sdxl else
+                                    "cond, random-init weights, cached latents, grad-ckpt off" % (args.rank_lora, B) if sdxl else
+                                    "SD1.5 UNet full fine-tune (all 859.5 M params, fp32 masters + AdamW), bf16 compute, bs=%d/GPU, "
+                                    "512x512, 77-token context, random-init weights, cached latents, grad-ckpt off" % B if fullft else
                                     "SD1.5 UNet LoRA rank=%d bf16, bs=%d/GPU, 512x512 (64x64 latents), 77-token context, "
-                                    "random-init weights, cached latents, grad-ckpt off") % (args.rank_lora, B),
+                                    "random-init weights, cached latents, grad-ckpt off" % (args.rank_lora, B)),
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
             "final_loss": round(loss_v, 5),
-            "step_mfma_frac": round(ips / world * (FLOP_PER_IMAGE_SDXL_LORA_NOCKPT if sdxl else FLOP_PER_IMAGE_LORA_NOCKPT)
-                                    / MFMA_BF16_PEAK, 4),
+            "step_mfma_frac": round(ips / world * (FLOP_PER_IMAGE_SDXL_LORA_NOCKPT if sdxl else FLOP_PER_IMAGE_FULLFT_NOCKPT if fullft
+                                                   else FLOP_PER_IMAGE_LORA_NOCKPT) / MFMA_BF16_PEAK, 4),
         }
         out["roofline"] = dominant_kernel_roofline(dev)
-        if world == 1 and not args.no_cpu_baseline and not sdxl:
+        if world == 1 and not args.no_cpu_baseline and not sdxl and not fullft:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
