@@ -52,10 +52,10 @@ _PROTOTYPES = {
     "hcp_upsample2x_bwd": (I, [P, P, I, I, I, I, P]),
     "hcp_timestep_embedding": (I, [P, P, I, I, F, P]),
     "hcp_timestep_embedding_f32": (I, [P, P, I, I, F, P]),
-    # dY, ldy, X, ldx, dW, ldw, M, N, K, stream
-    "hcp_wgrad_linear_bf16": (I, [P, I, P, I, P, I, I, I, I, P]),
-    # dY, ldy, X1, C1, X2, C2, dW, Cw, B, Hs, Ws, Ho, Wo, Cout, stride, upsample, stream
-    "hcp_wgrad_conv3x3_bf16": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, I, I, P]),
+    # dY, ldy, X, ldx, dW, ldw, M, N, K, workspace, workspace_bytes, stream
+    "hcp_wgrad_linear_bf16": (I, [P, I, P, I, P, I, I, I, I, P, c_size_t, P]),
+    # dY, ldy, X1, C1, X2, C2, dW, Cw, B, Hs, Ws, Ho, Wo, Cout, stride, upsample, workspace, workspace_bytes, stream
+    "hcp_wgrad_conv3x3_bf16": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, I, I, P, c_size_t, P]),
     # Y, ldy, out, ldo, M, N, rows_per_group, stream
     "hcp_colsum_bf16": (I, [P, I, P, I, I, I, I, P]),
     "hcp_debug_set_wgrad_tile": (I, [I]),

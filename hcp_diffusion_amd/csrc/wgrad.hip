@@ -7,8 +7,10 @@
 // Both operands arrive row-major ([tokens][channels], the activation layout of the whole path), so no operand is
 // ever transposed in memory: the 64-row tiles are DMA'd to LDS as they are (global_load_lds_dwordx4, lane-linear
 // destination, XOR-swizzled 32-byte segments) and the MFMA fragments whose k-slots run down the rows are gathered
-// with ds_read_b64_tr_b16.  Accumulation is fp32, straight into the flat gradient bucket with atomics (the token
-// dimension is split across workgroups to fill 256 CUs; `+=` is also what gradient accumulation needs).
+// with ds_read_b64_tr_b16.  Accumulation is fp32.  The token dimension is split across workgroups to fill 256 CUs:
+// each split writes its partial tile to a workspace slab and a reduce kernel adds the slabs into the flat gradient
+// bucket (`+=`, which is also what gradient accumulation needs); a single split adds in place.  (Device-scope fp32
+// atomics were measured first: ~100 G atomics/s made every small layer 5-10x slower than its data movement.)
 //
 // The conv3x3 variant gathers X rows on the fly exactly like the forward implicit GEMM (stride 2, nearest-2x upsample
 // folded into the gather, two-source channel concat), column k = tap * (C1 + C2) + c, and writes the gradient in the
@@ -28,6 +30,7 @@ struct WgradParams {
     float* D; int ldw; int Cw;
     int M, N, K;
     int rows_per_split, tiles_n;
+    float* slabs; int nsplit;       // nsplit > 1: partial sums go to slabs[split][N][K]
     int Hs, Ws, Ho, Wo, stride, up;
 };
 
@@ -153,7 +156,7 @@ HCP_KERNEL(256) wgrad_tn_kernel(WgradParams p) {
         HCP_SYNC();                                       // drains the DMA of tile t+1 and fences this tile's reads
     }
 
-    // lane holds D[n = .. + fr][k = .. + 4 fg + r]
+    // lane holds D[n = .. + fr][k = .. + 4 fg + r]   (K % 8 == 0: a lane's 4 columns are all in or all out)
 #pragma unroll
     for (int i = 0; i < TN_; ++i) {
         const int n = n0 + wn * 64 + i * 16 + fr;
@@ -162,17 +165,43 @@ HCP_KERNEL(256) wgrad_tn_kernel(WgradParams p) {
         for (int j = 0; j < TK_; ++j) {
             const int k = k0 + wk * (WX / 2) + j * 16 + 4 * fg;
             if (k >= p.K) continue;
+            if (p.nsplit > 1) {
+                *(hcp_f32x4*)(p.slabs + ((size_t)blockIdx.y * p.N + n) * p.K + k) = acc[i][j];
+                continue;
+            }
             float* dst; int lim;
             if (CONV) {
                 const int tap = k / Ctot, c = k - tap * Ctot;
                 dst = p.D + (size_t)n * p.ldw + tap * p.Cw + c; lim = p.Cw - c;
             } else {
-                dst = p.D + (size_t)n * p.ldw + k; lim = p.K - k;
+                dst = p.D + (size_t)n * p.ldw + k; lim = 4;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (r < lim) hcp_atomic_add(dst + r, acc[i][j][r]);
+                if (r < lim) dst[r] += acc[i][j][r];        // this workgroup is the only writer of its tile
         }
+    }
+}
+
+// D (+)= sum over the splits of slabs[s][n][k], with the conv column -> [tap][Cw] remap
+HCP_KERNEL(256) wgrad_reduce_kernel(WgradParams p, int conv) {
+    const int kv = p.K / 4;
+    const long total = (long)p.N * kv;
+    const int Ctot = p.C1 + p.C2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / kv), k = (int)(i - (long)n * kv) * 4;
+        hcp_f32x4 v = *(const hcp_f32x4*)(p.slabs + (size_t)n * p.K + k);
+        for (int s = 1; s < p.nsplit; ++s) v += *(const hcp_f32x4*)(p.slabs + ((size_t)s * p.N + n) * p.K + k);
+        float* dst; int lim = 4;
+        if (conv) {
+            const int tap = k / Ctot, c = k - tap * Ctot;
+            dst = p.D + (size_t)n * p.ldw + tap * p.Cw + c; lim = p.Cw - c;
+        } else {
+            dst = p.D + (size_t)n * p.ldw + k;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < lim) dst[r] += v[r];
     }
 }
 
@@ -209,48 +238,61 @@ HCP_KERNEL(256) colsum_kernel(const hcp_bf16* Y, int ldy, float* out, int ldo, i
 }
 
 int g_force_wx = 0;     // tools/tests: 64 or 128 forces the X-tile width, 0 = heuristic
+int g_force_split = 0;  // tools/tests: > 0 forces the number of token splits
 
 template <bool CONV>
-int launch_wgrad(WgradParams& p, hipStream_t stream) {
+int launch_wgrad(WgradParams& p, float* ws, size_t ws_bytes, hipStream_t stream) {
     const bool wide = g_force_wx ? g_force_wx == 128 : (p.K >= 512 && (!CONV || (p.C1 + p.C2) % 8 == 0));
     const int wx = wide ? 128 : 64;
     p.tiles_n = hcp_cdiv(p.N, WY);
     const int tiles_k = hcp_cdiv(p.K, wx);
     const long tiles = (long)p.tiles_n * tiles_k;
     const int row_tiles = hcp_cdiv(p.M, TM_ROWS);
-    int nsplit = (int)((1024 + tiles - 1) / tiles);               // ~4 workgroups per CU
+    int nsplit = (int)((768 + tiles - 1) / tiles);                // ~3 workgroups per CU ...
+    if (nsplit > row_tiles / 2) nsplit = row_tiles / 2;           // ... each with at least two row tiles to pipeline
+    if (g_force_split > 0) nsplit = g_force_split;
+    const size_t slab = (size_t)p.N * p.K * sizeof(float);
+    if (!ws || (size_t)nsplit * slab > ws_bytes) nsplit = ws ? (int)(ws_bytes / slab) : 1;
     if (nsplit > row_tiles) nsplit = row_tiles;
     if (nsplit < 1) nsplit = 1;
     p.rows_per_split = hcp_cdiv(row_tiles, nsplit) * TM_ROWS;
     nsplit = hcp_cdiv(p.M, p.rows_per_split);
+    p.nsplit = nsplit; p.slabs = ws;
     const size_t smem = (size_t)2 * TM_ROWS * (WY + wx) * sizeof(hcp_bf16);
     if (wide) HCP_LAUNCH((wgrad_tn_kernel<128, CONV>), dim3((unsigned)tiles, nsplit), dim3(256), smem, stream, p);
     else HCP_LAUNCH((wgrad_tn_kernel<64, CONV>), dim3((unsigned)tiles, nsplit), dim3(256), smem, stream, p);
+    if (nsplit > 1) {
+        long nv = (long)p.N * (p.K / 4);
+        int g = (int)((nv + 255) / 256); if (g > 2048) g = 2048;
+        HCP_LAUNCH(wgrad_reduce_kernel, dim3(g), dim3(256), 0, stream, p, CONV ? 1 : 0);
+    }
     HCP_LAUNCH_CHECK("wgrad_tn_kernel");
 }
 
 }  // namespace
 
-// TOOLS / TESTS ONLY: force the X-tile width (64 / 128), 0 restores the heuristic.
-HCP_API int hcp_debug_set_wgrad_tile(int wx) { g_force_wx = wx; return 0; }
+// TOOLS / TESTS ONLY: cfg = X-tile width (64 / 128 / 0 = heuristic) + 256 * forced token splits (0 = heuristic).
+HCP_API int hcp_debug_set_wgrad_tile(int cfg) { g_force_wx = cfg & 255; g_force_split = cfg >> 8; return 0; }
 
 // dW[N,K] (fp32, leading dim ldw) += dY[M,N]^T X[M,K]     (nn.Linear / 1x1 conv weight gradient)
+// workspace: optional fp32 scratch for the token-split partial sums (any size; more allows more parallelism)
 HCP_API int hcp_wgrad_linear_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, int M, int N, int K,
-                                  hipStream_t stream) {
+                                  float* workspace, size_t workspace_bytes, hipStream_t stream) {
     HCP_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0, "hcp_wgrad_linear_bf16: bad arguments");
     HCP_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldy >= (N + 7) / 8 * 8 && ldx >= K && ldw >= K,
                 "hcp_wgrad_linear_bf16: K (%d), ldx (%d), ldy (%d) must be multiples of 8 and cover the operands", K, ldx, ldy);
     WgradParams p = {};
     p.Y = (const hcp_bf16*)dY; p.ldy = ldy; p.X1 = (const hcp_bf16*)X; p.ldx = ldx; p.C1 = K;
     p.D = dW; p.ldw = ldw; p.Cw = K; p.M = M; p.N = N; p.K = K;
-    return launch_wgrad<false>(p, stream);
+    return launch_wgrad<false>(p, workspace, workspace_bytes, stream);
 }
 
 // dW[Cout][3][3][Cw] (fp32) += sum over output pixels of dY[b,py,px,co] * gathered X (the forward gather of
 // hcp_conv3x3_bf16: stride, fused nearest-2x upsample, channel concat X1|X2).  Cw <= C1 + C2 is the weight's true Cin
 // (conv_in stages 4 channels padded to 8).  dY rows have ldy >= Cout (conv_out: 4 channels padded to 8).
 HCP_API int hcp_wgrad_conv3x3_bf16(const void* dY, int ldy, const void* X1, int C1, const void* X2, int C2, float* dW, int Cw,
-                                   int B, int Hs, int Ws, int Ho, int Wo, int Cout, int stride, int upsample, hipStream_t stream) {
+                                   int B, int Hs, int Ws, int Ho, int Wo, int Cout, int stride, int upsample, float* workspace,
+                                   size_t workspace_bytes, hipStream_t stream) {
     HCP_REQUIRE(dY && X1 && dW && B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0 && Cout > 0, "hcp_wgrad_conv3x3_bf16: bad arguments");
     HCP_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && (C2 == 0 || X2), "hcp_wgrad_conv3x3_bf16: channel counts must be multiples of 8");
     HCP_REQUIRE(Cw > 0 && Cw <= C1 + C2 && ldy % 8 == 0 && ldy >= (Cout + 7) / 8 * 8, "hcp_wgrad_conv3x3_bf16: bad Cw / ldy");
@@ -260,7 +302,7 @@ HCP_API int hcp_wgrad_conv3x3_bf16(const void* dY, int ldy, const void* X1, int 
     p.Y = (const hcp_bf16*)dY; p.ldy = ldy; p.X1 = (const hcp_bf16*)X1; p.X2 = (const hcp_bf16*)X2; p.C1 = C1; p.C2 = C2;
     p.D = dW; p.ldw = 9 * Cw; p.Cw = Cw; p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * (C1 + C2);
     p.Hs = Hs; p.Ws = Ws; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.up = upsample;
-    return launch_wgrad<true>(p, stream);
+    return launch_wgrad<true>(p, workspace, workspace_bytes, stream);
 }
 
 // out[g][n] += sum over the rows of group g of Y[m][n]   (rows_per_group = M: one bias gradient; = Ho*Wo: the

@@ -151,8 +151,9 @@ def wgrad_linear(dy, x, dw):
     M, N = dy.shape
     K = x.shape[1]
     assert tuple(dw.shape) == (N, K)
-    _chk(lib().hcp_wgrad_linear_bf16(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), M, N, K, _stream(x)),
-         "hcp_wgrad_linear_bf16")
+    ws = _workspace(x)
+    _chk(lib().hcp_wgrad_linear_bf16(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), M, N, K, _p(ws), ws.numel(),
+                                     _stream(x)), "hcp_wgrad_linear_bf16")
 
 
 def wgrad_conv3x3(dy, x1, dw, *, x2=None, stride=1, upsample=False, cout=None):
@@ -168,8 +169,9 @@ def wgrad_conv3x3(dy, x1, dw, *, x2=None, stride=1, upsample=False, cout=None):
     cout = cout or ldy
     cw = dw.numel() // (cout * 9)
     assert dw.numel() == cout * 9 * cw and cw <= C1 + C2
+    ws = _workspace(x1)
     _chk(lib().hcp_wgrad_conv3x3_bf16(_p(dy), ldy, _p(x1), C1, _p(x2), C2, _p(dw), cw, B, Hs, Ws, Ho, Wo, cout, stride,
-                                      1 if upsample else 0, _stream(x1)), "hcp_wgrad_conv3x3_bf16")
+                                      1 if upsample else 0, _p(ws), ws.numel(), _stream(x1)), "hcp_wgrad_conv3x3_bf16")
 
 
 def colsum(y, out, rows_per_group=None):

@@ -97,13 +97,14 @@ int hcp_upsample2x_bwd(const void* dup, void* dx, int B, int H, int W, int C, hc
 
 /* ---- host-layer weight gradients (full fine-tuning: cfgs/train/examples/DreamBooth.yaml:6-10 trains every UNet
  * parameter; autograd's dW of nn.Linear / nn.Conv2d [ext]).  fp32 `+=` into the gradient buffer (atomics). ---- */
-/* dW[N,K] += dY[M,N]^T X[M,K] */
+/* dW[N,K] += dY[M,N]^T X[M,K]; workspace = optional fp32 scratch for token-split partial sums */
 int hcp_wgrad_linear_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, int M, int N, int K,
-                          hcpStream_t stream);
+                          float* workspace, size_t workspace_bytes, hcpStream_t stream);
 /* dW[Cout][3][3][Cw] += dY^T im2col(X1|X2): same gather as hcp_conv3x3_bf16 (stride, nearest-2x upsample, concat);
  * layout = torch channels_last storage of the diffusers weight [Cout,Cin,3,3] */
 int hcp_wgrad_conv3x3_bf16(const void* dY, int ldy, const void* X1, int C1, const void* X2, int C2, float* dW, int Cw, int B,
-                           int Hs, int Ws, int Ho, int Wo, int Cout, int stride, int upsample, hcpStream_t stream);
+                           int Hs, int Ws, int Ho, int Wo, int Cout, int stride, int upsample, float* workspace,
+                           size_t workspace_bytes, hcpStream_t stream);
 /* out[g][n] += sum of rows of group g of Y (bias gradients; per-sample time-embedding row-bias gradient) */
 int hcp_colsum_bf16(const void* Y, int ldy, float* out, int ldo, int M, int N, int rows_per_group, hcpStream_t stream);
 int hcp_debug_set_wgrad_tile(int wx);

@@ -405,7 +405,7 @@ WGL_CASES_EMU = [(64, 16, 64), (100, 36, 72), (200, 130, 200), (70, 4, 520), (13
 WGL_CASES_GPU = WGL_CASES_EMU + [(16384, 320, 320), (4096, 640, 2560), (308, 320, 768), (1024, 10240, 1280), (256, 1280, 1280), (4, 1280, 320)]
 
 
-@pytest.mark.parametrize("wx", [0, 64, 128])
+@pytest.mark.parametrize("wx", [0, 64, 128, 128 + 256 * 1, 64 + 256 * 3])      # X-tile width + 256 * forced token splits
 @pytest.mark.parametrize("case", range(len(WGL_CASES_GPU)))
 def test_wgrad_linear(backend, case, wx):
     if not backend.is_gpu and case >= len(WGL_CASES_EMU):
