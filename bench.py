@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_IMAGE_LORA_NOCKPT = 1.61e12      # BASELINE.md §2 (fwd 803.3 G + dX backward 803.3 G + LoRA side paths)
 FLOP_PER_IMAGE_SDXL_LORA_NOCKPT = 13.5e12 # SDXL fwd ~6.76 TFLOP/img @1024px, x2 (fwd + dX backward)
 FLOP_PER_IMAGE_FULLFT_NOCKPT = 2.41e12    # full fine-tune, ckpt off (fwd + dX + dW)
+FLOP_PER_IMAGE_CNET_NOCKPT = 2.18e12      # SURVEY §8d without recompute: base fwd 803 + branch fwd 285 + branch bwd 2x285 + decoder dX ~518
 MFMA_BF16_PEAK = 2.5e15                   # MI355X_MICROARCH.md: dense bf16 MFMA
 LORA_PATTERNS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]      # cfgs/train/examples/lora_conventional.yaml:10-12
 
@@ -86,9 +87,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["sd15", "sdxl", "dreambooth"], default="sd15",
+    ap.add_argument("--workload", choices=["sd15", "sdxl", "dreambooth", "controlnet"], default="sd15",
                     help="sd15 = the headline metric (BASELINE.json configs[1]); sdxl = configs[3] (SDXL LoRA r16 1024px bs2); "
-                         "dreambooth = configs[2] (SD1.5 full fine-tune, all 859.5 M parameters, bs2) — secondary lines")
+                         "dreambooth = configs[2] (SD1.5 full fine-tune, all 859.5 M parameters, bs2); controlnet = configs[4] (frozen SD1.5 + "
+                         "trainable ControlNet branch, bs4) — secondary lines")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--rank-lora", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true")
@@ -113,6 +115,7 @@ def main():
 
     sdxl = args.workload == "sdxl"
     fullft = args.workload == "dreambooth"
+    cnet = args.workload == "controlnet"
     args.batch = args.batch or (2 if (sdxl or fullft) else 4)
     args.rank_lora = args.rank_lora or (16 if sdxl else 8)
     torch.manual_seed(114514)                      # same weights on every rank (train_base.yaml:5)
@@ -127,7 +130,18 @@ def main():
                 p.fill_(1.0)
             else:
                 p.zero_()
-    if fullft:                                     # cfgs/train/examples/DreamBooth.yaml:6-10: unet: [{lr: 1e-6, layers: ['']}]
+    plugin_input = None
+    if cnet:                                       # cfgs/plugins/plugin_controlnet.yaml: frozen host + trainable branch, lr 1e-4
+        from hcp_diffusion_amd.controlnet import make_controlnet
+        plug = make_controlnet(unet)
+        with torch.no_grad():                      # zero convs leave a freshly built branch without gradient flow upstream:
+            for m in list(plug.controlnet_down_blocks) + [plug.controlnet_mid_block, plug.cond_head[-1]]:
+                m.weight.normal_(0, 0.02)          # time the steady state ("after some training") instead
+        tr = NativeTrainer(unet, None, lr=1e-4, weight_decay=1e-3, scale_lr_factor=args.batch * world, use_graph=not args.no_graph,
+                           plugins=[(plug, 1e-4)])
+        torch.manual_seed(114514 + rank)
+        plugin_input = dict(cond=torch.rand(args.batch, 3, 512, 512, device=dev))
+    elif fullft:                                   # cfgs/train/examples/DreamBooth.yaml:6-10: unet: [{lr: 1e-6, layers: ['']}]
         tr = NativeTrainer(unet, None, lr=1e-6, weight_decay=1e-3, scale_lr_factor=args.batch * world, use_graph=not args.no_graph,
                            train_cfg=[dict(layers=[""], lr=1e-6)])
         torch.manual_seed(114514 + rank)
@@ -159,11 +173,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        tr.train_one_step(latents, ehs, None, added)
+        tr.train_one_step(latents, ehs, None, added, plugin_input)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tr.train_one_step(latents, ehs, None, added)
+        loss = tr.train_one_step(latents, ehs, None, added, plugin_input)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev)
@@ -176,6 +190,7 @@ def main():
         out = {
             "metric": ("training images/sec (whole node), SDXL LoRA 1024px bs=%d/GPU" % B) if sdxl else
                       ("training images/sec (whole node), SD1.5 full fine-tune (DreamBooth) 512px bs=%d/GPU" % B) if fullft else
+                      ("training images/sec (whole node), SD1.5 + ControlNet branch training 512px bs=%d/GPU" % B) if cnet else
                       "training images/sec (whole node), SD1.5 LoRA 512px bs=4/GPU", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -183,15 +198,18 @@ def main():
                                     "cond, random-init weights, cached latents, grad-ckpt off" % (args.rank_lora, B) if sdxl else
                                     "SD1.5 UNet full fine-tune (all 859.5 M params, fp32 masters + AdamW), bf16 compute, bs=%d/GPU, "
                                     "512x512, 77-token context, random-init weights, cached latents, grad-ckpt off" % B if fullft else
+                                    "frozen SD1.5 UNet + trainable ControlNet branch (361 M params, fp32 masters + AdamW), bf16 compute, "
+                                    "bs=%d/GPU, 512x512 + control image [B,3,512,512], random-init weights, grad-ckpt off" % B if cnet else
                                     "SD1.5 UNet LoRA rank=%d bf16, bs=%d/GPU, 512x512 (64x64 latents), 77-token context, "
                                     "random-init weights, cached latents, grad-ckpt off" % (args.rank_lora, B)),
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
             "final_loss": round(loss_v, 5),
             "step_mfma_frac": round(ips / world * (FLOP_PER_IMAGE_SDXL_LORA_NOCKPT if sdxl else FLOP_PER_IMAGE_FULLFT_NOCKPT if fullft
+                                                   else FLOP_PER_IMAGE_CNET_NOCKPT if cnet
                                                    else FLOP_PER_IMAGE_LORA_NOCKPT) / MFMA_BF16_PEAK, 4),
         }
         out["roofline"] = dominant_kernel_roofline(dev)
-        if world == 1 and not args.no_cpu_baseline and not sdxl and not fullft:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "sd15":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

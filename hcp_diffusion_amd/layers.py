@@ -83,6 +83,21 @@ class HipConv2d(nn.Conv2d):
         return ops.conv3x3(x, self, x2=x2, rowbias=rowbias, residual=residual, stride=self.stride[0], upsample=upsample)
 
 
+class HipConvIn(HipConv2d):
+    """conv_in: NCHW fp32/bf16 latents -> channel-padded NHWC bf16 -> 3x3 conv.  A real module call, so forward
+    (pre-)hooks fire (the reference's ControlNet plugin hooks `pre_hook:conv_in`, cfgs/plugins/plugin_controlnet.yaml)."""
+
+    def forward(self, sample):
+        return ops.conv_in(sample, self)
+
+
+class HipConvOut(HipConv2d):
+    """conv_out: NHWC bf16 -> 3x3 conv -> NCHW fp32 (the `.sample` tensor)."""
+
+    def forward(self, x):
+        return ops.conv_out(x, self)
+
+
 class _F32Affine:
     _af = None
 

@@ -44,9 +44,11 @@ class _OptState:
 class NativeTrainer:
     def __init__(self, unet, lora_cfg=None, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000,
-                 overlap_wgrad=False, grouped_wgrad=True, train_cfg=None):
+                 overlap_wgrad=False, grouped_wgrad=True, train_cfg=None, plugins=None):
         """lora_cfg: the reference's ``lora_unet`` list ({layers, rank, alpha, lr, ...}); train_cfg: its ``unet`` list
-        ({layers, lr}) of host modules to fine-tune in full (DreamBooth.yaml:6-10 uses ``layers: ['']`` = everything)."""
+        ({layers, lr}) of host modules to fine-tune in full (DreamBooth.yaml:6-10 uses ``layers: ['']`` = everything);
+        plugins: [(plugin module, lr)] — trainable hook plugins such as controlnet.ControlNetHipPlugin (make_plugin,
+        cfg_net_tools.py:148-162: all of the plugin's parameters form one param group)."""
         self.unet = unet
         self.device = next(unet.parameters()).device
         unet.requires_grad_(False)            # config_model(): freeze host, eval (train_ac.py:264-268)
@@ -62,6 +64,12 @@ class NativeTrainer:
                         seen.add(id(p_)); params.append((full, p_))
             hb = HostBucket(unet, params)
             self.host_buckets.append(_OptState(hb, item.get("lr", lr) * scale_lr_factor, self.device))
+        self.plugins = []
+        for plugin, plr in (plugins or []):
+            plugin.train()
+            hb = HostBucket(plugin, list(plugin.named_parameters()))
+            self.host_buckets.append(_OptState(hb, plr * scale_lr_factor, self.device))
+            self.plugins.append(plugin)
         self.param_groups, self.lora_group, self.bucket = make_lora(unet, lora_cfg) if lora_cfg else ([], None, None)
         assert self.bucket is not None or self.host_buckets, "nothing to train: no LoRA layer matched and no host group given"
         self._lora_state = _OptState(self.bucket, lr * scale_lr_factor, self.device) if self.bucket is not None else None
@@ -92,8 +100,11 @@ class NativeTrainer:
         t = torch.randint(0, self.num_train_timesteps, (latents.shape[0],), device=latents.device).long()
         return K.add_noise(latents, noise, t, self.acp), noise, t
 
-    def forward_backward(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None):
+    def forward_backward(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None, plugin_input=None):
         noisy, noise, t = self.make_noise(latents)
+        if plugin_input:                                                  # wrapper.py:15,25-28: feeders see the batch dict
+            for feeder in getattr(self.unet, "input_feeder", []):
+                feeder(dict(noisy_latents=noisy, timesteps=t, encoder_hidden_states=encoder_hidden_states, **plugin_input))
         if added_cond_kwargs:                                             # SDXL: wrapper.py:66-73
             pred = self.unet(noisy, t, encoder_hidden_states, added_cond_kwargs=added_cond_kwargs).sample
         else:
@@ -140,16 +151,16 @@ class NativeTrainer:
             st.lr.fill_(lr)
 
     # ---- one optimisation step
-    def train_one_step(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None):
+    def train_one_step(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None, plugin_input=None):
         """latents [B,4,h,w] fp32 (cached VAE latents), encoder_hidden_states [B,L,D]; SDXL adds
         added_cond_kwargs={"text_embeds" [B,1280], "time_ids" [B,6]}. Returns the loss as a device tensor (no host sync)."""
         if not self.use_graph:
-            self.loss = self.forward_backward(latents.float().contiguous(), encoder_hidden_states, mask, added_cond_kwargs)
+            self.loss = self.forward_backward(latents.float().contiguous(), encoder_hidden_states, mask, added_cond_kwargs, plugin_input)
             self.all_reduce()
             self.optimizer_step()
             return self.loss
         if self._graphs is None:
-            self._capture(latents, encoder_hidden_states, mask, added_cond_kwargs)
+            self._capture(latents, encoder_hidden_states, mask, added_cond_kwargs, plugin_input)
         s = self._static
         s["latents"].copy_(latents)
         s["ehs"].copy_(encoder_hidden_states)
@@ -157,29 +168,32 @@ class NativeTrainer:
             s["mask"].copy_(mask)
         for k, v in (added_cond_kwargs or {}).items():
             s["added"][k].copy_(v)
+        for k, v in (plugin_input or {}).items():
+            s["plugin"][k].copy_(v)
         g1, g2 = self._graphs
         g1.replay()
         self.all_reduce()
         g2.replay()
         return self.loss
 
-    def _capture(self, latents, ehs, mask, added=None):
+    def _capture(self, latents, ehs, mask, added=None, plugin_input=None):
         s = {"latents": latents.float().contiguous().clone(), "ehs": ehs.clone(), "mask": mask.clone() if mask is not None else None,
-             "added": {k: v.clone() for k, v in added.items()} if added else None}
+             "added": {k: v.clone() for k, v in added.items()} if added else None,
+             "plugin": {k: v.clone() for k, v in plugin_input.items()} if plugin_input else None}
         self._static = s
         # warm-up on a side stream (allocator + lazy weight packing must not happen inside the capture)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                self.forward_backward(s["latents"], s["ehs"], s["mask"], s["added"])
+                self.forward_backward(s["latents"], s["ehs"], s["mask"], s["added"], s["plugin"])
                 self.all_reduce()
                 self.optimizer_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
-            loss = self.forward_backward(s["latents"], s["ehs"], s["mask"], s["added"])
+            loss = self.forward_backward(s["latents"], s["ehs"], s["mask"], s["added"], s["plugin"])
         self.loss = loss
         with torch.cuda.graph(g2, pool=g1.pool()):
             self.optimizer_step()

@@ -14,7 +14,7 @@ from torch import nn
 
 from . import kernels as K
 from . import ops
-from .layers import HipConv2d, HipGroupNorm, HipLayerNorm, HipLinear
+from .layers import HipConv2d, HipConvIn, HipConvOut, HipGroupNorm, HipLayerNorm, HipLinear
 
 BF16 = torch.bfloat16
 
@@ -364,7 +364,7 @@ class NativeUNet2DConditionModel(nn.Module):
         self.config = _Config(cfg)
         boc = cfg["block_out_channels"]
         temb_dim = boc[0] * 4
-        self.conv_in = HipConv2d(cfg["in_channels"], boc[0], 3, 1, 1)
+        self.conv_in = HipConvIn(cfg["in_channels"], boc[0], 3, 1, 1)
         self.time_proj = Timesteps(boc[0])
         self.time_embedding = TimestepEmbedding(boc[0], temb_dim)
         n = cfg["layers_per_block"]
@@ -386,7 +386,7 @@ class NativeUNet2DConditionModel(nn.Module):
         self.mid_block = UNetMidBlock2DCrossAttn(boc[-1], temb_dim, cfg)
         self.conv_norm_out = HipGroupNorm(cfg["norm_num_groups"], boc[0], eps=1e-5)
         self.conv_act = SiLU()
-        self.conv_out = HipConv2d(boc[0], cfg["out_channels"], 3, 1, 1)
+        self.conv_out = HipConvOut(boc[0], cfg["out_channels"], 3, 1, 1)
         self.class_embedding = None
         if cfg["addition_embed_type"] == "text_time":
             self.add_time_proj = Timesteps(cfg["addition_time_embed_dim"])
@@ -480,7 +480,7 @@ class NativeUNet2DConditionModel(nn.Module):
         if ctx.dtype != BF16:
             ctx = ctx.to(BF16)
         ctx = ctx.contiguous()
-        h = ops.conv_in(sample, self.conv_in)
+        h = self.conv_in(sample)
         skips = (h,)
         for blk in self.down_blocks:
             h, s = blk(h, temb_act, ctx)
@@ -491,4 +491,4 @@ class NativeUNet2DConditionModel(nn.Module):
             h = blk(h, skips[-k:], temb_act, ctx)
             skips = skips[:-k]
         h = self.conv_norm_out(h, silu=True)
-        return UNet2DConditionOutput(ops.conv_out(h, self.conv_out))
+        return UNet2DConditionOutput(self.conv_out(h))

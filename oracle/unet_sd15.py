@@ -322,7 +322,10 @@ class OracleUNet2DConditionModel(nn.Module):
         else:
             assert cfg["addition_embed_type"] is None
 
-    def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, added_cond_kwargs=None, **kwargs):
+    def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, added_cond_kwargs=None,
+                control_residuals=None, **kwargs):
+        """control_residuals: the 13 tensors of a ControlNet branch, applied as the reference's to_layer_hook does
+        (hcpdiff/models/controlnet.py:70-82): skip[j] += r[j] (r[0] on the conv_in skip), mid output += r[-1]."""
         assert encoder_attention_mask is None, "oracle: additive key mask not restated"
         temb = self.time_embedding(self.time_proj(timestep).to(sample.dtype))
         if self.config["addition_embed_type"] == "text_time":    # call contract: reference wrapper.py:66,73
@@ -336,11 +339,53 @@ class OracleUNet2DConditionModel(nn.Module):
             h, s = blk(h, temb, encoder_hidden_states)
             skips += s
         h = self.mid_block(h, temb, encoder_hidden_states)
+        if control_residuals is not None:
+            assert len(control_residuals) == len(skips) + 1
+            skips = tuple(s + r for s, r in zip(skips, control_residuals[:-1]))
+            h = h + control_residuals[-1]
         for blk in self.up_blocks:
             k = len(blk.resnets)
             h = blk(h, skips[-k:], temb, encoder_hidden_states)
             skips = skips[:-k]
         return UNetOutput(self.conv_out(self.conv_act(self.conv_norm_out(h))))
+
+
+class OracleControlNet(nn.Module):
+    """fp32 restatement of the reference ControlNetPlugin (hcpdiff/models/controlnet.py:11-62 construction, :88-183
+    forward): deep copy of the host encoder + cond_head conv/SiLU stack + zero 1x1 convs; same parameter names."""
+
+    def __init__(self, host, cond_block_channels=None, layers_per_block=None, block_out_channels=None):
+        super().__init__()
+        from copy import deepcopy
+        boc = tuple(block_out_channels or host.config["block_out_channels"])
+        n = layers_per_block if layers_per_block is not None else host.config["layers_per_block"]
+        ch = tuple(cond_block_channels or (3, 16, 32, 96, 256, boc[0]))
+        self.conv_in = deepcopy(host.conv_in)
+        self.time_proj = deepcopy(host.time_proj)
+        self.time_embedding = deepcopy(host.time_embedding)
+        self.down_blocks = deepcopy(host.down_blocks)
+        self.mid_block = deepcopy(host.mid_block)
+        head = [nn.Conv2d(ch[0], ch[1], 3, padding=1), nn.SiLU()]                       # controlnet.py:46-56
+        for i in range(2, (len(ch) - 2) * 2):
+            head += [nn.Conv2d(ch[i // 2], ch[(i + 1) // 2], 3, padding=1, stride=1 + i % 2), nn.SiLU()]
+        head.append(nn.Conv2d(ch[-2], ch[-1], 3, padding=1))
+        self.cond_head = nn.Sequential(*head)
+        zero = [nn.Conv2d(boc[0], boc[0], 1)] + [nn.Conv2d(c, c, 1) for c in boc for _ in range(n + 1)]   # controlnet.py:30-35
+        self.controlnet_mid_block = zero.pop()
+        self.controlnet_down_blocks = nn.ModuleList(zero)
+        for m in list(self.controlnet_down_blocks) + [self.controlnet_mid_block, self.cond_head[-1]]:
+            nn.init.constant_(m.weight, 0)                                              # controlnet.py:58-62
+
+    def forward(self, sample, timestep, encoder_hidden_states, cond):
+        temb = self.time_embedding(self.time_proj(timestep).to(sample.dtype))
+        h = self.conv_in(sample) + self.cond_head(cond)                                 # controlnet.py:143-147
+        res = (h,)
+        for blk in self.down_blocks:
+            h, s = blk(h, temb, encoder_hidden_states)
+            res += s
+        h = self.mid_block(h, temb, encoder_hidden_states)
+        out = tuple(zc(r) for r, zc in zip(res, self.controlnet_down_blocks))           # controlnet.py:174-181
+        return out + (self.controlnet_mid_block(h),)
 
 
 def ddpm_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):

@@ -284,3 +284,57 @@ def test_sdxl_full_size_forward_and_lora_grads_vs_golden():
     assert num / (da * db) > 0.99
     bad = [n for n in fp if g["fingerprint"][n][0] > 1e-7 and abs(fp[n][0] - g["fingerprint"][n][0]) / g["fingerprint"][n][0] > 0.1]
     assert len(bad) <= len(fp) // 100, bad
+
+
+def test_tiny_controlnet_train_step_vs_oracle(backend):
+    """ControlNet branch (reference hcpdiff/models/controlnet.py, cfgs/plugins/plugin_controlnet.yaml): frozen host UNet,
+    trainable deep copy of its encoder + cond_head + zero convs, wired in through the reference's hook layout; all branch
+    gradients vs fp32 autograd of the oracle restatement, then clip + AdamW.  Zero convs get non-zero seeded values (a branch
+    "after some training"), otherwise every gradient upstream of them is exactly zero."""
+    from hcp_diffusion_amd.controlnet import make_controlnet
+    from oracle.unet_sd15 import OracleControlNet
+    dev = backend.device
+    ora, nat = _pair(TINY_CONFIG, dev)
+    ora.requires_grad_(False)
+    torch.manual_seed(3)
+    ocn = OracleControlNet(ora)
+    for n_, p_ in ocn.named_parameters():
+        p_.requires_grad_(True)
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for n_, p_ in ocn.named_parameters():
+            if n_.startswith(("cond_head", "controlnet_")):
+                p_.copy_(torch.randn(p_.shape, generator=g) * (0.3 / max(1.0, p_[0].numel() ** 0.5) if p_.dim() > 1 else 0.05))
+    plug = make_controlnet(nat)
+    assert sorted(k for k, _ in plug.named_parameters()) == sorted(k for k, _ in ocn.named_parameters())
+    assert plug.cond_head[0].weight.shape == (16, 3, 3, 3) and [m.stride[0] for m in plug.cond_head if hasattr(m, "stride")] == [1, 1, 2, 1, 2, 1, 2, 1]
+    plug.load_state_dict(ocn.state_dict())
+    tr = NativeTrainer(nat, None, lr=1e-3, plugins=[(plug, 1e-3)])
+    assert not any(p.requires_grad for p in nat.parameters()) and all(p.requires_grad for p in plug.parameters())
+    g2 = torch.Generator().manual_seed(21)
+    B = 2
+    x0 = torch.randn(B, 4, 8, 8, generator=g2); ehs = torch.randn(B, 77, 64, generator=g2)
+    noise = torch.randn(B, 4, 8, 8, generator=g2); t = torch.tensor([30, 800]); cond = torch.rand(B, 3, 64, 64, generator=g2)
+    xt = add_noise(x0, noise, t, ddpm_alphas_cumprod())
+    pred = ora(xt, t, ehs, control_residuals=ocn(xt, t, ehs, cond)).sample
+    loss_o = F.mse_loss(pred, noise)
+    loss_o.backward()
+    tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
+    loss_n = tr.forward_backward(x0.to(dev), ehs.to(dev), None, None, dict(cond=cond.to(dev)))
+    assert abs(loss_o.item() - loss_n.item()) / loss_o.item() < 2e-2
+    po = dict(ocn.named_parameters())
+    num = da = db = 0.0
+    bad = []
+    for name, p in plug.named_parameters():
+        go, gn = po[name].grad, p.grad.cpu()
+        num += (go * gn).sum().item(); da += go.norm().item() ** 2; db += gn.norm().item() ** 2
+        cos = F.cosine_similarity(go.flatten(), gn.flatten(), dim=0).item()
+        if go.norm().item() > 1e-7 and cos < 0.97:
+            bad.append((name, round(cos, 4)))
+    assert num / (da * db) ** 0.5 > 0.995 and not bad, bad
+    tr.all_reduce(); tr.optimizer_step()
+    assert tr.host_buckets[0].bucket.grads.abs().max().item() == 0.0
+    plug.remove()
+    with torch.no_grad():                                              # hooks gone: the host is the plain UNet again
+        y0 = nat(backend.to(xt), backend.to(t), backend.to(ehs)).sample.cpu()
+        assert ((y0 - ora(xt, t, ehs).sample).norm() / y0.norm()).item() < 2e-2
