@@ -153,47 +153,87 @@ class NativeTrainer:
     # ---- one optimisation step
     def train_one_step(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None, plugin_input=None):
         """latents [B,4,h,w] fp32 (cached VAE latents), encoder_hidden_states [B,L,D]; SDXL adds
-        added_cond_kwargs={"text_embeds" [B,1280], "time_ids" [B,6]}. Returns the loss as a device tensor (no host sync)."""
+        added_cond_kwargs={"text_embeds" [B,1280], "time_ids" [B,6]}; plugins read plugin_input (ControlNet: {"cond"}).
+        Returns the loss as a device tensor (no host sync)."""
+        return self.train_data_list([dict(latents=latents, encoder_hidden_states=encoder_hidden_states, mask=mask,
+                                          added_cond_kwargs=added_cond_kwargs, plugin_input=plugin_input)])
+
+    @staticmethod
+    def _tensors(batch):
+        """(path, tensor) for every tensor input of a batch dict (nested one level: added_cond_kwargs / plugin_input)."""
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                yield (k,), v
+            elif isinstance(v, dict):
+                for k2, v2 in v.items():
+                    if torch.is_tensor(v2):
+                        yield (k, k2), v2
+
+    def train_data_list(self, data_list):
+        """The reference's ``train_one_step(data_list)`` (train_ac.py:467-504): one batch per dataset (DreamBooth: instance +
+        class images), each forward/backward accumulating into the same gradient buckets, then ONE clip + optimizer step.
+        Per-dataset ``loss_weight`` (train_ac.py:481, get_loss_weights) scales that batch's loss and gradient.  Returns the
+        summed loss (device tensor)."""
+        for b in data_list:
+            b["latents"] = b["latents"].float().contiguous()
         if not self.use_graph:
-            self.loss = self.forward_backward(latents.float().contiguous(), encoder_hidden_states, mask, added_cond_kwargs, plugin_input)
+            self.loss = None
+            for b in data_list:
+                lw = b.get("loss_weight", 1.0)
+                keep, self.loss_weight = self.loss_weight, self.loss_weight * lw
+                try:
+                    l = self.forward_backward(b["latents"], b["encoder_hidden_states"], b.get("mask"), b.get("added_cond_kwargs"),
+                                              b.get("plugin_input"))
+                finally:
+                    self.loss_weight = keep
+                self.loss = l if self.loss is None else self.loss + l
             self.all_reduce()
             self.optimizer_step()
             return self.loss
         if self._graphs is None:
-            self._capture(latents, encoder_hidden_states, mask, added_cond_kwargs, plugin_input)
-        s = self._static
-        s["latents"].copy_(latents)
-        s["ehs"].copy_(encoder_hidden_states)
-        if mask is not None:
-            s["mask"].copy_(mask)
-        for k, v in (added_cond_kwargs or {}).items():
-            s["added"][k].copy_(v)
-        for k, v in (plugin_input or {}).items():
-            s["plugin"][k].copy_(v)
+            self._capture(data_list)
+        assert len(data_list) == len(self._static), "hipGraph mode: the number of datasets per step is fixed at capture"
+        for sb, b in zip(self._static, data_list):
+            live = dict(self._tensors(b))
+            for path, t in self._tensors(sb):
+                t.copy_(live[path])
         g1, g2 = self._graphs
         g1.replay()
         self.all_reduce()
         g2.replay()
         return self.loss
 
-    def _capture(self, latents, ehs, mask, added=None, plugin_input=None):
-        s = {"latents": latents.float().contiguous().clone(), "ehs": ehs.clone(), "mask": mask.clone() if mask is not None else None,
-             "added": {k: v.clone() for k, v in added.items()} if added else None,
-             "plugin": {k: v.clone() for k, v in plugin_input.items()} if plugin_input else None}
-        self._static = s
+    def _capture(self, data_list):
+        def clone(b):
+            return {k: (v.clone() if torch.is_tensor(v) else {k2: v2.clone() for k2, v2 in v.items()} if isinstance(v, dict) else v)
+                    for k, v in b.items() if v is not None}
+        self._static = [clone(b) for b in data_list]
+
+        def run_all():
+            total = None
+            for sb in self._static:
+                lw = sb.get("loss_weight", 1.0)
+                keep, self.loss_weight = self.loss_weight, self.loss_weight * lw
+                try:
+                    l = self.forward_backward(sb["latents"], sb["encoder_hidden_states"], sb.get("mask"), sb.get("added_cond_kwargs"),
+                                              sb.get("plugin_input"))
+                finally:
+                    self.loss_weight = keep
+                total = l if total is None else total + l
+            return total
         # warm-up on a side stream (allocator + lazy weight packing must not happen inside the capture)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                self.forward_backward(s["latents"], s["ehs"], s["mask"], s["added"], s["plugin"])
+                run_all()
                 self.all_reduce()
                 self.optimizer_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
-            loss = self.forward_backward(s["latents"], s["ehs"], s["mask"], s["added"], s["plugin"])
+            loss = run_all()
         self.loss = loss
         with torch.cuda.graph(g2, pool=g1.pool()):
             self.optimizer_step()

@@ -338,3 +338,35 @@ def test_tiny_controlnet_train_step_vs_oracle(backend):
     with torch.no_grad():                                              # hooks gone: the host is the plain UNet again
         y0 = nat(backend.to(xt), backend.to(t), backend.to(ehs)).sample.cpu()
         assert ((y0 - ora(xt, t, ehs).sample).norm() / y0.norm()).item() < 2e-2
+
+
+def test_two_dataset_step_accumulates_like_reference(backend):
+    """train_ac.py:467-504: one batch per dataset, every backward accumulates, ONE optimizer step.  Two half batches with
+    loss weights (1, 0.5) must give the gradient of loss_a + 0.5 * loss_b."""
+    dev = backend.device
+    _, nat = _pair(TINY_CONFIG, dev)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=4)], lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for blk in tr.bucket.blocks:
+            blk.layer.W_up.copy_(backend.to(torch.randn(blk.layer.W_up.shape, generator=g) * 0.05))
+    tr.bucket.pack()
+    x = [backend.to(torch.randn(1, 4, 8, 8, generator=g)) for _ in range(2)]
+    e = [backend.to(torch.randn(1, 77, 64, generator=g)) for _ in range(2)]
+    n = [backend.to(torch.randn(1, 4, 8, 8, generator=g)) for _ in range(2)]
+    t = [backend.to(torch.tensor([100])), backend.to(torch.tensor([650]))]
+    cur = {"i": 0}
+    tr.make_noise = lambda lat: (K.add_noise(lat, n[cur["i"]], t[cur["i"]], tr.acp), n[cur["i"]], t[cur["i"]])
+    grads = []
+    for i in range(2):
+        cur["i"] = i
+        tr.forward_backward(x[i], e[i])
+        grads.append(tr.bucket.grads.clone()); tr.bucket.grads.zero_()
+    expect = grads[0] + 0.5 * grads[1]
+    seq = iter([0, 1])
+    tr.make_noise = lambda lat: (lambda i: (K.add_noise(lat, n[i], t[i], tr.acp), n[i], t[i]))(next(seq))
+    tr.optimizer_step = lambda: None                              # look at the accumulated gradient before it is consumed
+    loss = tr.train_data_list([dict(latents=x[0], encoder_hidden_states=e[0]),
+                               dict(latents=x[1], encoder_hidden_states=e[1], loss_weight=0.5)])
+    assert loss.numel() == 1
+    assert ((tr.bucket.grads - expect).norm() / expect.norm()).item() < 1e-5
