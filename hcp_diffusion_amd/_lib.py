@@ -30,9 +30,9 @@ _PROTOTYPES = {
     # residual, ldr, out_f32, workspace, workspace_bytes, stream
     "hcp_conv3x3_bf16": (I, [P, I, P, I, I, I, I, I, I, I, I, I, P, I, P, I, P, P, I, P, I, I, P, c_size_t, P]),
     # Q, K, V, O, lse, B, H, Nq, Nk, D, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale, stream
-    "hcp_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P]),
+    "hcp_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P, L, P]),
     # Q, K, V, O, dO, lse, delta, dQ, dK, dV, B, H, Nq, Nk, D, strides..., scale, workspace, workspace_bytes, stream
-    "hcp_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P, c_size_t, P]),
+    "hcp_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P, L, P, c_size_t, P]),
     "hcp_debug_set_attention_config": (I, [I]),
     "hcp_groupnorm_workspace_bytes": (c_size_t, [I, I, I, I]),
     # x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream

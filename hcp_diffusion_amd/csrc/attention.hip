@@ -29,6 +29,9 @@ struct AttnParams {
     int q_rs, k_rs, v_rs, o_rs;    // token-row strides (elements); head h starts at column h*D
     int H, Nq, Nk;
     float scale;
+    // optional additive key bias [B, Nk] fp32 (diffusers' encoder_attention_mask -> (1 - mask) * -10000, added to the SCALED
+    // scores of every head and query; reference models/wrapper.py:22-23,29): applied as bias/scale on the raw scores
+    const float* kbias; long kb_bs;
     // dK/dV kernel: the query loop may be split over gridDim.x / nkv workgroups that accumulate into fp32 buffers
     int qsplit;           // number of query-range splits (1 = none)
     float* dk32; float* dv32;   // [B, Nk, H*D] fp32 accumulators when qsplit > 1
@@ -180,6 +183,19 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int t = 0; t < QT; ++t) sc[t][kt] = hcp_mfma16(kf, qf[t][s], sc[t][kt]);
             }
+        if (p.kbias) {                                   // wave-uniform
+            const float* kb = p.kbias + (size_t)b * p.kb_bs + kv0;
+            const float inv = 1.0f / p.scale;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = kt * 16 + 4 * fg + r;
+                    const float bv = kk < nvalid ? kb[kk] * inv : 0.f;
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) sc[t][kt][r] += bv;
+                }
+        }
         hcp_bf16x8 pf[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -350,6 +366,19 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
                     dp[t][kt] = hcp_mfma16(vf, gf[t][s], dp[t][kt]);
                 }
             }
+        if (p.kbias) {
+            const float* kb = p.kbias + (size_t)b * p.kb_bs + kv0;
+            const float inv = 1.0f / p.scale;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = kt * 16 + 4 * fg + r;
+                    const float bv = kk < nvalid ? kb[kk] * inv : 0.f;
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) sc[t][kt][r] += bv;
+                }
+        }
         hcp_bf16x8 df[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -492,13 +521,14 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             const bool kok = k_base + t * 16 + fr < p.Nk;
+            const float kb2 = (p.kbias && kok) ? p.kbias[(size_t)b * p.kb_bs + k_base + t * 16 + fr] * LOG2E : 0.f;   // this lane's key
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
                 const hcp_f32x4 l4 = *(const hcp_f32x4*)(sL + qt * 16 + 4 * fg);
                 const hcp_f32x4 d4 = *(const hcp_f32x4*)(sL + KVT + qt * 16 + 4 * fg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pr = kok ? hcp_exp2(fmaf(sc[t][qt][r], c2, -l4[r])) : 0.f;      // lse2 = +inf for q >= Nq -> 0
+                    float pr = kok ? hcp_exp2(fmaf(sc[t][qt][r], c2, kb2 - l4[r])) : 0.f;  // lse2 = +inf for q >= Nq -> 0
                     sc[t][qt][r] = pr;
                     dp[t][qt][r] = pr * (dp[t][qt][r] - d4[r]);              // softmax scale applied once, at the store
                 }
@@ -670,8 +700,9 @@ HCP_API int hcp_debug_set_attention_config(int cfg) { g_attn_cfg = cfg; return 0
 // All tensors bf16, token-major: element (b, n, h, c) at  base + b*bs + n*rs + h*D + c.
 HCP_API int hcp_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int Nq, int Nk,
                               int D, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
-                              float scale, hipStream_t stream) {
+                              float scale, const float* key_bias, long key_bias_bs, hipStream_t stream) {
     AttnParams p = {};
+    p.kbias = key_bias; p.kb_bs = key_bias_bs;
     p.Q = (const hcp_bf16*)Q; p.K = (const hcp_bf16*)K; p.V = (const hcp_bf16*)V; p.Out = (hcp_bf16*)O; p.lse = lse;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = 1;
@@ -690,8 +721,9 @@ HCP_API int hcp_attention_fwd(const void* Q, const void* K, const void* V, void*
 HCP_API int hcp_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                               float* delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int D, long q_bs,
                               int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
-                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                              const float* key_bias, long key_bias_bs, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     AttnParams p = {};
+    p.kbias = key_bias; p.kb_bs = key_bias_bs;
     p.Q = (const hcp_bf16*)Q; p.K = (const hcp_bf16*)K; p.V = (const hcp_bf16*)V; p.O = (const hcp_bf16*)O;
     p.dO = (const hcp_bf16*)dO; p.lse = (float*)lse; p.delta = delta;
     p.dQ = (hcp_bf16*)dQ; p.dK = (hcp_bf16*)dK; p.dV = (hcp_bf16*)dV;

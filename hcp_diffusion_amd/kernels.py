@@ -188,8 +188,16 @@ def _attn_strides(t):
     return t.stride(0), t.stride(1)
 
 
-def attention_fwd(q, k, v, heads, scale=None):
-    """q [B,Nq,H*d], k/v [B,Nk,H*d] (views with arbitrary batch/row strides allowed) -> (o [B,Nq,H*d], lse [B,H,Nq])."""
+def _key_bias(key_bias, B, Nk):
+    if key_bias is None:
+        return None, 0
+    assert key_bias.dtype == torch.float32 and tuple(key_bias.shape) == (B, Nk) and key_bias.stride(1) == 1
+    return key_bias, key_bias.stride(0)
+
+
+def attention_fwd(q, k, v, heads, scale=None, key_bias=None):
+    """q [B,Nq,H*d], k/v [B,Nk,H*d] (views with arbitrary batch/row strides allowed) -> (o [B,Nq,H*d], lse [B,H,Nq]).
+    key_bias: optional fp32 [B,Nk] added to the scaled scores (additive key mask)."""
     B, Nq, C = q.shape
     Nk = k.shape[1]
     D = C // heads
@@ -197,12 +205,13 @@ def attention_fwd(q, k, v, heads, scale=None):
     o = torch.empty((B, Nq, C), dtype=BF16, device=q.device)
     lse = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
     qb, qr = _attn_strides(q); kb, kr = _attn_strides(k); vb, vr = _attn_strides(v); ob, orr = _attn_strides(o)
+    kbt, kbs = _key_bias(key_bias, B, Nk)
     _chk(lib().hcp_attention_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, heads, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
-                                 float(scale), _stream(q)), "hcp_attention_fwd")
+                                 float(scale), _p(kbt), kbs, _stream(q)), "hcp_attention_fwd")
     return o, lse
 
 
-def attention_bwd(q, k, v, o, do, lse, heads, scale=None, out=None):
+def attention_bwd(q, k, v, o, do, lse, heads, scale=None, out=None, key_bias=None):
     """Gradients (dq, dk, dv).  q/k/v may be column-slice views of a fused projection buffer; `out` = preallocated
     (dq, dk, dv) with the SAME strides as (q, k, v) (e.g. slices of one [B,N,3C] gradient buffer)."""
     B, Nq, C = q.shape
@@ -219,9 +228,10 @@ def attention_bwd(q, k, v, o, do, lse, heads, scale=None, out=None):
     delta = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
     qb, qr = _attn_strides(q); kb, kr = _attn_strides(k); vb, vr = _attn_strides(v); ob, orr = _attn_strides(o)
     ws = _workspace(q)
+    kbt, kbs = _key_bias(key_bias, B, Nk)
     _chk(lib().hcp_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, heads,
-                                 Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr, float(scale), _p(ws), ws.numel(), _stream(q)),
-         "hcp_attention_bwd")
+                                 Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr, float(scale), _p(kbt), kbs, _p(ws), ws.numel(),
+                                 _stream(q)), "hcp_attention_bwd")
     return dq, dk, dv
 
 

@@ -384,21 +384,23 @@ geglu = _GegluFn.apply
 
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, heads):
-        o, lse = K.attention_fwd(q, k, v, heads)
-        ctx.save_for_backward(q, k, v, o, lse)
+    def forward(ctx, q, k, v, heads, key_bias=None):
+        o, lse = K.attention_fwd(q, k, v, heads, key_bias=key_bias)
+        ctx.save_for_backward(q, k, v, o, lse, key_bias)
         ctx.heads = heads
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse = ctx.saved_tensors
-        dq, dk, dv = K.attention_bwd(q.contiguous(), k.contiguous(), v.contiguous(), o, do.contiguous(), lse, ctx.heads)
-        return dq, dk, dv, None
+        q, k, v, o, lse, key_bias = ctx.saved_tensors
+        dq, dk, dv = K.attention_bwd(q.contiguous(), k.contiguous(), v.contiguous(), o, do.contiguous(), lse, ctx.heads,
+                                     key_bias=key_bias)
+        return dq, dk, dv, None, None
 
 
-def attention(q, k, v, heads):
-    return _AttentionFn.apply(q, k, v, heads)
+def attention(q, k, v, heads, key_bias=None):
+    """key_bias: optional fp32 [B,Nk] additive key mask (constant: no gradient)."""
+    return _AttentionFn.apply(q, k, v, heads, key_bias)
 
 
 class _AttentionPackedFn(torch.autograd.Function):
@@ -407,34 +409,36 @@ class _AttentionPackedFn(torch.autograd.Function):
     into ONE buffer per input — no slice/concat nodes in the autograd graph."""
 
     @staticmethod
-    def forward(ctx, a, kv, heads):
+    def forward(ctx, a, kv, heads, key_bias=None):
         if kv is None:
             C = a.shape[-1] // 3
             q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
         else:
             C = a.shape[-1]
             q, k, v = a, kv[..., :C], kv[..., C:]
-        o, lse = K.attention_fwd(q, k, v, heads)
-        ctx.save_for_backward(a, kv, o, lse)
+        o, lse = K.attention_fwd(q, k, v, heads, key_bias=key_bias)
+        ctx.save_for_backward(a, kv, o, lse, key_bias)
         ctx.heads, ctx.C = heads, C
         return o
 
     @staticmethod
     def backward(ctx, do):
-        a, kv, o, lse = ctx.saved_tensors
+        a, kv, o, lse, key_bias = ctx.saved_tensors
         C = ctx.C
         if kv is None:
             da = torch.empty_like(a)
             q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
-            K.attention_bwd(q, k, v, o, do.contiguous(), lse, ctx.heads, out=(da[..., :C], da[..., C:2 * C], da[..., 2 * C:]))
-            return da, None, None
+            K.attention_bwd(q, k, v, o, do.contiguous(), lse, ctx.heads, out=(da[..., :C], da[..., C:2 * C], da[..., 2 * C:]),
+                            key_bias=key_bias)
+            return da, None, None, None
         da = torch.empty_like(a); dkv = torch.empty_like(kv)
-        K.attention_bwd(a, kv[..., :C], kv[..., C:], o, do.contiguous(), lse, ctx.heads, out=(da, dkv[..., :C], dkv[..., C:]))
-        return da, dkv, None
+        K.attention_bwd(a, kv[..., :C], kv[..., C:], o, do.contiguous(), lse, ctx.heads, out=(da, dkv[..., :C], dkv[..., C:]),
+                        key_bias=key_bias)
+        return da, dkv, None, None
 
 
-def attention_packed(a, kv, heads):
-    return _AttentionPackedFn.apply(a, kv, heads)
+def attention_packed(a, kv, heads, key_bias=None):
+    return _AttentionPackedFn.apply(a, kv, heads, key_bias)
 
 
 class _AddFn(torch.autograd.Function):

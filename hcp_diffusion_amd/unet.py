@@ -165,7 +165,7 @@ class CrossAttention(nn.Module):
         self._groups = {key: (group, mods)}          # keeps the modules alive so the ids stay unique
         return group
 
-    def forward(self, x, context=None, residual=None):
+    def forward(self, x, context=None, residual=None, key_bias=None):
         if context is None:
             g = self._group((self.to_q, self.to_k, self.to_v))
             if g is not None:                          # q|k|v in one fused-LoRA GEMM, attention reads the slices in place
@@ -176,9 +176,9 @@ class CrossAttention(nn.Module):
             q = self.to_q(x)
             g = self._group((self.to_k, self.to_v))
             if g is not None:
-                o = ops.attention_packed(q, ops.linear_group(context, g), self.heads)
+                o = ops.attention_packed(q, ops.linear_group(context, g), self.heads, key_bias)
             else:
-                o = ops.attention(q, self.to_k(context), self.to_v(context), self.heads)
+                o = ops.attention(q, self.to_k(context), self.to_v(context), self.heads, key_bias)
         return _call_res(self.to_out[0], o, residual) if residual is not None else self.to_out[0](o)
 
 
@@ -212,10 +212,11 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = HipLayerNorm(dim)
 
     def forward(self, x, context):
+        context, key_bias = context if isinstance(context, tuple) else (context, None)   # (states, additive key mask)
         h, x = self.norm1(x, fork=True)                        # (LN(x), x): the fork fuses the residual-gradient add
         x = self.attn1(h, residual=x)
         h, x = self.norm2(x, fork=True)
-        x = self.attn2(h, context, residual=x)
+        x = self.attn2(h, context, residual=x, key_bias=key_bias)
         h, x = self.norm3(x, fork=True)
         return self.ff(h, residual=x)
 
@@ -458,8 +459,6 @@ class NativeUNet2DConditionModel(nn.Module):
 
     def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, added_cond_kwargs=None,
                 cross_attention_kwargs=None, **kwargs):
-        if encoder_attention_mask is not None:
-            raise NotImplementedError("hcp_diffusion_amd: encoder_attention_mask (additive key mask) is not implemented yet")
         text_time = self.config["addition_embed_type"] == "text_time"
         if bool(added_cond_kwargs) != text_time:
             raise ValueError("hcp_diffusion_amd: added_cond_kwargs={text_embeds,time_ids} is required by (and only by) a UNet with "
@@ -480,6 +479,11 @@ class NativeUNet2DConditionModel(nn.Module):
         if ctx.dtype != BF16:
             ctx = ctx.to(BF16)
         ctx = ctx.contiguous()
+        if encoder_attention_mask is not None:         # [B,L] 1 = attend: diffusers turns it into (1 - mask) * -10000, added
+            m = encoder_attention_mask                 # to the cross-attention scores of every head / query [ext]
+            if m.shape != ctx.shape[:2]:
+                raise ValueError(f"encoder_attention_mask {tuple(m.shape)} does not match encoder_hidden_states {tuple(ctx.shape[:2])}")
+            ctx = (ctx, ((1.0 - m.to(torch.float32)) * -10000.0).contiguous())
         h = self.conv_in(sample)
         skips = (h,)
         for blk in self.down_blocks:

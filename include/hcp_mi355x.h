@@ -58,13 +58,16 @@ int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int B, int 
 
 /* Fused attention, element (b,n,h,c) at base + b*bs + n*rs + h*D + c; lse[B,H,Nq] = logsumexp(scale*QK^T).
  * Replaces diffusers CrossAttention/AttnProcessor2_0 (SDPA) or xformers (reference train_ac.py:258-260). D in {40,64,80,160}. */
+/* key_bias (optional, fp32 [B,Nk], batch stride key_bias_bs): additive bias on the SCALED scores of every head/query —
+ * diffusers' encoder_attention_mask -> (1 - mask) * -10000 (the attn_mask the reference passes at models/wrapper.py:22-29). */
 int hcp_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int Nq, int Nk, int D,
                       long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
-                      hcpStream_t stream);
+                      const float* key_bias, long key_bias_bs, hcpStream_t stream);
+/* workspace (optional, 2*B*Nk*H*D floats): lets short-key problems split the dK/dV query loop across workgroups */
 int hcp_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                       float* delta_ws /* [B,H,Nq] */, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int D,
                       long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
-                      hcpStream_t stream);
+                      const float* key_bias, long key_bias_bs, void* workspace, size_t workspace_bytes, hcpStream_t stream);
 
 int hcp_debug_set_attention_config(int cfg); /* tools only: bit0/1/2 = 32 rows per wave in fwd / dQ / dK,dV; -1 = heuristic */
 

@@ -116,14 +116,17 @@ class CrossAttention(nn.Module):  # unet_struct.txt:17-25, :34-42
         self.to_v = nn.Linear(ctx_dim, dim, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Dropout(0.0)])
 
-    def forward(self, x, context=None):
+    def forward(self, x, context=None, key_bias=None):
         ctx = x if context is None else context
         B, N, C = x.shape
         d = C // self.heads
         q = self.to_q(x).view(B, N, self.heads, d).transpose(1, 2)
         k = self.to_k(ctx).view(B, -1, self.heads, d).transpose(1, 2)
         v = self.to_v(ctx).view(B, -1, self.heads, d).transpose(1, 2)
-        p = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1)          # scale = dim_head^-0.5 [ext]
+        s = q @ k.transpose(-1, -2) * d ** -0.5                                 # scale = dim_head^-0.5 [ext]
+        if key_bias is not None:                                                # [B, L] additive, every head / query [ext]
+            s = s + key_bias[:, None, None, :]
+        p = torch.softmax(s, dim=-1)
         o = (p @ v).transpose(1, 2).reshape(B, N, C)
         return self.to_out[1](self.to_out[0](o))
 
@@ -160,8 +163,9 @@ class BasicTransformerBlock(nn.Module):  # unet_struct.txt:16-47 (module order a
         self.norm3 = nn.LayerNorm(dim)
 
     def forward(self, x, context):
+        context, key_bias = context if isinstance(context, tuple) else (context, None)
         x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), context) + x
+        x = self.attn2(self.norm2(x), context, key_bias) + x                    # the mask applies to cross-attention only [ext]
         x = self.ff(self.norm3(x)) + x
         return x
 
@@ -326,7 +330,8 @@ class OracleUNet2DConditionModel(nn.Module):
                 control_residuals=None, **kwargs):
         """control_residuals: the 13 tensors of a ControlNet branch, applied as the reference's to_layer_hook does
         (hcpdiff/models/controlnet.py:70-82): skip[j] += r[j] (r[0] on the conv_in skip), mid output += r[-1]."""
-        assert encoder_attention_mask is None, "oracle: additive key mask not restated"
+        if encoder_attention_mask is not None:     # diffusers UNet2DConditionModel.forward [ext]: (1 - mask) * -10000, unsqueeze(1)
+            encoder_hidden_states = (encoder_hidden_states, (1.0 - encoder_attention_mask.to(sample.dtype)) * -10000.0)
         temb = self.time_embedding(self.time_proj(timestep).to(sample.dtype))
         if self.config["addition_embed_type"] == "text_time":    # call contract: reference wrapper.py:66,73
             text_embeds, time_ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]

@@ -111,6 +111,28 @@ ATTN_CASES_GPU = ATTN_CASES_EMU + [(4, 8, 4096, 4096, 40), (4, 8, 4096, 77, 40),
                                    (4, 8, 256, 256, 160), (4, 8, 256, 77, 160), (4, 8, 64, 64, 160), (2, 10, 4096, 4096, 64)]
 
 
+def test_attention_additive_key_mask(backend):
+    """encoder_attention_mask path: fp32 [B,Nk] bias added to the scaled scores of every head / query, fwd + all gradients."""
+    B, H, Nq, Nk, D = 2, 2, 70, 80, 40
+    torch.manual_seed(4)
+    q, k, v, do = rnd(B, Nq, H * D), rnd(B, Nk, H * D), rnd(B, Nk, H * D), rnd(B, Nq, H * D)
+    mask = torch.ones(B, Nk); mask[0, 50:] = 0; mask[1, ::3] = 0
+    bias = (1.0 - mask) * -10000.0
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    def heads(t, n):
+        return t.view(B, n, H, D).transpose(1, 2)
+    s = heads(qr, Nq) @ heads(kr, Nk).transpose(-1, -2) * D ** -0.5 + bias[:, None, None, :]
+    o_ref = (torch.softmax(s, -1) @ heads(vr, Nk)).transpose(1, 2).reshape(B, Nq, H * D)
+    o_ref.backward(do.float())
+    to = backend.to
+    o, lse = K.attention_fwd(to(q), to(k), to(v), H, key_bias=to(bias))
+    assert relerr(o, o_ref) < 1.5e-2
+    assert (lse.cpu() - torch.logsumexp(s, -1).detach()).abs().max().item() < 2e-2
+    dq, dk, dv = K.attention_bwd(to(q), to(k), to(v), o, to(do), lse, H, key_bias=to(bias))
+    assert relerr(dq, qr.grad) < 2e-2 and relerr(dk, kr.grad) < 2e-2 and relerr(dv, vr.grad) < 2e-2
+    assert dk.cpu().float()[0, 50:].abs().max().item() < 1e-6          # masked keys receive no gradient
+
+
 def attn_ref(q, k, v, H, do=None):
     B, Nq, C = q.shape; D = C // H
     q = q.float().requires_grad_(True); k = k.float().requires_grad_(True); v = v.float().requires_grad_(True)

@@ -54,6 +54,20 @@ def test_tiny_forward_vs_oracle_and_golden(backend):
     assert ((yn - yo).norm() / yo.norm()).item() < 2e-2
 
 
+def test_tiny_forward_with_encoder_attention_mask(backend):
+    """The call contract's `encoder_attention_mask=[B,L]` (models/wrapper.py:22-29; the reference pads L to a multiple of 8)."""
+    ora, nat = _pair(TINY_CONFIG, backend.device)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 4, 8, 8, generator=g); t = torch.tensor([5, 900]); ehs = torch.randn(2, 80, 64, generator=g)
+    mask = torch.ones(2, 80); mask[0, 30:] = 0; mask[1, 77:] = 0
+    with torch.no_grad():
+        yo = ora(x, t, ehs, encoder_attention_mask=mask).sample
+        yo_nomask = ora(x, t, ehs).sample
+        yn = nat(backend.to(x), backend.to(t), backend.to(ehs), encoder_attention_mask=backend.to(mask)).sample.cpu()
+    assert ((yn - yo).norm() / yo.norm()).item() < 2e-2
+    assert ((yo - yo_nomask).norm() / yo.norm()).item() > 5e-2          # the mask matters for this input
+
+
 def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42, pooled_dim=None):
     dev = backend.device
     ora, nat = _pair(cfg, dev)
