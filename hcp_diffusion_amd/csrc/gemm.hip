@@ -785,9 +785,12 @@ HCP_API int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* 
 HCP_API int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int Bn, int Hs, int Ws, int Ho, int Wo,
                              int mode, int stride, int upsample, const void* Wp, int Cout, void* D, int ldd,
                              const float* bias, const float* rowbias, int rowbias_ld, const void* residual, int ldr,
-                             int out_f32, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                             int out_f32, const void* A2, const void* B2, void* workspace, size_t workspace_bytes,
+                             hipStream_t stream) {
     GemmParams p = {};
     HCP_REQUIRE(X1 && Wp && D, "hcp_conv3x3_bf16: null operand");
+    HCP_REQUIRE((A2 == nullptr) == (B2 == nullptr), "hcp_conv3x3_bf16: the rank-32 K-extension needs both A2 and B2");
+    if (A2) { p.A2 = (const hcp_bf16*)A2; p.lda2 = 32; p.B2 = (const hcp_bf16*)B2; p.ldb2 = 32; p.K2 = 32; }
     HCP_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && (C2 == 0 || X2), "hcp_conv3x3_bf16: channels must be multiples of 8");
     HCP_REQUIRE(stride == 1 || stride == 2, "hcp_conv3x3_bf16: stride must be 1 or 2");
     HCP_REQUIRE(mode == 0 || (mode == 1 && upsample == 0 && C2 == 0), "hcp_conv3x3_bf16: bad mode/options");

@@ -4,7 +4,8 @@
 // layouts per layer: row-major [N][K] (forward) and its transpose [K][N] (data gradient) — for 3x3 convolutions per
 // tap: [Cout][tap][Cin] and [Cin][tap][Cout].  ONE grouped launch converts and transposes every layer: a workgroup
 // looks its 64x64 tile up in a prefix table of 2-D pieces (a Linear is one piece, a 3x3 conv nine).  HBM-bound:
-// 4 B read + 2 x 2 B written per parameter (SD1.5: 6.9 GB per step).
+// 4 B read + 2 x 2 B written per parameter (SD1.5: 6.9 GB per step).  The conv (LoCon) LoRA factors use the same launch to
+// build their operand images (W_down per tap -> [32][tap][Cin] and [Cin][tap][32]; alpha * W_up -> [Cout][32] and [32][Cout]).
 #include "hcp_common.h"
 
 namespace {
@@ -16,7 +17,7 @@ struct PackPiece {              // 56 bytes, mirrored by fullft.py (numpy struct
     int rows, cols, src_ld, rm_ld, tr_ld;
     int tile0;                  // index of this piece's first tile in the launch
     int tiles_c;                // tiles along the column dimension
-    int pad_;
+    float scale;                // multiplies every element (LoRA: alpha folded into the W_up operand); 1.0 for plain copies
 };
 static_assert(sizeof(PackPiece) == 56, "descriptor layout is part of the ABI");
 
@@ -41,7 +42,7 @@ HCP_KERNEL(256) pack_weights_kernel(const PackPiece* pieces, int count) {
         const int r = r0 + rr, c = c0 + cc;
         hcp_bf16 v = 0;
         if (r < pc.rows && c < pc.cols) {
-            v = hcp_f2bf(pc.src[(size_t)r * pc.src_ld + c]);
+            v = hcp_f2bf(pc.src[(size_t)r * pc.src_ld + c] * pc.scale);
             if (pc.dst_rm) pc.dst_rm[(size_t)r * pc.rm_ld + c] = v;
         }
         tile[rr * TS + cc] = v;

@@ -16,7 +16,7 @@ from . import kernels as K
 from .layers import HipConv2d, HipLinear
 
 PIECE_DTYPE = np.dtype([("src", "<u8"), ("dst_rm", "<u8"), ("dst_tr", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("src_ld", "<i4"),
-                        ("rm_ld", "<i4"), ("tr_ld", "<i4"), ("tile0", "<i4"), ("tiles_c", "<i4"), ("pad", "<i4")])
+                        ("rm_ld", "<i4"), ("tr_ld", "<i4"), ("tile0", "<i4"), ("tiles_c", "<i4"), ("scale", "<f4")])
 
 
 def _is_conv3(p):
@@ -71,13 +71,13 @@ class HostBucket:
                 for tap in range(9):
                     tc = (ci + 63) // 64
                     rows.append((src.data_ptr() + 4 * tap * ci, pk.w.data_ptr() + 2 * tap * pk.cin_pad,
-                                 pk.wd.data_ptr() + 2 * tap * pk.cout_pad, co, ci, 9 * ci, 9 * pk.cin_pad, 9 * pk.cout_pad, tile0, tc, 0))
+                                 pk.wd.data_ptr() + 2 * tap * pk.cout_pad, co, ci, 9 * ci, 9 * pk.cin_pad, 9 * pk.cout_pad, tile0, tc, 1.0))
                     tile0 += ((co + 63) // 64) * tc
             else:
                 nn_, kk = w.shape[0], w.numel() // w.shape[0]
                 assert w.is_contiguous()
                 tc = (kk + 63) // 64
-                rows.append((w.data_ptr(), pk.w.data_ptr(), pk.wt.data_ptr(), nn_, kk, kk, kk, nn_, tile0, tc, 0))
+                rows.append((w.data_ptr(), pk.w.data_ptr(), pk.wt.data_ptr(), nn_, kk, kk, kk, nn_, tile0, tc, 1.0))
                 tile0 += ((nn_ + 63) // 64) * tc
         arr = np.array(rows, dtype=PIECE_DTYPE)
         assert arr.dtype.itemsize == K.lib().hcp_pack_piece_bytes()

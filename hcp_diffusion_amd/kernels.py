@@ -114,7 +114,7 @@ def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True):
 
 
 def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=None, bias=None, rowbias=None,
-            residual=None, out_f32=False):
+            residual=None, out_f32=False, a2=None, b2=None):
     """3x3 / pad 1 convolution on NHWC bf16. mode 0: forward (wp = [cout][3][3][C1+C2]); mode 1: data gradient
     (x1 = dY [B,Hs,Ws,C1], wp = [cin][3][3][C1], out_hw = spatial dims of the forward input)."""
     assert x1.dtype == BF16 and x1.dim() == 4 and x1.is_contiguous()
@@ -137,10 +137,14 @@ def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=N
         assert rowbias.dtype == torch.float32 and rowbias.shape == (B, cout) and rowbias.stride(1) == 1
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == cout and bias.is_contiguous()
+    if a2 is not None:          # rank-32 K-extension: out += a2 [M,32] @ b2 [cout,32]^T
+        assert a2.dtype == BF16 and b2.dtype == BF16 and a2.is_contiguous() and b2.is_contiguous()
+        assert a2.numel() == B * Ho * Wo * 32 and tuple(b2.shape) == (cout, 32)
     ws = _workspace(x1)
     _chk(lib().hcp_conv3x3_bf16(_p(x1), C1, _p(x2), C2, B, Hs, Ws, Ho, Wo, mode, stride, 1 if upsample else 0, _p(wp),
                                 cout, _p(out), cout, _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
-                                _p(residual), cout, 1 if out_f32 else 0, _p(ws), ws.numel(), _stream(x1)), "hcp_conv3x3_bf16")
+                                _p(residual), cout, 1 if out_f32 else 0, _p(a2), _p(b2), _p(ws), ws.numel(), _stream(x1)),
+         "hcp_conv3x3_bf16")
     return out
 
 

@@ -23,25 +23,31 @@ RANK_SLOT = 32   # the K-extension width every LoRA layer is padded to (one MFMA
 
 
 class LoraHipContainer(PatchPluginContainer):
-    """Stands where the host Linear stood (reference LoraPatchContainer, lora_base_patch.py:19-35)."""
+    """Stands where the host Linear / Conv2d stood (reference LoraPatchContainer, lora_base_patch.py:19-35)."""
     supports_fused_residual = True
 
     def forward(self, x, residual=None, **kwargs):
-        if kwargs:
-            raise NotImplementedError(f"LoraHipContainer: unsupported call arguments {list(kwargs)}")
         if len(self.plugin_names) != 1:
             raise NotImplementedError("hcp_diffusion_amd: more than one LoRA block on a host is not fused yet")
-        return ops.linear(x, self._host, self[self.plugin_names[0]], residual)
+        blk = self[self.plugin_names[0]]
+        if blk.host_type == "conv":                    # 3x3 host: same keyword surface as HipConv2d.forward
+            host = self._host
+            return ops.conv3x3(x, host, x2=kwargs.pop("x2", None), rowbias=kwargs.pop("rowbias", None), residual=residual,
+                               stride=host.stride[0], upsample=kwargs.pop("upsample", False), lora=blk, **kwargs)
+        if kwargs:
+            raise NotImplementedError(f"LoraHipContainer: unsupported call arguments {list(kwargs)}")
+        return ops.linear(x, self._host, blk, residual)
 
 
 class _Factors(nn.Module):
     """`layer` sub-module: holds W_down / W_up with the reference's names, shapes and init."""
 
-    def __init__(self, in_features, out_features, rank):
+    def __init__(self, in_features, out_features, rank, conv1x1=False):
         super().__init__()
         self.rank = rank
-        self.W_down = nn.Parameter(torch.empty(rank, in_features))
-        self.W_up = nn.Parameter(torch.empty(out_features, rank))
+        tail = (1, 1) if conv1x1 else ()                 # a Conv2d host keeps the reference's 4-D factor shapes
+        self.W_down = nn.Parameter(torch.empty(rank, in_features, *tail))
+        self.W_up = nn.Parameter(torch.empty(out_features, rank, *tail))
         self.register_parameter("bias", None)
 
     def reset_parameters(self):
@@ -49,10 +55,32 @@ class _Factors(nn.Module):
         nn.init.zeros_(self.W_up)
 
     def get_weight(self):
-        return torch.mm(self.W_up, self.W_down)
+        return torch.mm(self.W_up.flatten(1), self.W_down.flatten(1))
 
     def get_collapsed_param(self):
-        return self.W_up.data @ self.W_down.data, None
+        return self.W_up.data.flatten(1) @ self.W_down.data.flatten(1), None
+
+
+class _ConvFactors(nn.Module):
+    """3x3 conv host (LoCon): W_down [r,Cin,3,3], W_up [Cout,r,1,1] — names / shapes / init of the reference's
+    LoraLayer.Conv2dLayer (lora_layers_patch.py:64-100)."""
+
+    def __init__(self, cin, cout, rank):
+        super().__init__()
+        self.rank = rank
+        self.W_down = nn.Parameter(torch.empty(rank, cin, 3, 3))
+        self.W_up = nn.Parameter(torch.empty(cout, rank, 1, 1))
+        self.register_parameter("bias", None)
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.W_down, a=math.sqrt(5))
+        nn.init.zeros_(self.W_up)
+
+    def get_weight(self):
+        return torch.einsum("or,rikl->oikl", self.W_up[:, :, 0, 0], self.W_down)
+
+    def get_collapsed_param(self):
+        return torch.einsum("or,rikl->oikl", self.W_up.data[:, :, 0, 0], self.W_down.data), None
 
 
 class LoraHipLayer(PatchPluginBlock):
@@ -63,18 +91,22 @@ class LoraHipLayer(PatchPluginBlock):
                  host_name=None, **kwargs):
         super().__init__(f"lora_block_{lora_id}", host, parent_block=parent_block, host_name=host_name)
         host = self.host()
-        if isinstance(host, HipConv2d) and host.kernel_size != (1, 1) or not isinstance(host, (HipLinear, HipConv2d)):
-            raise NotImplementedError(f"lora_hip: host {type(host).__name__} is not a native Linear/1x1 layer (conv LoRA: later row)")
+        if not isinstance(host, (HipLinear, HipConv2d)):
+            raise NotImplementedError(f"lora_hip: host {type(host).__name__} is not a native Linear / Conv2d layer")
+        conv3 = isinstance(host, HipConv2d) and host.kernel_size == (3, 3)
         if bias or dropout != 0.0:
             raise NotImplementedError("lora_hip: bias=True / dropout>0 are not implemented (reference defaults are off)")
         out_f, in_f = host.weight.shape[0], host.weight.shape[1]
+        if conv3 and (in_f % 8 or out_f % 8 or type(host) is not HipConv2d):
+            raise NotImplementedError("lora_hip: conv LoRA needs channel counts that are multiples of 8 (conv_in / conv_out are excluded)")
         if isinstance(rank, float):
             rank = max(round(out_f * rank), 1)            # fractional rank, lora_base_patch.py:105-106
         if rank > RANK_SLOT:
             raise NotImplementedError(f"lora_hip: rank {rank} > {RANK_SLOT}")
-        self.host_type = "linear"
+        self.host_type = "conv" if conv3 else "linear"   # a 1x1 conv is a Linear on channels-last tokens
         self.bias = bias
-        self.layer = _Factors(in_f, out_f, rank).to(host.weight.device)
+        self.layer = (_ConvFactors(in_f, out_f, rank) if conv3 else
+                      _Factors(in_f, out_f, rank, conv1x1=isinstance(host, HipConv2d))).to(host.weight.device)
         self.dropout = nn.Dropout(dropout)
         self.rank = rank
         self.register_buffer("alpha", torch.tensor(alpha / rank if alpha_auto_scale else alpha, device=host.weight.device))
@@ -174,29 +206,45 @@ class LoraBucket:
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         self._ops = {}
-        self._gviews = {}
+        self._gviews = {}          # the 2-D / channels-last tensors the weight-gradient kernels write
+        self._pgrads = {}          # the same memory with the parameters' own shapes (their .grad)
         self._desc_bytes = bytearray()
         self._desc_count = 0
         self._images = []          # zero-initialised operand images (kept alive)
         self.groups = []
+        self._conv_rows, self._conv_tiles, self._conv_pieces = [], 0, None
         for b in self.blocks:
             views = []
             for p in (b.layer.W_down, b.layer.W_up):
-                v = self.params[off:off + p.numel()].view_as(p)
+                seg, gseg = self.params[off:off + p.numel()], self.grads[off:off + p.numel()]
+                if p.dim() == 4 and p.shape[2] == 3:       # conv W_down [r,Cin,3,3]: channels_last = the kernels' [r][ky][kx][Cin]
+                    v = seg.view(p.shape[0], 3, 3, p.shape[1]).permute(0, 3, 1, 2)
+                    g = gseg.view(p.shape[0], 3, 3, p.shape[1]).permute(0, 3, 1, 2)
+                else:
+                    v, g = seg.view_as(p), gseg.view_as(p)
                 v.copy_(p.data)
                 p.data = v
-                g = self.grads[off:off + p.numel()].view_as(p)
                 p.grad = g
                 views.append(g)
                 off += p.numel()
-            self._gviews[id(b)] = tuple(views)
-            r, k = b.layer.W_down.shape
+            k = b.layer.W_down.shape[1]
             n_out = b.layer.W_up.shape[0]
-            self._ops[id(b)] = self._new_images(k, n_out)
-            self._add_desc(b, self._ops[id(b)], 0, 0, n_out)
+            self._pgrads[id(b)] = tuple(views)
+            if b.host_type == "conv":
+                self._gviews[id(b)] = (views[0].permute(0, 2, 3, 1), views[1].view(n_out, -1))     # [r][3][3][Cin], [Cout, r]
+                self._ops[id(b)] = self._new_conv_images(b, k, n_out)
+            else:
+                self._gviews[id(b)] = (views[0].view(views[0].shape[0], k), views[1].view(n_out, -1))
+                self._ops[id(b)] = self._new_images(k, n_out)
+                self._add_desc(b, self._ops[id(b)], 0, 0, n_out)
             b._bucket = self
         assert K.lib().hcp_lora_pack_desc_bytes() == 80
         self._upload_descs()
+        if self._conv_rows:
+            import numpy as np
+            from .fullft import PIECE_DTYPE
+            arr = np.array(self._conv_rows, dtype=PIECE_DTYPE)
+            self._conv_pieces = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
         self._packed_version = None
         self.pack()
 
@@ -209,15 +257,38 @@ class LoraBucket:
         o.bu = img[2 * a:2 * a + c].view(n_total, RANK_SLOT); o.but = img[2 * a + c:2 * a + 2 * c].view(RANK_SLOT, n_total)
         return o
 
+    def _new_conv_images(self, b, cin, cout):
+        """Operand images of a 3x3 conv LoRA block (zero padding written once) + the pack pieces that refresh them:
+        ad [32][3][3][Cin] (T = conv3x3(x, W_down)), wdl [Cin][3][3][32] (its data gradient), bu [Cout][32] = alpha W_up,
+        but [32][Cout]."""
+        o = _LoraOperands()
+        img = torch.zeros(2 * RANK_SLOT * 9 * cin + 2 * RANK_SLOT * cout, dtype=BF16, device=self.device)
+        self._images.append(img)
+        a = RANK_SLOT * 9 * cin; c = RANK_SLOT * cout
+        o.ad = img[0:a].view(RANK_SLOT, 3, 3, cin); o.wdl = img[a:2 * a].view(cin, 3, 3, RANK_SLOT)
+        o.bu = img[2 * a:2 * a + c].view(cout, RANK_SLOT); o.but = img[2 * a + c:2 * a + 2 * c].view(RANK_SLOT, cout)
+        r = b.layer.W_down.shape[0]
+        wd = b.layer.W_down.permute(0, 2, 3, 1)            # physical [r][3][3][Cin] fp32
+        assert wd.is_contiguous()
+        tc = (cin + 63) // 64
+        for tap in range(9):
+            self._conv_rows.append((wd.data_ptr() + 4 * tap * cin, o.ad.data_ptr() + 2 * tap * cin, o.wdl.data_ptr() + 2 * tap * RANK_SLOT,
+                                    r, cin, 9 * cin, 9 * cin, 9 * RANK_SLOT, self._conv_tiles, tc, 1.0))
+            self._conv_tiles += tc                          # r <= 32 rows: one tile row
+        self._conv_rows.append((b.layer.W_up.data_ptr(), o.bu.data_ptr(), o.but.data_ptr(), cout, r, r, RANK_SLOT, cout,
+                                self._conv_tiles, 1, b.alpha_f))
+        self._conv_tiles += (cout + 63) // 64
+        return o
+
     def _add_desc(self, b, o, slot0, n0, n_total):
-        r, k = b.layer.W_down.shape
+        r, k = b.layer.W_down.shape[:2]
         n_out = b.layer.W_up.shape[0]
         self._desc_bytes += struct.pack("<6Q3if4i", b.layer.W_down.data_ptr(), b.layer.W_up.data_ptr(), o.ad.data_ptr(), o.adt.data_ptr(),
                                         o.bu.data_ptr(), o.but.data_ptr(), k, n_out, r, b.alpha_f, slot0, n0, n_total, 0)
         self._desc_count += 1
 
     def _upload_descs(self):
-        self.descs = torch.frombuffer(bytearray(self._desc_bytes), dtype=torch.uint8).to(self.device)
+        self.descs = torch.frombuffer(bytearray(self._desc_bytes or b"\0"), dtype=torch.uint8).to(self.device)
 
     def add_group(self, group):
         """Register a FusedLoraGroup: allocate its shared operand images and pack descriptors (one per member block)."""
@@ -234,7 +305,10 @@ class LoraBucket:
         return group
 
     def pack(self):
-        K.lora_pack(self.descs, self._desc_count)
+        if self._desc_count:
+            K.lora_pack(self.descs, self._desc_count)
+        if self._conv_pieces is not None:                  # conv (LoCon) blocks: the grouped convert/transpose kernel
+            K.pack_weights(self._conv_pieces, len(self._conv_rows), self._conv_tiles)
         self._packed_version = self.params._version
 
     def packed_for(self, blk):
@@ -250,7 +324,7 @@ class LoraBucket:
     def grad_views_for(self, blk):
         gd, gu = self._gviews[id(blk)]
         if blk.layer.W_down.grad is None:      # zero_grad(set_to_none=True) dropped the views: re-attach
-            blk.layer.W_down.grad, blk.layer.W_up.grad = gd, gu
+            blk.layer.W_down.grad, blk.layer.W_up.grad = self._pgrads[id(blk)]
         return gd, gu
 
     @property

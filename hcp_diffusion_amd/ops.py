@@ -212,16 +212,23 @@ class _Conv3x3Fn(torch.autograd.Function):
     input (channel concat), stride 2, fused nearest-2x upsample."""
 
     @staticmethod
-    def forward(ctx, x1, x2, rowbias, residual, host, stride, upsample, hw=None, hb=None):
+    def forward(ctx, x1, x2, rowbias, residual, host, stride, upsample, hw=None, hb=None, lora=None, w_down=None, w_up=None):
         pk = host.packed()
-        y = K.conv3x3(x1, pk.w, pk.cout, x2=x2, stride=stride, upsample=upsample, bias=pk.bias, rowbias=rowbias, residual=residual)
-        ctx.host, ctx.stride, ctx.upsample = host, stride, upsample
+        T = None
+        if lora is not None:       # LoCon side path: T = conv3x3(x, W_down) [.,32]; y = conv(x, W) + T (alpha W_up)^T as a K-extension
+            lp = lora.packed()
+            T = K.conv3x3(x1, lp.ad, 32, x2=x2, stride=stride, upsample=upsample)
+            y = K.conv3x3(x1, pk.w, pk.cout, x2=x2, stride=stride, upsample=upsample, bias=pk.bias, rowbias=rowbias, residual=residual,
+                          a2=T, b2=lp.bu)
+        else:
+            y = K.conv3x3(x1, pk.w, pk.cout, x2=x2, stride=stride, upsample=upsample, bias=pk.bias, rowbias=rowbias, residual=residual)
+        ctx.host, ctx.stride, ctx.upsample, ctx.lora = host, stride, upsample, lora
         ctx.in_shape = x1.shape
         ctx.c2 = x2.shape[-1] if x2 is not None else 0
         ctx.has_res = residual is not None
         ctx.train_w, ctx.train_b = hw is not None, hb is not None
-        if hw is not None:
-            ctx.save_for_backward(x1, x2)
+        keep_x = hw is not None or lora is not None
+        ctx.save_for_backward(x1 if keep_x else None, x2 if keep_x else None, T)
         return y
 
     @staticmethod
@@ -231,27 +238,41 @@ class _Conv3x3Fn(torch.autograd.Function):
         B, H, W, C1 = ctx.in_shape
         hw = (H * 2, W * 2) if ctx.upsample else (H, W)
         dx1 = dx2 = None
+        x1, x2, T = ctx.saved_tensors
+        lora = ctx.lora
+        dl1 = dl2 = None
+        if lora is not None:       # U = dY (alpha W_up) [.,32]; dW_up = alpha dY^T T; dW_down = U^T im2col(x); dX += dgrad(U, W_down)
+            lp = lora.packed()
+            U = K.gemm(dy.view(-1, dy.shape[-1]), lp.but).view(*dy.shape[:-1], 32)
+            gd, gu = lora.grad_views()
+            K.lora_wgrad(T.view(-1, 32), dy.view(-1, dy.shape[-1]), gu, lora.rank, lora.alpha_f, True)
+            K.wgrad_conv3x3(U, x1, gd, x2=x2, stride=ctx.stride, upsample=ctx.upsample, cout=lora.rank)
+            if ctx.needs_input_grad[0]:
+                dl1 = K.conv3x3(U, lp.wdl[:C1], C1, mode=1, stride=ctx.stride, out_hw=hw)
+            if ctx.c2 and ctx.needs_input_grad[1]:
+                dl2 = K.conv3x3(U, lp.wdl[C1:], ctx.c2, mode=1, stride=ctx.stride, out_hw=hw)
         if ctx.needs_input_grad[0]:
-            dx1 = K.conv3x3(dy, pk.wd[:C1], C1, mode=1, stride=ctx.stride, out_hw=hw)
+            dx1 = K.conv3x3(dy, pk.wd[:C1], C1, mode=1, stride=ctx.stride, out_hw=hw, residual=dl1)
             if ctx.upsample:
                 dx1 = K.upsample2x_bwd(dx1)
         if ctx.c2 and ctx.needs_input_grad[1]:
-            dx2 = K.conv3x3(dy, pk.wd[C1:], ctx.c2, mode=1, stride=ctx.stride, out_hw=hw)
+            dx2 = K.conv3x3(dy, pk.wd[C1:], ctx.c2, mode=1, stride=ctx.stride, out_hw=hw, residual=dl2)
         drb = None
         dy2 = dy.view(-1, dy.shape[-1])
         if ctx.needs_input_grad[2]:                    # per-sample row bias (time embedding): sum over the sample's pixels
             drb = torch.zeros((B, dy.shape[-1]), dtype=torch.float32, device=dy.device)
             K.colsum(dy2, drb, dy.shape[1] * dy.shape[2])
         if ctx.train_w:
-            x1, x2 = ctx.saved_tensors
             K.wgrad_conv3x3(dy, x1, grad_buffer(ctx.host.weight, True), x2=x2, stride=ctx.stride, upsample=ctx.upsample)
         if ctx.train_b:
             K.colsum(dy2, grad_buffer(ctx.host.bias))
-        return dx1, dx2, drb, (dy if ctx.has_res else None), None, None, None, None, None
+        return dx1, dx2, drb, (dy if ctx.has_res else None), None, None, None, None, None, None, None, None
 
 
-def conv3x3(x1, host, *, x2=None, rowbias=None, residual=None, stride=1, upsample=False):
-    return _Conv3x3Fn.apply(x1, x2, rowbias, residual, host, stride, upsample, _tr(host.weight), _tr(host.bias))
+def conv3x3(x1, host, *, x2=None, rowbias=None, residual=None, stride=1, upsample=False, lora=None):
+    wd = lora.layer.W_down if lora is not None else None
+    wu = lora.layer.W_up if lora is not None else None
+    return _Conv3x3Fn.apply(x1, x2, rowbias, residual, host, stride, upsample, _tr(host.weight), _tr(host.bias), lora, wd, wu)
 
 
 def _gn_affine(ctx, x, dy, g, b, stats):

@@ -49,12 +49,14 @@ int hcp_debug_set_gemm_glds(int on);    /* tools only: 1 = LDS-DMA main loop (de
 
 /* 3x3 / pad 1 convolution over NHWC bf16 as an implicit GEMM.  mode 0: forward, Wp = [Cout][3][3][C1+C2];
  * mode 1: data gradient, X1 = dY, Wp = [Cin][3][3][Cout].  Options: stride 1|2, nearest-2x upsampled source,
- * second source tensor (channel concat), bias, per-sample row bias (time embedding), residual.
+ * second source tensor (channel concat), bias, per-sample row bias (time embedding), residual, and a rank-32 K-extension
+ * D += A2[M,32] B2[Cout,32]^T — the conv (LoCon) LoRA side path T (alpha W_up)^T, T = conv3x3(x, W_down)
+ * (reference lora_layers_patch.py:64-100 merges W + alpha * einsum(W_up, W_down) into the conv weight instead).
  * Replaces F.conv2d in diffusers ResnetBlock2D / Downsample2D / Upsample2D (reference cfgs/unet_struct.txt:92-114,390-393). */
 int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int B, int Hs, int Ws, int Ho, int Wo, int mode,
                      int stride, int upsample, const void* Wp, int Cout, void* D, int ldd, const float* bias,
-                     const float* rowbias, int rowbias_ld, const void* residual, int ldr, int out_f32, void* workspace,
-                     size_t workspace_bytes, hcpStream_t stream);
+                     const float* rowbias, int rowbias_ld, const void* residual, int ldr, int out_f32, const void* A2,
+                     const void* B2, void* workspace, size_t workspace_bytes, hcpStream_t stream);
 
 /* Fused attention, element (b,n,h,c) at base + b*bs + n*rs + h*D + c; lse[B,H,Nq] = logsumexp(scale*QK^T).
  * Replaces diffusers CrossAttention/AttnProcessor2_0 (SDPA) or xformers (reference train_ac.py:258-260). D in {40,64,80,160}. */
@@ -113,7 +115,7 @@ int hcp_colsum_bf16(const void* Y, int ldy, float* out, int ldo, int M, int N, i
 int hcp_debug_set_wgrad_tile(int wx);
 /* After the optimizer step of a full fine-tune: refresh every layer's bf16 operand copies (row-major + transposed) from
  * the fp32 masters in ONE grouped launch.  pieces = device array of 56-byte descriptors
- * {const float* src; bf16* dst_rm; bf16* dst_tr; int rows, cols, src_ld, rm_ld, tr_ld, tile0, tiles_c, pad;} sorted by tile0. */
+ * {const float* src; bf16* dst_rm; bf16* dst_tr; int rows, cols, src_ld, rm_ld, tr_ld, tile0, tiles_c; float scale;} sorted by tile0. */
 int hcp_pack_piece_bytes(void);
 int hcp_pack_weights(const void* pieces, int count, int total_tiles, hcpStream_t stream);
 /* norm weight / bias gradients: dgamma[c] += sum dz * xhat, dbeta[c] += sum dz (dz includes the fused SiLU'), stats

@@ -44,9 +44,39 @@ class OracleLoraLinear(nn.Module):
         return y if self._host.bias is None else y + self._host.bias
 
 
-def wrap_lora(model, patterns, rank, alpha=1.0):
+class OracleLoraConv2d(nn.Module):
+    """Conv2d host (LoCon): hcpdiff/models/lora_layers_patch.py:64-100 — W_down [r,Cin,kh,kw] kaiming_uniform(a=sqrt 5),
+    W_up [Cout,r,1,1] zeros, merged weight = einsum('o r ..., r i ... -> o i ...') * alpha added to the host weight, ONE conv."""
+
+    class _Layer(nn.Module):
+        def __init__(self, host, rank):
+            super().__init__()
+            self.W_down = nn.Parameter(torch.empty(rank, host.in_channels, *host.kernel_size))
+            self.W_up = nn.Parameter(torch.empty(host.out_channels, rank, 1, 1))
+            nn.init.kaiming_uniform_(self.W_down, a=math.sqrt(5))
+            nn.init.zeros_(self.W_up)
+
+    class _Block(nn.Module):
+        def __init__(self, host, rank, alpha):
+            super().__init__()
+            self.layer = OracleLoraConv2d._Layer(host, rank)
+            self.register_buffer("alpha", torch.tensor(alpha / rank))
+
+    def __init__(self, host: nn.Conv2d, rank, alpha=1.0):
+        super().__init__()
+        self._host = host
+        self.lora_block_0 = self._Block(host, rank, alpha)
+
+    def forward(self, x):
+        blk, h = self.lora_block_0, self._host
+        dw = torch.einsum("or,rikl->oikl", blk.layer.W_up[:, :, 0, 0], blk.layer.W_down) * blk.alpha
+        return torch.nn.functional.conv2d(x, h.weight + dw, h.bias, h.stride, h.padding, h.dilation, h.groups)
+
+
+def wrap_lora(model, patterns, rank, alpha=1.0, conv=False):
     """Restates make_hcpdiff's layer selection (utils/cfg_net_tools.py:30-75,108-123): `re:` patterns are
-    `re.match`-anchored on module paths; every nn.Linear under a matched module is wrapped."""
+    `re.match`-anchored on module paths; every nn.Linear (conv=True: and nn.Conv2d, lora_base_patch.py:39) under a
+    matched module is wrapped."""
     named = dict(model.named_modules())
     hits = []
     for pat in patterns:
@@ -57,11 +87,11 @@ def wrap_lora(model, patterns, rank, alpha=1.0):
     wrapped = {}
     for top in sorted(set(hits), key=hits.index):
         for sub, mod in list(named[top].named_modules()):
-            if isinstance(mod, nn.Linear) and "_host" not in sub:
+            if isinstance(mod, (nn.Linear, nn.Conv2d) if conv else nn.Linear) and "_host" not in sub:
                 path = f"{top}.{sub}" if sub else top
                 parent_path, _, leaf = path.rpartition(".")
                 parent = dict(model.named_modules())[parent_path]
-                w = OracleLoraLinear(mod, rank, alpha)
+                w = OracleLoraLinear(mod, rank, alpha) if isinstance(mod, nn.Linear) else OracleLoraConv2d(mod, rank, alpha)
                 setattr(parent, leaf, w)
                 wrapped[path] = w
     return wrapped

@@ -103,6 +103,26 @@ def lora_reference_vectors():
                                                      for k, b in blocks.items()},
                            x=x.detach().clone(), ctx=ctx, dy=dy, y=y.detach().clone(), dx=x.grad.clone(),
                            state_keys=sorted(parent.state_dict().keys()))
+    # conv hosts (LoCon, cfgs/train/examples/locon.yaml): LoraLayer.Conv2dLayer, lora_layers_patch.py:64-100
+    for tag, (cin, cout, stride, rank, alpha, hw) in {"conv3x3_r4": (16, 24, 1, 4, 1.0, 6), "conv3x3_s2_r8": (8, 16, 2, 8, 2.0, 8)}.items():
+        parent = nn.Module()
+        parent.conv = nn.Conv2d(cin, cout, 3, stride, 1)
+        with torch.no_grad():
+            parent.conv.weight.copy_(rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5)); parent.conv.bias.copy_(rnd(cout, scale=0.1))
+        host_w = parent.conv.weight.detach().clone(); host_b = parent.conv.bias.detach().clone()
+        blocks = LoraLayer.wrap_model(0, parent.conv, parent_block=parent, host_name="conv", rank=rank, alpha=alpha, dropout=0.0)
+        blk = blocks[""]
+        assert type(parent.conv).__name__ == "LoraPatchContainer" and tuple(blk.layer.W_down.shape) == (rank, cin, 3, 3)
+        with torch.no_grad():
+            blk.layer.W_down.copy_(rnd(rank, cin, 3, 3, scale=0.2)); blk.layer.W_up.copy_(rnd(cout, rank, 1, 1, scale=0.3))
+        x = rnd(2, cin, hw, hw).requires_grad_(True)
+        y = parent.conv(x)
+        dy = rnd(*y.shape)
+        y.backward(dy)
+        out[tag] = dict(host_weight=host_w, host_bias=host_b, W_down=blk.layer.W_down.detach().clone(), W_up=blk.layer.W_up.detach().clone(),
+                        alpha_buffer=blk.alpha.clone(), cfg_alpha=alpha, rank=rank, stride=stride, x=x.detach().clone(), dy=dy,
+                        y=y.detach().clone(), dx=x.grad.clone(), dW_down=blk.layer.W_down.grad.clone(), dW_up=blk.layer.W_up.grad.clone(),
+                        state_keys=sorted(parent.state_dict().keys()))
     return out
 
 
@@ -217,6 +237,8 @@ if __name__ == "__main__":
                "shapes": shapes}, open(os.path.join(GOLD, "sd15_struct.json"), "w"), indent=0)
     print("sd15_struct.json:", len(shapes), "tensors")
     torch.save(lora_reference_vectors(), os.path.join(GOLD, "lora_reference.pt"))
+    if len(sys.argv) > 1 and sys.argv[1] == "lora":
+        sys.exit(0)
     torch.save(tiny_unet_vectors(), os.path.join(GOLD, "tiny_unet_oracle.pt"))
     torch.save(sd15_full_vectors(), os.path.join(GOLD, "sd15_full_oracle.pt"))
     for f in os.listdir(GOLD):

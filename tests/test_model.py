@@ -384,3 +384,78 @@ def test_two_dataset_step_accumulates_like_reference(backend):
                                dict(latents=x[1], encoder_hidden_states=e[1], loss_weight=0.5)])
     assert loss.numel() == 1
     assert ((tr.bucket.grads - expect).norm() / expect.norm()).item() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["conv3x3_r4", "conv3x3_s2_r8"])
+def test_conv_lora_layer_vs_reference_golden(backend, tag):
+    """LoCon: native conv LoRA (side path T = conv3x3(x, W_down), K-extension with alpha W_up) against vectors produced by the
+    reference's own LoraLayer.Conv2dLayer (tests/golden/lora_reference.pt, oracle/make_golden.py)."""
+    from hcp_diffusion_amd.layers import HipConv2d
+    g = torch.load(os.path.join(GOLD, "lora_reference.pt"))[tag]
+    dev = backend.device
+    cout, cin = g["host_weight"].shape[:2]
+    parent = torch.nn.Module(); parent.conv = HipConv2d(cin, cout, 3, g["stride"], 1)
+    with torch.no_grad():
+        parent.conv.weight.copy_(g["host_weight"]); parent.conv.bias.copy_(g["host_bias"])
+    parent.to(dev).requires_grad_(False)
+    blk = LoraHipLayer.wrap_model(0, parent.conv, parent_block=parent, host_name="conv", rank=g["rank"], alpha=g["cfg_alpha"])[""]
+    assert sorted(parent.state_dict().keys()) == g["state_keys"] and tuple(blk.layer.W_down.shape) == tuple(g["W_down"].shape)
+    assert torch.equal(blk.alpha.cpu(), g["alpha_buffer"])
+    with torch.no_grad():
+        blk.layer.W_down.copy_(backend.to(g["W_down"])); blk.layer.W_up.copy_(backend.to(g["W_up"]))
+    blk.packed()                                          # stand-alone layer: creates its private one-layer bucket
+    x = backend.to(g["x"].permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)).requires_grad_(True)
+    y = parent.conv(x)
+    y.backward(backend.to(g["dy"].permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)))
+    def rel(a, b):
+        return ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    assert rel(y.detach().permute(0, 3, 1, 2), g["y"]) < 2e-2 and rel(x.grad.permute(0, 3, 1, 2), g["dx"]) < 2e-2
+    assert rel(blk.layer.W_down.grad, g["dW_down"]) < 2e-2 and rel(blk.layer.W_up.grad, g["dW_up"]) < 2e-2
+    w_eff = g["host_weight"] + float(blk.alpha) * torch.einsum("or,rikl->oikl", g["W_up"][:, :, 0, 0], g["W_down"])
+    blk.reparameterization_to_host()
+    assert torch.allclose(parent.conv._host.weight.cpu(), w_eff, atol=1e-5)
+
+
+def test_tiny_locon_train_step_vs_oracle(backend):
+    """cfgs/train/examples/locon.yaml: LoRA on the attention / ff Linear layers AND on the resnets' convs, proj_in/out 1x1 convs
+    and the down/upsampler convs."""
+    pats_conv = [r"re:.*\.resnets$", r"re:.*\.proj_in$", r"re:.*\.proj_out$", r"re:.*\.conv$"]
+    dev = backend.device
+    ora, nat = _pair(TINY_CONFIG, dev)
+    ora.requires_grad_(False)
+    wr = wrap_lora(ora, PATS, rank=4)
+    wr.update(wrap_lora(ora, pats_conv, rank=4, conv=True))
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=4), dict(layers=pats_conv, rank=4)], lr=1e-3)
+    norm = lambda k: k.replace("lora_block_1", "lora_block_0")     # the reference names blocks by cfg-list index; the oracle always 0
+    assert sorted(k for k in ora.state_dict() if "lora" in k) == sorted(norm(k) for k in nat.state_dict() if "lora" in k)
+    assert {tuple(v.shape) for k, v in nat.state_dict().items() if k.endswith("conv1.lora_block_1.layer.W_down")} >= {(4, 80, 3, 3)}
+    assert any(k.endswith("proj_in.lora_block_1.layer.W_down") and v.dim() == 4 for k, v in nat.state_dict().items())
+    gen = torch.Generator().manual_seed(5)
+    sd_n = dict(nat.named_parameters())
+    with torch.no_grad():
+        for name, p in ora.named_parameters():
+            if "lora_block_" in name:
+                if name.endswith("W_up"):
+                    p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
+                sd_n[name.replace("lora_block_0", "lora_block_0" if name in sd_n else "lora_block_1")].copy_(p)
+    tr.bucket.pack()
+    g2 = torch.Generator().manual_seed(42)
+    x0 = torch.randn(2, 4, 8, 8, generator=g2); ehs = torch.randn(2, 77, 64, generator=g2)
+    noise = torch.randn(2, 4, 8, 8, generator=g2); t = torch.tensor([40, 710])
+    pred = ora(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ehs).sample
+    loss_o = F.mse_loss(pred, noise)
+    loss_o.backward()
+    tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
+    loss_n = tr.forward_backward(x0.to(dev), ehs.to(dev))
+    assert abs(loss_o.item() - loss_n.item()) / loss_o.item() < 2e-2
+    num = da = db = 0.0
+    bad = []
+    for name, p in ora.named_parameters():
+        if "lora_block_" not in name:
+            continue
+        gn = sd_n[name if name in sd_n else name.replace("lora_block_0", "lora_block_1")].grad.cpu()
+        go = p.grad
+        num += (go * gn).sum().item(); da += go.norm().item() ** 2; db += gn.norm().item() ** 2
+        if go.norm().item() > 1e-7 and F.cosine_similarity(go.flatten(), gn.flatten(), dim=0).item() < 0.97:
+            bad.append(name)
+    assert num / (da * db) ** 0.5 > 0.995 and not bad, bad

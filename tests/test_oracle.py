@@ -45,6 +45,28 @@ def test_lora_restatement_matches_reference_code(tag):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["conv3x3_r4", "conv3x3_s2_r8"])
+def test_conv_lora_restatement_matches_reference_code(tag):
+    """LoCon: the oracle's Conv2d LoRA vs vectors produced by the reference's own LoraLayer.Conv2dLayer (make_golden.py)."""
+    from oracle.lora_ref import OracleLoraConv2d
+    g = torch.load(os.path.join(GOLD, "lora_reference.pt"))[tag]
+    cout, cin = g["host_weight"].shape[:2]
+    host = torch.nn.Conv2d(cin, cout, 3, g["stride"], 1)
+    with torch.no_grad():
+        host.weight.copy_(g["host_weight"]); host.bias.copy_(g["host_bias"])
+    host.requires_grad_(False)
+    parent = torch.nn.Module(); parent.conv = OracleLoraConv2d(host, g["rank"], g["cfg_alpha"])
+    blk = parent.conv.lora_block_0
+    assert torch.equal(blk.alpha, g["alpha_buffer"]) and sorted(parent.state_dict().keys()) == g["state_keys"]
+    with torch.no_grad():
+        blk.layer.W_down.copy_(g["W_down"]); blk.layer.W_up.copy_(g["W_up"])
+    x = g["x"].clone().requires_grad_(True)
+    y = parent.conv(x)
+    y.backward(g["dy"])
+    for a, b in ((y, g["y"]), (x.grad, g["dx"]), (blk.layer.W_down.grad, g["dW_down"]), (blk.layer.W_up.grad, g["dW_up"])):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
 def test_attention_module_with_reference_lora():
     """Oracle CrossAttention + oracle LoRA == reference LoRA wrapped around the same module (golden)."""
     from oracle.lora_ref import wrap_lora
