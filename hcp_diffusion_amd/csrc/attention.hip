@@ -114,7 +114,9 @@ HCP_DEVICE void zero_lds(hcp_bf16* p, int elems, int tid) {
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int D, int QT>
+// KB: compile-time "has additive key bias" — the unmasked instantiation is exactly the bias-free code (the run-time
+// branch cost 10-50 VGPRs and a wave of occupancy in the dQ kernel).
+template <int D, int QT, bool KB = false>
 HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
@@ -183,7 +185,7 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int t = 0; t < QT; ++t) sc[t][kt] = hcp_mfma16(kf, qf[t][s], sc[t][kt]);
             }
-        if (p.kbias) {                                   // wave-uniform
+        if (KB) {                                   // wave-uniform
             const float* kb = p.kbias + (size_t)b * p.kb_bs + kv0;
             const float inv = 1.0f / p.scale;
 #pragma unroll
@@ -295,7 +297,7 @@ HCP_KERNEL(256) attn_delta_kernel(AttnParams p, int B) {
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-template <int D, int QT>
+template <int D, int QT, bool KB = false>
 HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
@@ -366,7 +368,7 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
                     dp[t][kt] = hcp_mfma16(vf, gf[t][s], dp[t][kt]);
                 }
             }
-        if (p.kbias) {
+        if (KB) {
             const float* kb = p.kbias + (size_t)b * p.kb_bs + kv0;
             const float inv = 1.0f / p.scale;
 #pragma unroll
@@ -426,7 +428,7 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
-template <int D, int KT>
+template <int D, int KT, bool KB = false>
 HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
@@ -521,7 +523,7 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             const bool kok = k_base + t * 16 + fr < p.Nk;
-            const float kb2 = (p.kbias && kok) ? p.kbias[(size_t)b * p.kb_bs + k_base + t * 16 + fr] * LOG2E : 0.f;   // this lane's key
+            const float kb2 = (KB && kok) ? p.kbias[(size_t)b * p.kb_bs + k_base + t * 16 + fr] * LOG2E : 0.f;   // this lane's key
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
                 const hcp_f32x4 l4 = *(const hcp_f32x4*)(sL + qt * 16 + 4 * fg);
@@ -612,7 +614,8 @@ template <int D, int QT>
 int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
     using G = AttnGeom<D>;
     size_t smem = (size_t)2 * (2 * G::RM_ELEMS) * sizeof(hcp_bf16);
-    HCP_LAUNCH((attn_fwd_kernel<D, QT>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), smem, stream, p);
+    if (p.kbias) HCP_LAUNCH((attn_fwd_kernel<D, QT, true>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), smem, stream, p);
+    else HCP_LAUNCH((attn_fwd_kernel<D, QT>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), smem, stream, p);
     HCP_LAUNCH_CHECK("attn_fwd");
 }
 template <int D>
@@ -626,7 +629,8 @@ template <int D, int QT>
 int launch_dq(AttnParams& p, int B, hipStream_t stream) {
     using G = AttnGeom<D>;
     size_t s1 = (size_t)2 * (2 * G::RM_ELEMS) * sizeof(hcp_bf16);
-    HCP_LAUNCH((attn_bwd_dq_kernel<D, QT>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), s1, stream, p);
+    if (p.kbias) HCP_LAUNCH((attn_bwd_dq_kernel<D, QT, true>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), s1, stream, p);
+    else HCP_LAUNCH((attn_bwd_dq_kernel<D, QT>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), s1, stream, p);
     HCP_LAUNCH_CHECK("attn_bwd_dq");
 }
 template <int D, int KT>
@@ -650,7 +654,8 @@ int launch_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t str
         p.dk32 = ws; p.dv32 = ws + (size_t)B * p.Nk * p.H * D;
         if (hcp_memset_async(ws, 0, need, stream)) return hcp_set_error("attention_bwd: memset failed");
     }
-    HCP_LAUNCH((attn_bwd_dkv_kernel<D, KT>), dim3(nkv * qsplit, p.H, B), dim3(256), s2, stream, p);
+    if (p.kbias) HCP_LAUNCH((attn_bwd_dkv_kernel<D, KT, true>), dim3(nkv * qsplit, p.H, B), dim3(256), s2, stream, p);
+    else HCP_LAUNCH((attn_bwd_dkv_kernel<D, KT>), dim3(nkv * qsplit, p.H, B), dim3(256), s2, stream, p);
     if (qsplit > 1) {
         long tot = (long)B * p.Nk * (p.H * D / 4);
         int g = (int)((tot + 255) / 256); if (g > 2048) g = 2048;
