@@ -26,9 +26,15 @@ class LoraHipContainer(PatchPluginContainer):
     """Stands where the host Linear / Conv2d stood (reference LoraPatchContainer, lora_base_patch.py:19-35)."""
     supports_fused_residual = True
 
+    _multi = None
+
     def forward(self, x, residual=None, **kwargs):
-        if len(self.plugin_names) != 1:
-            raise NotImplementedError("hcp_diffusion_amd: more than one LoRA block on a host is not fused yet")
+        if len(self.plugin_names) != 1:                # several blocks on one host: their rank slots side by side
+            if self._multi is None or self._multi.names != tuple(self.plugin_names):
+                self._multi = MultiLora([self[n] for n in self.plugin_names], tuple(self.plugin_names))
+            if kwargs:
+                raise NotImplementedError(f"LoraHipContainer: unsupported call arguments {list(kwargs)}")
+            return ops.linear(x, self._host, self._multi, residual)
         blk = self[self.plugin_names[0]]
         if blk.host_type == "conv":                    # 3x3 host: same keyword surface as HipConv2d.forward
             host = self._host
@@ -153,9 +159,44 @@ class LoraHipLayer(PatchPluginBlock):
             LoraBucket([self])
         return self._bucket.grad_views_for(self)
 
+    def members(self):
+        """[(block, first rank slot)] — one entry for a single block, several for MultiLora."""
+        return [(self, 0)]
+
 
 class _LoraOperands:
     pass
+
+
+class MultiLora:
+    """Several LoRA blocks on ONE Linear host — the reference container sums ``get_weight()`` over all its plugins
+    (LoraPatchContainer.forward, lora_base_patch.py:20-27).  Natively: one fused-LoRA GEMM whose 32 rank slots hold the
+    blocks' factors side by side (sum of ranks, each padded to 8, must fit 32)."""
+
+    def __init__(self, blocks, names):
+        self.blocks, self.names = list(blocks), names
+        if any(b.host_type != "linear" for b in self.blocks):
+            raise NotImplementedError("hcp_diffusion_amd: several LoRA blocks on one 3x3 conv host are not implemented")
+        self.slot_off, sl = [], 0
+        for b in self.blocks:
+            self.slot_off.append(sl); sl += 8 * ((b.rank + 7) // 8)
+        if sl > RANK_SLOT:
+            raise NotImplementedError(f"hcp_diffusion_amd: LoRA blocks on one host need {sl} > {RANK_SLOT} rank slots")
+        buckets = {id(b._bucket) for b in self.blocks}
+        if buckets == {id(None)}:
+            LoraBucket(self.blocks)                        # stand-alone layers: one private bucket for the host's blocks
+        elif len(buckets) != 1:
+            raise NotImplementedError("hcp_diffusion_amd: LoRA blocks of one host must live in the same LoraBucket")
+        self.bucket = self.blocks[0]._bucket
+        self.ops = None
+        self.bucket.add_multi(self)
+        self.layer = self.blocks[0].layer                  # autograd anchor: any trainable factor pair
+
+    def packed(self):
+        return self.bucket.packed_group(self)
+
+    def members(self):
+        return list(zip(self.blocks, self.slot_off))
 
 
 class FusedLoraGroup:
@@ -303,6 +344,17 @@ class LoraBucket:
         self.groups.append(group)
         self.pack()
         return group
+
+    def add_multi(self, multi):
+        """Shared operand images for several blocks on one host (MultiLora): same output columns, adjacent rank slots."""
+        b0 = multi.blocks[0]
+        k, n_out = b0.layer.W_down.shape[1], b0.layer.W_up.shape[0]
+        multi.ops = self._new_images(k, n_out)
+        for b, s0 in zip(multi.blocks, multi.slot_off):
+            assert b._bucket is self
+            self._add_desc(b, multi.ops, s0, 0, n_out)
+        self._upload_descs()
+        self.pack()
 
     def pack(self):
         if self._desc_count:

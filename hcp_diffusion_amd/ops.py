@@ -131,8 +131,9 @@ class _LinearFn(torch.autograd.Function):
                 dx, U = K.gemm_lora(dy2, pk.wt, lp.but, lp.adt)
             else:
                 U = K.gemm(dy2, lp.but)
-            gd, gu = lora.grad_views()
-            _wgrad(U, x2, gd, T, dy2, gu, lora.rank, lora.alpha_f)
+            for blk, s0 in lora.members():             # one block, or several sharing the 32 rank slots (lora.MultiLora)
+                gd, gu = blk.grad_views()
+                _wgrad(U, x2, gd, T, dy2, gu, blk.rank, blk.alpha_f, s0)
         elif ctx.needs_input_grad[0]:
             dx = K.gemm(dy2, pk.wt)
         if ctx.train_w:                                # dW[N,K] += dY^T X (nn.Linear [N,K]; 1x1 conv [N,K,1,1] = same memory)

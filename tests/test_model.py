@@ -459,3 +459,37 @@ def test_tiny_locon_train_step_vs_oracle(backend):
         if go.norm().item() > 1e-7 and F.cosine_similarity(go.flatten(), gn.flatten(), dim=0).item() < 0.97:
             bad.append(name)
     assert num / (da * db) ** 0.5 > 0.995 and not bad, bad
+
+
+def test_two_lora_blocks_on_one_host(backend):
+    """Two cfg groups matching the same layer -> lora_block_0 and lora_block_1 on one container; the reference sums their
+    get_weight() (lora_base_patch.py:20-27).  Native: adjacent rank slots of one fused-LoRA GEMM."""
+    from hcp_diffusion_amd.layers import HipLinear
+    dev = backend.device
+    torch.manual_seed(6)
+    parent = torch.nn.Module(); parent.fc = HipLinear(64, 48).to(dev)
+    parent.requires_grad_(False)
+    b0 = LoraHipLayer.wrap_model(0, parent.fc, parent_block=parent, host_name="fc", rank=4, alpha=1.0)[""]
+    b1 = LoraHipLayer.wrap_model(1, parent.fc, parent_block=parent, host_name="fc", rank=8, alpha=4.0)[""]
+    assert type(parent.fc).__name__ == "LoraHipContainer" and parent.fc.plugin_names == ["lora_block_0", "lora_block_1"]
+    with torch.no_grad():
+        b0.layer.W_up.normal_(0, 0.1); b1.layer.W_up.normal_(0, 0.1)
+    x = torch.randn(5, 7, 64).to(torch.bfloat16)
+    dy = torch.randn(5, 7, 48).to(torch.bfloat16)
+    xr = x.float().requires_grad_(True)
+    wd0, wu0, wd1, wu1 = (t.detach().cpu().clone().requires_grad_(True) for t in (b0.layer.W_down, b0.layer.W_up, b1.layer.W_down, b1.layer.W_up))
+    w_eff = parent.fc._host.weight.cpu() + float(b0.alpha) * (wu0 @ wd0) + float(b1.alpha) * (wu1 @ wd1)
+    yr = xr @ w_eff.T + parent.fc._host.bias.cpu()
+    yr.backward(dy.float())
+    xn = backend.to(x).requires_grad_(True)
+    y = parent.fc(xn)
+    y.backward(backend.to(dy))
+    rel = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    assert rel(y.detach(), yr.detach()) < 2e-2 and rel(xn.grad, xr.grad) < 2e-2
+    for blk, gd, gu in ((b0, wd0.grad, wu0.grad), (b1, wd1.grad, wu1.grad)):
+        assert rel(blk.layer.W_down.grad, gd) < 2e-2 and rel(blk.layer.W_up.grad, gu) < 2e-2
+    b1.remove()
+    assert parent.fc.plugin_names == ["lora_block_0"]
+    y1 = parent.fc(backend.to(x)).float().cpu()
+    ref1 = x.float() @ (parent.fc._host.weight.cpu() + float(b0.alpha) * (wu0 @ wd0)).T.detach() + parent.fc._host.bias.cpu()
+    assert rel(y1, ref1.detach()) < 2e-2
