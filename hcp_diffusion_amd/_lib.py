@@ -59,6 +59,7 @@ _PROTOTYPES = {
     # Y, ldy, out, ldo, M, N, rows_per_group, stream
     "hcp_colsum_bf16": (I, [P, I, P, I, I, I, I, P]),
     "hcp_debug_set_wgrad_tile": (I, [I]),
+    "hcp_debug_set_attention_ablation": (I, [I]),
     "hcp_pack_piece_bytes": (I, []),
     # pieces, count, total_tiles, stream
     "hcp_pack_weights": (I, [P, I, I, P]),

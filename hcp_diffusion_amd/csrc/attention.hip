@@ -32,6 +32,7 @@ struct AttnParams {
     // optional additive key bias [B, Nk] fp32 (diffusers' encoder_attention_mask -> (1 - mask) * -10000, added to the SCALED
     // scores of every head and query; reference models/wrapper.py:22-23,29): applied as bias/scale on the raw scores
     const float* kbias; long kb_bs;
+    int dbg;              // tools/ablate_attn.py only (wrong results): 1 = no global loads inside the tile loop, 2 = no barriers in the loop
     // dK/dV kernel: the query loop may be split over gridDim.x / nkv workgroups that accumulate into fp32 buffers
     int qsplit;           // number of query-range splits (1 = none)
     float* dk32; float* dv32;   // [B, Nk, H*D] fp32 accumulators when qsplit > 1
@@ -167,7 +168,7 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
         const int nvalid = p.Nk - kv0 < KVT ? p.Nk - kv0 : KVT;
         const hcp_bf16* sK = lds + (it & 1) * BUF;
         const hcp_bf16* sV = sK + G::RM_ELEMS;
-        if (it + 1 < nt) {
+        if (it + 1 < nt && !(p.dbg & 1)) {
             const int nv = p.Nk - kv0 - KVT < KVT ? p.Nk - kv0 - KVT : KVT;
             sk.load(Kb + (size_t)(kv0 + KVT) * p.k_rs, p.k_rs, nv, tid);
             sv.load(Vb + (size_t)(kv0 + KVT) * p.v_rs, p.v_rs, nv, tid);
@@ -252,7 +253,7 @@ HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
             hcp_bf16* nK = lds + ((it + 1) & 1) * BUF;
             sk.store_rm(nK, G::RS, tid); sv.store_rm(nK + G::RM_ELEMS, G::RS, tid);
         }
-        HCP_SYNC();
+        if (!(p.dbg & 2)) HCP_SYNC();
     }
     // epilogue: lane holds O[q = q_base + t*16 + fr][d*16 + 4*fg + r]
 #pragma unroll
@@ -346,7 +347,7 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
         const int nvalid = p.Nk - kv0 < KVT ? p.Nk - kv0 : KVT;
         const hcp_bf16* sK = lds + (it & 1) * BUF;
         const hcp_bf16* sV = sK + G::RM_ELEMS;
-        if (it + 1 < nt) {
+        if (it + 1 < nt && !(p.dbg & 1)) {
             const int nv = p.Nk - kv0 - KVT < KVT ? p.Nk - kv0 - KVT : KVT;
             sk.load(Kb + (size_t)(kv0 + KVT) * p.k_rs, p.k_rs, nv, tid);
             sv.load(Vb + (size_t)(kv0 + KVT) * p.v_rs, p.v_rs, nv, tid);
@@ -407,7 +408,7 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
             hcp_bf16* nb = lds + ((it + 1) & 1) * BUF;
             sk.store_rm(nb, G::RS, tid); sv.store_rm(nb + G::RM_ELEMS, G::RS, tid);
         }
-        HCP_SYNC();
+        if (!(p.dbg & 2)) HCP_SYNC();
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -496,47 +497,54 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
         const hcp_bf16* sQ = lds + (NB == 2 ? ((it - it0) & 1) : 0) * BUF;
         const hcp_bf16* sG = sQ + G::RM_ELEMS;
         const float* sL = (const float*)(sG + G::RM_ELEMS);
-        if (it + 1 < nt) {
+        if (it + 1 < nt && !(p.dbg & 1)) {
             const int nv = p.Nq - q0 - KVT < KVT ? p.Nq - q0 - KVT : KVT;
             sq.load(Qb + (size_t)(q0 + KVT) * p.q_rs, p.q_rs, nv, tid);
             sg.load(dOb + (size_t)(q0 + KVT) * p.o_rs, p.o_rs, nv, tid);
             load_stats(q0 + KVT);
         }
-        hcp_f32x4 sc[KT][4], dp[KT][4];
-#pragma unroll
-        for (int t = 0; t < KT; ++t)
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; sc[t][qt] = z; dp[t][qt] = z; }
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-            for (int s = 0; s < G::NQK; ++s) {
-                hcp_bf16x8 qa = *(const hcp_bf16x8*)(sQ + (qt * 16 + fr) * G::RS + s * 32 + fg * 8);
-                hcp_bf16x8 ga = *(const hcp_bf16x8*)(sG + (qt * 16 + fr) * G::RS + s * 32 + fg * 8);
-#pragma unroll
-                for (int t = 0; t < KT; ++t) {
-                    sc[t][qt] = hcp_mfma16(qa, kf[t][s], sc[t][qt]);   // S[q = qt*16 + 4fg + r][key = fr]
-                    dp[t][qt] = hcp_mfma16(ga, vf[t][s], dp[t][qt]);
-                }
-            }
+        // two halves of the 64-query tile, one after the other: only 2 x KT score / dP blocks are live at a time
+        // (all four at once put this kernel at 266 VGPR+AGPR = ONE wave per SIMD)
         hcp_bf16x8 pf[KT][2], df[KT][2];
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const bool kok = k_base + t * 16 + fr < p.Nk;
-            const float kb2 = (KB && kok) ? p.kbias[(size_t)b * p.kb_bs + k_base + t * 16 + fr] * LOG2E : 0.f;   // this lane's key
+        for (int hf = 0; hf < 2; ++hf) {
+            hcp_f32x4 sc[KT][2], dp[KT][2];
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                const hcp_f32x4 l4 = *(const hcp_f32x4*)(sL + qt * 16 + 4 * fg);
-                const hcp_f32x4 d4 = *(const hcp_f32x4*)(sL + KVT + qt * 16 + 4 * fg);
+            for (int t = 0; t < KT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pr = kok ? hcp_exp2(fmaf(sc[t][qt][r], c2, kb2 - l4[r])) : 0.f;  // lse2 = +inf for q >= Nq -> 0
-                    sc[t][qt][r] = pr;
-                    dp[t][qt][r] = pr * (dp[t][qt][r] - d4[r]);              // softmax scale applied once, at the store
+                for (int q2 = 0; q2 < 2; ++q2) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; sc[t][q2] = z; dp[t][q2] = z; }
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int s = 0; s < G::NQK; ++s) {
+                    const int qt = 2 * hf + q2;
+                    hcp_bf16x8 qa = *(const hcp_bf16x8*)(sQ + (qt * 16 + fr) * G::RS + s * 32 + fg * 8);
+                    hcp_bf16x8 ga = *(const hcp_bf16x8*)(sG + (qt * 16 + fr) * G::RS + s * 32 + fg * 8);
+#pragma unroll
+                    for (int t = 0; t < KT; ++t) {
+                        sc[t][q2] = hcp_mfma16(qa, kf[t][s], sc[t][q2]);   // S[q = qt*16 + 4fg + r][key = fr]
+                        dp[t][q2] = hcp_mfma16(ga, vf[t][s], dp[t][q2]);
+                    }
                 }
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const bool kok = k_base + t * 16 + fr < p.Nk;
+                const float kb2 = (KB && kok) ? p.kbias[(size_t)b * p.kb_bs + k_base + t * 16 + fr] * LOG2E : 0.f;   // this lane's key
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int qt = 2 * hf + q2;
+                    const hcp_f32x4 l4 = *(const hcp_f32x4*)(sL + qt * 16 + 4 * fg);
+                    const hcp_f32x4 d4 = *(const hcp_f32x4*)(sL + KVT + qt * 16 + 4 * fg);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pr = kok ? hcp_exp2(fmaf(sc[t][q2][r], c2, kb2 - l4[r])) : 0.f;  // lse2 = +inf for q >= Nq -> 0
+                        sc[t][q2][r] = pr;
+                        dp[t][q2][r] = pr * (dp[t][q2][r] - d4[r]);          // softmax scale applied once, at the store
+                    }
+                }
+                pf[t][hf] = pack8(sc[t][0], sc[t][1]);
+                df[t][hf] = pack8(dp[t][0], dp[t][1]);
             }
-            pf[t][0] = pack8(sc[t][0], sc[t][1]); pf[t][1] = pack8(sc[t][2], sc[t][3]);
-            df[t][0] = pack8(dp[t][0], dp[t][1]); df[t][1] = pack8(dp[t][2], dp[t][3]);
         }
 #pragma unroll
         for (int d = 0; d < G::NDV; ++d)
@@ -552,7 +560,7 @@ HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
             }
         if (NB == 2) {
             if (it + 1 < nt) store_all(lds + ((it + 1 - it0) & 1) * BUF);
-            HCP_SYNC();
+            if (!(p.dbg & 2)) HCP_SYNC();
         } else {
             HCP_SYNC();
             if (it + 1 < nt) store_all(lds);
@@ -608,6 +616,7 @@ HCP_KERNEL(256) attn_dkv_convert_kernel(AttnParams p, int B, int C) {
     }
 }
 
+int g_attn_dbg = 0;    // tools only, see AttnParams::dbg
 int g_attn_cfg = -1;   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32; -1 = heuristic
 
 template <int D, int QT>
@@ -678,7 +687,8 @@ template <int D>
 int run_bwd(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t stream) {
     if (int e = launch_delta<D>(p, B, stream)) return e;
     // measured on MI355X: 32 rows per wave pay off once the grid has >= 512 such workgroups
-    bool wq = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512, wk = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nk, 128) >= 512;
+    // (dK/dV with 32 keys per wave: 224 VGPR+AGPR at d=40 = 2 waves/SIMD, but 280 at d=64 = ONE wave/SIMD -> narrow there)
+    bool wq = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512, wk = D <= 40 && (long)B * p.H * hcp_cdiv(p.Nk, 128) >= 512;
     if (g_attn_cfg >= 0) { wq = kWide<D> && (g_attn_cfg & 2); wk = kWide<D> && (g_attn_cfg & 4); }
     int e;
     if constexpr (kWide<D>) { e = wq ? launch_dq<D, 2>(p, B, stream) : launch_dq<D, 1>(p, B, stream); }
@@ -700,6 +710,8 @@ int attn_check(const AttnParams& p, int B, int D) {
 
 // TOOLS ONLY: bit0 forward / bit1 dQ / bit2 dK,dV use 32 rows per wave; -1 restores the heuristic.
 HCP_API int hcp_debug_set_attention_config(int cfg) { g_attn_cfg = cfg; return 0; }
+// TOOLS ONLY (results are wrong when != 0): 1 = skip the global loads inside the tile loops (latency ablation).
+HCP_API int hcp_debug_set_attention_ablation(int flags) { g_attn_dbg = flags; return 0; }
 
 // O[b,q,h,:] = softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,:];  lse[b,h,q] = logsumexp of the scaled scores.
 // All tensors bf16, token-major: element (b, n, h, c) at  base + b*bs + n*rs + h*D + c.
@@ -707,7 +719,7 @@ HCP_API int hcp_attention_fwd(const void* Q, const void* K, const void* V, void*
                               int D, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
                               float scale, const float* key_bias, long key_bias_bs, hipStream_t stream) {
     AttnParams p = {};
-    p.kbias = key_bias; p.kb_bs = key_bias_bs;
+    p.kbias = key_bias; p.kb_bs = key_bias_bs; p.dbg = g_attn_dbg;
     p.Q = (const hcp_bf16*)Q; p.K = (const hcp_bf16*)K; p.V = (const hcp_bf16*)V; p.Out = (hcp_bf16*)O; p.lse = lse;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = 1;
@@ -728,7 +740,7 @@ HCP_API int hcp_attention_bwd(const void* Q, const void* K, const void* V, const
                               int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
                               const float* key_bias, long key_bias_bs, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     AttnParams p = {};
-    p.kbias = key_bias; p.kb_bs = key_bias_bs;
+    p.kbias = key_bias; p.kb_bs = key_bias_bs; p.dbg = g_attn_dbg;
     p.Q = (const hcp_bf16*)Q; p.K = (const hcp_bf16*)K; p.V = (const hcp_bf16*)V; p.O = (const hcp_bf16*)O;
     p.dO = (const hcp_bf16*)dO; p.lse = (float*)lse; p.delta = delta;
     p.dQ = (hcp_bf16*)dQ; p.dK = (hcp_bf16*)dK; p.dV = (hcp_bf16*)dV;
