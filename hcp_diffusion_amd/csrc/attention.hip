@@ -117,8 +117,16 @@ HCP_DEVICE void zero_lds(hcp_bf16* p, int elems, int tid) {
 // ------------------------------------------------------------------------------------------ forward
 // KB: compile-time "has additive key bias" — the unmasked instantiation is exactly the bias-free code (the run-time
 // branch cost 10-50 VGPRs and a wave of occupancy in the dQ kernel).
+// Occupancy targets (amdgpu_waves_per_eu): left alone the compiler parks MFMA accumulators in AGPRs "because there is room"
+// and lands at VGPR+AGPR > 256 = ONE wave per SIMD for several variants (all d=160 kernels, dK/dV wide); with an explicit
+// target it fits the same code into the VGPR budget of 2-4 waves/SIMD with (almost) no scratch.
+#if defined(HCP_EMU)
+#define HCP_WAVES_PER_SIMD(n)
+#else
+#define HCP_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
 template <int D, int QT, bool KB = false>
-HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
+HCP_WAVES_PER_SIMD(D > 80 ? 2 : QT == 2 ? 3 : 4) HCP_KERNEL(256) attn_fwd_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
     hcp_bf16* lds = (hcp_bf16*)smem;                // 2 x { K [64][RS] | V [64][RS] }   (both row-major)
@@ -299,7 +307,7 @@ HCP_KERNEL(256) attn_delta_kernel(AttnParams p, int B) {
 
 // ------------------------------------------------------------------------------------------ dQ
 template <int D, int QT, bool KB = false>
-HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
+HCP_WAVES_PER_SIMD(D > 80 ? 2 : 3) HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
     hcp_bf16* lds = (hcp_bf16*)smem;                // 2 x { K [64][RS] | V [64][RS] }
@@ -430,7 +438,7 @@ HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams p) {
 
 // ------------------------------------------------------------------------------------------ dK, dV
 template <int D, int KT, bool KB = false>
-HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
+HCP_WAVES_PER_SIMD((D > 80 || KT == 2) ? 2 : 3) HCP_KERNEL(256) attn_bwd_dkv_kernel(AttnParams p) {
     using G = AttnGeom<D>;
     HCP_DYN_SMEM(smem);
     hcp_bf16* lds = (hcp_bf16*)smem;     // 2 x { Q [64][RS] | dO [64][RS] | lse2[64], delta[64] (fp32) }
@@ -687,8 +695,7 @@ template <int D>
 int run_bwd(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t stream) {
     if (int e = launch_delta<D>(p, B, stream)) return e;
     // measured on MI355X: 32 rows per wave pay off once the grid has >= 512 such workgroups
-    // (dK/dV with 32 keys per wave: 224 VGPR+AGPR at d=40 = 2 waves/SIMD, but 280 at d=64 = ONE wave/SIMD -> narrow there)
-    bool wq = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512, wk = D <= 40 && (long)B * p.H * hcp_cdiv(p.Nk, 128) >= 512;
+    bool wq = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512, wk = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nk, 128) >= 512;
     if (g_attn_cfg >= 0) { wq = kWide<D> && (g_attn_cfg & 2); wk = kWide<D> && (g_attn_cfg & 4); }
     int e;
     if constexpr (kWide<D>) { e = wq ? launch_dq<D, 2>(p, B, stream) : launch_dq<D, 1>(p, B, stream); }
