@@ -48,6 +48,17 @@ def _call_res(mod, x, residual):
     return ops.add(mod(x), residual)     # e.g. the reference's own LoraPatchContainer swallows extra kwargs
 
 
+def _ckpt(module, fn, *args, **kwargs):
+    """Gradient checkpointing at diffusers' granularity (one ResnetBlock2D / Transformer2DModel call per segment), always
+    non-reentrant like the reference forces it (hcpdiff/train_ac.py:44-47).  A memory-for-recompute trade the reference
+    defaults to on 24 GB GPUs (train_base.yaml:69); with 288 GB HBM it only costs an extra forward, so it stays off unless
+    enable_gradient_checkpointing() is called."""
+    if getattr(module, "gradient_checkpointing", False) and torch.is_grad_enabled():
+        from torch.utils.checkpoint import checkpoint
+        return checkpoint(fn, *args, use_reentrant=False, preserve_rng_state=False, **kwargs)
+    return fn(*args, **kwargs)
+
+
 def _tb(temb_act, resnet):
     """This resnet's slice of the batched time-embedding projection, if the UNet attached one to `temb_act`."""
     table = getattr(temb_act, "_hcp_tb", None)
@@ -281,9 +292,9 @@ class _DownBlock(nn.Module):
     def forward(self, h, temb_act, context):
         skips = ()
         for i, res in enumerate(self.resnets):
-            h = res(h, temb_act, temb_bias=_tb(temb_act, res))
+            h = _ckpt(self, res, h, temb_act, temb_bias=_tb(temb_act, res))
             if self.has_attn:
-                h = self.attentions[i](h, context)
+                h = _ckpt(self, self.attentions[i], h, context)
             skips += (h,)
         if hasattr(self, "downsamplers"):
             h = self.downsamplers[0](h)
@@ -309,8 +320,8 @@ class UNetMidBlock2DCrossAttn(nn.Module):
 
     def forward(self, h, temb_act, context):
         h = self.resnets[0](h, temb_act, temb_bias=_tb(temb_act, self.resnets[0]))
-        h = self.attentions[0](h, context)
-        return self.resnets[1](h, temb_act, temb_bias=_tb(temb_act, self.resnets[1]))
+        h = _ckpt(self, self.attentions[0], h, context)
+        return _ckpt(self, self.resnets[1], h, temb_act, temb_bias=_tb(temb_act, self.resnets[1]))
 
 
 class _UpBlock(nn.Module):
@@ -332,10 +343,10 @@ class _UpBlock(nn.Module):
 
     def forward(self, h, skips, temb_act, context):
         for i, res in enumerate(self.resnets):
-            h = res(h, temb_act, skip=skips[-1], temb_bias=_tb(temb_act, res))
+            h = _ckpt(self, res, h, temb_act, skip=skips[-1], temb_bias=_tb(temb_act, res))
             skips = skips[:-1]
             if self.has_attn:
-                h = self.attentions[i](h, context)
+                h = _ckpt(self, self.attentions[i], h, context)
         if hasattr(self, "upsamplers"):
             h = self.upsamplers[0](h)
         return h
@@ -433,8 +444,16 @@ class NativeUNet2DConditionModel(nn.Module):
         return None                                   # attention is always the fused flash kernel
 
     def enable_gradient_checkpointing(self):
-        raise NotImplementedError("hcp_diffusion_amd: gradient checkpointing is not implemented (288 GB HBM holds all SD1.5/SDXL "
-                                  "activations at the benchmark batch sizes); set model.gradient_checkpointing: False")
+        """diffusers API used by the reference wrapper (models/wrapper.py:39-49): every block with a
+        ``gradient_checkpointing`` attribute recomputes its ResnetBlock2D / Transformer2DModel segments in backward."""
+        for m in self.modules():
+            if hasattr(m, "gradient_checkpointing"):
+                m.gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        for m in self.modules():
+            if hasattr(m, "gradient_checkpointing"):
+                m.gradient_checkpointing = False
 
     def _batched_time_proj(self, temb_act):
         """All ResnetBlock2D.time_emb_proj layers read the same SiLU(temb): evaluate them as ONE GEMM against the

@@ -493,3 +493,26 @@ def test_two_lora_blocks_on_one_host(backend):
     y1 = parent.fc(backend.to(x)).float().cpu()
     ref1 = x.float() @ (parent.fc._host.weight.cpu() + float(b0.alpha) * (wu0 @ wd0)).T.detach() + parent.fc._host.bias.cpu()
     assert rel(y1, ref1.detach()) < 2e-2
+
+
+def test_gradient_checkpointing_matches_plain_backward(backend):
+    """model.gradient_checkpointing: True (reference default, train_base.yaml:69; wrapper.py:39-49): same loss and LoRA
+    gradients as the un-checkpointed step (segments recomputed by the same kernels)."""
+    dev = backend.device
+    _, nat = _pair(TINY_CONFIG, dev)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=4)], lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for blk in tr.bucket.blocks:
+            blk.layer.W_up.copy_(backend.to(torch.randn(blk.layer.W_up.shape, generator=g) * 0.05))
+    tr.bucket.pack()
+    x0 = backend.to(torch.randn(2, 4, 8, 8, generator=g)); ehs = backend.to(torch.randn(2, 77, 64, generator=g))
+    noise = backend.to(torch.randn(2, 4, 8, 8, generator=g)); t = backend.to(torch.tensor([12, 640]))
+    tr.make_noise = lambda lat: (K.add_noise(lat, noise, t, tr.acp), noise, t)
+    l0 = tr.forward_backward(x0, ehs).item()
+    g0 = tr.bucket.grads.clone(); tr.bucket.grads.zero_()
+    nat.enable_gradient_checkpointing()
+    assert nat.down_blocks[0].gradient_checkpointing and nat.mid_block.gradient_checkpointing
+    l1 = tr.forward_backward(x0, ehs).item()
+    assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0))
+    assert ((tr.bucket.grads - g0).norm() / g0.norm()).item() < 1e-4
