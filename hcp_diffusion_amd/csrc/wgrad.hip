@@ -242,13 +242,15 @@ int g_force_split = 0;  // tools/tests: > 0 forces the number of token splits
 
 template <bool CONV>
 int launch_wgrad(WgradParams& p, float* ws, size_t ws_bytes, hipStream_t stream) {
-    const bool wide = g_force_wx ? g_force_wx == 128 : (p.K >= 512 && (!CONV || (p.C1 + p.C2) % 8 == 0));
+    // fitted to a sweep over the SD1.5 layer shapes (tools/bench_wgrad.py, profiles/r1_wgrad_sweep_bs2.txt): the narrow X tile
+    // with ~450 workgroups in flight is within 7 % of the per-shape optimum; the 128-wide tile only wins on a few deep layers
+    const bool wide = g_force_wx == 128;
     const int wx = wide ? 128 : 64;
     p.tiles_n = hcp_cdiv(p.N, WY);
     const int tiles_k = hcp_cdiv(p.K, wx);
     const long tiles = (long)p.tiles_n * tiles_k;
     const int row_tiles = hcp_cdiv(p.M, TM_ROWS);
-    int nsplit = (int)((768 + tiles - 1) / tiles);                // ~3 workgroups per CU ...
+    int nsplit = (int)((450 + tiles / 2) / tiles);                // ~450 workgroups ...
     if (nsplit > row_tiles / 2) nsplit = row_tiles / 2;           // ... each with at least two row tiles to pipeline
     if (g_force_split > 0) nsplit = g_force_split;
     const size_t slab = (size_t)p.N * p.K * sizeof(float);
