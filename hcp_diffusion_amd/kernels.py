@@ -64,6 +64,9 @@ def _workspace(t):
     return ws
 
 
+TRACE = None        # tools/autotune.py: a list collects the (kind, shape...) key of every GEMM-family launch
+
+
 def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, residual=None, alpha=1.0,
          out_f32=False, out=None):
     """out[M,N] = alpha*(a[M,K] @ b[N,K]^T + a2 @ b2^T) + bias + rowbias[m // rows_per_group] + residual."""
@@ -76,6 +79,8 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, r
         _bf16_2d(a2, "a2"); _bf16_2d(b2, "b2")
         K2 = a2.shape[1]
         assert a2.shape[0] == M and b2.shape == (N, K2)
+    if TRACE is not None:
+        TRACE.append(("gemm", M, N, K, 1 if K2 else 0))
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=a.device)
     assert out.stride(1) == 1
@@ -100,6 +105,8 @@ def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True):
     M, Kd = a.shape
     N = b.shape[0]
     assert b.shape[1] == Kd and l.shape == (32, Kd) and e.shape == (N, 32) and l.is_contiguous() and e.is_contiguous()
+    if TRACE is not None:
+        TRACE.append(("lora", M, N, Kd))
     out = torch.empty((M, N), dtype=BF16, device=a.device)
     t = torch.empty((M, 32), dtype=BF16, device=a.device) if want_t else None
     if bias is not None:
@@ -130,6 +137,8 @@ def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=N
         Wo = (Ws * up + 2 - 3) // stride + 1
     else:
         Ho, Wo = out_hw
+    if TRACE is not None:
+        TRACE.append(("conv", mode, B, Hs, Ws, C1, C2, cout, stride, 1 if upsample else 0, Ho, Wo, 1 if a2 is not None else 0))
     out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32 if out_f32 else BF16, device=x1.device)
     if residual is not None:
         assert residual.dtype == BF16 and residual.is_contiguous() and residual.numel() == out.numel()
