@@ -43,6 +43,17 @@ HCP_KERNEL(256) adamw_kernel(float* p, float* g, float* m, float* v, long n, con
     }
 }
 
+// ema <- lerp(ema, p, 1 - decay), decay = clip(1 - (1 + step / inv_gamma)^-power, 0, decay_max)   (reference utils/ema.py:18-27)
+HCP_KERNEL(256) ema_kernel(float* ema, const float* p, long n, const int* step_p, float inv_gamma, float power, float decay_max) {
+    float decay = 1.f - powf(1.f + (float)(*step_p) / inv_gamma, -power);
+    decay = fminf(fmaxf(decay, 0.f), decay_max);
+    const float w = 1.f - decay;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float e = ema[i];
+        ema[i] = e + w * (p[i] - e);
+    }
+}
+
 inline int opt_grid(long n) { long g = (n + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1; return (int)g; }
 
 }  // namespace
@@ -67,4 +78,13 @@ HCP_API int hcp_adamw_clip_fused(float* p, float* g, float* m, float* v, long n,
     HCP_LAUNCH(adamw_kernel, dim3(opt_grid(n)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                sumsq, grad_scale, max_norm, (const int*)step);
     HCP_LAUNCH_CHECK("adamw_clip_fused");
+}
+
+// ModelEMA.update for a flat bucket (reference hcpdiff/utils/ema.py:17-27, train_ac.py:503,517-521): one launch, the decay
+// schedule evaluated on the device from the optimizer's own step counter (graph-capturable, no host sync).
+HCP_API int hcp_ema_update(float* ema, const float* p, long n, const int* step, float inv_gamma, float power, float decay_max,
+                           hipStream_t stream) {
+    HCP_REQUIRE(ema && p && step && n > 0 && inv_gamma > 0.f, "hcp_ema_update: bad arguments");
+    HCP_LAUNCH(ema_kernel, dim3(opt_grid(n)), dim3(256), 0, stream, ema, p, n, step, inv_gamma, power, decay_max);
+    HCP_LAUNCH_CHECK("ema_update");
 }

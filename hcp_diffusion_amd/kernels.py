@@ -522,3 +522,10 @@ def adamw_clip_fused(p, g, m, v, lr, step, *, beta1=0.9, beta2=0.999, eps=1e-8, 
     assert lr.dtype == torch.float32 and step.dtype == torch.int32
     _chk(lib().hcp_adamw_clip_fused(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr), beta1, beta2, eps, weight_decay,
                                     _p(sumsq_t), float(grad_scale), float(max_norm), _p(step), _stream(p)), "hcp_adamw_clip_fused")
+
+
+def ema_update(ema, p, step, inv_gamma=1.0, power=2.0 / 3.0, decay_max=0.9997):
+    assert ema.dtype == torch.float32 and p.dtype == torch.float32 and ema.is_contiguous() and p.is_contiguous() and ema.numel() == p.numel()
+    assert step.dtype == torch.int32
+    _chk(lib().hcp_ema_update(_p(ema), _p(p), p.numel(), _p(step), float(inv_gamma), float(power), float(decay_max), _stream(p)),
+         "hcp_ema_update")

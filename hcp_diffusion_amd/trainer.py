@@ -44,11 +44,13 @@ class _OptState:
 class NativeTrainer:
     def __init__(self, unet, lora_cfg=None, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000,
-                 overlap_wgrad=False, grouped_wgrad=True, train_cfg=None, plugins=None):
+                 overlap_wgrad=False, grouped_wgrad=True, train_cfg=None, plugins=None, ema=None):
         """lora_cfg: the reference's ``lora_unet`` list ({layers, rank, alpha, lr, ...}); train_cfg: its ``unet`` list
         ({layers, lr}) of host modules to fine-tune in full (DreamBooth.yaml:6-10 uses ``layers: ['']`` = everything);
         plugins: [(plugin module, lr)] — trainable hook plugins such as controlnet.ControlNetHipPlugin (make_plugin,
-        cfg_net_tools.py:148-162: all of the plugin's parameters form one param group)."""
+        cfg_net_tools.py:148-162: all of the plugin's parameters form one param group); ema: None or the ModelEMA arguments
+        {decay_max, inv_gamma, power} (``model.ema``, train_ac.py:238-242): an EMA copy of every trainable bucket, updated by
+        one kernel per bucket after the optimizer step (train_ac.py:503)."""
         self.unet = unet
         self.device = next(unet.parameters()).device
         unet.requires_grad_(False)            # config_model(): freeze host, eval (train_ac.py:264-268)
@@ -76,6 +78,11 @@ class NativeTrainer:
         if self._lora_state is not None:      # historical attribute names (tests / tools read them)
             st = self._lora_state
             self.exp_avg, self.exp_avg_sq, self.lr, self.step_count, self.sumsq = st.exp_avg, st.exp_avg_sq, st.lr, st.step_count, st.sumsq
+        self.ema_cfg = None
+        if ema is not None:
+            self.ema_cfg = {**dict(decay_max=0.9997, inv_gamma=1.0, power=2.0 / 3.0), **ema}
+            for st in self._states():
+                st.ema = st.bucket.params.clone()
         for st in self.host_buckets:
             st.bucket.repack()
         self.weight_decay, self.betas, self.eps, self.max_grad_norm = weight_decay, betas, eps, max_grad_norm
@@ -141,10 +148,28 @@ class NativeTrainer:
             K.adamw_clip_fused(b.params, b.grads, st.exp_avg, st.exp_avg_sq, st.lr, st.step_count, beta1=self.betas[0],
                                beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, sumsq_t=total,
                                grad_scale=1.0 / self.world, max_norm=self.max_grad_norm)
+        if self.ema_cfg is not None:           # update_ema (train_ac.py:503,517-521)
+            for st in states:
+                K.ema_update(st.ema, st.bucket.params, st.step_count, **self.ema_cfg)
         if self.bucket is not None:
             self.bucket.pack()                 # refresh the bf16 LoRA operands for the next forward
         for st in self.host_buckets:
             st.bucket.repack()                 # ... and the bf16 host operands (one grouped launch)
+
+    def ema_state_dict(self):
+        """{parameter name: EMA tensor} with the parameters' own shapes (what ModelEMA.state_dict() returns, utils/ema.py:46-47)."""
+        out = {}
+        for st in self._states():
+            b = st.bucket
+            named = getattr(b, "named", None)
+            if named is None:              # LoraBucket: names from the model
+                ids = {id(p): n for n, p in self.unet.named_parameters()}
+                named = [(ids.get(id(p), f"lora.{i}"), p) for i, blk in enumerate(b.blocks) for p in (blk.layer.W_down, blk.layer.W_up)]
+            base = b.params.data_ptr()
+            for name, p in named:
+                off = (p.data_ptr() - base) // 4
+                out[name] = st.ema[off:off + p.numel()].as_strided(p.shape, p.stride())
+        return out
 
     def set_lr(self, lr):
         for st in self._states():

@@ -158,6 +158,9 @@ int hcp_sumsq_f32(const float* g, long n, float* out, hcpStream_t stream);
 int hcp_adamw_clip_fused(float* p, float* g, float* m, float* v, long n, const float* lr, float beta1, float beta2,
                          float eps, float weight_decay, const float* sumsq, float grad_scale, float max_norm, int* step,
                          hcpStream_t stream);
+/* ModelEMA.update (reference hcpdiff/utils/ema.py:17-27) over a flat bucket: ema <- lerp(ema, p, 1 - decay(step)) */
+int hcp_ema_update(float* ema, const float* p, long n, const int* step, float inv_gamma, float power, float decay_max,
+                   hcpStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -516,3 +516,22 @@ def test_gradient_checkpointing_matches_plain_backward(backend):
     l1 = tr.forward_backward(x0, ehs).item()
     assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0))
     assert ((tr.bucket.grads - g0).norm() / g0.norm()).item() < 1e-4
+
+
+def test_ema_matches_reference_schedule(backend):
+    """model.ema (reference utils/ema.py ModelEMA): decay = clip(1 - (1 + step / inv_gamma)^-power, 0, decay_max), one fused
+    launch per bucket with the step read on the device."""
+    dev = backend.device
+    _, nat = _pair(TINY_CONFIG, dev)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=4)], lr=1e-2, ema=dict(decay_max=0.9997))
+    ema_ref = tr.bucket.params.cpu().clone()
+    g = torch.Generator().manual_seed(1)
+    for step in (1, 2, 3):
+        tr.bucket.grads.copy_(backend.to(torch.randn(tr.bucket.numel, generator=g)))
+        tr.optimizer_step()
+        decay = min(max(1 - (1 + step / 1.0) ** -(2 / 3), 0.0), 0.9997)
+        ema_ref.lerp_(tr.bucket.params.cpu(), 1 - decay)
+    assert ((tr._lora_state.ema.cpu() - ema_ref).abs().max() / ema_ref.abs().max()).item() < 1e-5
+    sd = tr.ema_state_dict()
+    name = next(n for n, _ in nat.named_parameters() if n.endswith("W_down"))
+    assert sd[name].shape == dict(nat.named_parameters())[name].shape and len(sd) == 2 * len(tr.bucket.blocks)
