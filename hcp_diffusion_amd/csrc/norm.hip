@@ -68,42 +68,46 @@ HCP_KERNEL(1024) gn_fwd_partial(const hcp_bf16* x, float* ws, int HW, int C, int
     }
 }
 
-// One wave per (b, g): merge the chunk partials.  mode 0: Chan-merge (mean, M2) -> stats (mean, rstd);
-// mode 1: plain sums (S1, S2) -> (S1/n, S2/n).
-HCP_KERNEL(256) gn_finalize(const float* ws, float* out, int BG, int G, int nchunk, int rows_per_chunk, int HW, int Cg, float eps,
-                            int mode) {
-    const int lane = threadIdx.x & 63;
-    const int bg = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool live = bg < BG;
-    const int b = live ? bg / G : 0, g = live ? bg % G : 0;
+// In-block merge of one sample's chunk partials (ws_b = [nchunk][G][2]) into s_out [G][2]: 4 adjacent lanes per group walk
+// the chunks, two xor-shuffles combine them.  mode 0: Chan merge of (mean, M2) -> (mean, rstd); mode 1: sums -> (S1/n, S2/n).
+// Every apply workgroup does this itself (a few hundred L2-resident floats) instead of a separate finalize launch.
+HCP_DEVICE void gn_merge(const float* ws_b, float* s_out, int G, int nchunk, int rows_per_chunk, int HW, int Cg, float eps,
+                         int mode, int tid) {
+    const int g = tid >> 2, sub = tid & 3;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int c = lane; c < nchunk; c += 64) {
-        const float* o = ws + (((size_t)b * nchunk + c) * G + g) * 2;
-        if (mode == 0) {
-            int r0 = c * rows_per_chunk; int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
-            float nb = (float)(r1 - r0) * Cg, nn = n + nb, d = o[0] - mean;
-            mean += d * nb / nn; m2 += o[1] + d * d * n * nb / nn; n = nn;
-        } else { mean += o[0]; m2 += o[1]; }
-    }
+    if (g < G)
+        for (int c = sub; c < nchunk; c += 4) {
+            const float* o = ws_b + ((size_t)c * G + g) * 2;
+            if (mode == 0) {
+                int r0 = c * rows_per_chunk; int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
+                float nb = (float)(r1 - r0) * Cg, nn = n + nb, d = o[0] - mean;
+                mean += d * nb / nn; m2 += o[1] + d * d * n * nb / nn; n = nn;
+            } else { mean += o[0]; m2 += o[1]; }
+        }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = 1; off <= 2; off <<= 1) {
         float n2 = hcp_shfl_xor(n, off), mean2 = hcp_shfl_xor(mean, off), m22 = hcp_shfl_xor(m2, off);
         if (mode == 0) {
             float nn = n + n2;
             if (nn > 0.f) { float d = mean2 - mean; mean += d * n2 / nn; m2 += m22 + d * d * n * n2 / nn; n = nn; }
         } else { mean += mean2; m2 += m22; }
     }
-    if (live && lane == 0) {
-        if (mode == 0) { out[(size_t)bg * 2] = mean; out[(size_t)bg * 2 + 1] = 1.0f / sqrtf(m2 / n + eps); }
-        else { float cnt = (float)HW * Cg; out[(size_t)bg * 2] = mean / cnt; out[(size_t)bg * 2 + 1] = m2 / cnt; }
+    if (sub == 0 && g < G) {
+        if (mode == 0) { s_out[g * 2] = mean; s_out[g * 2 + 1] = 1.0f / sqrtf(m2 / n + eps); }
+        else { float cnt = (float)HW * Cg; s_out[g * 2] = mean / cnt; s_out[g * 2 + 1] = m2 / cnt; }
     }
+    HCP_SYNC();
 }
 
-HCP_KERNEL(1024) gn_fwd_apply(const hcp_bf16* x, const float* gamma, const float* beta, const float* stats, hcp_bf16* y,
-                              int HW, int C, int G, int TX, int R, int rows_per_chunk, int silu) {
+HCP_KERNEL(1024) gn_fwd_apply(const hcp_bf16* x, const float* gamma, const float* beta, const float* ws, float* stats, hcp_bf16* y,
+                              int HW, int C, int G, int TX, int R, int rows_per_chunk, int silu, float eps) {
+    HCP_DYN_SMEM(smem);
+    float* s_st = (float*)smem;                      // [G][2] (mean, rstd) of this sample
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int Cg = C / G;
+    gn_merge(ws + (size_t)b * gridDim.x * G * 2, s_st, G, gridDim.x, rows_per_chunk, HW, Cg, eps, 0, tid);
+    if (chunk == 0 && tid < 2 * G) stats[(size_t)b * G * 2 + tid] = s_st[tid];       // saved for backward
     const int cx = tid % TX, ry = tid / TX;
     const int r0 = chunk * rows_per_chunk;
     int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
@@ -111,8 +115,8 @@ HCP_KERNEL(1024) gn_fwd_apply(const hcp_bf16* x, const float* gamma, const float
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         int c = cx * 8 + i; int g = c / Cg;
-        float a = stats[((size_t)b * G + g) * 2 + 1] * gamma[c];
-        a8[i] = a; b8[i] = beta[c] - stats[((size_t)b * G + g) * 2] * a;
+        float a = s_st[g * 2 + 1] * gamma[c];
+        a8[i] = a; b8[i] = beta[c] - s_st[g * 2] * a;
     }
     const size_t base = (size_t)b * HW * C + cx * 8;
     for (int r = r0 + ry; r < r1; r += R) {
@@ -181,11 +185,14 @@ HCP_KERNEL(1024) gn_bwd_partial(const hcp_bf16* x, const hcp_bf16* dy, const flo
 }
 
 HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float* gamma, const float* beta,
-                              const float* stats, const float* c12, const hcp_bf16* addend, hcp_bf16* dx, int HW, int C, int G,
+                              const float* stats, const float* ws, const hcp_bf16* addend, hcp_bf16* dx, int HW, int C, int G,
                               int TX, int R, int rows_per_chunk, int silu) {
+    HCP_DYN_SMEM(smem);
+    float* s_c12 = (float*)smem;                     // [G][2] (mean of dxhat, mean of dxhat * xhat) of this sample
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int Cg = C / G;
+    gn_merge(ws + (size_t)b * gridDim.x * G * 2, s_c12, G, gridDim.x, rows_per_chunk, HW, Cg, 0.f, 1, tid);
     const int cx = tid % TX, ry = tid / TX;
     const int r0 = chunk * rows_per_chunk;
     int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
@@ -194,7 +201,7 @@ HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float
     for (int i = 0; i < 8; ++i) {
         int c = cx * 8 + i; int g = c / Cg;
         mean8[i] = stats[((size_t)b * G + g) * 2]; rstd8[i] = stats[((size_t)b * G + g) * 2 + 1];
-        g8[i] = gamma[c]; be8[i] = beta[c]; c1[i] = c12[((size_t)b * G + g) * 2]; c2[i] = c12[((size_t)b * G + g) * 2 + 1];
+        g8[i] = gamma[c]; be8[i] = beta[c]; c1[i] = s_c12[g * 2]; c2[i] = s_c12[g * 2 + 1];
     }
     const size_t base = (size_t)b * HW * C + cx * 8;
     for (int r = r0 + ry; r < r1; r += R) {
@@ -370,7 +377,7 @@ HCP_API size_t hcp_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
 }
 
 // y = [silu](group_norm(x; gamma, beta, eps)); stats[B,G,2] = (mean, rstd) saved for backward.
-// Three launches: per-chunk (mean, M2) partials -> wave-parallel Chan merge -> elementwise apply.
+// Two launches: per-chunk (mean, M2) partials -> apply (every workgroup Chan-merges its sample's partials itself).
 HCP_API int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                    void* workspace, int B, int HW, int C, int G, float eps, int silu, hipStream_t stream) {
     if (int e = gn_check(B, HW, C, G)) return e;
@@ -379,10 +386,8 @@ HCP_API int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const floa
     size_t sm1 = (size_t)2 * g.R * C * sizeof(float);
     HCP_LAUNCH(gn_fwd_partial, dim3(g.nchunk, B), dim3(g.threads), sm1, stream, (const hcp_bf16*)x, (float*)workspace, HW, C,
                G, g.TX, g.R, g.rows_per_chunk);
-    HCP_LAUNCH(gn_finalize, dim3(hcp_cdiv(B * G, 4)), dim3(256), 0, stream, (const float*)workspace, stats, B * G, G, g.nchunk,
-               g.rows_per_chunk, HW, C / G, eps, 0);
-    HCP_LAUNCH(gn_fwd_apply, dim3(g.nchunk, B), dim3(g.threads), 0, stream, (const hcp_bf16*)x, gamma, beta, (const float*)stats,
-               (hcp_bf16*)y, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu);
+    HCP_LAUNCH(gn_fwd_apply, dim3(g.nchunk, B), dim3(g.threads), (size_t)2 * G * sizeof(float), stream, (const hcp_bf16*)x, gamma,
+               beta, (const float*)workspace, stats, (hcp_bf16*)y, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu, eps);
     HCP_LAUNCH_CHECK("groupnorm_fwd");
 }
 
@@ -394,15 +399,12 @@ HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* g
     if (int e = gn_check(B, HW, C, G)) return e;
     HCP_REQUIRE(x && dy && gamma && beta && stats && dx && workspace, "hcp_groupnorm_silu_bwd: null pointer");
     GNGeom g = gn_geom(HW, C);
-    float* c12 = (float*)workspace + (size_t)B * g.nchunk * G * 2;
     size_t sm1 = (size_t)2 * g.R * C * sizeof(float);
     HCP_LAUNCH(gn_bwd_partial, dim3(g.nchunk, B), dim3(g.threads), sm1, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy,
                gamma, beta, stats, (float*)workspace, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu);
-    HCP_LAUNCH(gn_finalize, dim3(hcp_cdiv(B * G, 4)), dim3(256), 0, stream, (const float*)workspace, c12, B * G, G, g.nchunk,
-               g.rows_per_chunk, HW, C / G, 0.f, 1);
-    HCP_LAUNCH(gn_bwd_apply, dim3(g.nchunk, B), dim3(g.threads), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy,
-               gamma, beta, stats, (const float*)c12, (const hcp_bf16*)addend, (hcp_bf16*)dx, HW, C, G, g.TX, g.R,
-               g.rows_per_chunk, silu);
+    HCP_LAUNCH(gn_bwd_apply, dim3(g.nchunk, B), dim3(g.threads), (size_t)2 * G * sizeof(float), stream, (const hcp_bf16*)x,
+               (const hcp_bf16*)dy, gamma, beta, stats, (const float*)workspace, (const hcp_bf16*)addend, (hcp_bf16*)dx, HW, C, G,
+               g.TX, g.R, g.rows_per_chunk, silu);
     HCP_LAUNCH_CHECK("groupnorm_bwd");
 }
 
