@@ -18,10 +18,12 @@ GNGeom gn_geom(int HW, int C) {
     g.TX = C / 8;
     g.R = 256 / g.TX; if (g.R < 1) g.R = 1;
     g.threads = g.TX * g.R;
-    g.rows_per_chunk = 4 * g.R;
+    g.rows_per_chunk = (HW >= 2048 ? 8 : 4) * g.R;       // big maps: half as many partials to merge, grid still >= 300 workgroups
     g.nchunk = (HW + g.rows_per_chunk - 1) / g.rows_per_chunk;
     return g;
 }
+
+inline size_t gn_merge_smem(int threads, int G) { return ((size_t)2 * G + (size_t)(threads / G) * G * 3) * sizeof(float); }
 
 // ws layout: [B][nchunk][G][2]  (fwd: mean, M2 of the chunk; bwd: S1, S2)
 HCP_KERNEL(1024) gn_fwd_partial(const hcp_bf16* x, float* ws, int HW, int C, int G, int TX, int R, int rows_per_chunk) {
@@ -68,33 +70,51 @@ HCP_KERNEL(1024) gn_fwd_partial(const hcp_bf16* x, float* ws, int HW, int C, int
     }
 }
 
-// In-block merge of one sample's chunk partials (ws_b = [nchunk][G][2]) into s_out [G][2]: 4 adjacent lanes per group walk
-// the chunks, two xor-shuffles combine them.  mode 0: Chan merge of (mean, M2) -> (mean, rstd); mode 1: sums -> (S1/n, S2/n).
-// Every apply workgroup does this itself (a few hundred L2-resident floats) instead of a separate finalize launch.
+// In-block merge of one sample's chunk partials (ws_b = [nchunk][G][2]) into s_out [G][2].  Thread (j, g) = (tid / G, tid % G)
+// walks chunks j, j+J, ... (coalesced float2 loads, four in flight), the J per-group results meet in LDS and the first G
+// threads combine them.  mode 0: Chan merge of (mean, M2) -> (mean, rstd); mode 1: sums -> (S1/n, S2/n).
+// Every apply workgroup does this itself (L2-resident partials) instead of a separate finalize launch.
 HCP_DEVICE void gn_merge(const float* ws_b, float* s_out, int G, int nchunk, int rows_per_chunk, int HW, int Cg, float eps,
-                         int mode, int tid) {
-    const int g = tid >> 2, sub = tid & 3;
+                         int mode, int tid, int nthreads) {
+    float* s_tmp = s_out + 2 * G;                                // [J][G][3]
+    const int J = nthreads / G;
+    const int g = tid % G, j = tid / G;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (g < G)
-        for (int c = sub; c < nchunk; c += 4) {
-            const float* o = ws_b + ((size_t)c * G + g) * 2;
-            if (mode == 0) {
-                int r0 = c * rows_per_chunk; int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
-                float nb = (float)(r1 - r0) * Cg, nn = n + nb, d = o[0] - mean;
-                mean += d * nb / nn; m2 += o[1] + d * d * n * nb / nn; n = nn;
-            } else { mean += o[0]; m2 += o[1]; }
-        }
+    if (j < J) {
+        for (int c0 = j; c0 < nchunk; c0 += 4 * J) {
+            float a[4], bq[4];
 #pragma unroll
-    for (int off = 1; off <= 2; off <<= 1) {
-        float n2 = hcp_shfl_xor(n, off), mean2 = hcp_shfl_xor(mean, off), m22 = hcp_shfl_xor(m2, off);
-        if (mode == 0) {
-            float nn = n + n2;
-            if (nn > 0.f) { float d = mean2 - mean; mean += d * n2 / nn; m2 += m22 + d * d * n * n2 / nn; n = nn; }
-        } else { mean += mean2; m2 += m22; }
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * J;
+                const float* o = ws_b + ((size_t)(c < nchunk ? c : 0) * G + g) * 2;
+                a[u] = o[0]; bq[u] = o[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * J;
+                if (c >= nchunk) continue;
+                if (mode == 0) {
+                    int r0 = c * rows_per_chunk; int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
+                    float nb = (float)(r1 - r0) * Cg, nn = n + nb, d = a[u] - mean;
+                    mean += d * nb / nn; m2 += bq[u] + d * d * n * nb / nn; n = nn;
+                } else { mean += a[u]; m2 += bq[u]; }
+            }
+        }
+        float* t = s_tmp + ((size_t)j * G + g) * 3;
+        t[0] = n; t[1] = mean; t[2] = m2;
     }
-    if (sub == 0 && g < G) {
-        if (mode == 0) { s_out[g * 2] = mean; s_out[g * 2 + 1] = 1.0f / sqrtf(m2 / n + eps); }
-        else { float cnt = (float)HW * Cg; s_out[g * 2] = mean / cnt; s_out[g * 2 + 1] = m2 / cnt; }
+    HCP_SYNC();
+    if (tid < G) {
+        n = 0.f; mean = 0.f; m2 = 0.f;
+        for (int jj = 0; jj < J; ++jj) {
+            const float* t = s_tmp + ((size_t)jj * G + tid) * 3;
+            if (mode == 0) {
+                float n2 = t[0], nn = n + n2;
+                if (nn > 0.f) { float d = t[1] - mean; mean += d * n2 / nn; m2 += t[2] + d * d * n * n2 / nn; n = nn; }
+            } else { mean += t[1]; m2 += t[2]; }
+        }
+        if (mode == 0) { s_out[tid * 2] = mean; s_out[tid * 2 + 1] = 1.0f / sqrtf(m2 / n + eps); }
+        else { float cnt = (float)HW * Cg; s_out[tid * 2] = mean / cnt; s_out[tid * 2 + 1] = m2 / cnt; }
     }
     HCP_SYNC();
 }
@@ -106,7 +126,7 @@ HCP_KERNEL(1024) gn_fwd_apply(const hcp_bf16* x, const float* gamma, const float
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int Cg = C / G;
-    gn_merge(ws + (size_t)b * gridDim.x * G * 2, s_st, G, gridDim.x, rows_per_chunk, HW, Cg, eps, 0, tid);
+    gn_merge(ws + (size_t)b * gridDim.x * G * 2, s_st, G, gridDim.x, rows_per_chunk, HW, Cg, eps, 0, tid, blockDim.x);
     if (chunk == 0 && tid < 2 * G) stats[(size_t)b * G * 2 + tid] = s_st[tid];       // saved for backward
     const int cx = tid % TX, ry = tid / TX;
     const int r0 = chunk * rows_per_chunk;
@@ -192,7 +212,7 @@ HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int Cg = C / G;
-    gn_merge(ws + (size_t)b * gridDim.x * G * 2, s_c12, G, gridDim.x, rows_per_chunk, HW, Cg, 0.f, 1, tid);
+    gn_merge(ws + (size_t)b * gridDim.x * G * 2, s_c12, G, gridDim.x, rows_per_chunk, HW, Cg, 0.f, 1, tid, blockDim.x);
     const int cx = tid % TX, ry = tid / TX;
     const int r0 = chunk * rows_per_chunk;
     int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
@@ -386,7 +406,7 @@ HCP_API int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const floa
     size_t sm1 = (size_t)2 * g.R * C * sizeof(float);
     HCP_LAUNCH(gn_fwd_partial, dim3(g.nchunk, B), dim3(g.threads), sm1, stream, (const hcp_bf16*)x, (float*)workspace, HW, C,
                G, g.TX, g.R, g.rows_per_chunk);
-    HCP_LAUNCH(gn_fwd_apply, dim3(g.nchunk, B), dim3(g.threads), (size_t)2 * G * sizeof(float), stream, (const hcp_bf16*)x, gamma,
+    HCP_LAUNCH(gn_fwd_apply, dim3(g.nchunk, B), dim3(g.threads), gn_merge_smem(g.threads, G), stream, (const hcp_bf16*)x, gamma,
                beta, (const float*)workspace, stats, (hcp_bf16*)y, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu, eps);
     HCP_LAUNCH_CHECK("groupnorm_fwd");
 }
@@ -402,7 +422,7 @@ HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* g
     size_t sm1 = (size_t)2 * g.R * C * sizeof(float);
     HCP_LAUNCH(gn_bwd_partial, dim3(g.nchunk, B), dim3(g.threads), sm1, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy,
                gamma, beta, stats, (float*)workspace, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu);
-    HCP_LAUNCH(gn_bwd_apply, dim3(g.nchunk, B), dim3(g.threads), (size_t)2 * G * sizeof(float), stream, (const hcp_bf16*)x,
+    HCP_LAUNCH(gn_bwd_apply, dim3(g.nchunk, B), dim3(g.threads), gn_merge_smem(g.threads, G), stream, (const hcp_bf16*)x,
                (const hcp_bf16*)dy, gamma, beta, stats, (const float*)workspace, (const hcp_bf16*)addend, (hcp_bf16*)dx, HW, C, G,
                g.TX, g.R, g.rows_per_chunk, silu);
     HCP_LAUNCH_CHECK("groupnorm_bwd");
