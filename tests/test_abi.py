@@ -45,3 +45,41 @@ def test_argument_validation_returns_error_codes():
     assert rc < 0 and b"null" in lib.hcp_last_error()
     rc = lib.hcp_layernorm_fwd(None, None, None, None, None, 4, 7, 1e-5, None)
     assert rc < 0 and b"bad shape" in lib.hcp_last_error()
+
+
+def test_every_entry_point_rejects_bad_arguments_without_launching():
+    """Error convention of the boundary: negative return code + hcp_last_error(), never a crash.  Every check
+    below fails in host-side validation, so no kernel is launched (works on the GPU-less build box)."""
+    lib = _lib.load()
+    N = None
+    bad = {
+        "hcp_conv3x3_bf16": (N, 8, N, 0, 1, 4, 4, 4, 4, 0, 1, 0, N, 8, N, 8, N, N, 0, N, 0, 0, N, N, N, 0, N),
+        "hcp_gemm_lora_bf16": (N, 8, N, 8, N, N, N, N, 8, 8, 8, 8, N, N, 0, N, 0, N),
+        "hcp_attention_fwd": (N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, N),
+        "hcp_attention_bwd": (N, N, N, N, N, N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, N, 0, N),
+        "hcp_groupnorm_silu_fwd": (N, N, N, N, N, N, 1, 16, 30, 32, 1e-5, 1, N),          # C % G != 0
+        "hcp_groupnorm_silu_bwd": (N, N, N, N, N, N, N, N, 1, 16, 32, 32, 1, N),
+        "hcp_groupnorm_affine_grad": (N, N, N, N, N, N, N, 1, 16, 32, 32, 1, N),
+        "hcp_layernorm_bwd": (N, N, N, N, N, N, 4, 8, N),
+        "hcp_layernorm_affine_grad": (N, N, N, N, N, 4, 8, N),
+        "hcp_wgrad_linear_bf16": (N, 8, N, 8, N, 8, 8, 8, 8, N, 0, N),
+        "hcp_wgrad_conv3x3_bf16": (N, 8, N, 8, N, 0, N, 8, 1, 4, 4, 4, 4, 8, 1, 0, N, 0, N),
+        "hcp_colsum_bf16": (N, 8, N, 8, 8, 8, 8, N),
+        "hcp_pack_weights": (N, 0, 0, N),
+        "hcp_lora_wgrad": (N, 8, N, 8, N, 8, 8, 40, 8, 1.0, 0, N),                           # P > 32
+        "hcp_sumsq_f32": (N, 0, N, N),
+        "hcp_adamw_clip_fused": (N, N, N, N, 0, N, 0.9, 0.999, 1e-8, 0.0, N, 1.0, 1.0, N, N),
+        "hcp_ema_update": (N, N, 0, N, 1.0, 0.6, 0.99, N),
+        "hcp_timestep_embedding": (N, N, 0, 3, 1e4, N),
+        "hcp_add_noise": (N, N, N, N, N, 0, 0, N),
+        "hcp_mse_masked_mean": (N, N, N, 1, N, N, 0, 0, 0, 1.0, N),
+        "hcp_copy2d_bf16": (N, 8, N, 8, 0, 7, N),
+    }
+    for name, args in bad.items():
+        assert name in _lib.EXPORTED_SYMBOLS, name
+        rc = getattr(lib, name)(*args)
+        assert rc < 0 and len(lib.hcp_last_error()) > 0, name
+    # unsupported head dimension is reported, not mis-dispatched
+    one = ctypes.c_void_p(16)
+    rc = lib.hcp_attention_fwd(one, one, one, one, one, 1, 1, 8, 8, 48, 0, 48, 0, 48, 0, 48, 0, 48, 0.1, None, 0, None)
+    assert rc < 0 and b"head_dim" in lib.hcp_last_error()

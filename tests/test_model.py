@@ -535,3 +535,30 @@ def test_ema_matches_reference_schedule(backend):
     sd = tr.ema_state_dict()
     name = next(n for n, _ in nat.named_parameters() if n.endswith("W_down"))
     assert sd[name].shape == dict(nat.named_parameters())[name].shape and len(sd) == 2 * len(tr.bucket.blocks)
+
+
+@pytest.mark.parametrize("cfg_name", ["sd15", "sdxl"])
+def test_from_pretrained_reads_diffusers_layout(tmp_path, cfg_name):
+    """`model.unet: {_target_: ...NativeUNet2DConditionModel.from_pretrained, path, subfolder: unet}`:
+    diffusers' on-disk layout (config.json with its historical key names + diffusion_pytorch_model.safetensors)."""
+    from safetensors.torch import save_file
+    cfg = TINY_CONFIG if cfg_name == "sd15" else TINY_SDXL_CONFIG
+    ora = seeded_init_(OracleUNet2DConditionModel(**cfg), 3)
+    d = tmp_path / "unet"
+    d.mkdir()
+    heads = cfg["num_attention_heads"]
+    disk = dict(_class_name="UNet2DConditionModel", in_channels=4, out_channels=4, block_out_channels=list(cfg["block_out_channels"]),
+                layers_per_block=cfg["layers_per_block"], down_block_types=list(cfg["down_block_types"]), up_block_types=list(cfg["up_block_types"]),
+                attention_head_dim=heads if isinstance(heads, int) else list(heads),          # diffusers stores the head COUNT under this name
+                cross_attention_dim=cfg["cross_attention_dim"], norm_num_groups=cfg["norm_num_groups"],
+                use_linear_projection=cfg["use_linear_projection"], addition_embed_type=cfg["addition_embed_type"],
+                addition_time_embed_dim=cfg["addition_time_embed_dim"],
+                projection_class_embeddings_input_dim=cfg["projection_class_embeddings_input_dim"])
+    tl = cfg["transformer_layers_per_block"]
+    disk["transformer_layers_per_block"] = tl if isinstance(tl, int) else list(tl)
+    json.dump(disk, open(d / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in ora.state_dict().items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    nat = NativeUNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet")
+    sd = nat.state_dict()
+    assert set(sd) == set(ora.state_dict()) and all(torch.equal(sd[k], v) for k, v in ora.state_dict().items())
+    assert nat.config.cross_attention_dim == cfg["cross_attention_dim"] and nat.dtype == torch.float32
