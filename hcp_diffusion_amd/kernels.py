@@ -437,13 +437,16 @@ def mse_masked_mean(pred, target, mask=None, weight=1.0, want_grad=True):
     return loss, grad
 
 
-def lora_wgrad(L, R, out, P, scale, transpose_out):
-    """out (fp32, atomically accumulated) += scale * L[:, :P]^T @ R ; transpose_out writes out[q, p]."""
+def lora_wgrad(L, R, out, P, scale, transpose_out, out_col0=0):
+    """out (fp32, atomically accumulated) += scale * L[:, :P]^T @ R ; transpose_out writes out[q, out_col0 + p]
+    (out_col0: first rank column of a 32-wide block when the rank exceeds one slot group)."""
     _bf16_2d(L, "L"); _bf16_2d(R, "R")
     M, Q = R.shape
     assert L.shape[0] == M and out.dtype == torch.float32 and out.is_contiguous()
+    assert out_col0 == 0 or transpose_out
     ldo = out.shape[1]
-    _chk(lib().hcp_lora_wgrad(_p(L), L.stride(0), _p(R), R.stride(0), _p(out), ldo, M, P, Q, float(scale),
+    ptr = ctypes.c_void_p(out.data_ptr() + 4 * out_col0)
+    _chk(lib().hcp_lora_wgrad(_p(L), L.stride(0), _p(R), R.stride(0), ptr, ldo, M, P, Q, float(scale),
                               1 if transpose_out else 0, _stream(L)), "hcp_lora_wgrad")
 
 

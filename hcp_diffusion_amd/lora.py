@@ -107,8 +107,12 @@ class LoraHipLayer(PatchPluginBlock):
             raise NotImplementedError("lora_hip: conv LoRA needs channel counts that are multiples of 8 (conv_in / conv_out are excluded)")
         if isinstance(rank, float):
             rank = max(round(out_f * rank), 1)            # fractional rank, lora_base_patch.py:105-106
-        if rank > RANK_SLOT:
-            raise NotImplementedError(f"lora_hip: rank {rank} > {RANK_SLOT}")
+        if rank > RANK_SLOT and (conv3 or rank > 4 * RANK_SLOT):
+            raise NotImplementedError(f"lora_hip: rank {rank} is limited to {RANK_SLOT} on 3x3 conv hosts and {4 * RANK_SLOT} on Linear hosts")
+        # rank <= 32: one MFMA k-step of rank slots, fused into the host GEMM.  33..128: the side path runs as its own skinny
+        # GEMM (T = x W_down^T) and rides into the host GEMM as a K-extension of ceil(rank/32)*32 columns.
+        self.wide = rank > RANK_SLOT
+        self.rank_pad = (rank + RANK_SLOT - 1) // RANK_SLOT * RANK_SLOT
         self.host_type = "conv" if conv3 else "linear"   # a 1x1 conv is a Linear on channels-last tokens
         self.bias = bias
         self.layer = (_ConvFactors(in_f, out_f, rank) if conv3 else
@@ -175,8 +179,8 @@ class MultiLora:
 
     def __init__(self, blocks, names):
         self.blocks, self.names = list(blocks), names
-        if any(b.host_type != "linear" for b in self.blocks):
-            raise NotImplementedError("hcp_diffusion_amd: several LoRA blocks on one 3x3 conv host are not implemented")
+        if any(b.host_type != "linear" or b.wide for b in self.blocks):
+            raise NotImplementedError("hcp_diffusion_amd: several LoRA blocks on one host need Linear hosts and ranks <= 32")
         self.slot_off, sl = [], 0
         for b in self.blocks:
             self.slot_off.append(sl); sl += 8 * ((b.rank + 7) // 8)
@@ -274,6 +278,9 @@ class LoraBucket:
             if b.host_type == "conv":
                 self._gviews[id(b)] = (views[0].permute(0, 2, 3, 1), views[1].view(n_out, -1))     # [r][3][3][Cin], [Cout, r]
                 self._ops[id(b)] = self._new_conv_images(b, k, n_out)
+            elif b.wide:
+                self._gviews[id(b)] = (views[0].view(views[0].shape[0], k), views[1].view(n_out, -1))
+                self._ops[id(b)] = self._new_wide_images(b, k, n_out)
             else:
                 self._gviews[id(b)] = (views[0].view(views[0].shape[0], k), views[1].view(n_out, -1))
                 self._ops[id(b)] = self._new_images(k, n_out)
@@ -319,6 +326,24 @@ class LoraBucket:
         self._conv_rows.append((b.layer.W_up.data_ptr(), o.bu.data_ptr(), o.but.data_ptr(), cout, r, r, RANK_SLOT, cout,
                                 self._conv_tiles, 1, b.alpha_f))
         self._conv_tiles += (cout + 63) // 64
+        return o
+
+    def _new_wide_images(self, b, k, n_out):
+        """rank 33..128 on a Linear host: ad [Rp][K] = W_down, wdt [K][Rp] = W_down^T, bu [N][Rp] = alpha W_up,
+        but [Rp][N] = alpha W_up^T (Rp = rank padded to 32; padding stays zero), refreshed by two pack pieces."""
+        o = _LoraOperands()
+        rp, r = b.rank_pad, b.rank
+        img = torch.zeros(2 * rp * (k + n_out), dtype=BF16, device=self.device)
+        self._images.append(img)
+        a = rp * k; c = rp * n_out
+        o.ad = img[0:a].view(rp, k); o.wdt = img[a:2 * a].view(k, rp)
+        o.bu = img[2 * a:2 * a + c].view(n_out, rp); o.but = img[2 * a + c:2 * a + 2 * c].view(rp, n_out)
+        tc = (k + 63) // 64
+        self._conv_rows.append((b.layer.W_down.data_ptr(), o.ad.data_ptr(), o.wdt.data_ptr(), r, k, k, k, rp, self._conv_tiles, tc, 1.0))
+        self._conv_tiles += ((r + 63) // 64) * tc
+        tc = (r + 63) // 64
+        self._conv_rows.append((b.layer.W_up.data_ptr(), o.bu.data_ptr(), o.but.data_ptr(), n_out, r, r, rp, n_out, self._conv_tiles, tc, b.alpha_f))
+        self._conv_tiles += ((n_out + 63) // 64) * tc
         return o
 
     def _add_desc(self, b, o, slot0, n0, n_total):

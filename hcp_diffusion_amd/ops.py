@@ -104,7 +104,11 @@ class _LinearFn(torch.autograd.Function):
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
         pk = host.packed()
         T = None
-        if lora is not None:
+        if lora is not None and getattr(lora, "wide", False):      # rank 33..128: skinny side GEMM + K-extension
+            lp = lora.packed()
+            T = K.gemm(x2, lp.ad)
+            y = K.gemm(x2, pk.w, a2=T, b2=lp.bu, bias=pk.bias, residual=res2)
+        elif lora is not None:
             lp = lora.packed()
             y, T = K.gemm_lora(x2, pk.w, lp.ad, lp.bu, bias=pk.bias, residual=res2)
         else:
@@ -125,7 +129,17 @@ class _LinearFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         pk = host.packed()
         dx = None
-        if lora is not None:
+        if lora is not None and getattr(lora, "wide", False):
+            lp = lora.packed()
+            U = K.gemm(dy2, lp.but)                    # dY (alpha W_up): [M, Rp]
+            if ctx.needs_input_grad[0]:
+                dx = K.gemm(dy2, pk.wt, a2=U, b2=lp.wdt)
+            gd, gu = lora.grad_views()
+            for j in range(0, lora.rank, 32):          # 32 rank columns per launch of the skinny reduction kernel
+                pj = min(32, lora.rank - j)
+                K.lora_wgrad(U[:, j:j + 32], x2, gd[j:j + pj], pj, 1.0, False)                # dW_down = U^T x
+                K.lora_wgrad(T[:, j:j + 32], dy2, gu, pj, lora.alpha_f, True, out_col0=j)    # dW_up = alpha dY^T T
+        elif lora is not None:
             lp = lora.packed()
             if ctx.needs_input_grad[0]:
                 dx, U = K.gemm_lora(dy2, pk.wt, lp.but, lp.adt)

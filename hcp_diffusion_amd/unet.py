@@ -141,6 +141,8 @@ def _fusable_linear(m):
         return None
     if host.weight.requires_grad:                      # trainable host: the fused (concatenated) operand would go stale
         return None
+    if blk is not None and blk.wide:                   # rank > 32 runs as its own skinny GEMM, not in a shared slot group
+        return None
     return host, blk
 
 

@@ -562,3 +562,28 @@ def test_from_pretrained_reads_diffusers_layout(tmp_path, cfg_name):
     sd = nat.state_dict()
     assert set(sd) == set(ora.state_dict()) and all(torch.equal(sd[k], v) for k, v in ora.state_dict().items())
     assert nat.config.cross_attention_dim == cfg["cross_attention_dim"] and nat.dtype == torch.float32
+
+
+@pytest.mark.parametrize("rank", [48, 128])
+def test_lora_rank_above_one_slot_group(backend, rank):
+    """rank 33..128 on a Linear host: skinny side GEMM + K-extension instead of the fused 32-slot form; same reference arithmetic."""
+    from hcp_diffusion_amd.layers import HipLinear
+    dev = backend.device
+    torch.manual_seed(rank)
+    parent = torch.nn.Module(); parent.fc = HipLinear(72, 40).to(dev)
+    parent.requires_grad_(False)
+    blk = LoraHipLayer.wrap_model(0, parent.fc, parent_block=parent, host_name="fc", rank=rank, alpha=8.0)[""]
+    assert tuple(blk.layer.W_down.shape) == (rank, 72) and abs(float(blk.alpha) - 8.0 / rank) < 1e-7
+    with torch.no_grad():
+        blk.layer.W_up.normal_(0, 0.1)
+    x = torch.randn(6, 9, 72).to(torch.bfloat16); dy = torch.randn(6, 9, 40).to(torch.bfloat16)
+    wd, wu = (t.detach().cpu().clone().requires_grad_(True) for t in (blk.layer.W_down, blk.layer.W_up))
+    xr = x.float().requires_grad_(True)
+    yr = xr @ (parent.fc._host.weight.cpu() + float(blk.alpha) * (wu @ wd)).T + parent.fc._host.bias.cpu()
+    yr.backward(dy.float())
+    xn = backend.to(x).requires_grad_(True)
+    y = parent.fc(xn)
+    y.backward(backend.to(dy))
+    rel = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    assert rel(y.detach(), yr.detach()) < 2e-2 and rel(xn.grad, xr.grad) < 2e-2
+    assert rel(blk.layer.W_down.grad, wd.grad) < 2e-2 and rel(blk.layer.W_up.grad, wu.grad) < 2e-2
