@@ -656,7 +656,7 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
 struct TileCfg { int bm, bn; };
 constexpr TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}, {256, 128}, {256, 160}, {128, 320},
                              {128, 160}, {128, 160}, {256, 160},    // 8: 8 waves x 3 stages, 9: 4 waves x 3 stages, 10: 8 waves x 3 stages
-                             {128, 320}, {256, 160}, {128, 160}};   // 11: 16 waves (4x4), 12: 16 waves (8x2), 13: 8 waves as 4x2
+                             {128, 320}, {256, 160}, {128, 160}, {64, 160}, {128, 128}};   // 11: 16 waves (4x4), 12: 16 waves (8x2), 13-15: 8 waves as 4x2
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 template <int MODE, bool FAST>
@@ -675,6 +675,8 @@ int launch_by_id(int id, GemmParams& p, hipStream_t stream) {
         case 11: return launch_cfg<128, 320, 4, 4, MODE, FAST>(p, stream);
         case 12: return launch_cfg<256, 160, 8, 2, MODE, FAST>(p, stream);
         case 13: return launch_cfg<128, 160, 4, 2, MODE, FAST>(p, stream);
+        case 14: return launch_cfg<64, 160, 4, 2, MODE, FAST>(p, stream);
+        case 15: return launch_cfg<128, 128, 4, 2, MODE, FAST>(p, stream);
         default: return launch_cfg<128, 320, 2, 4, MODE, FAST>(p, stream);
     }
 }
@@ -689,7 +691,10 @@ int launch_lora_by_id(int id, GemmParams& p, hipStream_t stream) {
         case 6: return launch_cfg<256, 160, 4, 2, 0, false, true>(p, stream);
         case 8: return launch_cfg<128, 160, 4, 2, 0, false, true, 3>(p, stream);
         case 9: return launch_cfg<128, 160, 2, 2, 0, false, true, 3>(p, stream);
+        case 12: return launch_cfg<256, 160, 8, 2, 0, false, true>(p, stream);
         case 13: return launch_cfg<128, 160, 4, 2, 0, false, true>(p, stream);
+        case 14: return launch_cfg<64, 160, 4, 2, 0, false, true>(p, stream);
+        case 15: return launch_cfg<128, 128, 4, 2, 0, false, true>(p, stream);
         default: return launch_cfg<64, 160, 2, 2, 0, false, true>(p, stream);
     }
 }
@@ -843,7 +848,7 @@ HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, c
         else id = 2;
     }
     if (g_force_cfg >= 0) id = g_force_cfg % 16;
-    if (id == 7 || (id >= 10 && id != 13)) id = 6;
+    if (id == 7 || id == 10 || id == 11) id = 6;
     if (id < 0) {
         // two-launch form: T = A L^T, then D = A B^T + T E^T with the measured tile / split-K choice
         HCP_REQUIRE(Tout, "hcp_gemm_lora_bf16: this shape runs as two launches and needs the T buffer");

@@ -378,7 +378,7 @@ def test_adamw_clip(backend):
     assert relerr(p, pr.detach()) < 1e-5 and step.item() == 3
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 2 + 16 * 2, 3 + 16 * 4, 1 + 16 * 3, 8 + 16 * 2, 11 + 16 * 2])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 2 + 16 * 2, 3 + 16 * 4, 1 + 16 * 3, 8 + 16 * 2, 11 + 16 * 2])
 def test_gemm_every_tile_config_and_splitk(backend, cfg):
     """Each tile shape / split-K decomposition the dispatcher can pick gives the same answer (forced via the tuning hook)."""
     torch.manual_seed(cfg)
@@ -390,7 +390,7 @@ def test_gemm_every_tile_config_and_splitk(backend, cfg):
     K.lib().hcp_debug_set_gemm_config(cfg)
     try:
         out = K.gemm(to(a), to(b), a2=to(a2), b2=to(b2), bias=to(bias), residual=to(res), out_f32=True)
-        if cfg % 16 not in (7, 10, 11, 12) and cfg < 16:
+        if cfg % 16 not in (7, 10, 11) and cfg < 16:
             l, e = rnd(32, Kd), rnd(N, 32)                                  # fused-LoRA instantiation of the same tile
             yl, tl = K.gemm_lora(to(a), to(b), to(l), to(e), bias=to(bias), residual=to(res))
             t_ref = (a.float() @ l.float().T).to(BF).float()

@@ -21,7 +21,7 @@ from hcp_diffusion_amd.unet import SDXL_CONFIG, NativeUNet2DConditionModel
 BF = torch.bfloat16
 dev = torch.device("cuda:0")
 CFG_NAMES = ["128x128", "128x64", "64x64", "128x160", "64x160", "256x128", "256x160", "128x320", "128x160w8s3", "128x160w4s3", "256x160w8s3",
-             "128x320w16", "256x160w16", "128x160w8"]
+             "128x320w16", "256x160w16", "128x160w8", "64x160w8", "128x128w8"]
 PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
 
 
@@ -132,7 +132,7 @@ def main():
             heur = round(timeit(lambda: K.gemm_lora(a, b, l, e)), 1)
             t_two = round(timeit(two), 1)
             res = {}
-            for cid in (0, 1, 2, 3, 4, 5, 6, 8, 9, 13):
+            for cid in (0, 1, 2, 3, 4, 5, 6, 8, 9, 12, 13, 14, 15):
                 K.lib().hcp_debug_set_gemm_config(cid + 16)
                 res[cid] = round(timeit(lambda: K.gemm_lora(a, b, l, e)), 1)
             K.lib().hcp_debug_set_gemm_config(-1)

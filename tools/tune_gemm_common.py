@@ -2,7 +2,7 @@ import torch
 
 BF = torch.bfloat16
 dev = torch.device("cuda:0")
-CFG_NAMES = ["128x128", "128x64", "64x64", "128x160", "64x160", "256x128", "256x160", "128x320", "128x160w8s3", "128x160w4s3", "256x160w8s3", "128x320w16", "256x160w16", "128x160w8"]
+CFG_NAMES = ["128x128", "128x64", "64x64", "128x160", "64x160", "256x128", "256x160", "128x320", "128x160w8s3", "128x160w4s3", "256x160w8s3", "128x320w16", "256x160w16", "128x160w8", "64x160w8", "128x128w8"]
 
 
 def timeit(fn, iters=10, warm=2):

@@ -26,7 +26,7 @@ for (M, N, Kd) in SHAPES:
         return K.gemm(a, b, a2=t, b2=e)
     t_two = timeit(two)
     res = {}
-    for cid in (0, 1, 2, 3, 4, 5, 6, 8, 9, 13):
+    for cid in (0, 1, 2, 3, 4, 5, 6, 8, 9, 12, 13, 14, 15):
         K.lib().hcp_debug_set_gemm_config(cid + 16)
         res[CFG_NAMES[cid]] = round(timeit(lambda: K.gemm_lora(a, b, l, e)), 1)
     K.lib().hcp_debug_set_gemm_config(-1)
