@@ -613,6 +613,192 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
     }
 }
 
+// ---- v2 main loop ------------------------------------------------------------------------------------------------------
+// Same tiles, LDS image and MFMA schedule as gemm_glds_kernel, with the per-K-tile overhead stripped out (the ISA of the loop
+// above spends ~250 scalar/vector instructions, three in-loop kernarg loads and nine s_waitcnt per 20 MFMAs on address
+// arithmetic and masking):
+//   * sources are addressed through BUFFER resources (buffer_load_dwordx4 ... offen lds): the wave-uniform resource base is
+//     re-pointed at each K tile (a few SALU ops), every lane's byte offset is LOOP-INVARIANT, and a masked row / conv tap is
+//     an out-of-range offset that the hardware turns into zeros — no zero page, no exec-mask branches, no 64-bit VALU math;
+//   * LDS fragment addresses are two precomputed VGPRs per operand (the XOR swizzle does not depend on the 16-row block);
+//   * the rank-32 K-extension tile and the epilogue are outside the loop; no ablation hooks.
+// Requirements (else the dispatcher keeps the kernel above): K % 64 == 0; conv gathers in their FAST form.
+template <int BM, int BN, int WGM, int WGN, int MODE>
+HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int RPP = NT / 8;
+    constexpr int A_IT = (BM + RPP - 1) / RPP, B_IT = (BN + RPP - 1) / RPP;
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 8 == 0 && BN % 8 == 0, "tile shape");
+    HCP_DYN_SMEM(smem);
+    hcp_bf16* lds = (hcp_bf16*)smem;
+    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, BUF_ELEMS = A_ELEMS + B_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = hcp_uniform(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int kc = tid & 7, lrow = tid >> 3;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int nk1 = p.K / BK;
+    const int kt_begin = split * p.kt_per_split;
+    int kt_end = kt_begin + p.kt_per_split; if (kt_end > nk1) kt_end = nk1;
+    const int nprim = kt_end - kt_begin;
+    const bool has_ext = (split == p.nsplit - 1) && p.K2 > 0;
+    const int nk = nprim + (has_ext ? 1 : 0);
+
+    // ---- loop-invariant per-lane byte offsets (HCP_BUF_OOB = this lane contributes zeros)
+    const int Ctot = p.cv.C1 + p.cv.C2;
+    unsigned va[A_IT], va2[A_IT], vb[B_IT];
+    int a_msk[A_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int r = lrow + RPP * i, n = n0 + r;
+        vb[i] = (r < BN && n < p.N) ? (unsigned)(((size_t)n * p.ldb + ((kc ^ ((r >> 1) & 7)) << 3)) * 2) : HCP_BUF_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int r = lrow + RPP * i, m = m0 + r;
+        const int chunk = (kc ^ ((r >> 1) & 7)) << 3;
+        va[i] = HCP_BUF_OOB; va2[i] = HCP_BUF_OOB; a_msk[i] = 0;
+        if (r < BM && m < p.M) {
+            if (MODE == 0) {
+                va[i] = (unsigned)(((size_t)m * p.lda + chunk) * 2);
+            } else {
+                const int hw = p.cv.Ho * p.cv.Wo;
+                const int b = m / hw; const int rem = m - b * hw;
+                const int py = rem / p.cv.Wo, px = rem - py * p.cv.Wo;
+                const int s = MODE == 1 ? p.cv.stride : 1;
+                const int pix = (b * p.cv.Hs + py * s) * p.cv.Ws + px * s;
+                va[i] = (unsigned)(((size_t)pix * p.cv.C1 + chunk) * 2);
+                va2[i] = (unsigned)(((size_t)pix * p.cv.C2 + chunk) * 2);
+                int msk = 0;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int sy = MODE == 1 ? py * s + ky - 1 : py + 1 - ky;
+                        const int sx = MODE == 1 ? px * s + kx - 1 : px + 1 - kx;
+                        if (sy >= 0 && sy < p.cv.Hs && sx >= 0 && sx < p.cv.Ws) msk |= 1 << (ky * 3 + kx);
+                    }
+                a_msk[i] = msk;
+            }
+        }
+    }
+    // conv: (tap, channel cursor) of the NEXT tile to issue; advanced by one K tile per issue
+    int tap = 0, cb = 0;
+    if (MODE != 0) { const int k0 = kt_begin * BK; tap = k0 / Ctot; cb = k0 - tap * Ctot; }
+    const hcp_bf16* Ab = p.A + (size_t)kt_begin * BK;      // MODE 0: first element of this split's first A tile column block
+    const hcp_bf16* Bb = p.B + (size_t)kt_begin * BK;
+
+    auto issue = [&](int buf) {                             // issues the next primary tile (called in tile order)
+        hcp_bf16* la = lds + buf * BUF_ELEMS;
+        hcp_bf16* lb = la + A_ELEMS;
+        const hcp_rsrc rb = hcp_make_rsrc(Bb);
+        Bb += BK;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            if (wave * 8 + RPP * i < BN) hcp_buf_glds16(rb, vb[i], lb + (wave * 8 + RPP * i) * BK);
+        if (MODE == 0) {
+            const hcp_rsrc ra = hcp_make_rsrc(Ab);
+            Ab += BK;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i)
+                if (wave * 8 + RPP * i < BM) hcp_buf_glds16(ra, va[i], la + (wave * 8 + RPP * i) * BK);
+        } else {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int doff = MODE == 1 ? (ky - 1) * p.cv.Ws + (kx - 1) : (1 - ky) * p.cv.Ws + (1 - kx);
+            const bool first = cb < p.cv.C1;
+            const hcp_bf16* base = first ? p.cv.X1 + (long)doff * p.cv.C1 + cb : p.cv.X2 + (long)doff * p.cv.C2 + (cb - p.cv.C1);
+            const hcp_rsrc ra = hcp_make_rsrc(base);
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i)
+                if (wave * 8 + RPP * i < BM) {
+                    const unsigned v = ((a_msk[i] >> tap) & 1) ? (first ? va[i] : va2[i]) : HCP_BUF_OOB;
+                    hcp_buf_glds16(ra, v, la + (wave * 8 + RPP * i) * BK);
+                }
+            cb += BK;
+            if (cb >= Ctot) { cb -= Ctot; ++tap; }
+        }
+    };
+    auto issue_ext = [&](int buf) {                         // the rank-32 K-extension tile: plain rows of A2 / B2, k < K2 only
+        hcp_bf16* la = lds + buf * BUF_ELEMS;
+        hcp_bf16* lb = la + A_ELEMS;
+        const hcp_rsrc rb = hcp_make_rsrc(p.B2), ra = hcp_make_rsrc(p.A2);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            if (wave * 8 + RPP * i < BN) {
+                const int r = lrow + RPP * i, n = n0 + r, k = (kc ^ ((r >> 1) & 7)) << 3;
+                hcp_buf_glds16(rb, (n < p.N && k < p.K2) ? (unsigned)(((size_t)n * p.ldb2 + k) * 2) : HCP_BUF_OOB, lb + (wave * 8 + RPP * i) * BK);
+            }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            if (wave * 8 + RPP * i < BM) {
+                const int r = lrow + RPP * i, m = m0 + r, k = (kc ^ ((r >> 1) & 7)) << 3;
+                hcp_buf_glds16(ra, (m < p.M && k < p.K2) ? (unsigned)(((size_t)m * p.lda2 + k) * 2) : HCP_BUF_OOB, la + (wave * 8 + RPP * i) * BK);
+            }
+    };
+
+    hcp_f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+
+    // fragment addresses (elements) inside a stage: row R = base + 16*i, slot (ks*4 + fg) ^ ((R >> 1) & 7) — the swizzle term only
+    // depends on fr because every 16-row block starts at a multiple of 16
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int q = ks * 4 + fg;
+        a_rd[ks] = (wm * WTM + fr) * BK + ((q ^ ((fr >> 1) & 7)) << 3);
+        b_rd[ks] = A_ELEMS + (wn * WTN + fr) * BK + ((q ^ ((fr >> 1) & 7)) << 3);
+    }
+    auto compute = [&](int stage) {
+        const hcp_bf16* st = lds + stage * BUF_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            hcp_bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const hcp_bf16x8*)(st + a_rd[ks] + i * 16 * BK);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const hcp_bf16x8*)(st + b_rd[ks] + j * 16 * BK);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fb[j], fa[i], acc[i][j]);
+        }
+    };
+
+    if (nprim > 0) issue(0); else if (has_ext) issue_ext(0);
+    HCP_SYNC();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nprim) issue(cur ^ 1);
+        else if (t + 1 == nprim && has_ext) issue_ext(cur ^ 1);
+        compute(cur);
+        HCP_SYNC();                                         // drains the DMA of tile t+1 and fences the LDS reads of tile t
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + 4 * fg;
+            if (n >= p.N) continue;
+            if (p.nsplit > 1) *(hcp_f32x4*)(p.slabs + ((size_t)split * p.M + m) * p.N + n) = acc[i][j];
+            else epilogue_store(p, m, n, acc[i][j]);
+        }
+    }
+}
+
 // sum the split-K slabs and apply the epilogue
 HCP_KERNEL(256) splitk_reduce_kernel(GemmParams p) {
     const int nv = p.N / 4;
@@ -628,12 +814,26 @@ HCP_KERNEL(256) splitk_reduce_kernel(GemmParams p) {
 int g_force_cfg = -1;   // tools/tune: force a tile configuration (see hcp_debug_set_gemm_config)
 int g_dbg_ablate = 0;   // tools only, see GemmParams::dbg
 int g_use_glds = 1;     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
+int g_use_v2 = 1;       // 1: buffer-addressed v2 main loop where its requirements hold (default), 0: gemm_glds_kernel everywhere
 
 template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false, int NSTAGE = 2>
 int launch_cfg(GemmParams& p, hipStream_t stream) {
     p.tiles_m = hcp_cdiv(p.M, BM);
     const int tiles_n = hcp_cdiv(p.N, BN);
     p.dbg = g_dbg_ablate;
+    if constexpr (!LORA && NSTAGE == 2 && (MODE == 0 || FAST)) {
+        if (g_use_v2 && g_use_glds && !p.dbg && p.K % BK == 0 && (p.K2 == 0 || p.K2 == 32) &&
+            (size_t)p.M * p.lda * 2 < (1ul << 31) && (size_t)p.N * p.ldb * 2 < (1ul << 31)) {
+            const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(hcp_bf16);
+            HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN), smem, stream, p);
+            if (p.nsplit > 1) {
+                long nv = (long)p.M * (p.N / 4);
+                int g = (int)((nv + 255) / 256); if (g > 2048) g = 2048;
+                HCP_LAUNCH(splitk_reduce_kernel, dim3(g), dim3(256), 0, stream, p);
+            }
+            HCP_LAUNCH_CHECK("gemm_v2_kernel");
+        }
+    }
     if (g_use_glds || NSTAGE == 3) {
         size_t smem = (size_t)NSTAGE * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
         const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);      // fused-LoRA tail images
@@ -760,8 +960,8 @@ int check_common(const GemmParams& p) {
 
 // TOOLS ONLY (tools/tune_gemm.py): cfg = tile id + 16 * nsplit; -1 restores the heuristic.
 HCP_API int hcp_debug_set_gemm_config(int cfg) { g_force_cfg = cfg; return 0; }
-// TOOLS ONLY: 1 = LDS-DMA main loop (default), 0 = register-staged main loop.
-HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = on; return 0; }
+// TOOLS ONLY: 1 = LDS-DMA main loop (default), 0 = register-staged main loop; 2 = LDS-DMA but never the v2 loop.
+HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = on != 0; g_use_v2 = on == 1; return 0; }
 // TOOLS ONLY: ablation of the 2-stage LDS-DMA loop (results are wrong when != 0): 1 no DMA after tile 0, 2 no MFMA, 4 no LDS reads.
 HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; return 0; }
 

@@ -68,6 +68,18 @@ HCP_DEVICE void hcp_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// Buffer-addressed LDS-DMA (buffer_load_dwordx4 ... offen lds): source = resource base + per-lane byte offset; a lane whose
+// offset is >= the resource's num_records (HCP_BUF_OOB) reads ZEROS, so masked rows / taps need no branch and no zero page.
+// The resource is wave-uniform (SGPRs): rebasing it per K tile keeps every per-lane offset loop-invariant.
+typedef __amdgpu_buffer_rsrc_t hcp_rsrc;
+#define HCP_BUF_OOB 0x80000000u
+HCP_DEVICE hcp_rsrc hcp_make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, 0x7fffffff, 0x00020000);
+}
+HCP_DEVICE void hcp_buf_glds16(hcp_rsrc rsrc, unsigned voffset, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset, 0, 0, 0);
+}
+HCP_DEVICE int hcp_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }   // value known to be wave-uniform -> SGPR
 #define HCP_DEVICE_GLOBAL __device__
 HCP_DEVICE bool hcp_all(bool pred) { return __all(pred); }   // wave-uniform vote
 // Counted wait on the vector-memory counter (LDS-DMA loads are VM operations): returns when at most n of this wave's
