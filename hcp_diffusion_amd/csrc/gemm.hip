@@ -623,8 +623,9 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
 //   * LDS fragment addresses are two precomputed VGPRs per operand (the XOR swizzle does not depend on the 16-row block);
 //   * the rank-32 K-extension tile and the epilogue are outside the loop; no ablation hooks.
 // Requirements (else the dispatcher keeps the kernel above): K % 64 == 0; conv gathers in their FAST form.
-template <int BM, int BN, int WGM, int WGN, int MODE>
+template <int BM, int BN, int WGM, int WGN, int MODE, bool LORA = false>
 HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
+    static_assert(!LORA || (MODE == 0 && WGN == 2), "fused LoRA: plain GEMM, two waves across N");
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -633,7 +634,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
     static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 8 == 0 && BN % 8 == 0, "tile shape");
     HCP_DYN_SMEM(smem);
     hcp_bf16* lds = (hcp_bf16*)smem;
-    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, BUF_ELEMS = A_ELEMS + B_ELEMS;
+    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, L_ELEMS = LORA ? 32 * BK : 0, BUF_ELEMS = A_ELEMS + B_ELEMS + L_ELEMS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -695,6 +696,8 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
     if (MODE != 0) { const int k0 = kt_begin * BK; tap = k0 / Ctot; cb = k0 - tap * Ctot; }
     const hcp_bf16* Ab = p.A + (size_t)kt_begin * BK;      // MODE 0: first element of this split's first A tile column block
     const hcp_bf16* Bb = p.B + (size_t)kt_begin * BK;
+    const hcp_bf16* Lb = LORA ? p.L + (size_t)kt_begin * BK : nullptr;      // fused LoRA: 32 rows of L [32, K], staged by waves 0..3
+    const unsigned vl = (unsigned)(((size_t)lrow * p.K + ((kc ^ ((lrow >> 1) & 7)) << 3)) * 2);
 
     auto issue = [&](int buf) {                             // issues the next primary tile (called in tile order)
         hcp_bf16* la = lds + buf * BUF_ELEMS;
@@ -704,6 +707,11 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
             if (wave * 8 + RPP * i < BN) hcp_buf_glds16(rb, vb[i], lb + (wave * 8 + RPP * i) * BK);
+        if (LORA) {
+            const hcp_rsrc rl = hcp_make_rsrc(Lb);
+            Lb += BK;
+            if (wave < 4) hcp_buf_glds16(rl, vl, lb + B_ELEMS + (wave * 8) * BK);
+        }
         if (MODE == 0) {
             const hcp_rsrc ra = hcp_make_rsrc(Ab);
             Ab += BK;
@@ -745,19 +753,23 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
     };
 
     hcp_f32x4 acc[TM][TN];
+    hcp_f32x4 tacc[LORA ? TM : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+#pragma unroll
+    for (int i = 0; i < (LORA ? TM : 1); ++i) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; tacc[i] = z; }
 
     // fragment addresses (elements) inside a stage: row R = base + 16*i, slot (ks*4 + fg) ^ ((R >> 1) & 7) — the swizzle term only
     // depends on fr because every 16-row block starts at a multiple of 16
-    int a_rd[2], b_rd[2];
+    int a_rd[2], b_rd[2], l_rd[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int q = ks * 4 + fg;
         a_rd[ks] = (wm * WTM + fr) * BK + ((q ^ ((fr >> 1) & 7)) << 3);
         b_rd[ks] = A_ELEMS + (wn * WTN + fr) * BK + ((q ^ ((fr >> 1) & 7)) << 3);
+        l_rd[ks] = A_ELEMS + B_ELEMS + (wn * 16 + fr) * BK + ((q ^ ((fr >> 1) & 7)) << 3);
     }
     auto compute = [&](int stage) {
         const hcp_bf16* st = lds + stage * BUF_ELEMS;
@@ -772,6 +784,11 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fb[j], fa[i], acc[i][j]);
+            if (LORA) {                                    // this wave's 16 of the 32 rank slots: T += A L^T from the same A fragments
+                const hcp_bf16x8 fl = *(const hcp_bf16x8*)(st + l_rd[ks]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) tacc[i] = hcp_mfma16(fl, fa[i], tacc[i]);
+            }
         }
     };
 
@@ -783,6 +800,38 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
         else if (t + 1 == nprim && has_ext) issue_ext(cur ^ 1);
         compute(cur);
         HCP_SYNC();                                         // drains the DMA of tile t+1 and fences the LDS reads of tile t
+    }
+
+    if (LORA) {
+        // T (bf16-rounded) and E = alpha * W_up rows of this N tile meet in LDS; one extra k-step adds T E^T
+        constexpr int TS2 = 40;
+        hcp_bf16* lt = lds;
+        hcp_bf16* le = lds + BM * TS2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            hcp_bf16x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(tacc[i][q]);
+            const int ml = wm * WTM + i * 16 + fr;
+            *(hcp_bf16x4*)(lt + ml * TS2 + wn * 16 + 4 * fg) = o;
+            if (tile_n == 0 && p.Tout && m0 + ml < p.M) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * 32 + wn * 16 + 4 * fg) = o;
+        }
+        for (int c = tid; c < BN * 4; c += NT) {
+            const int r = c >> 2, q = c & 3;
+            hcp_bf16x8 v = hcp_zero8();
+            if (n0 + r < p.N) v = *(const hcp_bf16x8*)(p.E + (size_t)(n0 + r) * 32 + q * 8);
+            *(hcp_bf16x8*)(le + r * TS2 + q * 8) = v;
+        }
+        HCP_SYNC();
+        hcp_bf16x8 ft[TM], fe[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ft[i] = *(const hcp_bf16x8*)(lt + (wm * WTM + i * 16 + fr) * TS2 + fg * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fe[j] = *(const hcp_bf16x8*)(le + (wn * WTN + j * 16 + fr) * TS2 + fg * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
     }
 
 #pragma unroll
@@ -821,11 +870,13 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
     p.tiles_m = hcp_cdiv(p.M, BM);
     const int tiles_n = hcp_cdiv(p.N, BN);
     p.dbg = g_dbg_ablate;
-    if constexpr (!LORA && NSTAGE == 2 && (MODE == 0 || FAST)) {
+    if constexpr (NSTAGE == 2 && (MODE == 0 || FAST)) {
         if (g_use_v2 && g_use_glds && !p.dbg && p.K % BK == 0 && (p.K2 == 0 || p.K2 == 32) &&
             (size_t)p.M * p.lda * 2 < (1ul << 31) && (size_t)p.N * p.ldb * 2 < (1ul << 31)) {
-            const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(hcp_bf16);
-            HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN), smem, stream, p);
+            size_t smem = (size_t)2 * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
+            const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);
+            if (LORA && smem < tail) smem = tail;
+            HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN), smem, stream, p);
             if (p.nsplit > 1) {
                 long nv = (long)p.M * (p.N / 4);
                 int g = (int)((nv + 255) / 256); if (g > 2048) g = 2048;
