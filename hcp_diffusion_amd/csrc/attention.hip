@@ -81,12 +81,15 @@ struct TileStage {
     static constexpr int NC = D / 8;
     static constexpr int IT = (KVT * NC + 255) / 256;
     hcp_bf16x8 r[IT];
+    // buffer-addressed: the resource covers exactly the `nvalid` live rows of this tile, so rows past the end (ragged last
+    // tile) and the unused lanes of the last pass read zeros in hardware — no exec-mask branches, 32-bit offsets only
     HCP_MEMBER void load(const hcp_bf16* src, int rs, int nvalid, int tid) {
+        const hcp_rsrc rsrc = hcp_make_rsrc_n(src, (unsigned)(nvalid > 0 ? ((nvalid - 1) * rs + D) * 2 : 0));
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int c = tid + 256 * i;
             const int row = c / NC, dc = c - row * NC;
-            r[i] = (c < KVT * NC && row < nvalid) ? *(const hcp_bf16x8*)(src + (size_t)row * rs + dc * 8) : hcp_zero8();
+            r[i] = hcp_buf_load16(rsrc, c < KVT * NC ? (unsigned)((row * rs + dc * 8) * 2) : HCP_BUF_OOB);
         }
     }
     HCP_MEMBER void store_rm(hcp_bf16* rm, int RSv, int tid) const {

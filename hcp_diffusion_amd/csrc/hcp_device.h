@@ -79,6 +79,16 @@ HCP_DEVICE hcp_rsrc hcp_make_rsrc(const void* base) {
 HCP_DEVICE void hcp_buf_glds16(hcp_rsrc rsrc, unsigned voffset, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voffset, 0, 0, 0);
 }
+// Bounded resource + 16-byte load into VGPRs: lanes whose offset falls outside [0, nbytes) get zeros (ragged last tiles need no
+// per-lane predicate and no exec-mask branch).
+HCP_DEVICE hcp_rsrc hcp_make_rsrc_n(const void* base, unsigned nbytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)nbytes, 0x00020000);
+}
+HCP_DEVICE hcp_bf16x8 hcp_buf_load16(hcp_rsrc rsrc, unsigned voffset) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffset, 0, 0);
+    return __builtin_bit_cast(hcp_bf16x8, v);
+}
 HCP_DEVICE int hcp_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }   // value known to be wave-uniform -> SGPR
 #define HCP_DEVICE_GLOBAL __device__
 HCP_DEVICE bool hcp_all(bool pred) { return __all(pred); }   // wave-uniform vote

@@ -102,12 +102,18 @@ HCP_DEVICE hcp_bf16x4 hcp_lds_read_tr4(const unsigned short* p) {
 HCP_DEVICE void hcp_glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((unsigned char*)lds_wave_base + 16 * hcp_emu::g_cur->lane, gsrc, 16);
 }
-struct hcp_rsrc { const unsigned char* base; };
+struct hcp_rsrc { const unsigned char* base; unsigned nbytes; };
 #define HCP_BUF_OOB 0x80000000u
-HCP_DEVICE hcp_rsrc hcp_make_rsrc(const void* base) { hcp_rsrc r; r.base = (const unsigned char*)base; return r; }
+HCP_DEVICE hcp_rsrc hcp_make_rsrc(const void* base) { hcp_rsrc r; r.base = (const unsigned char*)base; r.nbytes = 0x7fffffffu; return r; }
+HCP_DEVICE hcp_rsrc hcp_make_rsrc_n(const void* base, unsigned nbytes) { hcp_rsrc r; r.base = (const unsigned char*)base; r.nbytes = nbytes; return r; }
 HCP_DEVICE void hcp_buf_glds16(hcp_rsrc rsrc, unsigned voffset, void* lds_wave_base) {
     unsigned char* dst = (unsigned char*)lds_wave_base + 16 * hcp_emu::g_cur->lane;
-    if (voffset >= 0x7fffffffu) memset(dst, 0, 16); else memcpy(dst, rsrc.base + voffset, 16);
+    if (voffset >= rsrc.nbytes || voffset + 16 > rsrc.nbytes) memset(dst, 0, 16); else memcpy(dst, rsrc.base + voffset, 16);
+}
+HCP_DEVICE hcp_bf16x8 hcp_buf_load16(hcp_rsrc rsrc, unsigned voffset) {
+    hcp_bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (voffset < rsrc.nbytes && voffset + 16 <= rsrc.nbytes) memcpy(&v, rsrc.base + voffset, 16);
+    return v;
 }
 HCP_DEVICE int hcp_uniform(int v) { return v; }
 #define HCP_DEVICE_GLOBAL static
