@@ -174,6 +174,10 @@ HCP_WAVES_PER_SIMD(D > 80 ? 2 : QT == 2 ? 3 : 4) HCP_KERNEL(256) attn_fwd_kernel
     sk.store_rm(lds, G::RS, tid); sv.store_rm(lds + G::RM_ELEMS, G::RS, tid);
     HCP_SYNC();
 
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int s = 0; s < G::NQK; ++s) hcp_force_ready(qf[t][s]);      // retire the Q loads here, not inside the loop
     for (int it = 0; it < nt; ++it) {
         const int kv0 = it * KVT;
         const int nvalid = p.Nk - kv0 < KVT ? p.Nk - kv0 : KVT;
@@ -353,6 +357,12 @@ HCP_WAVES_PER_SIMD(D > 80 ? 2 : 3) HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams
     sk.store_rm(lds, G::RS, tid); sv.store_rm(lds + G::RM_ELEMS, G::RS, tid);
     HCP_SYNC();
 
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int s = 0; s < G::NQK; ++s) { hcp_force_ready(qf[t][s]); hcp_force_ready(gf[t][s]); }
+        hcp_force_ready(lse2[t]); hcp_force_ready(del_i[t]);
+    }
     for (int it = 0; it < nt; ++it) {
         const int kv0 = it * KVT;
         const int nvalid = p.Nk - kv0 < KVT ? p.Nk - kv0 : KVT;
@@ -467,9 +477,13 @@ HCP_WAVES_PER_SIMD((D > 80 || KT == 2) ? 2 : 3) HCP_KERNEL(256) attn_bwd_dkv_ker
     const int per = (nt_all + p.qsplit - 1) / p.qsplit;
     const int it0 = qs * per;
     const int nt = it0 + per < nt_all ? it0 + per : nt_all;      // this workgroup walks query tiles [it0, nt)
+    // raw value only: the LOG2E scaling / out-of-range defaults are applied when it is stored to LDS, so that nothing waits on
+    // this load (a use right here makes the compiler drain vmcnt — including the Q/dO tile prefetch issued just before)
+    const float* stat_ptr = tid < KVT ? lse_b : del_b - KVT;           // lse for tid < 64, delta for 64 <= tid < 128
+    bool rl_ok = false;
     auto load_stats = [&](int q0) {
-        if (tid < KVT) rl = q0 + tid < p.Nq ? lse_b[q0 + tid] * LOG2E : INFINITY;
-        else if (tid < 2 * KVT) rl = q0 + tid - KVT < p.Nq ? del_b[q0 + tid - KVT] : 0.f;
+        rl_ok = tid < 2 * KVT && q0 + (tid & (KVT - 1)) < p.Nq;
+        rl = rl_ok ? stat_ptr[q0 + tid] : 0.f;
     };
     {
         const int q0 = it0 * KVT;
@@ -497,12 +511,16 @@ HCP_WAVES_PER_SIMD((D > 80 || KT == 2) ? 2 : 3) HCP_KERNEL(256) attn_bwd_dkv_ker
     auto store_all = [&](hcp_bf16* base) {
         sq.store_rm(base, G::RS, tid); sg.store_rm(base + G::RM_ELEMS, G::RS, tid);
         float* sl = (float*)(base + 2 * G::RM_ELEMS);
-        if (tid < 2 * KVT) sl[tid] = rl;
+        if (tid < 2 * KVT) sl[tid] = tid < KVT ? (rl_ok ? rl * LOG2E : INFINITY) : (rl_ok ? rl : 0.f);
     };
     HCP_SYNC();
     store_all(lds);
     HCP_SYNC();
 
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int s = 0; s < G::NQK; ++s) { hcp_force_ready(kf[t][s]); hcp_force_ready(vf[t][s]); }
     for (int it = it0; it < nt; ++it) {
         const int q0 = it * KVT;
         const hcp_bf16* sQ = lds + (NB == 2 ? ((it - it0) & 1) : 0) * BUF;

@@ -90,6 +90,11 @@ HCP_DEVICE hcp_bf16x8 hcp_buf_load16(hcp_rsrc rsrc, unsigned voffset) {
     return __builtin_bit_cast(hcp_bf16x8, v);
 }
 HCP_DEVICE int hcp_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }   // value known to be wave-uniform -> SGPR
+// "This register is consumed here": makes the compiler retire the global load that produces `v` BEFORE a loop instead of at the
+// loop's first use — otherwise its conservative s_waitcnt vmcnt(0) at the loop head also drains the tile prefetch issued a few
+// instructions earlier in every iteration (seen in the attention kernels' ISA).
+HCP_DEVICE void hcp_force_ready(hcp_bf16x8& v) { asm volatile("" : "+v"(v)); }
+HCP_DEVICE void hcp_force_ready(float& v) { asm volatile("" : "+v"(v)); }
 #define HCP_DEVICE_GLOBAL __device__
 HCP_DEVICE bool hcp_all(bool pred) { return __all(pred); }   // wave-uniform vote
 // Counted wait on the vector-memory counter (LDS-DMA loads are VM operations): returns when at most n of this wave's

@@ -116,6 +116,8 @@ HCP_DEVICE hcp_bf16x8 hcp_buf_load16(hcp_rsrc rsrc, unsigned voffset) {
     return v;
 }
 HCP_DEVICE int hcp_uniform(int v) { return v; }
+HCP_DEVICE void hcp_force_ready(hcp_bf16x8&) {}
+HCP_DEVICE void hcp_force_ready(float&) {}
 #define HCP_DEVICE_GLOBAL static
 HCP_DEVICE void hcp_wait_vmcnt(int) {}                       // DMA is synchronous in the interpreter
 HCP_DEVICE void hcp_barrier_keep_dma() { hcp_emu::yield_barrier(); }
