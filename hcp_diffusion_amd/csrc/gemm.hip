@@ -834,16 +834,73 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
             for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
     }
 
+    if (p.nsplit > 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + 4 * fg;
+                if (n < p.N) *(hcp_f32x4*)(p.slabs + ((size_t)split * p.M + m) * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+    // epilogue: ALL of the lane's bias / row-bias / residual loads are issued before the first store (one vmcnt wait instead
+    // of one per 16x16 block: with K = 320 the serialized form cost as much as the whole main loop)
+    hcp_f32x4 bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + 4 * fg;
+        hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        bias_v[j] = (p.bias && n < p.N) ? *(const hcp_f32x4*)(p.bias + n) : z;
+    }
+    hcp_bf16x4 res_v[TM][TN];
+    if (p.residual) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + 4 * fg;
+                hcp_bf16x4 z = {0, 0, 0, 0};
+                res_v[i][j] = (m < p.M && n < p.N) ? *(const hcp_bf16x4*)(p.residual + (size_t)m * p.ldr + n) : z;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * 16 + fr;
         if (m >= p.M) continue;
+        hcp_f32x4 rb_v[TN];
+        if (p.rowbias) {
+            const float* rbp = p.rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + 4 * fg;
+                hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                rb_v[j] = n < p.N ? *(const hcp_f32x4*)(rbp + n) : z;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WTN + j * 16 + 4 * fg;
             if (n >= p.N) continue;
-            if (p.nsplit > 1) *(hcp_f32x4*)(p.slabs + ((size_t)split * p.M + m) * p.N + n) = acc[i][j];
-            else epilogue_store(p, m, n, acc[i][j]);
+            hcp_f32x4 v = acc[i][j] * p.alpha + bias_v[j];
+            if (p.rowbias) v += rb_v[j];
+            if (p.residual) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)res_v[i][j][q]);
+            }
+            if (p.out_f32) {
+                *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
+            } else {
+                hcp_bf16x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(v[q]);
+                *(hcp_bf16x4*)((hcp_bf16*)p.D + (size_t)m * p.ldd + n) = o;
+            }
         }
     }
 }
