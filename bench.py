@@ -77,12 +77,13 @@ def dominant_kernel_roofline(dev):
     dt = e0.elapsed_time(e1) * 1e-3 / n
     flops = 2.0 * B * H * H * C * 9 * C
     ach = flops / dt / 1e12
-    return {"bound": "mfma", "kernel": "gemm_glds_kernel<MODE=1,FAST> implicit-GEMM conv3x3 C320->320 @64x64, B=4 (+ split-K reduce when chosen)", "achieved": round(ach, 1),
+    return {"bound": "mfma", "kernel": "gemm_v2_kernel<128,160,4,2,MODE=1> implicit-GEMM conv3x3 C320->320 @64x64, B=4 (no split-K)", "achieved": round(ach, 1),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4),
-            # HBM bytes per launch from the committed PMC passes (profiles/r1_pmc_attention_conv.md: FETCH_SIZE x 2 gfx950
-            # correction + WRITE_SIZE, conv kernel 35.7 + 42.4 MB, split-K reduce 42.0 + 10.5 MB) vs 22.8 MB algorithmic:
-            # 84 MB of it is the fp32 split-K slab round trip.  Not re-measured by this run (rocprofv3 cannot nest).
-            "traffic": 130.6e6, "traffic_unit": "bytes/launch (PMC, profiles/r1_pmc_attention_conv.md)", "algorithmic_bytes": 22.8e6,
+            # HBM bytes per launch from the committed PMC passes (profiles/r1_pmc_attention_conv_final.md: FETCH_SIZE x 2 gfx950
+            # correction 35.6 MB + WRITE_SIZE 10.5 MB) vs 22.8 MB algorithmic: the 3x3 halo rows are re-fetched by workgroups
+            # on other XCDs.  (The first version of this kernel moved 130.6 MB: 84 MB of split-K slabs, now gone.)
+            # Not re-measured by this run (rocprofv3 cannot nest).
+            "traffic": 46.1e6, "traffic_unit": "bytes/launch (PMC, profiles/r1_pmc_attention_conv_final.md)", "algorithmic_bytes": 22.8e6,
             "avg_launch_us": round(dt * 1e6, 1)}
 
 
