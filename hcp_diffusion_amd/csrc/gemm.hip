@@ -706,7 +706,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
         Bb += BK;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            if (wave * 8 + RPP * i < BN) hcp_buf_glds16(rb, vb[i], lb + (wave * 8 + RPP * i) * BK);
+            if ((i + 1) * RPP <= BN || wave * 8 + RPP * i < BN) hcp_buf_glds16(rb, vb[i], lb + (wave * 8 + RPP * i) * BK);
         if (LORA) {
             const hcp_rsrc rl = hcp_make_rsrc(Lb);
             Lb += BK;
@@ -717,7 +717,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
             Ab += BK;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i)
-                if (wave * 8 + RPP * i < BM) hcp_buf_glds16(ra, va[i], la + (wave * 8 + RPP * i) * BK);
+                if ((i + 1) * RPP <= BM || wave * 8 + RPP * i < BM) hcp_buf_glds16(ra, va[i], la + (wave * 8 + RPP * i) * BK);
         } else {
             const int ky = tap / 3, kx = tap - ky * 3;
             const int doff = MODE == 1 ? (ky - 1) * p.cv.Ws + (kx - 1) : (1 - ky) * p.cv.Ws + (1 - kx);
@@ -726,7 +726,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
             const hcp_rsrc ra = hcp_make_rsrc(base);
 #pragma unroll
             for (int i = 0; i < A_IT; ++i)
-                if (wave * 8 + RPP * i < BM) {
+                if ((i + 1) * RPP <= BM || wave * 8 + RPP * i < BM) {
                     const unsigned v = ((a_msk[i] >> tap) & 1) ? (first ? va[i] : va2[i]) : HCP_BUF_OOB;
                     hcp_buf_glds16(ra, v, la + (wave * 8 + RPP * i) * BK);
                 }
@@ -740,13 +740,13 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
         const hcp_rsrc rb = hcp_make_rsrc(p.B2), ra = hcp_make_rsrc(p.A2);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            if (wave * 8 + RPP * i < BN) {
+            if ((i + 1) * RPP <= BN || wave * 8 + RPP * i < BN) {
                 const int r = lrow + RPP * i, n = n0 + r, k = (kc ^ ((r >> 1) & 7)) << 3;
                 hcp_buf_glds16(rb, (n < p.N && k < p.K2) ? (unsigned)(((size_t)n * p.ldb2 + k) * 2) : HCP_BUF_OOB, lb + (wave * 8 + RPP * i) * BK);
             }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            if (wave * 8 + RPP * i < BM) {
+            if ((i + 1) * RPP <= BM || wave * 8 + RPP * i < BM) {
                 const int r = lrow + RPP * i, m = m0 + r, k = (kc ^ ((r >> 1) & 7)) << 3;
                 hcp_buf_glds16(ra, (m < p.M && k < p.K2) ? (unsigned)(((size_t)m * p.lda2 + k) * 2) : HCP_BUF_OOB, la + (wave * 8 + RPP * i) * BK);
             }
