@@ -22,8 +22,6 @@ namespace {
 constexpr int TM_ROWS = 64;    // token rows per LDS tile (two 32-deep MFMA k-steps)
 constexpr int WY = 128;        // output rows (n) per workgroup = columns of the Y tile
 
-HCP_DEVICE_GLOBAL __attribute__((aligned(16))) unsigned char g_wzero[16];
-
 struct WgradParams {
     const hcp_bf16* Y; int ldy;
     const hcp_bf16* X1; const hcp_bf16* X2; int C1, C2; int ldx;
@@ -71,59 +69,71 @@ HCP_KERNEL(256) wgrad_tn_kernel(WgradParams p) {
     const int n0 = tile_n * WY, k0 = tile_k * WX;
     const int mb = blockIdx.y * p.rows_per_split;
     int me = mb + p.rows_per_split; if (me > p.M) me = p.M;
-    const hcp_bf16* zero = (const hcp_bf16*)g_wzero;
     const int Ctot = p.C1 + p.C2;
 
-    // loop-invariant part of this lane's DMA sources: the output columns of a workgroup are fixed, only rows advance
-    int y_row[NI_Y], y_col[NI_Y];
+    // Buffer-addressed DMA (see gemm_v2_kernel): per-lane byte offsets are loop-invariant for Y and for a linear X — the
+    // resource base advances by 64 rows per tile and its num_records ends at row `me`, so the ragged last tile reads zeros.
+    // The conv X gather recomputes the pixel per tile (shift/mask when the output map is a power of two wide, as in SD).
+    unsigned vy[NI_Y], vx[NI_X];
+    int x_row[NI_X], x_tap[NI_X], x_cs[NI_X];
+    bool x_second[NI_X];
 #pragma unroll
     for (int i = 0; i < NI_Y; ++i) {
-        y_row[i] = (wave * NI_Y + i) * RPI_Y + lane / CPR_Y;
-        y_col[i] = n0 + (((lane % CPR_Y) ^ sw_chunk<WY>(y_row[i])) << 3);
+        const int r = (wave * NI_Y + i) * RPI_Y + lane / CPR_Y;
+        const int col = n0 + (((lane % CPR_Y) ^ sw_chunk<WY>(r)) << 3);
+        vy[i] = col < p.N ? (unsigned)(((size_t)r * p.ldy + col) * 2) : HCP_BUF_OOB;
     }
-    int x_row[NI_X], x_col[NI_X], x_tap[NI_X], x_cs[NI_X];
-    const hcp_bf16* x_src[NI_X];
 #pragma unroll
     for (int i = 0; i < NI_X; ++i) {
-        x_row[i] = (wave * NI_X + i) * RPI_X + lane / CPR_X;
-        const int k = k0 + (((lane % CPR_X) ^ sw_chunk<WX>(x_row[i])) << 3);
-        x_col[i] = k; x_tap[i] = 0; x_cs[i] = p.ldx; x_src[i] = p.X1 + k;
+        const int r = (wave * NI_X + i) * RPI_X + lane / CPR_X;
+        const int k = k0 + (((lane % CPR_X) ^ sw_chunk<WX>(r)) << 3);
+        x_row[i] = r; x_tap[i] = -1; x_cs[i] = p.ldx; x_second[i] = false;
+        vx[i] = k < p.K ? (unsigned)(((size_t)r * p.ldx + k) * 2) : HCP_BUF_OOB;
         if (CONV) {
-            const int tap = k / Ctot, c = k - tap * Ctot;
-            x_tap[i] = tap;
-            if (c < p.C1) { x_src[i] = p.X1 + c; x_cs[i] = p.C1; }
-            else { x_src[i] = p.X2 + (c - p.C1); x_cs[i] = p.C2; }
+            vx[i] = HCP_BUF_OOB;
+            if (k < p.K) {
+                const int tap = k / Ctot, c = k - tap * Ctot;
+                x_tap[i] = tap;
+                x_second[i] = c >= p.C1;
+                x_cs[i] = x_second[i] ? p.C2 : p.C1;
+                vx[i] = (unsigned)((x_second[i] ? c - p.C1 : c) * 2);          // channel byte offset inside the pixel
+            }
         }
     }
+    const hcp_rsrc rx1 = hcp_make_rsrc(p.X1), rx2 = hcp_make_rsrc(p.X2 ? p.X2 : p.X1);
+    const int hw = p.Ho * p.Wo;
+    const bool pow2 = (hw & (hw - 1)) == 0 && (p.Wo & (p.Wo - 1)) == 0;
+    const int hw_shift = pow2 ? __builtin_ctz(hw) : 0, wo_shift = pow2 ? __builtin_ctz(p.Wo) : 0;
 
     auto issue_tile = [&](int m0, int buf) {
         hcp_bf16* ly = lds + buf * BUF;
         hcp_bf16* lx = ly + Y_ELEMS;
+        const int live = me - m0;                                  // rows of this tile that exist (>= 1)
+        const hcp_rsrc ry = hcp_make_rsrc_n(p.Y + (size_t)m0 * p.ldy, (unsigned)(((size_t)(live < TM_ROWS ? live : TM_ROWS) - 1) * p.ldy * 2 + p.ldy * 2));
 #pragma unroll
-        for (int i = 0; i < NI_Y; ++i) {
-            const int m = m0 + y_row[i];
-            const hcp_bf16* src = (m < me && y_col[i] < p.N) ? p.Y + (size_t)m * p.ldy + y_col[i] : zero;
-            hcp_glds16(src, ly + (wave * NI_Y + i) * RPI_Y * WY);
-        }
+        for (int i = 0; i < NI_Y; ++i) hcp_buf_glds16(ry, vy[i], ly + (wave * NI_Y + i) * RPI_Y * WY);
+        if (!CONV) {
+            const hcp_rsrc rx = hcp_make_rsrc_n(p.X1 + (size_t)m0 * p.ldx, (unsigned)((size_t)(live < TM_ROWS ? live : TM_ROWS) * p.ldx * 2));
 #pragma unroll
-        for (int i = 0; i < NI_X; ++i) {
-            const int m = m0 + x_row[i];
-            const hcp_bf16* src = zero;
-            if (m < me && x_col[i] < p.K) {
-                if (!CONV) {
-                    src = x_src[i] + (size_t)m * p.ldx;
-                } else {
-                    const int hw = p.Ho * p.Wo;
-                    const int b = m / hw; const int rem = m - b * hw;
-                    const int py = rem / p.Wo, px = rem - py * p.Wo;
+            for (int i = 0; i < NI_X; ++i) hcp_buf_glds16(rx, vx[i], lx + (wave * NI_X + i) * RPI_X * WX);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI_X; ++i) {
+                const int m = m0 + x_row[i];
+                unsigned v = HCP_BUF_OOB;
+                if (m < me && x_tap[i] >= 0) {
+                    int b, py, px;
+                    if (pow2) { b = m >> hw_shift; const int rem = m & (hw - 1); py = rem >> wo_shift; px = rem & (p.Wo - 1); }
+                    else { b = m / hw; const int rem = m - b * hw; py = rem / p.Wo; px = rem - py * p.Wo; }
                     const int ky = x_tap[i] / 3, kx = x_tap[i] - ky * 3;
                     int sy = py * p.stride + ky - 1, sx = px * p.stride + kx - 1;
                     const bool ok = sy >= 0 && sx >= 0 && sy < (p.Hs << p.up) && sx < (p.Ws << p.up);
                     sy >>= p.up; sx >>= p.up;
-                    if (ok) src = x_src[i] + ((size_t)(b * p.Hs + sy) * p.Ws + sx) * x_cs[i];
+                    if (ok) v = (unsigned)(((b * p.Hs + sy) * p.Ws + sx) * x_cs[i] * 2) + vx[i];
                 }
+                if (x_second[i]) hcp_buf_glds16(rx2, v, lx + (wave * NI_X + i) * RPI_X * WX);
+                else hcp_buf_glds16(rx1, v, lx + (wave * NI_X + i) * RPI_X * WX);
             }
-            hcp_glds16(src, lx + (wave * NI_X + i) * RPI_X * WX);
         }
     };
 
@@ -300,6 +310,7 @@ HCP_API int hcp_wgrad_conv3x3_bf16(const void* dY, int ldy, const void* X1, int 
     HCP_REQUIRE(Cw > 0 && Cw <= C1 + C2 && ldy % 8 == 0 && ldy >= (Cout + 7) / 8 * 8, "hcp_wgrad_conv3x3_bf16: bad Cw / ldy");
     HCP_REQUIRE((stride == 1 || stride == 2) && (upsample == 0 || upsample == 1) && !(stride == 2 && upsample),
                 "hcp_wgrad_conv3x3_bf16: stride must be 1 or 2, upsample 0 or 1");
+    HCP_REQUIRE((long)B * Hs * Ws * (C1 > C2 ? C1 : C2) < (1L << 30), "hcp_wgrad_conv3x3_bf16: source tensor too large for 32-bit byte offsets");
     WgradParams p = {};
     p.Y = (const hcp_bf16*)dY; p.ldy = ldy; p.X1 = (const hcp_bf16*)X1; p.X2 = (const hcp_bf16*)X2; p.C1 = C1; p.C2 = C2;
     p.D = dW; p.ldw = 9 * Cw; p.Cw = Cw; p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * (C1 + C2);
