@@ -48,6 +48,12 @@ TINY_SDXL_CONFIG = dict(SDXL_CONFIG, block_out_channels=(64, 128, 256), layers_p
                         addition_time_embed_dim=32, projection_class_embeddings_input_dim=256)
 
 
+# Two-level miniature (head dims 40 / 80) for the CPU-interpreted tests of the secondary features: same block types, ~4x less work.
+MICRO_CONFIG = dict(SD15_CONFIG, block_out_channels=(40, 80), layers_per_block=1, num_attention_heads=1, cross_attention_dim=32,
+                    norm_num_groups=8, down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+
+
 def per_block(v, i):
     """diffusers accepts an int or a per-down-block tuple for heads / transformer depth."""
     return v[i] if isinstance(v, (tuple, list)) else v

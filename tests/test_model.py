@@ -16,8 +16,8 @@ from hcp_diffusion_amd.lora import LoraHipLayer, make_lora
 from hcp_diffusion_amd.trainer import NativeTrainer
 from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
 from oracle.lora_ref import wrap_lora
-from oracle.unet_sd15 import (OracleUNet2DConditionModel, SD15_CONFIG, SDXL_CONFIG, TINY_CONFIG, TINY_SDXL_CONFIG, add_noise,
-                              ddpm_alphas_cumprod, seeded_init_)
+from oracle.unet_sd15 import (MICRO_CONFIG, OracleUNet2DConditionModel, SD15_CONFIG, SDXL_CONFIG, TINY_CONFIG, TINY_SDXL_CONFIG,
+                              add_noise, ddpm_alphas_cumprod, seeded_init_)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
@@ -165,8 +165,8 @@ def _full_ft_pair(cfg, backend, shape, ctx_len, ctx_dim, pooled_dim=None, seed=1
 def test_tiny_full_finetune_step_vs_oracle(backend, cfg_name):
     """Every UNet parameter trainable (reference cfgs/train/examples/DreamBooth.yaml:6-10): weight / bias / norm-affine
     gradients of all layers vs fp32 autograd of the oracle, then clip + AdamW + bf16 operand refresh."""
-    cfg, extra = (TINY_CONFIG, {}) if cfg_name == "sd15" else (TINY_SDXL_CONFIG, dict(pooled_dim=64))
-    ora, nat, tr, lo, ln, batch = _full_ft_pair(cfg, backend, (2, 4, 8, 8), 77, 64, **extra)
+    cfg, extra = (MICRO_CONFIG, {}) if cfg_name == "sd15" else (TINY_SDXL_CONFIG, dict(pooled_dim=64))
+    ora, nat, tr, lo, ln, batch = _full_ft_pair(cfg, backend, (2, 4, 8, 8), 24, cfg["cross_attention_dim"], **extra)
     assert abs(lo - ln) / abs(lo) < 2e-2
     po = dict(ora.named_parameters())
     hb = tr.host_buckets[0].bucket
@@ -308,7 +308,8 @@ def test_tiny_controlnet_train_step_vs_oracle(backend):
     from hcp_diffusion_amd.controlnet import make_controlnet
     from oracle.unet_sd15 import OracleControlNet
     dev = backend.device
-    ora, nat = _pair(TINY_CONFIG, dev)
+    cfg = TINY_CONFIG if backend.is_gpu else MICRO_CONFIG          # the interpreter gets the two-level miniature
+    ora, nat = _pair(cfg, dev)
     ora.requires_grad_(False)
     torch.manual_seed(3)
     ocn = OracleControlNet(ora)
@@ -322,12 +323,13 @@ def test_tiny_controlnet_train_step_vs_oracle(backend):
     plug = make_controlnet(nat)
     assert sorted(k for k, _ in plug.named_parameters()) == sorted(k for k, _ in ocn.named_parameters())
     assert plug.cond_head[0].weight.shape == (16, 3, 3, 3) and [m.stride[0] for m in plug.cond_head if hasattr(m, "stride")] == [1, 1, 2, 1, 2, 1, 2, 1]
+    cd = cfg["cross_attention_dim"]
     plug.load_state_dict(ocn.state_dict())
     tr = NativeTrainer(nat, None, lr=1e-3, plugins=[(plug, 1e-3)])
     assert not any(p.requires_grad for p in nat.parameters()) and all(p.requires_grad for p in plug.parameters())
     g2 = torch.Generator().manual_seed(21)
     B = 2
-    x0 = torch.randn(B, 4, 8, 8, generator=g2); ehs = torch.randn(B, 77, 64, generator=g2)
+    x0 = torch.randn(B, 4, 8, 8, generator=g2); ehs = torch.randn(B, 24, cd, generator=g2)
     noise = torch.randn(B, 4, 8, 8, generator=g2); t = torch.tensor([30, 800]); cond = torch.rand(B, 3, 64, 64, generator=g2)
     xt = add_noise(x0, noise, t, ddpm_alphas_cumprod())
     pred = ora(xt, t, ehs, control_residuals=ocn(xt, t, ehs, cond)).sample
@@ -358,7 +360,7 @@ def test_two_dataset_step_accumulates_like_reference(backend):
     """train_ac.py:467-504: one batch per dataset, every backward accumulates, ONE optimizer step.  Two half batches with
     loss weights (1, 0.5) must give the gradient of loss_a + 0.5 * loss_b."""
     dev = backend.device
-    _, nat = _pair(TINY_CONFIG, dev)
+    _, nat = _pair(MICRO_CONFIG, dev)
     tr = NativeTrainer(nat, [dict(layers=PATS, rank=4)], lr=1e-3)
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
@@ -366,7 +368,7 @@ def test_two_dataset_step_accumulates_like_reference(backend):
             blk.layer.W_up.copy_(backend.to(torch.randn(blk.layer.W_up.shape, generator=g) * 0.05))
     tr.bucket.pack()
     x = [backend.to(torch.randn(1, 4, 8, 8, generator=g)) for _ in range(2)]
-    e = [backend.to(torch.randn(1, 77, 64, generator=g)) for _ in range(2)]
+    e = [backend.to(torch.randn(1, 24, 32, generator=g)) for _ in range(2)]
     n = [backend.to(torch.randn(1, 4, 8, 8, generator=g)) for _ in range(2)]
     t = [backend.to(torch.tensor([100])), backend.to(torch.tensor([650]))]
     cur = {"i": 0}
@@ -499,14 +501,14 @@ def test_gradient_checkpointing_matches_plain_backward(backend):
     """model.gradient_checkpointing: True (reference default, train_base.yaml:69; wrapper.py:39-49): same loss and LoRA
     gradients as the un-checkpointed step (segments recomputed by the same kernels)."""
     dev = backend.device
-    _, nat = _pair(TINY_CONFIG, dev)
+    _, nat = _pair(MICRO_CONFIG, dev)
     tr = NativeTrainer(nat, [dict(layers=PATS, rank=4)], lr=1e-3)
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
         for blk in tr.bucket.blocks:
             blk.layer.W_up.copy_(backend.to(torch.randn(blk.layer.W_up.shape, generator=g) * 0.05))
     tr.bucket.pack()
-    x0 = backend.to(torch.randn(2, 4, 8, 8, generator=g)); ehs = backend.to(torch.randn(2, 77, 64, generator=g))
+    x0 = backend.to(torch.randn(2, 4, 8, 8, generator=g)); ehs = backend.to(torch.randn(2, 24, 32, generator=g))
     noise = backend.to(torch.randn(2, 4, 8, 8, generator=g)); t = backend.to(torch.tensor([12, 640]))
     tr.make_noise = lambda lat: (K.add_noise(lat, noise, t, tr.acp), noise, t)
     l0 = tr.forward_backward(x0, ehs).item()
