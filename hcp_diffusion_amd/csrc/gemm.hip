@@ -1031,7 +1031,7 @@ const TunedEntry kTuned[] = {
 bool lookup_tuned(const GemmParams& p, int mode, int* cfg, int* split) {
     for (const TunedEntry& e : kTuned) {
         if (e.mode == mode && e.M == p.M && e.N == p.N && e.K == p.K && e.has_k2 == (p.K2 > 0) &&
-            (mode == 0 || (e.stride == p.cv.stride && e.up == p.cv.up))) {
+            (mode == 0 || mode == 3 || (e.stride == p.cv.stride && e.up == p.cv.up))) {     // 0 / 3: plain GEMMs carry no conv geometry
             *cfg = e.cfg; *split = e.split; return true;
         }
     }
