@@ -59,6 +59,7 @@ _PROTOTYPES = {
     # Y, ldy, out, ldo, M, N, rows_per_group, stream
     "hcp_colsum_bf16": (I, [P, I, P, I, I, I, I, P]),
     "hcp_debug_set_wgrad_tile": (I, [I]),
+    "hcp_debug_gemm_table_stats": (I, [P, P]),
     # ema, p, n, step, inv_gamma, power, decay_max, stream
     "hcp_ema_update": (I, [P, P, L, P, F, F, F, P]),
     "hcp_debug_set_attention_ablation": (I, [I]),

@@ -1028,14 +1028,18 @@ const TunedEntry kTuned[] = {
 #include "gemm_tuned.inc"
 };
 
+long g_table_hits = 0, g_table_misses = 0;   // tools: how much of a workload the measured dispatch table covers
+
 bool lookup_tuned(const GemmParams& p, int mode, int* cfg, int* split) {
+    bool hit = false;
     for (const TunedEntry& e : kTuned) {
         if (e.mode == mode && e.M == p.M && e.N == p.N && e.K == p.K && e.has_k2 == (p.K2 > 0) &&
             (mode == 0 || mode == 3 || (e.stride == p.cv.stride && e.up == p.cv.up))) {     // 0 / 3: plain GEMMs carry no conv geometry
-            *cfg = e.cfg; *split = e.split; return true;
+            *cfg = e.cfg; *split = e.split; hit = true; break;
         }
     }
-    return false;
+    (hit ? g_table_hits : g_table_misses) += 1;
+    return hit;
 }
 
 template <int MODE, bool FAST>
@@ -1066,6 +1070,13 @@ int check_common(const GemmParams& p) {
 
 }  // namespace
 
+// TOOLS ONLY: dispatch-table lookups since the last call (hits, misses); resets the counters.
+HCP_API int hcp_debug_gemm_table_stats(long* hits, long* misses) {
+    if (hits) *hits = g_table_hits;
+    if (misses) *misses = g_table_misses;
+    g_table_hits = 0; g_table_misses = 0;
+    return 0;
+}
 // TOOLS ONLY (tools/tune_gemm.py): cfg = tile id + 16 * nsplit; -1 restores the heuristic.
 HCP_API int hcp_debug_set_gemm_config(int cfg) { g_force_cfg = cfg; return 0; }
 // TOOLS ONLY: 1 = LDS-DMA main loop (default), 0 = register-staged main loop; 2 = LDS-DMA but never the v2 loop.

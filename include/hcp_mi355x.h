@@ -43,6 +43,7 @@ int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const voi
                        size_t workspace_bytes, hcpStream_t stream);
 /* fp32 split-K scratch (optional: workspace may be NULL, then small-M problems run unsplit). */
 size_t hcp_gemm_workspace_bytes(int M, int N);
+int hcp_debug_gemm_table_stats(long* hits, long* misses); /* tools only: dispatch-table lookups since the last call; resets */
 int hcp_debug_set_gemm_config(int cfg); /* tools/tune_gemm.py only: force tile id + 16*nsplit, -1 = heuristic */
 int hcp_debug_set_gemm_ablation(int flags); /* tools only (wrong results when != 0): 1 no DMA, 2 no MFMA, 4 no LDS reads */
 int hcp_debug_set_gemm_glds(int on);    /* tools only: 1 = LDS-DMA main loop (default), 0 = register-staged loop */

@@ -72,10 +72,15 @@ def trace(workload, B):
     if sdxl:
         kw["added_cond_kwargs"] = dict(text_embeds=torch.randn(B, 1280, device=dev), time_ids=torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * B, device=dev))
     tr.train_one_step(lat, ehs, **kw)          # warm-up (lazy packing)
+    K.lib().hcp_debug_gemm_table_stats(None, None)
     K.TRACE = []
     tr.train_one_step(lat, ehs, **kw)
     keys = collections.Counter(K.TRACE)
     K.TRACE = None
+    import ctypes
+    h, m = ctypes.c_long(), ctypes.c_long()
+    K.lib().hcp_debug_gemm_table_stats(ctypes.byref(h), ctypes.byref(m))
+    print(f"dispatch table during the traced step(s): {h.value} hits, {m.value} misses", flush=True)
     del tr, unet
     torch.cuda.empty_cache()
     return keys
