@@ -55,7 +55,6 @@ struct GemmParams {
 };
 
 constexpr int BK = 64;
-constexpr int LDS_STRIDE = BK + 8;  // bf16 elements per LDS row
 
 HCP_DEVICE void epilogue_store(const GemmParams& p, int m, int n, hcp_f32x4 v) {
     v = v * p.alpha;
@@ -77,248 +76,7 @@ HCP_DEVICE void epilogue_store(const GemmParams& p, int m, int n, hcp_f32x4 v) {
 }
 
 // MODE: 0 plain A, 1 conv forward gather, 2 conv data-gradient gather.  FAST: hoisted im2col addressing.
-template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false>
-HCP_KERNEL(64 * WGM * WGN) gemm_kernel(GemmParams p) {
-    static_assert(!LORA || (MODE == 0 && WGN == 2), "fused LoRA: plain GEMM, two waves across N");
-    constexpr int NT = 64 * WGM * WGN;
-    constexpr int WTM = BM / WGM, WTN = BN / WGN;
-    constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int RPP = NT / 8;                       // rows staged per pass (8 chunks of 8 bf16 per row)
-    constexpr int A_IT = (BM + RPP - 1) / RPP, B_IT = (BN + RPP - 1) / RPP;
-    constexpr bool A_EXACT = BM % RPP == 0, B_EXACT = BN % RPP == 0;
-    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA tile");
-    HCP_DYN_SMEM(smem);
-    hcp_bf16* lds = (hcp_bf16*)smem;
-    constexpr int A_ELEMS = BM * LDS_STRIDE, B_ELEMS = BN * LDS_STRIDE;
-    constexpr int L_ELEMS = LORA ? 32 * LDS_STRIDE : 0;
-    constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS + L_ELEMS;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.y;
-
-    const int kc = tid & 7;
-    const int lrow = tid >> 3;
-
-    const int nk1 = (p.K + BK - 1) / BK;
-    const int kt_begin = split * p.kt_per_split;
-    int kt_end = kt_begin + p.kt_per_split; if (kt_end > nk1) kt_end = nk1;
-    const bool last_split = split == p.nsplit - 1;
-    const int nk2 = last_split ? (p.K2 + BK - 1) / BK : 0;
-    const int nk = (kt_end - kt_begin) + nk2;          // tiles this block walks; tile index t -> primary kt_begin+t or ext
-
-    // ---- per-thread row descriptors for the A operand
-    int a_pix[A_IT];     // slow conv path: packed (b<<20 | py<<10 | px) or -1;  fast path: element offset of the row base
-    int a_msk[A_IT];     // fast path: 9-bit tap validity (bit ky*3+kx), 0 for rows >= M
-    const int Ctot = p.cv.C1 + p.cv.C2;
-    if (MODE != 0) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            int m = m0 + lrow + RPP * i;
-            a_pix[i] = -1; a_msk[i] = 0;
-            if ((A_EXACT || lrow + RPP * i < BM) && m < p.M) {
-                int hw = p.cv.Ho * p.cv.Wo;
-                int b = m / hw; int rem = m - b * hw;
-                int py = rem / p.cv.Wo; int px = rem - py * p.cv.Wo;
-                if (!FAST) {
-                    a_pix[i] = (b << 20) | (py << 10) | px;
-                } else {
-                    // source pixel of tap (ky,kx):  fwd: (py*s + ky - 1, px*s + kx - 1);  dgrad (s=1): (py + 1 - ky, px + 1 - kx)
-                    const int s = MODE == 1 ? p.cv.stride : 1;
-                    a_pix[i] = (b * p.cv.Hs + py * s) * p.cv.Ws + px * s;          // pixel index of the centre tap
-                    int msk = 0;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            int sy = MODE == 1 ? py * s + ky - 1 : py + 1 - ky;
-                            int sx = MODE == 1 ? px * s + kx - 1 : px + 1 - kx;
-                            if (sy >= 0 && sy < p.cv.Hs && sx >= 0 && sx < p.cv.Ws) msk |= 1 << (ky * 3 + kx);
-                        }
-                    a_msk[i] = msk;
-                }
-            }
-        }
-    }
-
-    hcp_bf16x8 ra[A_IT], rb[B_IT];
-    hcp_bf16x8 rl = hcp_zero8();
-
-    auto load_tile = [&](int t) {
-        const bool ext = t >= (kt_end - kt_begin);
-        const int kt = ext ? t - (kt_end - kt_begin) : kt_begin + t;
-        const int k = kt * BK + kc * 8;
-        const int klim = ext ? p.K2 : p.K;
-        {
-            const hcp_bf16* Bp = ext ? p.B2 : p.B; const int ld = ext ? p.ldb2 : p.ldb;
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                int r = lrow + RPP * i; int n = n0 + r;
-                if ((B_EXACT || r < BN) && n < p.N && k < klim) rb[i] = *(const hcp_bf16x8*)(Bp + (size_t)n * ld + k);
-                else rb[i] = hcp_zero8();
-            }
-        }
-        if (LORA && tid < 256) rl = k < klim ? *(const hcp_bf16x8*)(p.L + (size_t)lrow * p.K + k) : hcp_zero8();
-        if (MODE == 0 || ext) {
-            const hcp_bf16* Ap = ext ? p.A2 : p.A; const int ld = ext ? p.lda2 : p.lda;
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                int r = lrow + RPP * i; int m = m0 + r;
-                if ((A_EXACT || r < BM) && m < p.M && k < klim) ra[i] = *(const hcp_bf16x8*)(Ap + (size_t)m * ld + k);
-                else ra[i] = hcp_zero8();
-            }
-        } else if (FAST) {
-            // Ctot % 64 == 0: the whole K tile lies in one tap; (tap, c0) are wave-uniform
-            const int k0 = kt * BK;
-            const int tap = k0 / Ctot; const int c0 = k0 - tap * Ctot + kc * 8;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int doff = MODE == 1 ? (ky - 1) * p.cv.Ws + (kx - 1) : (1 - ky) * p.cv.Ws + (1 - kx);
-            const hcp_bf16* src; int cs, c;
-            if (c0 < p.cv.C1) { src = p.cv.X1; cs = p.cv.C1; c = c0; }
-            else { src = p.cv.X2; cs = p.cv.C2; c = c0 - p.cv.C1; }
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                hcp_bf16x8 v = hcp_zero8();
-                if ((a_msk[i] >> tap) & 1) v = *(const hcp_bf16x8*)(src + (size_t)(a_pix[i] + doff) * cs + c);
-                ra[i] = v;
-            }
-        } else {
-            int tap = k / Ctot; int ci = k - tap * Ctot;
-            int ky = tap / 3, kx = tap - ky * 3;
-            const hcp_bf16* src; int cs, c;
-            if (ci < p.cv.C1) { src = p.cv.X1; cs = p.cv.C1; c = ci; }
-            else { src = p.cv.X2; cs = p.cv.C2; c = ci - p.cv.C1; }
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                hcp_bf16x8 v = hcp_zero8();
-                int pix = a_pix[i];
-                if (pix >= 0 && k < klim) {
-                    int b = pix >> 20, py = (pix >> 10) & 1023, px = pix & 1023;
-                    int sy, sx; bool ok;
-                    if (MODE == 1) {
-                        sy = py * p.cv.stride + ky - 1; sx = px * p.cv.stride + kx - 1;
-                        int He = p.cv.Hs << p.cv.up, We = p.cv.Ws << p.cv.up;
-                        ok = sy >= 0 && sy < He && sx >= 0 && sx < We;
-                        sy >>= p.cv.up; sx >>= p.cv.up;
-                    } else {
-                        int ty = py + 1 - ky, tx = px + 1 - kx;
-                        ok = ty >= 0 && tx >= 0;
-                        if (p.cv.stride == 2) { ok = ok && ((ty | tx) & 1) == 0; ty >>= 1; tx >>= 1; }
-                        ok = ok && ty < p.cv.Hs && tx < p.cv.Ws;
-                        sy = ty; sx = tx;
-                    }
-                    if (ok) v = *(const hcp_bf16x8*)(src + ((size_t)(b * p.cv.Hs + sy) * p.cv.Ws + sx) * cs + c);
-                }
-                ra[i] = v;
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-        hcp_bf16* la = lds + buf * BUF_ELEMS;
-        hcp_bf16* lb = la + A_ELEMS;
-        if (LORA && tid < 256) *(hcp_bf16x8*)(lb + B_ELEMS + lrow * LDS_STRIDE + kc * 8) = rl;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-            if (A_EXACT || lrow + RPP * i < BM) *(hcp_bf16x8*)(la + (lrow + RPP * i) * LDS_STRIDE + kc * 8) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i)
-            if (B_EXACT || lrow + RPP * i < BN) *(hcp_bf16x8*)(lb + (lrow + RPP * i) * LDS_STRIDE + kc * 8) = rb[i];
-    };
-
-    hcp_f32x4 acc[TM][TN];
-    hcp_f32x4 tacc[LORA ? TM : 1];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
-#pragma unroll
-    for (int i = 0; i < (LORA ? TM : 1); ++i) { hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; tacc[i] = z; }
-
-    if (nk > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    HCP_SYNC();
-
-    const int fr = lane & 15, fg = lane >> 4;
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) load_tile(t + 1);
-        const hcp_bf16* la = lds + cur * BUF_ELEMS;
-        const hcp_bf16* lb = la + A_ELEMS;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            hcp_bf16x8 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = *(const hcp_bf16x8*)(la + (wm * WTM + i * 16 + fr) * LDS_STRIDE + (ks * 4 + fg) * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = *(const hcp_bf16x8*)(lb + (wn * WTN + j * 16 + fr) * LDS_STRIDE + (ks * 4 + fg) * 8);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = hcp_mfma16(fb[j], fa[i], acc[i][j]);   // swapped: lane owns 4 consecutive n
-            if (LORA) {   // T[m][p]: this wave owns rank columns [16 wn, 16 wn + 16)
-                hcp_bf16x8 fl = *(const hcp_bf16x8*)(lb + B_ELEMS + (wn * 16 + fr) * LDS_STRIDE + (ks * 4 + fg) * 8);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) tacc[i] = hcp_mfma16(fl, fa[i], tacc[i]);
-            }
-        }
-        if (t + 1 < nk) store_tile(cur ^ 1);
-        HCP_SYNC();
-    }
-
-    if (LORA) {
-        // T tile (bf16) -> LDS [BM][40]; E tile [BN][32] -> LDS [BN][40]; one more k-step of 32: D += T E^T
-        constexpr int TS2 = 40;
-        hcp_bf16* lt = lds;                       // all waves are past the last barrier: both buffers are free
-        hcp_bf16* le = lds + BM * TS2;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            hcp_bf16x4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(tacc[i][q]);
-            const int ml = wm * WTM + i * 16 + fr;
-            *(hcp_bf16x4*)(lt + ml * TS2 + wn * 16 + 4 * fg) = o;
-            if (tile_n == 0 && p.Tout && m0 + ml < p.M) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * 32 + wn * 16 + 4 * fg) = o;
-        }
-        for (int c = tid; c < BN * 4; c += NT) {
-            const int r = c >> 2, q = c & 3;
-            hcp_bf16x8 v = hcp_zero8();
-            if (n0 + r < p.N) v = *(const hcp_bf16x8*)(p.E + (size_t)(n0 + r) * 32 + q * 8);
-            *(hcp_bf16x8*)(le + r * TS2 + q * 8) = v;
-        }
-        HCP_SYNC();
-        hcp_bf16x8 ft[TM], fe[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) ft[i] = *(const hcp_bf16x8*)(lt + (wm * WTM + i * 16 + fr) * TS2 + fg * 8);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fe[j] = *(const hcp_bf16x8*)(le + (wn * WTN + j * 16 + fr) * TS2 + fg * 8);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
-    }
-
-    // ---- epilogue: lane holds D[m = .. + fr][n = .. + 4*fg + r]
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + fr;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + 4 * fg;
-            if (n >= p.N) continue;
-            if (p.nsplit > 1) *(hcp_f32x4*)(p.slabs + ((size_t)split * p.M + m) * p.N + n) = acc[i][j];
-            else epilogue_store(p, m, n, acc[i][j]);
-        }
-    }
-}
+// (The first, register-staged main loop — global -> VGPR -> ds_write_b128 — was removed after the LDS-DMA loop replaced it.)
 
 // 16 zero bytes in device memory: the source of every masked lane of an LDS-DMA load (out-of-range rows / columns,
 // the zero padding of the convolution, K tails).
@@ -942,16 +700,12 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
             HCP_LAUNCH_CHECK("gemm_v2_kernel");
         }
     }
-    if (g_use_glds || NSTAGE == 3) {
+    {
         size_t smem = (size_t)NSTAGE * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
         const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);      // fused-LoRA tail images
         if (LORA && smem < tail) smem = tail;
         HCP_LAUNCH((gemm_glds_kernel<BM, BN, WGM, WGN, MODE, FAST, LORA, NSTAGE>), dim3(p.tiles_m * tiles_n, p.nsplit),
                    dim3(64 * WGM * WGN), smem, stream, p);
-    } else {
-        const size_t smem = (size_t)2 * (BM + BN + (LORA ? 32 : 0)) * LDS_STRIDE * sizeof(hcp_bf16);
-        HCP_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, MODE, FAST, LORA>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN),
-                   smem, stream, p);
     }
     if (p.nsplit > 1) {
         long nv = (long)p.M * (p.N / 4);
@@ -1079,8 +833,8 @@ HCP_API int hcp_debug_gemm_table_stats(long* hits, long* misses) {
 }
 // TOOLS ONLY (tools/tune_gemm.py): cfg = tile id + 16 * nsplit; -1 restores the heuristic.
 HCP_API int hcp_debug_set_gemm_config(int cfg) { g_force_cfg = cfg; return 0; }
-// TOOLS ONLY: 1 = LDS-DMA main loop (default), 0 = register-staged main loop; 2 = LDS-DMA but never the v2 loop.
-HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = on != 0; g_use_v2 = on == 1; return 0; }
+// TOOLS ONLY: 1 = default (v2 main loop where its requirements hold), 0 / 2 = the first LDS-DMA loop (gemm_glds_kernel) everywhere.
+HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = 1; g_use_v2 = on == 1; return 0; }
 // TOOLS ONLY: ablation of the 2-stage LDS-DMA loop (results are wrong when != 0): 1 no DMA after tile 0, 2 no MFMA, 4 no LDS reads.
 HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; return 0; }
 
