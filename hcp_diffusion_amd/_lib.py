@@ -71,7 +71,8 @@ _PROTOTYPES = {
     # x, dy, stats, dgamma, dbeta, M, C, stream
     "hcp_layernorm_affine_grad": (I, [P, P, P, P, P, I, I, P]),
     "hcp_add_noise": (I, [P, P, P, P, P, I, L, P]),
-    "hcp_mse_masked_mean": (I, [P, P, P, I, P, P, I, I, I, F, P]),
+    "hcp_snr_loss_weight": (I, [P, P, P, I, I, F, P]),
+    "hcp_mse_masked_mean": (I, [P, P, P, I, P, P, P, I, I, I, F, P]),
     # L, ldl, R, ldr, out, ldo, M, P, Q, scale, transpose_out, stream
     "hcp_lora_wgrad": (I, [P, I, P, I, P, I, I, I, I, F, I, P]),
     # U, x, ldx, K, grad_down, T, dY, ldy, N, grad_up, M, r, scale, stream

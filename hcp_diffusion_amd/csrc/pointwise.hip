@@ -156,9 +156,30 @@ HCP_KERNEL(256) add_noise_kernel(const float* x0, const float* noise, const long
     }
 }
 
-// loss += sum((pred-target)^2 * mask) * scale ; grad = 2*(pred-target)*mask*scale
-HCP_KERNEL(256) mse_kernel(const float* pred, const float* target, const float* mask, int mask_c, float* loss, float* grad,
-                           int B, int C, int HW, float scale) {
+// Per-sample loss weight from the noise level of the sample's timestep (reference hcpdiff/loss/min_snr_loss.py):
+//   snr = acp/(1-acp) (= (alpha/sigma)^2, :14-19), sigma^2 = 1-acp
+//   kind 0 MinSNRLoss      min(gamma/snr, 1)                                   (:21-25)
+//   kind 1 SoftMinSNRLoss  gamma^3 / (snr^2 + gamma^3)                         (:31-35)
+//   kind 2 KDiffMinSNRLoss 4 (gamma snr)^2 / (snr^2 + gamma^2)^2               (:39-43)
+//   kind 3 EDMLoss         (sigma^2 + gamma^2) / (snr (sigma gamma)^2)         (:47-52)
+HCP_KERNEL(64) snr_weight_kernel(const long long* t, const float* acp, float* w, int B, int kind, float gamma) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float a = acp[t[b]];
+    const float alpha = sqrtf(a), sigma = sqrtf(1.0f - a);
+    const float r = alpha / sigma;
+    const float snr = r * r;
+    float v;
+    if (kind == 0) { v = gamma / snr; v = v > 1.0f ? 1.0f : v; }
+    else if (kind == 1) { const float g3 = gamma * gamma * gamma; v = g3 / (snr * snr + g3); }
+    else if (kind == 2) { const float gs = gamma * snr, d = snr * snr + gamma * gamma; v = 4.0f * (gs * gs / (d * d)); }
+    else { const float sg = sigma * gamma; v = (sigma * sigma + gamma * gamma) / (snr * (sg * sg)); }
+    w[b] = v;
+}
+
+// loss += sum((pred-target)^2 * mask * w[b]) * scale ; grad = 2*(pred-target)*mask*w[b]*scale
+HCP_KERNEL(256) mse_kernel(const float* pred, const float* target, const float* mask, int mask_c, const float* sw, float* loss,
+                           float* grad, int B, int C, int HW, float scale) {
     const long total = (long)B * C * HW;
     float acc = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -167,6 +188,7 @@ HCP_KERNEL(256) mse_kernel(const float* pred, const float* target, const float* 
             int hw = (int)(i % HW); long r = i / HW; int c = (int)(r % C); int b = (int)(r / C);
             m = mask[((size_t)b * mask_c + (mask_c == 1 ? 0 : c)) * HW + hw];
         }
+        if (sw) m *= sw[i / ((long)C * HW)];
         float d = pred[i] - target[i];
         acc += d * d * m;
         if (grad) grad[i] = 2.0f * d * m * scale;
@@ -254,15 +276,24 @@ HCP_API int hcp_add_noise(const float* x0, const float* noise, const long long* 
                alphas_cumprod, xt, B, per_sample);
     HCP_LAUNCH_CHECK("add_noise");
 }
-// loss (device scalar, zeroed here) = mean((pred-target)^2 * mask) * weight; grad (optional) = d loss / d pred.
-HCP_API int hcp_mse_masked_mean(const float* pred, const float* target, const float* mask, int mask_channels, float* loss,
-                                float* grad, int B, int C, int HW, float weight, hipStream_t stream) {
+// w[b] = loss weight of sample b from its timestep (kinds above); w feeds hcp_mse_masked_mean's sample_weight.
+HCP_API int hcp_snr_loss_weight(const long long* timesteps, const float* alphas_cumprod, float* w, int B, int kind, float gamma,
+                                hipStream_t stream) {
+    HCP_REQUIRE(timesteps && alphas_cumprod && w && B > 0 && kind >= 0 && kind <= 3 && gamma > 0.f, "hcp_snr_loss_weight: bad arguments");
+    HCP_LAUNCH(snr_weight_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, timesteps, alphas_cumprod, w, B, kind, gamma);
+    HCP_LAUNCH_CHECK("snr_loss_weight");
+}
+// loss (device scalar, zeroed here) = mean((pred-target)^2 * mask * sample_weight[b]) * weight; grad (optional) = d loss / d pred.
+// sample_weight: null or float[B] (train_ac.py:506-515 with a need_timesteps criterion).
+HCP_API int hcp_mse_masked_mean(const float* pred, const float* target, const float* mask, int mask_channels,
+                                const float* sample_weight, float* loss, float* grad, int B, int C, int HW, float weight,
+                                hipStream_t stream) {
     HCP_REQUIRE(pred && target && loss && B > 0 && C > 0 && HW > 0, "hcp_mse_masked_mean: bad arguments");
     HCP_REQUIRE(!mask || mask_channels == 1 || mask_channels == C, "hcp_mse_masked_mean: mask channels must be 1 or C");
     if (hcp_memset_async(loss, 0, sizeof(float), stream)) return hcp_set_error("hcp_mse_masked_mean: memset failed");
     float scale = weight / (float)((long)B * C * HW);
     HCP_LAUNCH(mse_kernel, dim3(pw_grid((long)B * C * HW)), dim3(PW_THREADS), 0, stream, pred, target, mask, mask_channels,
-               loss, grad, B, C, HW, scale);
+               sample_weight, loss, grad, B, C, HW, scale);
     HCP_LAUNCH_CHECK("mse_masked_mean");
 }
 

@@ -421,8 +421,20 @@ def add_noise(x0, noise, t, alphas_cumprod):
     return xt
 
 
-def mse_masked_mean(pred, target, mask=None, weight=1.0, want_grad=True):
-    """(mean((pred-target)^2 * mask) * weight as a device scalar, d loss / d pred)."""
+SNR_LOSS_KINDS = {"min_snr": 0, "soft_min_snr": 1, "kdiff_min_snr": 2, "edm": 3}
+
+
+def snr_loss_weight(t, alphas_cumprod, kind, gamma):
+    """float[B] loss weights of the reference's MinSNRLoss family (hcpdiff/loss/min_snr_loss.py) for timesteps t."""
+    assert t.dtype == torch.int64 and alphas_cumprod.dtype == torch.float32 and t.is_contiguous()
+    w = torch.empty(t.shape[0], dtype=torch.float32, device=t.device)
+    _chk(lib().hcp_snr_loss_weight(_p(t), _p(alphas_cumprod), _p(w), t.shape[0], SNR_LOSS_KINDS[kind], float(gamma), _stream(t)),
+         "hcp_snr_loss_weight")
+    return w
+
+
+def mse_masked_mean(pred, target, mask=None, weight=1.0, want_grad=True, sample_weight=None):
+    """(mean((pred-target)^2 * mask * sample_weight[b]) * weight as a device scalar, d loss / d pred)."""
     assert pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.is_contiguous() and target.is_contiguous()
     B, C = pred.shape[0], pred.shape[1]
     HW = pred.numel() // (B * C)
@@ -432,7 +444,10 @@ def mse_masked_mean(pred, target, mask=None, weight=1.0, want_grad=True):
     if mask is not None:
         mask = mask.to(torch.float32).contiguous()
         mc = mask.shape[1]
-    _chk(lib().hcp_mse_masked_mean(_p(pred), _p(target), _p(mask), mc, _p(loss), _p(grad), B, C, HW, float(weight), _stream(pred)),
+    if sample_weight is not None:
+        assert sample_weight.dtype == torch.float32 and sample_weight.numel() == B and sample_weight.is_contiguous()
+    _chk(lib().hcp_mse_masked_mean(_p(pred), _p(target), _p(mask), mc, _p(sample_weight), _p(loss), _p(grad), B, C, HW, float(weight),
+                                   _stream(pred)),
          "hcp_mse_masked_mean")
     return loss, grad
 

@@ -44,13 +44,15 @@ class _OptState:
 class NativeTrainer:
     def __init__(self, unet, lora_cfg=None, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000,
-                 overlap_wgrad=False, grouped_wgrad=True, train_cfg=None, plugins=None, ema=None):
+                 overlap_wgrad=False, grouped_wgrad=True, train_cfg=None, plugins=None, ema=None, loss_cfg=None):
         """lora_cfg: the reference's ``lora_unet`` list ({layers, rank, alpha, lr, ...}); train_cfg: its ``unet`` list
         ({layers, lr}) of host modules to fine-tune in full (DreamBooth.yaml:6-10 uses ``layers: ['']`` = everything);
         plugins: [(plugin module, lr)] — trainable hook plugins such as controlnet.ControlNetHipPlugin (make_plugin,
         cfg_net_tools.py:148-162: all of the plugin's parameters form one param group); ema: None or the ModelEMA arguments
         {decay_max, inv_gamma, power} (``model.ema``, train_ac.py:238-242): an EMA copy of every trainable bucket, updated by
-        one kernel per bucket after the optimizer step (train_ac.py:503)."""
+        one kernel per bucket after the optimizer step (train_ac.py:503); loss_cfg: None = ``train.loss.criterion`` MSELoss
+        (train_base.yaml), or {type: 'min_snr'|'soft_min_snr'|'kdiff_min_snr'|'edm', gamma} = the reference's timestep-aware
+        criteria (hcpdiff/loss/min_snr_loss.py, selected through ``need_timesteps`` in train_ac.py:509-510)."""
         self.unet = unet
         self.device = next(unet.parameters()).device
         unet.requires_grad_(False)            # config_model(): freeze host, eval (train_ac.py:264-268)
@@ -87,6 +89,11 @@ class NativeTrainer:
             st.bucket.repack()
         self.weight_decay, self.betas, self.eps, self.max_grad_norm = weight_decay, betas, eps, max_grad_norm
         self.loss_weight = loss_weight
+        self.loss_kind, self.loss_gamma = None, 1.0
+        if loss_cfg is not None and loss_cfg.get("type", "mse") != "mse":
+            if loss_cfg["type"] not in K.SNR_LOSS_KINDS:
+                raise ValueError(f"Unknown loss criterion {loss_cfg['type']}")
+            self.loss_kind, self.loss_gamma = loss_cfg["type"], float(loss_cfg.get("gamma", 1.0))
         self.acp = ddpm_alphas_cumprod(num_train_timesteps, device=self.device)
         self.num_train_timesteps = num_train_timesteps
         self.pg = process_group
@@ -116,7 +123,8 @@ class NativeTrainer:
             pred = self.unet(noisy, t, encoder_hidden_states, added_cond_kwargs=added_cond_kwargs).sample
         else:
             pred = self.unet(noisy, t, encoder_hidden_states).sample      # wrapper.py:29
-        loss, grad = K.mse_masked_mean(pred.detach(), noise, mask, weight=self.loss_weight)    # loss.type == 'eps'
+        sw = K.snr_loss_weight(t, self.acp, self.loss_kind, self.loss_gamma) if self.loss_kind else None
+        loss, grad = K.mse_masked_mean(pred.detach(), noise, mask, weight=self.loss_weight, sample_weight=sw)    # loss.type == 'eps'
         ops.enable_wgrad_side_stream(self.overlap_wgrad)
         ops.enable_grouped_wgrad(self.grouped_wgrad)
         try:

@@ -134,9 +134,15 @@ int hcp_timestep_embedding_f32(const float* values, void* emb, int B, int dim, f
 /* DDPMScheduler.add_noise as called by train_ac.py:447 */
 int hcp_add_noise(const float* x0, const float* noise, const long long* timesteps, const float* alphas_cumprod, float* xt,
                   int B, long per_sample, hcpStream_t stream);
-/* (MSE(reduction none) * mask).mean() * weight and its gradient (train_ac.py:506-515) */
-int hcp_mse_masked_mean(const float* pred, const float* target, const float* mask, int mask_channels, float* loss,
-                        float* grad, int B, int C, int HW, float weight, hcpStream_t stream);
+/* per-sample loss weights of the reference's timestep-aware criteria (hcpdiff/loss/min_snr_loss.py): kind 0 MinSNRLoss :21-25,
+ * 1 SoftMinSNRLoss :31-35, 2 KDiffMinSNRLoss :39-43, 3 EDMLoss :47-52; snr = acp/(1-acp) as in :14-19.  w: float[B]. */
+int hcp_snr_loss_weight(const long long* timesteps, const float* alphas_cumprod, float* w, int B, int kind, float gamma,
+                        hcpStream_t stream);
+/* (criterion(pred, target[, timesteps]) * mask).mean() * weight and its gradient (train_ac.py:506-515); criterion = MSE
+ * (reduction none) times the optional per-sample weight sample_weight[B] (null: plain MSELoss) */
+int hcp_mse_masked_mean(const float* pred, const float* target, const float* mask, int mask_channels,
+                        const float* sample_weight, float* loss, float* grad, int B, int C, int HW, float weight,
+                        hcpStream_t stream);
 
 /* out[p,q] (+)= scale * sum_m L[m,p] R[m,q]  (fp32 atomics): the rank-r LoRA weight gradients
  * dW_down = alpha (dY W_up)^T x, dW_up = alpha dY^T (x W_down^T) (autograd of lora_base_patch.py:61-74). */

@@ -225,7 +225,36 @@ def sdxl_full_vectors():
                 fingerprint=grad_fingerprint([(n, p.grad) for n, p in lora_named]))
 
 
+def minsnr_reference_vectors():
+    """Outputs of the REFERENCE's MinSNRLoss / SoftMinSNRLoss / KDiffMinSNRLoss / EDMLoss (min_snr_loss.py) wrapped in
+    Trainer.get_loss's reduction (train_ac.py:506-515) on seeded inputs, SD beta schedule."""
+    from oracle.ref_shims import load_reference_loss
+    from oracle.loss_ref import KINDS, REFERENCE_CLASS
+    from oracle.unet_sd15 import ddpm_alphas_cumprod
+    ref = load_reference_loss()
+    g = torch.Generator().manual_seed(31)
+    pred = torch.randn(6, 4, 8, 8, generator=g); target = torch.randn(6, 4, 8, 8, generator=g)
+    mask = (torch.rand(6, 1, 8, 8, generator=g) > 0.25).float()
+    t = torch.tensor([0, 17, 250, 500, 871, 999], dtype=torch.int64)
+    sched = type("Sched", (), {"alphas_cumprod": ddpm_alphas_cumprod()})()
+    out = dict(pred=pred, target=target, mask=mask, timesteps=t, cases={})
+    for kind in KINDS:
+        for gamma in (1.0, 5.0):
+            crit = getattr(ref, REFERENCE_CLASS[kind])(gamma=gamma, noise_scheduler=sched, device="cpu")
+            assert crit.need_timesteps
+            pr = pred.clone().requires_grad_(True)
+            per = crit(pr.float(), target.float(), t)                        # train_ac.py:510
+            loss = (per * mask).mean()
+            loss.backward()
+            out["cases"][(kind, gamma)] = dict(loss=float(loss), grad=pr.grad.clone(), weight=(per.detach() / ((pred - target) ** 2))[:, 0, 0, 0].clone())
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "minsnr":
+        torch.save(minsnr_reference_vectors(), os.path.join(GOLD, "minsnr_reference.pt"))
+        print("minsnr_reference.pt", os.path.getsize(os.path.join(GOLD, "minsnr_reference.pt")))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sdxl":
         torch.save(sdxl_full_vectors(), os.path.join(GOLD, "sdxl_full_oracle.pt"))
         print("sdxl_full_oracle.pt", os.path.getsize(os.path.join(GOLD, "sdxl_full_oracle.pt")))

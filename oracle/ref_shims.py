@@ -57,3 +57,21 @@ def load_reference_lora():
     importlib.import_module("hcpdiff.models.lora_base_patch")
     layers = importlib.import_module("hcpdiff.models.lora_layers_patch")
     return layers, plugin
+
+
+def load_reference_loss():
+    """The reference's hcpdiff/loss/min_snr_loss.py, executed where it lies (its one third-party import,
+    ``from diffusers import SchedulerMixin``, is an annotation only -> an empty shim class)."""
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    import importlib.util
+    d = sys.modules.get("diffusers")
+    if d is None:
+        d = types.ModuleType("diffusers"); d.__path__ = []
+        sys.modules["diffusers"] = d
+    if not hasattr(d, "SchedulerMixin"):
+        d.SchedulerMixin = type("SchedulerMixin", (), {})
+    spec = importlib.util.spec_from_file_location("_hcp_ref_min_snr_loss", os.path.join(REFERENCE_ROOT, "hcpdiff", "loss", "min_snr_loss.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

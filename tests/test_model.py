@@ -68,12 +68,12 @@ def test_tiny_forward_with_encoder_attention_mask(backend):
     assert ((yo - yo_nomask).norm() / yo.norm()).item() > 5e-2          # the mask matters for this input
 
 
-def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42, pooled_dim=None):
+def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42, pooled_dim=None, loss_cfg=None):
     dev = backend.device
     ora, nat = _pair(cfg, dev)
     ora.requires_grad_(False)
     wr = wrap_lora(ora, PATS, rank=rank)
-    tr = NativeTrainer(nat, [dict(layers=PATS, rank=rank)], lr=1e-3)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=rank)], lr=1e-3, loss_cfg=loss_cfg)
     assert sorted(k for k in ora.state_dict() if "lora" in k) == sorted(k for k in nat.state_dict() if "lora" in k)
     gen = torch.Generator().manual_seed(5)
     with torch.no_grad():
@@ -90,7 +90,11 @@ def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42, poole
         added = dict(text_embeds=torch.randn(shape[0], pooled_dim, generator=g2),
                      time_ids=torch.tensor([[shape[2] * 8.0, shape[3] * 8.0, 0.0, 16.0, shape[2] * 8.0, shape[3] * 8.0]] * shape[0]))
     pred = ora(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ehs, added_cond_kwargs=added).sample
-    loss_o = F.mse_loss(pred, noise)
+    if loss_cfg:
+        from oracle.loss_ref import get_loss
+        loss_o = get_loss(pred, noise, None, kind=loss_cfg["type"], timesteps=t, alphas_cumprod=ddpm_alphas_cumprod(), gamma=loss_cfg["gamma"])
+    else:
+        loss_o = F.mse_loss(pred, noise)
     loss_o.backward()
     tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
     loss_n = tr.forward_backward(x0.to(dev), ehs.to(dev), None, {k: v.to(dev) for k, v in added.items()} if added else None)
@@ -113,6 +117,16 @@ def test_tiny_lora_train_step_vs_oracle(backend):
     po = torch.cat([p.detach().flatten() for p in params])
     assert ((po - tr.bucket.params.cpu()).abs().max() / po.abs().max()).item() < 1e-5
     assert tr.bucket.grads.abs().max().item() == 0.0
+
+
+def test_tiny_lora_train_step_min_snr_loss(backend):
+    """train.loss.criterion = MinSNRLoss(gamma=5) (hcpdiff/loss/min_snr_loss.py): loss and LoRA gradients vs the oracle UNet
+    under oracle/loss_ref.get_loss (itself pinned to the reference classes); the weights differ from 1 for this batch."""
+    lo, ln, go, tr, _ = _train_step_pair(MICRO_CONFIG, backend, 4, (2, 4, 8, 8), 77, 32, loss_cfg=dict(type="min_snr", gamma=5.0))
+    assert abs(lo - ln) / abs(lo) < 2e-2
+    assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.995
+    with pytest.raises(ValueError):
+        NativeTrainer(tr.unet, None, train_cfg=[dict(layers=[""])], loss_cfg=dict(type="huber"))
 
 
 def test_sdxl_structure_matches_public_config():

@@ -121,3 +121,29 @@ def test_golden_is_reproducible_from_reference():
         for k in ("y", "dx", "dW_down", "dW_up"):
             assert torch.equal(new[tag][k], old[tag][k])
     assert parse_unet_struct("/root/reference/cfgs/unet_struct.txt") == json.load(open(os.path.join(GOLD, "sd15_struct.json")))["shapes"]
+
+
+@pytest.mark.parametrize("kind", ["min_snr", "soft_min_snr", "kdiff_min_snr", "edm"])
+def test_snr_loss_restatement_matches_reference_code(kind):
+    """oracle/loss_ref.py == the reference's MinSNRLoss family (hcpdiff/loss/min_snr_loss.py, run unmodified by
+    oracle/make_golden.py minsnr) under Trainer.get_loss's reduction: loss, d loss / d pred and the per-sample weights."""
+    from oracle.loss_ref import get_loss, snr_weight
+    from oracle.unet_sd15 import ddpm_alphas_cumprod
+    g = torch.load(os.path.join(GOLD, "minsnr_reference.pt"))
+    acp = ddpm_alphas_cumprod()
+    for gamma in (1.0, 5.0):
+        case = g["cases"][(kind, gamma)]
+        pr = g["pred"].clone().requires_grad_(True)
+        loss = get_loss(pr, g["target"], g["mask"], kind=kind, timesteps=g["timesteps"], alphas_cumprod=acp, gamma=gamma)
+        loss.backward()
+        assert abs(float(loss) - case["loss"]) <= 1e-6 * abs(case["loss"])
+        assert torch.allclose(pr.grad, case["grad"], rtol=1e-5, atol=1e-9)
+        assert torch.allclose(snr_weight(kind, g["timesteps"], acp, gamma), case["weight"], rtol=1e-4)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+def test_minsnr_golden_is_reproducible_from_reference():
+    from oracle.make_golden import minsnr_reference_vectors
+    new, old = minsnr_reference_vectors(), torch.load(os.path.join(GOLD, "minsnr_reference.pt"))
+    for k, case in old["cases"].items():
+        assert new["cases"][k]["loss"] == case["loss"] and torch.equal(new["cases"][k]["grad"], case["grad"])
