@@ -179,6 +179,20 @@ class NativeTrainer:
                 out[name] = st.ema[off:off + p.numel()].as_strided(p.shape, p.stride())
         return out
 
+    def save_model(self, ckpt_manager, step, name="unet"):
+        """Trainer.save_model for the UNet half (train_ac.py:523-528): ``{name}-{step}`` with base / lora (+ _ema) sections and one
+        ``{name}-{plugin}-{step}`` file per plugin, through a ckpt.CkptManagerNative (or the reference's own manager)."""
+        from .ckpt import _EMAView
+        from .patch_api import PluginGroup
+        ema = _EMAView(self.ema_state_dict(), self.unet) if self.ema_cfg else None
+        paths = [ckpt_manager.save_model_with_lora(self.unet, self.lora_group, name=name, step=step, model_ema=ema)]
+        for plugin in self.plugins:
+            pema = None
+            if ema is not None:             # EMA names of a plugin bucket are relative to the plugin; a whole-model plugin's
+                pema = _EMAView({f".{plugin.name}.{k}": v for k, v in ema.state_dict().items()}, torch.nn.Module())   # block path is ''
+            paths += ckpt_manager.save_plugins(self.unet, {plugin.name: PluginGroup({"": plugin})}, name=name, step=step, model_ema=pema)
+        return paths
+
     def set_lr(self, lr):
         for st in self._states():
             st.lr.fill_(lr)

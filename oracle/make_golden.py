@@ -225,6 +225,45 @@ def sdxl_full_vectors():
                 fingerprint=grad_fingerprint([(n, p.grad) for n, p in lora_named]))
 
 
+class _Item(dict):
+    """The reference reads cfg items both as mappings and as attribute bags (OmegaConf DictConfig)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+
+def ref_lora_ckpt_fixture(out_dir):
+    """A LoRA checkpoint WRITTEN BY THE REFERENCE: its LoraLayer (lora_layers_patch.py) wrapped around the MICRO oracle UNet
+    by the make_hcpdiff loop (cfg_net_tools.py:108-123), saved by CkptManagerSafe.save_model_with_lora (ckpt_pkl.py:56-72,
+    ckpt_safetensor.py:20-27) -> tests/golden/ref_lora_unet-7.safetensors, and the prediction of that model (the reference's
+    LoraPatchContainer forward) on seeded inputs -> tests/golden/ref_lora_ckpt_expect.pt."""
+    from oracle.ref_shims import load_reference_ckpt
+    from oracle.unet_sd15 import MICRO_CONFIG, OracleUNet2DConditionModel, seeded_init_
+    CkptManagerSafe, tools = load_reference_ckpt()
+    m = seeded_init_(OracleUNet2DConditionModel(**MICRO_CONFIG), 1)
+    m.requires_grad_(False)
+    cfg = [_Item(layers=[r"re:.*\.attn.?$", r"re:.*\.ff$"], rank=4, alpha=2.0), _Item(layers=[r"re:.*\.resnets\.0\.conv1$"], rank=8, alpha=2.0)]
+    _, group = tools.make_hcpdiff(m, None, cfg)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for blk in group.plugin_dict.values():
+            blk.layer.W_up.copy_(torch.randn(blk.layer.W_up.shape, generator=g) * 0.05)
+    mgr = CkptManagerSafe()
+    mgr.set_save_dir(out_dir)
+    mgr.save_model_with_lora(m, group, name="ref_lora_unet", step=7)
+    x = torch.randn(2, 4, 8, 8, generator=g); ehs = torch.randn(2, 77, MICRO_CONFIG["cross_attention_dim"], generator=g)
+    t = torch.tensor([30, 700])
+    with torch.no_grad():
+        pred = m(x, t, ehs).sample
+    keys = sorted(group.state_dict().keys())
+    torch.save(dict(x=x, ehs=ehs, t=t, pred=pred, keys=keys, cfg=[dict(c) for c in cfg], host_seed=1),
+               os.path.join(out_dir, "ref_lora_ckpt_expect.pt"))
+    return keys
+
+
 def minsnr_reference_vectors():
     """Outputs of the REFERENCE's MinSNRLoss / SoftMinSNRLoss / KDiffMinSNRLoss / EDMLoss (min_snr_loss.py) wrapped in
     Trainer.get_loss's reduction (train_ac.py:506-515) on seeded inputs, SD beta schedule."""
@@ -251,6 +290,10 @@ def minsnr_reference_vectors():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ckpt":
+        ks = ref_lora_ckpt_fixture(GOLD)
+        print(len(ks), "lora tensors;", os.path.getsize(os.path.join(GOLD, "ref_lora_unet-7.safetensors")), "bytes")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "minsnr":
         torch.save(minsnr_reference_vectors(), os.path.join(GOLD, "minsnr_reference.pt"))
         print("minsnr_reference.pt", os.path.getsize(os.path.join(GOLD, "minsnr_reference.pt")))

@@ -75,3 +75,25 @@ def load_reference_loss():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_reference_ckpt():
+    """(CkptManagerSafe class, cfg_net_tools module) of the reference, executed from REFERENCE_ROOT: the checkpoint writer
+    (ckpt_manager/ckpt_safetensor.py, ckpt_pkl.py) and the loader (utils/cfg_net_tools.py HCPModelLoader).  Extra shims:
+    ``diffusers.StableDiffusionPipeline`` / ``diffusers.models.lora.LoRACompatibleLinear`` (annotations in
+    ckpt_manager/base.py:1-2) and the names hcpdiff/models/__init__.py would have re-exported."""
+    layers, plugin = load_reference_lora()
+    d = sys.modules["diffusers"]
+    if not hasattr(d, "StableDiffusionPipeline"):
+        d.StableDiffusionPipeline = type("StableDiffusionPipeline", (), {})
+        dm = types.ModuleType("diffusers.models"); dm.__path__ = []
+        dml = types.ModuleType("diffusers.models.lora")
+        dml.LoRACompatibleLinear = type("LoRACompatibleLinear", (), {})
+        sys.modules["diffusers.models"] = dm; sys.modules["diffusers.models.lora"] = dml
+    models = sys.modules["hcpdiff.models"]
+    patch = sys.modules["hcpdiff.models.lora_base_patch"]
+    models.LoraBlock, models.LoraGroup, models.lora_layer_map = patch.LoraBlock, patch.LoraGroup, layers.lora_layer_map
+    _stub_pkg("hcpdiff.tools", os.path.join(REFERENCE_ROOT, "hcpdiff", "tools"))
+    ckpt = importlib.import_module("hcpdiff.ckpt_manager")          # its real 4-line __init__ runs
+    tools = importlib.import_module("hcpdiff.utils.cfg_net_tools")
+    return ckpt.CkptManagerSafe, tools
