@@ -246,6 +246,7 @@ def ref_lora_ckpt_fixture(out_dir):
     m = seeded_init_(OracleUNet2DConditionModel(**MICRO_CONFIG), 1)
     m.requires_grad_(False)
     cfg = [_Item(layers=[r"re:.*\.attn.?$", r"re:.*\.ff$"], rank=4, alpha=2.0), _Item(layers=[r"re:.*\.resnets\.0\.conv1$"], rank=8, alpha=2.0)]
+    torch.manual_seed(123)                      # W_down: the reference's kaiming_uniform_ draws from the global generator
     _, group = tools.make_hcpdiff(m, None, cfg)
     g = torch.Generator().manual_seed(9)
     with torch.no_grad():
