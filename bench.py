@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="LoRA wgrad kernels on a side stream (measured slower)")
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="one wgrad launch per layer instead of one grouped launch")
+    ap.add_argument("--gn-target", type=int, default=None, help="A/B only: hcp_debug_set_gn_target (workgroups a GroupNorm launch aims for)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +118,9 @@ def main():
 
     from hcp_diffusion_amd.trainer import NativeTrainer
     from hcp_diffusion_amd.unet import SDXL_CONFIG, NativeUNet2DConditionModel
+    if args.gn_target is not None:
+        from hcp_diffusion_amd import kernels as _K
+        assert _K.lib().hcp_debug_set_gn_target(args.gn_target) == 0
 
     sdxl = args.workload == "sdxl"
     fullft = args.workload == "dreambooth"

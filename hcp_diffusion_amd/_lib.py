@@ -25,6 +25,7 @@ _PROTOTYPES = {
     "hcp_gemm_workspace_bytes": (c_size_t, [I, I]),
     "hcp_debug_set_gemm_config": (I, [I]),
     "hcp_debug_set_gemm_glds": (I, [I]),
+    "hcp_debug_set_gn_target": (I, [I]),
     "hcp_debug_set_gemm_ablation": (I, [I]),
     # X1, C1, X2, C2, B, Hs, Ws, Ho, Wo, mode, stride, upsample, Wp, Cout, D, ldd, bias, rowbias, rowbias_ld,
     # residual, ldr, out_f32, workspace, workspace_bytes, stream

@@ -11,14 +11,19 @@ namespace {
 
 struct GNGeom { int TX, R, threads, nchunk, rows_per_chunk; };
 
-// Thread (cx, ry) owns channels [8cx, 8cx+8) and rows ry, ry+R, ...; a chunk is 4R rows, so every thread has 4
-// independent 16-byte loads in flight and the grid has HW/(4R) x B workgroups (hundreds to thousands).
-GNGeom gn_geom(int HW, int C) {
+// Thread (cx, ry) owns channels [8cx, 8cx+8) and rows ry, ry+R, ...; a chunk is >= 4R rows (every thread has >= 4 independent
+// 16-byte loads in flight) and is sized so that the launch has about g_gn_target_wgs workgroups (2 per CU): enough to fill the
+// chip, few enough that the per-sample partial table every apply workgroup merges stays ~100 entries per group.
+int g_gn_target_wgs = 512;
+GNGeom gn_geom(int B, int HW, int C) {
     GNGeom g;
     g.TX = C / 8;
     g.R = 256 / g.TX; if (g.R < 1) g.R = 1;
     g.threads = g.TX * g.R;
-    g.rows_per_chunk = (HW >= 2048 ? 8 : 4) * g.R;       // big maps: half as many partials to merge, grid still >= 300 workgroups
+    long rows = ((long)HW * B + g_gn_target_wgs - 1) / g_gn_target_wgs;
+    rows = (rows + g.R - 1) / g.R * g.R;
+    if (rows < 4 * g.R) rows = 4 * g.R;
+    g.rows_per_chunk = (int)rows;
     g.nchunk = (HW + g.rows_per_chunk - 1) / g.rows_per_chunk;
     return g;
 }
@@ -71,50 +76,57 @@ HCP_KERNEL(1024) gn_fwd_partial(const hcp_bf16* x, float* ws, int HW, int C, int
 }
 
 // In-block merge of one sample's chunk partials (ws_b = [nchunk][G][2]) into s_out [G][2].  Thread (j, g) = (tid / G, tid % G)
-// walks chunks j, j+J, ... (coalesced float2 loads, four in flight), the J per-group results meet in LDS and the first G
-// threads combine them.  mode 0: Chan merge of (mean, M2) -> (mean, rstd); mode 1: sums -> (S1/n, S2/n).
+// takes chunks j, j+J, ... (coalesced float2 loads, eight in flight); everything it accumulates is a PLAIN SUM, so there is no
+// dependent chain of divisions (the first version Chan-merged sequentially: ~100 cycles per chunk per thread, which made every
+// apply workgroup spend longer merging than streaming its rows).  The J per-group partial sums meet in LDS.
+//   mode 0: (mean_c, M2_c) -> (mean, rstd).  With K = mean of chunk 0 as a shift and n_c the chunk's element count:
+//           S1 = sum n_c (mean_c - K), S2 = sum n_c (mean_c - K)^2, SM = sum M2_c;
+//           mean = K + S1/N, M2 = SM + S2 - S1^2/N   (the shifted form of Chan's pairwise formula: exact up to rounding, and
+//           the subtraction only cancels the small between-chunk term because K is already within a chunk's spread of the mean)
+//   mode 1: sums -> (S1/n, S2/n).
 // Every apply workgroup does this itself (L2-resident partials) instead of a separate finalize launch.
 HCP_DEVICE void gn_merge(const float* ws_b, float* s_out, int G, int nchunk, int rows_per_chunk, int HW, int Cg, float eps,
                          int mode, int tid, int nthreads) {
     float* s_tmp = s_out + 2 * G;                                // [J][G][3]
     const int J = nthreads / G;
     const int g = tid % G, j = tid / G;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
     if (j < J) {
-        for (int c0 = j; c0 < nchunk; c0 += 4 * J) {
-            float a[4], bq[4];
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        const float K = mode == 0 ? ws_b[g * 2] : 0.f;
+        for (int c0 = j; c0 < nchunk; c0 += 8 * J) {
+            float a[8], bq[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int c = c0 + u * J;
                 const float* o = ws_b + ((size_t)(c < nchunk ? c : 0) * G + g) * 2;
                 a[u] = o[0]; bq[u] = o[1];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int c = c0 + u * J;
                 if (c >= nchunk) continue;
                 if (mode == 0) {
                     int r0 = c * rows_per_chunk; int r1 = r0 + rows_per_chunk; if (r1 > HW) r1 = HW;
-                    float nb = (float)(r1 - r0) * Cg, nn = n + nb, d = a[u] - mean;
-                    mean += d * nb / nn; m2 += bq[u] + d * d * n * nb / nn; n = nn;
-                } else { mean += a[u]; m2 += bq[u]; }
+                    const float nb = (float)(r1 - r0) * Cg, d = a[u] - K;
+                    t0 += nb * d; t1 += nb * d * d; t2 += bq[u];
+                } else { t0 += a[u]; t1 += bq[u]; }
             }
         }
         float* t = s_tmp + ((size_t)j * G + g) * 3;
-        t[0] = n; t[1] = mean; t[2] = m2;
+        t[0] = t0; t[1] = t1; t[2] = t2;
     }
     HCP_SYNC();
     if (tid < G) {
-        n = 0.f; mean = 0.f; m2 = 0.f;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
         for (int jj = 0; jj < J; ++jj) {
             const float* t = s_tmp + ((size_t)jj * G + tid) * 3;
-            if (mode == 0) {
-                float n2 = t[0], nn = n + n2;
-                if (nn > 0.f) { float d = t[1] - mean; mean += d * n2 / nn; m2 += t[2] + d * d * n * n2 / nn; n = nn; }
-            } else { mean += t[1]; m2 += t[2]; }
+            t0 += t[0]; t1 += t[1]; t2 += t[2];
         }
-        if (mode == 0) { s_out[tid * 2] = mean; s_out[tid * 2 + 1] = 1.0f / sqrtf(m2 / n + eps); }
-        else { float cnt = (float)HW * Cg; s_out[tid * 2] = mean / cnt; s_out[tid * 2 + 1] = m2 / cnt; }
+        const float cnt = (float)HW * Cg;
+        if (mode == 0) {
+            float m2 = t2 + t1 - t0 * t0 / cnt; if (m2 < 0.f) m2 = 0.f;
+            s_out[tid * 2] = ws_b[tid * 2] + t0 / cnt; s_out[tid * 2 + 1] = 1.0f / sqrtf(m2 / cnt + eps);
+        } else { s_out[tid * 2] = t0 / cnt; s_out[tid * 2 + 1] = t1 / cnt; }
     }
     HCP_SYNC();
 }
@@ -383,26 +395,33 @@ int affine_grad_blocks(int rows, int col_tiles, int groups, int* rows_per_block)
 int gn_check(int B, int HW, int C, int G) {
     HCP_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0, "groupnorm: empty problem");
     HCP_REQUIRE(C % 8 == 0 && C % G == 0 && C <= 8192 && G <= 32, "groupnorm: C=%d G=%d unsupported", C, G);
-    HCP_REQUIRE(gn_geom(HW, C).threads >= 4 * G, "groupnorm: C=%d too small for G=%d", C, G);
+    HCP_REQUIRE(gn_geom(1, HW, C).threads >= 4 * G, "groupnorm: C=%d too small for G=%d", C, G);
     return 0;
 }
 
 }  // namespace
 
+// TOOLS ONLY (tools/bench_norm.py): workgroups a GroupNorm launch aims for (default 512).  Changes the workspace size.
+HCP_API int hcp_debug_set_gn_target(int workgroups) {
+    HCP_REQUIRE(workgroups >= 1 && workgroups <= 65536, "hcp_debug_set_gn_target: bad arguments");
+    g_gn_target_wgs = workgroups;
+    return 0;
+}
+
 // Workspace (bytes) both GroupNorm entry points need: [B][nchunk][G][2] fp32 partials + [B][G][2] merged sums.
 HCP_API size_t hcp_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
     if (B <= 0 || HW <= 0 || C <= 0 || C % 8) return 0;
-    GNGeom g = gn_geom(HW, C);
+    GNGeom g = gn_geom(B, HW, C);
     return ((size_t)B * g.nchunk * G * 2 + (size_t)B * G * 2) * sizeof(float);
 }
 
 // y = [silu](group_norm(x; gamma, beta, eps)); stats[B,G,2] = (mean, rstd) saved for backward.
-// Two launches: per-chunk (mean, M2) partials -> apply (every workgroup Chan-merges its sample's partials itself).
+// Two launches: per-chunk (mean, M2) partials -> apply (every workgroup merges its sample's partials itself).
 HCP_API int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                    void* workspace, int B, int HW, int C, int G, float eps, int silu, hipStream_t stream) {
     if (int e = gn_check(B, HW, C, G)) return e;
     HCP_REQUIRE(x && gamma && beta && y && stats && workspace, "hcp_groupnorm_silu_fwd: null pointer");
-    GNGeom g = gn_geom(HW, C);
+    GNGeom g = gn_geom(B, HW, C);
     size_t sm1 = (size_t)2 * g.R * C * sizeof(float);
     HCP_LAUNCH(gn_fwd_partial, dim3(g.nchunk, B), dim3(g.threads), sm1, stream, (const hcp_bf16*)x, (float*)workspace, HW, C,
                G, g.TX, g.R, g.rows_per_chunk);
@@ -418,7 +437,7 @@ HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* g
                                    int G, int silu, hipStream_t stream) {
     if (int e = gn_check(B, HW, C, G)) return e;
     HCP_REQUIRE(x && dy && gamma && beta && stats && dx && workspace, "hcp_groupnorm_silu_bwd: null pointer");
-    GNGeom g = gn_geom(HW, C);
+    GNGeom g = gn_geom(B, HW, C);
     size_t sm1 = (size_t)2 * g.R * C * sizeof(float);
     HCP_LAUNCH(gn_bwd_partial, dim3(g.nchunk, B), dim3(g.threads), sm1, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy,
                gamma, beta, stats, (float*)workspace, HW, C, G, g.TX, g.R, g.rows_per_chunk, silu);

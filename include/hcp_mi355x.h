@@ -46,6 +46,7 @@ size_t hcp_gemm_workspace_bytes(int M, int N);
 int hcp_debug_gemm_table_stats(long* hits, long* misses); /* tools only: dispatch-table lookups since the last call; resets */
 int hcp_debug_set_gemm_config(int cfg); /* tools/tune_gemm.py only: force tile id + 16*nsplit, -1 = heuristic */
 int hcp_debug_set_gemm_ablation(int flags); /* tools only (wrong results when != 0): 1 no DMA, 2 no MFMA, 4 no LDS reads */
+int hcp_debug_set_gn_target(int workgroups);   /* tools only: workgroups a GroupNorm launch aims for (default 512) */
 int hcp_debug_set_gemm_glds(int on);    /* tools only: 1 = default (v2 main loop where eligible), 0/2 = first LDS-DMA loop everywhere */
 
 /* 3x3 / pad 1 convolution over NHWC bf16 as an implicit GEMM.  mode 0: forward, Wp = [Cout][3][3][C1+C2];

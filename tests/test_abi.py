@@ -73,6 +73,7 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
         "hcp_timestep_embedding": (N, N, 0, 3, 1e4, N),
         "hcp_add_noise": (N, N, N, N, N, 0, 0, N),
         "hcp_snr_loss_weight": (N, N, N, 0, 0, 5.0, N),
+        "hcp_debug_set_gn_target": (0,),
         "hcp_mse_masked_mean": (N, N, N, 1, N, N, N, 0, 0, 0, 1.0, N),
         "hcp_copy2d_bf16": (N, 8, N, 8, 0, 7, N),
     }

@@ -234,6 +234,28 @@ def test_groupnorm_silu(backend, case):
     assert relerr(dx2.permute(0, 3, 1, 2), xr.grad + skip.float()) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,W,C", [(1, 10, 10, 320), (2, 12, 14, 1280), (4, 64, 64, 320), (2, 128, 128, 320), (4, 32, 32, 1920)])
+def test_groupnorm_statistics_many_chunks_large_mean(backend, B, H, W, C):
+    """The per-sample merge of chunk partials (shifted-sum form of Chan's formula, csrc/norm.hip gn_merge): ragged last chunk,
+    more chunks than one merge round (12x14 @ C=1280: 42 chunks, 5 merge threads per group), |mean| >> std (offsets up to 60
+    standard deviations, different per group).  (mean, rstd) vs an fp64 reference to 2e-4 relative."""
+    if not backend.is_gpu and H * W > 200:
+        pytest.skip("large shape: GPU only")
+    torch.manual_seed(C + H)
+    off = (torch.arange(32).float() - 10.0).repeat_interleave(C // 32) * 3.0          # group g sits at 3 (g - 10)
+    x = (torch.randn(B, C, H, W) * 0.5 + off.view(1, C, 1, 1)).to(BF)
+    gamma, beta = torch.ones(C), torch.zeros(C)
+    y, stats = K.groupnorm_fwd(backend.to(nhwc(x)), backend.to(gamma), backend.to(beta), 32, 1e-5, False)
+    xd = x.double().view(B, 32, -1)
+    mean, var = xd.mean(-1), xd.var(-1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    st = stats.double().cpu()
+    assert ((st[..., 0] - mean).abs() / (mean.abs() + 1)).max().item() < 2e-4
+    assert ((st[..., 1] - rstd).abs() / rstd).max().item() < 2e-4
+    yr = ((xd - mean[..., None]) * rstd[..., None]).view(B, C, H, W).float()
+    assert relerr(y.permute(0, 3, 1, 2), yr) < 1e-2
+
+
 @pytest.mark.parametrize("M,C", [(10, 320), (7, 640), (5, 1280), (16384, 320), (1024, 1280)])
 def test_layernorm(backend, M, C):
     if not backend.is_gpu and M > 100:
