@@ -29,7 +29,7 @@ _PROTOTYPES = {
     "hcp_debug_set_gemm_ablation": (I, [I]),
     # X1, C1, X2, C2, B, Hs, Ws, Ho, Wo, mode, stride, upsample, Wp, Cout, D, ldd, bias, rowbias, rowbias_ld,
     # residual, ldr, out_f32, workspace, workspace_bytes, stream
-    "hcp_conv3x3_bf16": (I, [P, I, P, I, I, I, I, I, I, I, I, I, P, I, P, I, P, P, I, P, I, I, P, P, P, c_size_t, P]),
+    "hcp_conv3x3_bf16": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, P, I, P, I, P, P, I, P, I, I, P, P, P, c_size_t, P]),
     # Q, K, V, O, lse, B, H, Nq, Nk, D, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale, stream
     "hcp_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P, L, P]),
     # Q, K, V, O, dO, lse, delta, dQ, dK, dV, B, H, Nq, Nk, D, strides..., scale, workspace, workspace_bytes, stream
@@ -73,6 +73,9 @@ _PROTOTYPES = {
     "hcp_layernorm_affine_grad": (I, [P, P, P, P, P, I, I, P]),
     "hcp_add_noise": (I, [P, P, P, P, P, I, L, P]),
     "hcp_snr_loss_weight": (I, [P, P, P, I, I, F, P]),
+    "hcp_transpose_bf16": (I, [P, P, I, I, I, P]),
+    "hcp_softmax_rows": (I, [P, L, P, L, I, I, F, P]),
+    "hcp_vae_latent_sample": (I, [P, P, P, P, P, I, I, L, F, P]),
     "hcp_mse_masked_mean": (I, [P, P, P, I, P, P, P, I, I, I, F, P]),
     # L, ldl, R, ldr, out, ldo, M, P, Q, scale, transpose_out, stream
     "hcp_lora_wgrad": (I, [P, I, P, I, P, I, I, I, I, F, I, P]),

@@ -31,6 +31,7 @@ struct ConvDesc {
     int Ho, Wo;                   // output spatial dims (rows of the implicit A matrix)
     int stride;                   // 1 or 2
     int up;                       // 1: source is nearest-upsampled 2x before the conv (fwd only)
+    int pad;                      // 1: taps -1..+1 (padding 1); 0: taps 0..+2 (F.pad(0,1,0,1) + padding 0: the VAE encoder's Downsample2D), fwd only
 };
 
 struct GemmParams {
@@ -141,8 +142,8 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
-                            int sy = MODE == 1 ? py * s + ky - 1 : py + 1 - ky;
-                            int sx = MODE == 1 ? px * s + kx - 1 : px + 1 - kx;
+                            int sy = MODE == 1 ? py * s + ky - p.cv.pad : py + 1 - ky;
+                            int sx = MODE == 1 ? px * s + kx - p.cv.pad : px + 1 - kx;
                             if (sy >= 0 && sy < p.cv.Hs && sx >= 0 && sx < p.cv.Ws) msk |= 1 << (ky * 3 + kx);
                         }
                     a_msk[i] = msk;
@@ -195,7 +196,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
             const int k0 = kt * BK;
             const int tap = k0 / Ctot; const int cb = k0 - tap * Ctot;
             const int ky = tap / 3, kx = tap - ky * 3;
-            const int doff = MODE == 1 ? (ky - 1) * p.cv.Ws + (kx - 1) : (1 - ky) * p.cv.Ws + (1 - kx);
+            const int doff = MODE == 1 ? (ky - p.cv.pad) * p.cv.Ws + (kx - p.cv.pad) : (1 - ky) * p.cv.Ws + (1 - kx);
             const hcp_bf16* srcb; int cs, cbase;
             if (cb < p.cv.C1) { srcb = p.cv.X1; cs = p.cv.C1; cbase = cb; }
             else { srcb = p.cv.X2; cs = p.cv.C2; cbase = cb - p.cv.C1; }
@@ -225,7 +226,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
                         int b = pix >> 20, py = (pix >> 10) & 1023, px = pix & 1023;
                         int sy, sx; bool ok;
                         if (MODE == 1) {
-                            sy = py * p.cv.stride + ky - 1; sx = px * p.cv.stride + kx - 1;
+                            sy = py * p.cv.stride + ky - p.cv.pad; sx = px * p.cv.stride + kx - p.cv.pad;
                             int He = p.cv.Hs << p.cv.up, We = p.cv.Ws << p.cv.up;
                             ok = sy >= 0 && sy < He && sx >= 0 && sx < We;
                             sy >>= p.cv.up; sx >>= p.cv.up;
@@ -441,8 +442,8 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int sy = MODE == 1 ? py * s + ky - 1 : py + 1 - ky;
-                        const int sx = MODE == 1 ? px * s + kx - 1 : px + 1 - kx;
+                        const int sy = MODE == 1 ? py * s + ky - p.cv.pad : py + 1 - ky;
+                        const int sx = MODE == 1 ? px * s + kx - p.cv.pad : px + 1 - kx;
                         if (sy >= 0 && sy < p.cv.Hs && sx >= 0 && sx < p.cv.Ws) msk |= 1 << (ky * 3 + kx);
                     }
                 a_msk[i] = msk;
@@ -478,7 +479,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
                 if ((i + 1) * RPP <= BM || wave * 8 + RPP * i < BM) hcp_buf_glds16(ra, va[i], la + (wave * 8 + RPP * i) * BK);
         } else {
             const int ky = tap / 3, kx = tap - ky * 3;
-            const int doff = MODE == 1 ? (ky - 1) * p.cv.Ws + (kx - 1) : (1 - ky) * p.cv.Ws + (1 - kx);
+            const int doff = MODE == 1 ? (ky - p.cv.pad) * p.cv.Ws + (kx - p.cv.pad) : (1 - ky) * p.cv.Ws + (1 - kx);
             const bool first = cb < p.cv.C1;
             const hcp_bf16* base = first ? p.cv.X1 + (long)doff * p.cv.C1 + cb : p.cv.X2 + (long)doff * p.cv.C2 + (cb - p.cv.C1);
             const hcp_rsrc ra = hcp_make_rsrc(base);
@@ -866,7 +867,7 @@ HCP_API int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* 
 // (diffusers ResnetBlock2D.conv1/conv2, Downsample2D.conv (stride 2), Upsample2D = nearest-2x + conv,
 //  skip-concat inputs of the up blocks; structure: reference cfgs/unet_struct.txt:92-114,390-393.)
 HCP_API int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int Bn, int Hs, int Ws, int Ho, int Wo,
-                             int mode, int stride, int upsample, const void* Wp, int Cout, void* D, int ldd,
+                             int mode, int stride, int upsample, int pad, const void* Wp, int Cout, void* D, int ldd,
                              const float* bias, const float* rowbias, int rowbias_ld, const void* residual, int ldr,
                              int out_f32, const void* A2, const void* B2, void* workspace, size_t workspace_bytes,
                              hipStream_t stream) {
@@ -877,10 +878,11 @@ HCP_API int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int
     HCP_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && (C2 == 0 || X2), "hcp_conv3x3_bf16: channels must be multiples of 8");
     HCP_REQUIRE(stride == 1 || stride == 2, "hcp_conv3x3_bf16: stride must be 1 or 2");
     HCP_REQUIRE(mode == 0 || (mode == 1 && upsample == 0 && C2 == 0), "hcp_conv3x3_bf16: bad mode/options");
+    HCP_REQUIRE(pad == 1 || (pad == 0 && mode == 0 && !upsample), "hcp_conv3x3_bf16: pad must be 1 (or 0 for a forward conv without upsampling)");
     HCP_REQUIRE(Ho < 1024 && Wo < 1024 && Bn < 2048, "hcp_conv3x3_bf16: dims too large for packed pixel ids");
     HCP_REQUIRE((long)Bn * Hs * Ws * (C1 > C2 ? C1 : C2) < (1L << 31), "hcp_conv3x3_bf16: source tensor too large for 32-bit offsets");
     p.cv.X1 = (const hcp_bf16*)X1; p.cv.C1 = C1; p.cv.X2 = (const hcp_bf16*)X2; p.cv.C2 = C2;
-    p.cv.Hs = Hs; p.cv.Ws = Ws; p.cv.Ho = Ho; p.cv.Wo = Wo; p.cv.stride = stride; p.cv.up = upsample ? 1 : 0;
+    p.cv.Hs = Hs; p.cv.Ws = Ws; p.cv.Ho = Ho; p.cv.Wo = Wo; p.cv.stride = stride; p.cv.up = upsample ? 1 : 0; p.cv.pad = pad;
     p.M = Bn * Ho * Wo; p.N = Cout; p.K = 9 * (C1 + C2);
     p.B = (const hcp_bf16*)Wp; p.ldb = p.K;
     p.D = D; p.ldd = ldd; p.out_f32 = out_f32; p.bias = bias;

@@ -207,6 +207,67 @@ HCP_KERNEL(256) copy2d_kernel(const hcp_bf16* src, int sld, hcp_bf16* dst, int d
     }
 }
 
+// dst[b][c][r] = src[b][r][c]  (bf16, per-sample 2-D transpose through a 64x64 LDS tile, padded against bank conflicts)
+HCP_KERNEL(256) transpose_kernel(const hcp_bf16* src, hcp_bf16* dst, int R, int C) {
+    HCP_DYN_SMEM(smem);
+    hcp_bf16* tile = (hcp_bf16*)smem;                 // [64][66]
+    const int b = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const hcp_bf16* s = src + (size_t)b * R * C;
+    hcp_bf16* d = dst + (size_t)b * R * C;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        if (r0 + i < R && c0 + tx < C) tile[i * 66 + tx] = s[(size_t)(r0 + i) * C + c0 + tx];
+    HCP_SYNC();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < C && r0 + tx < R) d[(size_t)(c0 + i) * R + r0 + tx] = tile[tx * 66 + i];
+}
+
+// p[m, :N] = softmax(scale * s[m, :N])  (fp32 scores in, bf16 probabilities out; one workgroup per row, three passes over an
+// L2-resident row).  The single-head d=512 attention of the VAE encoder's mid block runs as GEMM -> this -> GEMM.
+HCP_KERNEL(256) softmax_rows_kernel(const float* s, long lds_, hcp_bf16* p, long ldp, int N, float scale) {
+    HCP_DYN_SMEM(smem);
+    float* red = (float*)smem;                         // [4]
+    const float* row = s + (size_t)blockIdx.x * lds_;
+    hcp_bf16* out = p + (size_t)blockIdx.x * ldp;
+    const int tid = threadIdx.x;
+    float mx = -3.0e38f;
+    for (int i = tid; i < N; i += 256) { float v = row[i] * scale; mx = v > mx ? v : mx; }
+    mx = hcp_wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    HCP_SYNC();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    HCP_SYNC();
+    float sum = 0.f;
+    for (int i = tid; i < N; i += 256) sum += expf(row[i] * scale - mx);
+    sum = hcp_wave_sum(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    HCP_SYNC();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int i = tid; i < N; i += 256) out[i] = hcp_f2bf(expf(row[i] * scale - mx) * inv);
+}
+
+// AutoencoderKL.encode(...).latent_dist.sample() * scaling_factor (reference data/pair_dataset.py:72-75, train_ac.py:431-432) from
+// the encoder's conv_out moments [B, 2L, hw] (fp32 NCHW): quant_conv (1x1, 2L -> 2L) per pixel, mean | logvar = chunk, logvar
+// clamped to [-30, 20], latent = (mean + exp(0.5 logvar) * noise) * scale; noise == null -> the distribution's mode (mean).
+HCP_KERNEL(256) vae_sample_kernel(const float* mom, const float* Wq, const float* bq, const float* noise, float* out, int B, int L,
+                                  long hw, float scale) {
+    const long total = (long)B * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / hw, px = i - b * hw;
+        const float* m = mom + (size_t)b * 2 * L * hw + px;
+        float in[16];
+        for (int c = 0; c < 2 * L; ++c) in[c] = m[(size_t)c * hw];
+        for (int l = 0; l < L; ++l) {
+            float mean = bq[l], logvar = bq[L + l];
+            for (int c = 0; c < 2 * L; ++c) { mean += Wq[l * 2 * L + c] * in[c]; logvar += Wq[(L + l) * 2 * L + c] * in[c]; }
+            logvar = fminf(fmaxf(logvar, -30.0f), 20.0f);
+            float v = mean;
+            if (noise) v += expf(0.5f * logvar) * noise[((size_t)b * L + l) * hw + px];
+            out[((size_t)b * L + l) * hw + px] = v * scale;
+        }
+    }
+}
+
 }  // namespace
 
 HCP_API int hcp_geglu_fwd(const void* h, void* y, long M, int F, hipStream_t stream) {
@@ -304,4 +365,25 @@ HCP_API int hcp_copy2d_bf16(const void* src, int sld, void* dst, int dld, long M
     HCP_LAUNCH(copy2d_kernel, dim3(pw_grid(M * (C / 8))), dim3(PW_THREADS), 0, stream, (const hcp_bf16*)src, sld,
                (hcp_bf16*)dst, dld, M, C);
     HCP_LAUNCH_CHECK("copy2d");
+}
+
+// dst[b][c][r] = src[b][r][c] for `batch` row-major bf16 matrices
+HCP_API int hcp_transpose_bf16(const void* src, void* dst, int batch, int R, int C, hipStream_t stream) {
+    HCP_REQUIRE(src && dst && batch > 0 && R > 0 && C > 0 && batch < 65536, "hcp_transpose_bf16: bad arguments");
+    HCP_LAUNCH(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64, batch), dim3(256), 64 * 66 * sizeof(hcp_bf16), stream,
+               (const hcp_bf16*)src, (hcp_bf16*)dst, R, C);
+    HCP_LAUNCH_CHECK("transpose_bf16");
+}
+// P[m, :N] (bf16, row stride ldp) = softmax(scale * S[m, :N]) (fp32, row stride lds)
+HCP_API int hcp_softmax_rows(const float* S, long lds, void* P, long ldp, int M, int N, float scale, hipStream_t stream) {
+    HCP_REQUIRE(S && P && M > 0 && N > 0 && lds >= N && ldp >= N, "hcp_softmax_rows: bad arguments");
+    HCP_LAUNCH(softmax_rows_kernel, dim3(M), dim3(256), 4 * sizeof(float), stream, S, lds, (hcp_bf16*)P, ldp, N, scale);
+    HCP_LAUNCH_CHECK("softmax_rows");
+}
+// latents[B, L, hw] = (mean + std * noise) * scale from conv_out moments [B, 2L, hw] and quant_conv (Wq [2L,2L], bq [2L]); L <= 8
+HCP_API int hcp_vae_latent_sample(const float* moments, const float* Wq, const float* bq, const float* noise, float* latents, int B,
+                                  int L, long hw, float scale, hipStream_t stream) {
+    HCP_REQUIRE(moments && Wq && bq && latents && B > 0 && L > 0 && L <= 8 && hw > 0, "hcp_vae_latent_sample: bad arguments");
+    HCP_LAUNCH(vae_sample_kernel, dim3(pw_grid((long)B * hw)), dim3(PW_THREADS), 0, stream, moments, Wq, bq, noise, latents, B, L, hw, scale);
+    HCP_LAUNCH_CHECK("vae_latent_sample");
 }

@@ -121,9 +121,10 @@ def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True):
 
 
 def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=None, bias=None, rowbias=None,
-            residual=None, out_f32=False, a2=None, b2=None):
-    """3x3 / pad 1 convolution on NHWC bf16. mode 0: forward (wp = [cout][3][3][C1+C2]); mode 1: data gradient
-    (x1 = dY [B,Hs,Ws,C1], wp = [cin][3][3][C1], out_hw = spatial dims of the forward input)."""
+            residual=None, out_f32=False, a2=None, b2=None, pad=1):
+    """3x3 convolution on NHWC bf16. mode 0: forward (wp = [cout][3][3][C1+C2]); mode 1: data gradient
+    (x1 = dY [B,Hs,Ws,C1], wp = [cin][3][3][C1], out_hw = spatial dims of the forward input).  pad=0 (forward only): the VAE
+    encoder's asymmetric Downsample2D, F.pad(x, (0,1,0,1)) + padding 0."""
     assert x1.dtype == BF16 and x1.dim() == 4 and x1.is_contiguous()
     B, Hs, Ws, C1 = x1.shape
     C2 = 0
@@ -133,8 +134,8 @@ def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=N
     assert wp.dtype == BF16 and wp.is_contiguous() and wp.numel() == cout * 9 * (C1 + C2)
     if mode == 0:
         up = 2 if upsample else 1
-        Ho = (Hs * up + 2 - 3) // stride + 1
-        Wo = (Ws * up + 2 - 3) // stride + 1
+        Ho = (Hs * up + (2 if pad else 1) - 3) // stride + 1
+        Wo = (Ws * up + (2 if pad else 1) - 3) // stride + 1
     else:
         Ho, Wo = out_hw
     if TRACE is not None:
@@ -150,7 +151,7 @@ def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=N
         assert a2.dtype == BF16 and b2.dtype == BF16 and a2.is_contiguous() and b2.is_contiguous()
         assert a2.numel() == B * Ho * Wo * 32 and tuple(b2.shape) == (cout, 32)
     ws = _workspace(x1)
-    _chk(lib().hcp_conv3x3_bf16(_p(x1), C1, _p(x2), C2, B, Hs, Ws, Ho, Wo, mode, stride, 1 if upsample else 0, _p(wp),
+    _chk(lib().hcp_conv3x3_bf16(_p(x1), C1, _p(x2), C2, B, Hs, Ws, Ho, Wo, mode, stride, 1 if upsample else 0, pad, _p(wp),
                                 cout, _p(out), cout, _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
                                 _p(residual), cout, 1 if out_f32 else 0, _p(a2), _p(b2), _p(ws), ws.numel(), _stream(x1)),
          "hcp_conv3x3_bf16")
@@ -419,6 +420,39 @@ def add_noise(x0, noise, t, alphas_cumprod):
     B = x0.shape[0]
     _chk(lib().hcp_add_noise(_p(x0), _p(noise), _p(t), _p(alphas_cumprod), _p(xt), B, x0.numel() // B, _stream(x0)), "hcp_add_noise")
     return xt
+
+
+def transpose_bf16(x):
+    """[b, R, C] bf16 -> [b, C, R]."""
+    assert x.dtype == BF16 and x.dim() == 3 and x.is_contiguous()
+    b, R, C = x.shape
+    out = torch.empty((b, C, R), dtype=BF16, device=x.device)
+    _chk(lib().hcp_transpose_bf16(_p(x), _p(out), b, R, C, _stream(x)), "hcp_transpose_bf16")
+    return out
+
+
+def softmax_rows(s, scale=1.0):
+    """softmax(scale * s) over the last dim: fp32 [M, N] (row stride >= N) -> bf16 [M, N]."""
+    assert s.dtype == torch.float32 and s.dim() == 2 and s.stride(1) == 1
+    M, N = s.shape
+    out = torch.empty((M, N), dtype=BF16, device=s.device)
+    _chk(lib().hcp_softmax_rows(_p(s), s.stride(0), _p(out), N, M, N, float(scale), _stream(s)), "hcp_softmax_rows")
+    return out
+
+
+def vae_latent_sample(moments, wq, bq, noise, scale):
+    """(mean + exp(0.5 clamp(logvar)) * noise) * scale with (mean | logvar) = quant_conv(moments); moments fp32 [B, 2L, h, w] NCHW,
+    wq [2L, 2L], bq [2L], noise fp32 [B, L, h, w] or None (-> the mode)."""
+    assert moments.dtype == torch.float32 and moments.is_contiguous() and moments.dim() == 4
+    B, L2, h, w = moments.shape
+    L = L2 // 2
+    assert wq.dtype == torch.float32 and wq.is_contiguous() and wq.numel() == L2 * L2 and bq.dtype == torch.float32 and bq.numel() == L2
+    if noise is not None:
+        assert noise.dtype == torch.float32 and noise.is_contiguous() and tuple(noise.shape) == (B, L, h, w)
+    out = torch.empty((B, L, h, w), dtype=torch.float32, device=moments.device)
+    _chk(lib().hcp_vae_latent_sample(_p(moments), _p(wq), _p(bq), _p(noise), _p(out), B, L, h * w, float(scale), _stream(moments)),
+         "hcp_vae_latent_sample")
+    return out
 
 
 SNR_LOSS_KINDS = {"min_snr": 0, "soft_min_snr": 1, "kdiff_min_snr": 2, "edm": 3}

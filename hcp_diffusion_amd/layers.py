@@ -68,7 +68,9 @@ class HipConv2d(nn.Conv2d):
                 w2 = w.reshape(cout, cin)
                 pk.w = w2.to(BF16).contiguous(); pk.wt = w2.t().to(BF16).contiguous()
             else:
-                assert self.kernel_size == (3, 3) and self.padding == (1, 1), "only 3x3/pad1 and 1x1 convolutions exist in the SD UNet"
+                # 3x3 / padding 1 everywhere in the UNet; padding 0 + stride 2 is the VAE encoder's Downsample2D (vae.py passes pad=0)
+                assert self.kernel_size == (3, 3) and (self.padding == (1, 1) or (self.padding == (0, 0) and self.stride == (2, 2))), \
+                    "only 3x3 (padding 1, or the VAE's padding-0 stride-2 downsample) and 1x1 convolutions exist in SD models"
                 pk.cin_pad = (cin + 7) // 8 * 8
                 pk.cout_pad = (cout + 7) // 8 * 8
                 pk.w = _pad_last(w.permute(0, 2, 3, 1), 8).to(BF16).contiguous()       # [Cout][ky][kx][Cin_pad]

@@ -49,14 +49,16 @@ int hcp_debug_set_gemm_ablation(int flags); /* tools only (wrong results when !=
 int hcp_debug_set_gn_target(int workgroups);   /* tools only: workgroups a GroupNorm launch aims for (default 512) */
 int hcp_debug_set_gemm_glds(int on);    /* tools only: 1 = default (v2 main loop where eligible), 0/2 = first LDS-DMA loop everywhere */
 
-/* 3x3 / pad 1 convolution over NHWC bf16 as an implicit GEMM.  mode 0: forward, Wp = [Cout][3][3][C1+C2];
- * mode 1: data gradient, X1 = dY, Wp = [Cin][3][3][Cout].  Options: stride 1|2, nearest-2x upsampled source,
+/* 3x3 convolution over NHWC bf16 as an implicit GEMM.  mode 0: forward, Wp = [Cout][3][3][C1+C2];
+ * mode 1: data gradient, X1 = dY, Wp = [Cin][3][3][Cout].  pad 1 = padding 1 (every conv of the UNet); pad 0 (forward only) = taps
+ * 0..+2 with zeros past the bottom/right edge, i.e. F.pad(x,(0,1,0,1)) + padding 0: the VAE encoder's Downsample2D.
+ * Options: stride 1|2, nearest-2x upsampled source,
  * second source tensor (channel concat), bias, per-sample row bias (time embedding), residual, and a rank-32 K-extension
  * D += A2[M,32] B2[Cout,32]^T — the conv (LoCon) LoRA side path T (alpha W_up)^T, T = conv3x3(x, W_down)
  * (reference lora_layers_patch.py:64-100 merges W + alpha * einsum(W_up, W_down) into the conv weight instead).
  * Replaces F.conv2d in diffusers ResnetBlock2D / Downsample2D / Upsample2D (reference cfgs/unet_struct.txt:92-114,390-393). */
 int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int B, int Hs, int Ws, int Ho, int Wo, int mode,
-                     int stride, int upsample, const void* Wp, int Cout, void* D, int ldd, const float* bias,
+                     int stride, int upsample, int pad, const void* Wp, int Cout, void* D, int ldd, const float* bias,
                      const float* rowbias, int rowbias_ld, const void* residual, int ldr, int out_f32, const void* A2,
                      const void* B2, void* workspace, size_t workspace_bytes, hcpStream_t stream);
 
@@ -135,6 +137,15 @@ int hcp_timestep_embedding_f32(const float* values, void* emb, int B, int dim, f
 /* DDPMScheduler.add_noise as called by train_ac.py:447 */
 int hcp_add_noise(const float* x0, const float* noise, const long long* timesteps, const float* alphas_cumprod, float* xt,
                   int B, long per_sample, hcpStream_t stream);
+/* --- VAE encode (AutoencoderKL.encode(...).latent_dist.sample() * scaling_factor, reference
+ * data/pair_dataset.py:72-75 and train_ac.py:428-435).  The encoder reuses the conv / GroupNorm / GEMM entry points above; these
+ * three finish it: the single-head d=512 mid-block attention runs as GEMM -> hcp_softmax_rows -> GEMM (V transposed by
+ * hcp_transpose_bf16), and hcp_vae_latent_sample folds quant_conv (1x1), the logvar clamp [-30,20] and the reparameterised
+ * draw (noise == NULL: the mode) into one pass over the fp32 moments [B,2L,hw]. */
+int hcp_transpose_bf16(const void* src, void* dst, int batch, int R, int C, hcpStream_t stream);
+int hcp_softmax_rows(const float* S, long lds, void* P, long ldp, int M, int N, float scale, hcpStream_t stream);
+int hcp_vae_latent_sample(const float* moments, const float* Wq, const float* bq, const float* noise, float* latents, int B, int L,
+                          long hw, float scale, hcpStream_t stream);
 /* per-sample loss weights of the reference's timestep-aware criteria (hcpdiff/loss/min_snr_loss.py): kind 0 MinSNRLoss :21-25,
  * 1 SoftMinSNRLoss :31-35, 2 KDiffMinSNRLoss :39-43, 3 EDMLoss :47-52; snr = acp/(1-acp) as in :14-19.  w: float[B]. */
 int hcp_snr_loss_weight(const long long* timesteps, const float* alphas_cumprod, float* w, int B, int kind, float gamma,

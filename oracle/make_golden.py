@@ -265,6 +265,21 @@ def ref_lora_ckpt_fixture(out_dir):
     return keys
 
 
+def vae_full_vectors():
+    """Oracle latents of the full-size SD VAE encoder (seeded weights) for one seeded 256 px and one 512 px image."""
+    from oracle.unet_sd15 import seeded_init_
+    from oracle.vae_ref import SD_VAE_CONFIG, OracleVAEEncoder
+    m = seeded_init_(OracleVAEEncoder(**SD_VAE_CONFIG), 7)
+    out = {}
+    for side in (256, 512):
+        gen = torch.Generator().manual_seed(100 + side)
+        img = torch.rand(1, 3, side, side, generator=gen) * 2 - 1
+        noise = torch.randn(1, 4, side // 8, side // 8, generator=gen)
+        with torch.no_grad():
+            out[side] = dict(seed=7, input_seed=100 + side, latents=m.encode(img, noise))
+    return out
+
+
 def minsnr_reference_vectors():
     """Outputs of the REFERENCE's MinSNRLoss / SoftMinSNRLoss / KDiffMinSNRLoss / EDMLoss (min_snr_loss.py) wrapped in
     Trainer.get_loss's reduction (train_ac.py:506-515) on seeded inputs, SD beta schedule."""
@@ -291,6 +306,10 @@ def minsnr_reference_vectors():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "vae":
+        torch.save(vae_full_vectors(), os.path.join(GOLD, "vae_full_oracle.pt"))
+        print("vae_full_oracle.pt", os.path.getsize(os.path.join(GOLD, "vae_full_oracle.pt")))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":
         ks = ref_lora_ckpt_fixture(GOLD)
         print(len(ks), "lora tensors;", os.path.getsize(os.path.join(GOLD, "ref_lora_unet-7.safetensors")), "bytes")

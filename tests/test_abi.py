@@ -53,7 +53,7 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
     lib = _lib.load()
     N = None
     bad = {
-        "hcp_conv3x3_bf16": (N, 8, N, 0, 1, 4, 4, 4, 4, 0, 1, 0, N, 8, N, 8, N, N, 0, N, 0, 0, N, N, N, 0, N),
+        "hcp_conv3x3_bf16": (N, 8, N, 0, 1, 4, 4, 4, 4, 0, 1, 0, 1, N, 8, N, 8, N, N, 0, N, 0, 0, N, N, N, 0, N),
         "hcp_gemm_lora_bf16": (N, 8, N, 8, N, N, N, N, 8, 8, 8, 8, N, N, 0, N, 0, N),
         "hcp_attention_fwd": (N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, N),
         "hcp_attention_bwd": (N, N, N, N, N, N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, N, 0, N),
@@ -73,6 +73,9 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
         "hcp_timestep_embedding": (N, N, 0, 3, 1e4, N),
         "hcp_add_noise": (N, N, N, N, N, 0, 0, N),
         "hcp_snr_loss_weight": (N, N, N, 0, 0, 5.0, N),
+        "hcp_transpose_bf16": (N, N, 0, 8, 8, N),
+        "hcp_softmax_rows": (N, 8, N, 8, 0, 8, 1.0, N),
+        "hcp_vae_latent_sample": (N, N, N, N, N, 1, 9, 16, 1.0, N),
         "hcp_debug_set_gn_target": (0,),
         "hcp_mse_masked_mean": (N, N, N, 1, N, N, N, 0, 0, 0, 1.0, N),
         "hcp_copy2d_bf16": (N, 8, N, 8, 0, 7, N),

@@ -84,6 +84,20 @@ def test_conv3x3_forward(backend, case):
     assert relerr(out.permute(0, 3, 1, 2), ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,C,H,W,Cout", [(2, 16, 8, 6, 8), (1, 8, 6, 6, 24), (2, 128, 64, 64, 128), (1, 256, 128, 128, 256), (2, 512, 32, 32, 512)])
+def test_conv3x3_stride2_asymmetric_pad(backend, B, C, H, W, Cout):
+    """pad=0: the VAE encoder's Downsample2D — F.pad(x, (0,1,0,1)) then a stride-2 conv with padding 0 (diffusers
+    Downsample2D(padding=0); public AutoencoderKL architecture, [ext] like the rest of diffusers)."""
+    if not backend.is_gpu and C > 16:
+        pytest.skip("large shape: GPU only")
+    torch.manual_seed(C + H)
+    x = rnd(B, C, H, W); w = rnd(Cout, C, 3, 3, scale=1.0 / math.sqrt(9 * C)); bias = torch.randn(Cout)
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), bias, 2, 0)
+    out = K.conv3x3(backend.to(nhwc(x)), backend.to(w.permute(0, 2, 3, 1).contiguous()), Cout, stride=2, pad=0, bias=backend.to(bias), out_f32=True)
+    assert tuple(out.shape) == (B, H // 2, W // 2, Cout)
+    assert relerr(out.permute(0, 3, 1, 2), ref) < 2e-5
+
+
 DGRAD_CASES_EMU = [(2, 16, 6, 5, 24, 1), (1, 8, 8, 8, 16, 2), (1, 8, 7, 5, 16, 2)]
 DGRAD_CASES_GPU = DGRAD_CASES_EMU + [(2, 320, 64, 64, 320, 1), (2, 320, 64, 64, 320, 2), (4, 2560, 8, 8, 1280, 1), (2, 320, 32, 32, 8, 1)]
 
@@ -333,6 +347,44 @@ def test_pointwise_misc(backend):
     lref.backward()
     loss, grad = K.mse_masked_mean(to(pred), to(noise), to(mask), weight=0.7)
     assert abs(loss.item() - lref.item()) < 1e-5 * max(1, abs(lref.item())) and relerr(grad, pr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("b,R,C", [(2, 10, 24), (1, 70, 130), (2, 4096, 512), (3, 77, 768)])
+def test_transpose_bf16(backend, b, R, C):
+    if not backend.is_gpu and R * C > 20000:
+        pytest.skip("large shape: GPU only")
+    x = rnd(b, R, C)
+    assert torch.equal(K.transpose_bf16(backend.to(x)).cpu(), x.transpose(1, 2).contiguous())      # a permutation: bit-exact
+
+
+@pytest.mark.parametrize("M,N", [(5, 37), (3, 700), (4096, 4096), (64, 16384)])
+def test_softmax_rows(backend, M, N):
+    if not backend.is_gpu and M * N > 5000:
+        pytest.skip("large shape: GPU only")
+    torch.manual_seed(N)
+    s = torch.randn(M, N) * 6
+    s[0, :3] = 40.0                                          # a row dominated by a few large scores
+    ref = torch.softmax(s * 0.125, -1)
+    out = K.softmax_rows(backend.to(s), 0.125).float().cpu()
+    assert (out - ref).abs().max().item() < 4e-3 * ref.max().item() and (out.sum(-1) - 1).abs().max().item() < 2e-2
+
+
+def test_vae_latent_sample(backend):
+    """quant_conv + DiagonalGaussianDistribution.sample() * scaling_factor (public diffusers AutoencoderKL, [ext]): fp32 arithmetic,
+    so the kernel must match torch to 1e-5."""
+    torch.manual_seed(0)
+    B, L, h, w = 2, 4, 6, 5
+    mom = torch.randn(B, 2 * L, h, w) * 3; wq = torch.randn(2 * L, 2 * L) * 0.5; bq = torch.randn(2 * L); noise = torch.randn(B, L, h, w)
+    mom[0, L:, 0, 0] = 100.0; mom[0, L:, 0, 1] = -100.0       # both clamp limits
+    m2 = F.conv2d(mom, wq.view(2 * L, 2 * L, 1, 1), bq)
+    mean, logvar = m2.chunk(2, 1)
+    logvar = logvar.clamp(-30.0, 20.0)
+    ref = (mean + torch.exp(0.5 * logvar) * noise) * 0.18215
+    to = backend.to
+    out = K.vae_latent_sample(to(mom), to(wq), to(bq), to(noise), 0.18215).cpu()
+    assert torch.allclose(out, ref, rtol=2e-5, atol=1e-6)
+    mode = K.vae_latent_sample(to(mom), to(wq), to(bq), None, 0.18215).cpu()
+    assert torch.allclose(mode, mean * 0.18215, rtol=2e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("kind", ["min_snr", "soft_min_snr", "kdiff_min_snr", "edm"])
