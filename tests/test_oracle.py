@@ -136,7 +136,7 @@ def test_snr_loss_restatement_matches_reference_code(kind):
         pr = g["pred"].clone().requires_grad_(True)
         loss = get_loss(pr, g["target"], g["mask"], kind=kind, timesteps=g["timesteps"], alphas_cumprod=acp, gamma=gamma)
         loss.backward()
-        assert abs(float(loss) - case["loss"]) <= 1e-6 * abs(case["loss"])
+        assert abs(loss.item() - case["loss"]) <= 1e-6 * abs(case["loss"])
         assert torch.allclose(pr.grad, case["grad"], rtol=1e-5, atol=1e-9)
         assert torch.allclose(snr_weight(kind, g["timesteps"], acp, gamma), case["weight"], rtol=1e-4)
 
