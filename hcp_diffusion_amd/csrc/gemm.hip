@@ -879,7 +879,7 @@ HCP_API int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int
     HCP_REQUIRE(stride == 1 || stride == 2, "hcp_conv3x3_bf16: stride must be 1 or 2");
     HCP_REQUIRE(mode == 0 || (mode == 1 && upsample == 0 && C2 == 0), "hcp_conv3x3_bf16: bad mode/options");
     HCP_REQUIRE(pad == 1 || (pad == 0 && mode == 0 && !upsample), "hcp_conv3x3_bf16: pad must be 1 (or 0 for a forward conv without upsampling)");
-    HCP_REQUIRE(Ho < 1024 && Wo < 1024 && Bn < 2048, "hcp_conv3x3_bf16: dims too large for packed pixel ids");
+    HCP_REQUIRE(Ho <= 1024 && Wo <= 1024 && Bn < 2048, "hcp_conv3x3_bf16: dims too large for packed pixel ids (10 bits per output axis)");
     HCP_REQUIRE((long)Bn * Hs * Ws * (C1 > C2 ? C1 : C2) < (1L << 31), "hcp_conv3x3_bf16: source tensor too large for 32-bit offsets");
     p.cv.X1 = (const hcp_bf16*)X1; p.cv.C1 = C1; p.cv.X2 = (const hcp_bf16*)X2; p.cv.C2 = C2;
     p.cv.Hs = Hs; p.cv.Ws = Ws; p.cv.Ho = Ho; p.cv.Wo = Wo; p.cv.stride = stride; p.cv.up = upsample ? 1 : 0; p.cv.pad = pad;

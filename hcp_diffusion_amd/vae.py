@@ -14,7 +14,7 @@ kernel over the fp32 moments.  Parameter names and shapes are diffusers' (``enco
 
 The reference keeps the VAE in fp32 (``vae_dtype``, train_ac.py:274); here activations are bf16 with fp32 accumulation and
 fp32 statistics, like the UNet — latents agree with the fp32 oracle to bf16 rounding (tests/test_vae.py states the tolerance).
-Image sides up to 1016 px (the convolution kernels index pixels with 10 bits per axis).
+Image sides up to 1024 px (the convolution kernels index output pixels with 10 bits per axis): SD 512 px and SDXL 1024 px.
 """
 import json
 import os
@@ -160,8 +160,8 @@ class NativeVAEEncoder(nn.Module):
         the distribution's mode."""
         if image.dim() != 4 or image.shape[1] != self.config["in_channels"]:
             raise ValueError(f"expected an image batch [B,{self.config['in_channels']},H,W], got {tuple(image.shape)}")
-        if max(image.shape[2:]) > 1016 or image.shape[2] % 8 or image.shape[3] % 8:
-            raise NotImplementedError("hcp_diffusion_amd: VAE encode takes image sides that are multiples of 8 up to 1016 px")
+        if max(image.shape[2:]) > 1024 or image.shape[2] % 8 or image.shape[3] % 8:
+            raise NotImplementedError("hcp_diffusion_amd: VAE encode takes image sides that are multiples of 8 up to 1024 px")
         mom = self.encoder(image)
         B, L2, h, w = mom.shape
         if sample and noise is None:

@@ -266,12 +266,12 @@ def ref_lora_ckpt_fixture(out_dir):
 
 
 def vae_full_vectors():
-    """Oracle latents of the full-size SD VAE encoder (seeded weights) for one seeded 256 px and one 512 px image."""
+    """Oracle latents of the full-size SD VAE encoder (seeded weights) for one seeded 256 px, 512 px and 1024 px (SDXL-size) image."""
     from oracle.unet_sd15 import seeded_init_
     from oracle.vae_ref import SD_VAE_CONFIG, OracleVAEEncoder
     m = seeded_init_(OracleVAEEncoder(**SD_VAE_CONFIG), 7)
     out = {}
-    for side in (256, 512):
+    for side in (256, 512, 1024):
         gen = torch.Generator().manual_seed(100 + side)
         img = torch.rand(1, 3, side, side, generator=gen) * 2 - 1
         noise = torch.randn(1, 4, side // 8, side // 8, generator=gen)

@@ -82,7 +82,7 @@ def test_vae_from_pretrained_reads_diffusers_layout(backend, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("side", [256, 512])
+@pytest.mark.parametrize("side", [256, 512, 1024])
 def test_sd_vae_full_size_encode_vs_golden(side):
     """Full SD VAE encoder (34.2 M parameters, seeded weights) on one seeded image vs the oracle's latents committed in
     tests/golden/vae_full_oracle.pt (oracle/make_golden.py vae)."""
