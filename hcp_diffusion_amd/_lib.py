@@ -31,9 +31,9 @@ _PROTOTYPES = {
     # residual, ldr, out_f32, workspace, workspace_bytes, stream
     "hcp_conv3x3_bf16": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, P, I, P, I, P, P, I, P, I, I, P, P, P, c_size_t, P]),
     # Q, K, V, O, lse, B, H, Nq, Nk, D, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale, stream
-    "hcp_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P, L, P]),
+    "hcp_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P, L, I, P]),
     # Q, K, V, O, dO, lse, delta, dQ, dK, dV, B, H, Nq, Nk, D, strides..., scale, workspace, workspace_bytes, stream
-    "hcp_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P, L, P, c_size_t, P]),
+    "hcp_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P, L, I, P, c_size_t, P]),
     "hcp_debug_set_attention_config": (I, [I]),
     "hcp_groupnorm_workspace_bytes": (c_size_t, [I, I, I, I]),
     # x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream
@@ -73,6 +73,8 @@ _PROTOTYPES = {
     "hcp_layernorm_affine_grad": (I, [P, P, P, P, P, I, I, P]),
     "hcp_add_noise": (I, [P, P, P, P, P, I, L, P]),
     "hcp_snr_loss_weight": (I, [P, P, P, I, I, F, P]),
+    "hcp_quick_gelu": (I, [P, P, P, L, P]),
+    "hcp_embedding_bf16": (I, [P, P, P, P, P, L, I, I, P]),
     "hcp_transpose_bf16": (I, [P, P, I, I, I, P]),
     "hcp_softmax_rows": (I, [P, L, P, L, I, I, F, P]),
     "hcp_vae_latent_sample": (I, [P, P, P, P, P, I, I, L, F, P]),

@@ -32,6 +32,7 @@ struct AttnParams {
     // optional additive key bias [B, Nk] fp32 (diffusers' encoder_attention_mask -> (1 - mask) * -10000, added to the SCALED
     // scores of every head and query; reference models/wrapper.py:22-23,29): applied as bias/scale on the raw scores
     const float* kbias; long kb_bs;
+    int causal;                     // 1: key k is visible to query q only if k <= q (CLIP text encoder); handled by the KB instantiations
     int dbg;              // tools/ablate_attn.py only (wrong results): 1 = no global loads inside the tile loop, 2 = no barriers in the loop
     // dK/dV kernel: the query loop may be split over gridDim.x / nkv workgroups that accumulate into fp32 buffers
     int qsplit;           // number of query-range splits (1 = none)
@@ -202,16 +203,19 @@ HCP_WAVES_PER_SIMD(D > 80 ? 2 : QT == 2 ? 3 : 4) HCP_KERNEL(256) attn_fwd_kernel
                 for (int t = 0; t < QT; ++t) sc[t][kt] = hcp_mfma16(kf, qf[t][s], sc[t][kt]);
             }
         if (KB) {                                   // wave-uniform
-            const float* kb = p.kbias + (size_t)b * p.kb_bs + kv0;
+            const float* kb = p.kbias ? p.kbias + (size_t)b * p.kb_bs + kv0 : nullptr;
             const float inv = 1.0f / p.scale;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kk = kt * 16 + 4 * fg + r;
-                    const float bv = kk < nvalid ? kb[kk] * inv : 0.f;
+                    const float bv = (kb && kk < nvalid) ? kb[kk] * inv : 0.f;
 #pragma unroll
-                    for (int t = 0; t < QT; ++t) sc[t][kt][r] += bv;
+                    for (int t = 0; t < QT; ++t) {
+                        sc[t][kt][r] += bv;
+                        if (p.causal && kv0 + kk > q_base + t * 16 + fr) sc[t][kt][r] = -INFINITY;     // future key: p = exp2(-inf) = 0
+                    }
                 }
         }
         hcp_bf16x8 pf[QT][2];
@@ -391,16 +395,19 @@ HCP_WAVES_PER_SIMD(D > 80 ? 2 : 3) HCP_KERNEL(256) attn_bwd_dq_kernel(AttnParams
                 }
             }
         if (KB) {
-            const float* kb = p.kbias + (size_t)b * p.kb_bs + kv0;
+            const float* kb = p.kbias ? p.kbias + (size_t)b * p.kb_bs + kv0 : nullptr;
             const float inv = 1.0f / p.scale;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kk = kt * 16 + 4 * fg + r;
-                    const float bv = kk < nvalid ? kb[kk] * inv : 0.f;
+                    const float bv = (kb && kk < nvalid) ? kb[kk] * inv : 0.f;
 #pragma unroll
-                    for (int t = 0; t < QT; ++t) sc[t][kt][r] += bv;
+                    for (int t = 0; t < QT; ++t) {
+                        sc[t][kt][r] += bv;
+                        if (p.causal && kv0 + kk > q_base + t * 16 + fr) sc[t][kt][r] = -INFINITY;     // future key: p = exp2(-inf) = 0
+                    }
                 }
         }
         hcp_bf16x8 df[QT][2];
@@ -558,7 +565,7 @@ HCP_WAVES_PER_SIMD((D > 80 || KT == 2) ? 2 : 3) HCP_KERNEL(256) attn_bwd_dkv_ker
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
                 const bool kok = k_base + t * 16 + fr < p.Nk;
-                const float kb2 = (KB && kok) ? p.kbias[(size_t)b * p.kb_bs + k_base + t * 16 + fr] * LOG2E : 0.f;   // this lane's key
+                const float kb2 = (KB && kok && p.kbias) ? p.kbias[(size_t)b * p.kb_bs + k_base + t * 16 + fr] * LOG2E : 0.f;   // this lane's key
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
                     const int qt = 2 * hf + q2;
@@ -567,6 +574,7 @@ HCP_WAVES_PER_SIMD((D > 80 || KT == 2) ? 2 : 3) HCP_KERNEL(256) attn_bwd_dkv_ker
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float pr = kok ? hcp_exp2(fmaf(sc[t][q2][r], c2, kb2 - l4[r])) : 0.f;  // lse2 = +inf for q >= Nq -> 0
+                        if (KB && p.causal && k_base + t * 16 + fr > q0 + qt * 16 + 4 * fg + r) pr = 0.f;   // future key
                         sc[t][q2][r] = pr;
                         dp[t][q2][r] = pr * (dp[t][q2][r] - d4[r]);          // softmax scale applied once, at the store
                     }
@@ -652,7 +660,7 @@ template <int D, int QT>
 int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
     using G = AttnGeom<D>;
     size_t smem = (size_t)2 * (2 * G::RM_ELEMS) * sizeof(hcp_bf16);
-    if (p.kbias) HCP_LAUNCH((attn_fwd_kernel<D, QT, true>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), smem, stream, p);
+    if (p.kbias || p.causal) HCP_LAUNCH((attn_fwd_kernel<D, QT, true>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), smem, stream, p);
     else HCP_LAUNCH((attn_fwd_kernel<D, QT>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), smem, stream, p);
     HCP_LAUNCH_CHECK("attn_fwd");
 }
@@ -667,7 +675,7 @@ template <int D, int QT>
 int launch_dq(AttnParams& p, int B, hipStream_t stream) {
     using G = AttnGeom<D>;
     size_t s1 = (size_t)2 * (2 * G::RM_ELEMS) * sizeof(hcp_bf16);
-    if (p.kbias) HCP_LAUNCH((attn_bwd_dq_kernel<D, QT, true>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), s1, stream, p);
+    if (p.kbias || p.causal) HCP_LAUNCH((attn_bwd_dq_kernel<D, QT, true>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), s1, stream, p);
     else HCP_LAUNCH((attn_bwd_dq_kernel<D, QT>), dim3(hcp_cdiv(p.Nq, 64 * QT), p.H, B), dim3(256), s1, stream, p);
     HCP_LAUNCH_CHECK("attn_bwd_dq");
 }
@@ -692,7 +700,7 @@ int launch_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t str
         p.dk32 = ws; p.dv32 = ws + (size_t)B * p.Nk * p.H * D;
         if (hcp_memset_async(ws, 0, need, stream)) return hcp_set_error("attention_bwd: memset failed");
     }
-    if (p.kbias) HCP_LAUNCH((attn_bwd_dkv_kernel<D, KT, true>), dim3(nkv * qsplit, p.H, B), dim3(256), s2, stream, p);
+    if (p.kbias || p.causal) HCP_LAUNCH((attn_bwd_dkv_kernel<D, KT, true>), dim3(nkv * qsplit, p.H, B), dim3(256), s2, stream, p);
     else HCP_LAUNCH((attn_bwd_dkv_kernel<D, KT>), dim3(nkv * qsplit, p.H, B), dim3(256), s2, stream, p);
     if (qsplit > 1) {
         long tot = (long)B * p.Nk * (p.H * D / 4);
@@ -745,13 +753,14 @@ HCP_API int hcp_debug_set_attention_ablation(int flags) { g_attn_dbg = flags; re
 // All tensors bf16, token-major: element (b, n, h, c) at  base + b*bs + n*rs + h*D + c.
 HCP_API int hcp_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int Nq, int Nk,
                               int D, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
-                              float scale, const float* key_bias, long key_bias_bs, hipStream_t stream) {
+                              float scale, const float* key_bias, long key_bias_bs, int causal, hipStream_t stream) {
     AttnParams p = {};
-    p.kbias = key_bias; p.kb_bs = key_bias_bs; p.dbg = g_attn_dbg;
+    p.kbias = key_bias; p.kb_bs = key_bias_bs; p.causal = causal ? 1 : 0; p.dbg = g_attn_dbg;
     p.Q = (const hcp_bf16*)Q; p.K = (const hcp_bf16*)K; p.V = (const hcp_bf16*)V; p.Out = (hcp_bf16*)O; p.lse = lse;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = 1;
     HCP_REQUIRE(Q && K && V && O && lse, "hcp_attention_fwd: null pointer");
+    HCP_REQUIRE(!causal || Nq == Nk, "hcp_attention_fwd: causal masking is defined for self-attention (Nq == Nk)");
     if (int e = attn_check(p, B, D)) return e;
     switch (D) {
         case 40: return run_fwd<40>(p, B, stream);
@@ -766,15 +775,17 @@ HCP_API int hcp_attention_fwd(const void* Q, const void* K, const void* V, void*
 HCP_API int hcp_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                               float* delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int D, long q_bs,
                               int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
-                              const float* key_bias, long key_bias_bs, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                              const float* key_bias, long key_bias_bs, int causal, void* workspace, size_t workspace_bytes,
+                              hipStream_t stream) {
     AttnParams p = {};
-    p.kbias = key_bias; p.kb_bs = key_bias_bs; p.dbg = g_attn_dbg;
+    p.kbias = key_bias; p.kb_bs = key_bias_bs; p.causal = causal ? 1 : 0; p.dbg = g_attn_dbg;
     p.Q = (const hcp_bf16*)Q; p.K = (const hcp_bf16*)K; p.V = (const hcp_bf16*)V; p.O = (const hcp_bf16*)O;
     p.dO = (const hcp_bf16*)dO; p.lse = (float*)lse; p.delta = delta;
     p.dQ = (hcp_bf16*)dQ; p.dK = (hcp_bf16*)dK; p.dV = (hcp_bf16*)dV;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = 1;
     HCP_REQUIRE(Q && K && V && O && dO && lse && delta && dQ && dK && dV, "hcp_attention_bwd: null pointer");
+    HCP_REQUIRE(!causal || Nq == Nk, "hcp_attention_bwd: causal masking is defined for self-attention (Nq == Nk)");
     if (int e = attn_check(p, B, D)) return e;
     float* ws = (float*)workspace; const size_t wb = workspace ? workspace_bytes : 0;
     switch (D) {

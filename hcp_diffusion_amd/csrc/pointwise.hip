@@ -207,6 +207,38 @@ HCP_KERNEL(256) copy2d_kernel(const hcp_bf16* src, int sld, hcp_bf16* dst, int d
     }
 }
 
+// CLIP text encoder MLP activation: quick_gelu(x) = x * sigmoid(1.702 x)   (cfgs/te_struct.txt QuickGELUActivation)
+HCP_KERNEL(256) quick_gelu_kernel(const hcp_bf16* x, const hcp_bf16* dy, hcp_bf16* out, long nvec) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        hcp_bf16x8 v = *(const hcp_bf16x8*)(x + i * 8);
+        hcp_bf16x8 d = dy ? *(const hcp_bf16x8*)(dy + i * 8) : hcp_zero8();
+        hcp_bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float f = hcp_bf2f((unsigned short)v[q]);
+            const float sg = hcp_sigmoid(1.702f * f);
+            o[q] = (short)hcp_f2bf(dy ? hcp_bf2f((unsigned short)d[q]) * (sg + 1.702f * f * sg * (1.f - sg)) : f * sg);
+        }
+        *(hcp_bf16x8*)(out + i * 8) = o;
+    }
+}
+
+// out[i, :] = tok[ids[i], :] + pos[pos_ids ? pos_ids[i] : i % L, :]   (CLIPTextEmbeddings, te_struct.txt; fp32 tables -> bf16 rows)
+HCP_KERNEL(256) embedding_kernel(const float* tok, const long long* ids, const float* pos, const long long* pos_ids, hcp_bf16* out,
+                                 long n, int C, int L) {
+    const int cv = C / 8;
+    const long total = n * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cv; const int c = (int)(i - r * cv) * 8;
+        const float* t = tok + (size_t)ids[r] * C + c;
+        const float* q = pos + (size_t)(pos_ids ? pos_ids[r] : r % L) * C + c;
+        hcp_bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)hcp_f2bf(t[j] + q[j]);
+        *(hcp_bf16x8*)(out + r * C + c) = o;
+    }
+}
+
 // dst[b][c][r] = src[b][r][c]  (bf16, per-sample 2-D transpose through a 64x64 LDS tile, padded against bank conflicts)
 HCP_KERNEL(256) transpose_kernel(const hcp_bf16* src, hcp_bf16* dst, int R, int C) {
     HCP_DYN_SMEM(smem);
@@ -386,4 +418,19 @@ HCP_API int hcp_vae_latent_sample(const float* moments, const float* Wq, const f
     HCP_REQUIRE(moments && Wq && bq && latents && B > 0 && L > 0 && L <= 8 && hw > 0, "hcp_vae_latent_sample: bad arguments");
     HCP_LAUNCH(vae_sample_kernel, dim3(pw_grid((long)B * hw)), dim3(PW_THREADS), 0, stream, moments, Wq, bq, noise, latents, B, L, hw, scale);
     HCP_LAUNCH_CHECK("vae_latent_sample");
+}
+
+// y = quick_gelu(x) (dy == NULL) or dx = dy * quick_gelu'(x); n bf16 elements, n % 8 == 0
+HCP_API int hcp_quick_gelu(const void* x, const void* dy, void* out, long n, hipStream_t stream) {
+    HCP_REQUIRE(x && out && n > 0 && n % 8 == 0, "hcp_quick_gelu: bad arguments");
+    HCP_LAUNCH(quick_gelu_kernel, dim3(pw_grid(n / 8)), dim3(PW_THREADS), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy, (hcp_bf16*)out, n / 8);
+    HCP_LAUNCH_CHECK("quick_gelu");
+}
+// out[n, C] (bf16) = token_table[ids] + position_table[position_ids or (row % L)]; fp32 tables, int64 ids, C % 8 == 0
+HCP_API int hcp_embedding_bf16(const float* token_table, const long long* ids, const float* position_table, const long long* position_ids,
+                               void* out, long n, int C, int L, hipStream_t stream) {
+    HCP_REQUIRE(token_table && ids && position_table && out && n > 0 && C > 0 && C % 8 == 0 && L > 0, "hcp_embedding_bf16: bad arguments");
+    HCP_LAUNCH(embedding_kernel, dim3(pw_grid(n * (C / 8))), dim3(PW_THREADS), 0, stream, token_table, ids, position_table, position_ids,
+               (hcp_bf16*)out, n, C, L);
+    HCP_LAUNCH_CHECK("embedding_bf16");
 }

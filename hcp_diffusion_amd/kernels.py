@@ -209,9 +209,9 @@ def _key_bias(key_bias, B, Nk):
     return key_bias, key_bias.stride(0)
 
 
-def attention_fwd(q, k, v, heads, scale=None, key_bias=None):
+def attention_fwd(q, k, v, heads, scale=None, key_bias=None, causal=False):
     """q [B,Nq,H*d], k/v [B,Nk,H*d] (views with arbitrary batch/row strides allowed) -> (o [B,Nq,H*d], lse [B,H,Nq]).
-    key_bias: optional fp32 [B,Nk] added to the scaled scores (additive key mask)."""
+    key_bias: optional fp32 [B,Nk] added to the scaled scores (additive key mask); causal: key k visible to query q iff k <= q."""
     B, Nq, C = q.shape
     Nk = k.shape[1]
     D = C // heads
@@ -221,11 +221,11 @@ def attention_fwd(q, k, v, heads, scale=None, key_bias=None):
     qb, qr = _attn_strides(q); kb, kr = _attn_strides(k); vb, vr = _attn_strides(v); ob, orr = _attn_strides(o)
     kbt, kbs = _key_bias(key_bias, B, Nk)
     _chk(lib().hcp_attention_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, heads, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
-                                 float(scale), _p(kbt), kbs, _stream(q)), "hcp_attention_fwd")
+                                 float(scale), _p(kbt), kbs, 1 if causal else 0, _stream(q)), "hcp_attention_fwd")
     return o, lse
 
 
-def attention_bwd(q, k, v, o, do, lse, heads, scale=None, out=None, key_bias=None):
+def attention_bwd(q, k, v, o, do, lse, heads, scale=None, out=None, key_bias=None, causal=False):
     """Gradients (dq, dk, dv).  q/k/v may be column-slice views of a fused projection buffer; `out` = preallocated
     (dq, dk, dv) with the SAME strides as (q, k, v) (e.g. slices of one [B,N,3C] gradient buffer)."""
     B, Nq, C = q.shape
@@ -244,8 +244,8 @@ def attention_bwd(q, k, v, o, do, lse, heads, scale=None, out=None, key_bias=Non
     ws = _workspace(q)
     kbt, kbs = _key_bias(key_bias, B, Nk)
     _chk(lib().hcp_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, heads,
-                                 Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr, float(scale), _p(kbt), kbs, _p(ws), ws.numel(),
-                                 _stream(q)), "hcp_attention_bwd")
+                                 Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr, float(scale), _p(kbt), kbs, 1 if causal else 0, _p(ws),
+                                 ws.numel(), _stream(q)), "hcp_attention_bwd")
     return dq, dk, dv
 
 
@@ -420,6 +420,25 @@ def add_noise(x0, noise, t, alphas_cumprod):
     B = x0.shape[0]
     _chk(lib().hcp_add_noise(_p(x0), _p(noise), _p(t), _p(alphas_cumprod), _p(xt), B, x0.numel() // B, _stream(x0)), "hcp_add_noise")
     return xt
+
+
+def quick_gelu(x, dy=None):
+    """quick_gelu(x) = x * sigmoid(1.702 x) (dy None) or dy * quick_gelu'(x); bf16, any shape with numel % 8 == 0."""
+    assert x.dtype == BF16 and x.is_contiguous() and (dy is None or (dy.dtype == BF16 and dy.is_contiguous() and dy.shape == x.shape))
+    out = torch.empty_like(x)
+    _chk(lib().hcp_quick_gelu(_p(x), _p(dy), _p(out), x.numel(), _stream(x)), "hcp_quick_gelu")
+    return out
+
+
+def embedding(token_table, ids, position_table, position_ids=None):
+    """[.., L] int64 ids -> bf16 [.., L, C] = token_table[ids] + position_table[position_ids or arange(L)]."""
+    assert token_table.dtype == torch.float32 and position_table.dtype == torch.float32 and token_table.is_contiguous() and position_table.is_contiguous()
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and (position_ids is None or (position_ids.dtype == torch.int64 and position_ids.shape == ids.shape))
+    C, L = token_table.shape[1], ids.shape[-1]
+    out = torch.empty(tuple(ids.shape) + (C,), dtype=BF16, device=ids.device)
+    _chk(lib().hcp_embedding_bf16(_p(token_table), _p(ids), _p(position_table), _p(position_ids.contiguous() if position_ids is not None else None),
+                                  _p(out), ids.numel(), C, L, _stream(ids)), "hcp_embedding_bf16")
+    return out
 
 
 def transpose_bf16(x):

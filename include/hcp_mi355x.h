@@ -65,15 +65,18 @@ int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int B, int 
 /* Fused attention, element (b,n,h,c) at base + b*bs + n*rs + h*D + c; lse[B,H,Nq] = logsumexp(scale*QK^T).
  * Replaces diffusers CrossAttention/AttnProcessor2_0 (SDPA) or xformers (reference train_ac.py:258-260). D in {40,64,80,160}. */
 /* key_bias (optional, fp32 [B,Nk], batch stride key_bias_bs): additive bias on the SCALED scores of every head/query —
- * diffusers' encoder_attention_mask -> (1 - mask) * -10000 (the attn_mask the reference passes at models/wrapper.py:22-29). */
+ * diffusers' encoder_attention_mask -> (1 - mask) * -10000 (the attn_mask the reference passes at models/wrapper.py:22-29).
+ * causal != 0 (self-attention only, Nq == Nk): key k contributes to query q only if k <= q — the CLIP text encoder's
+ * causal_attention_mask (cfgs/te_struct.txt CLIPAttention; text-encoder LoRA, cfgs/train/examples/lora_conventional.yaml:14-19). */
 int hcp_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int Nq, int Nk, int D,
                       long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
-                      const float* key_bias, long key_bias_bs, hcpStream_t stream);
+                      const float* key_bias, long key_bias_bs, int causal, hcpStream_t stream);
 /* workspace (optional, 2*B*Nk*H*D floats): lets short-key problems split the dK/dV query loop across workgroups */
 int hcp_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                       float* delta_ws /* [B,H,Nq] */, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int D,
                       long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
-                      const float* key_bias, long key_bias_bs, void* workspace, size_t workspace_bytes, hcpStream_t stream);
+                      const float* key_bias, long key_bias_bs, int causal, void* workspace, size_t workspace_bytes,
+                      hcpStream_t stream);
 
 int hcp_debug_set_attention_ablation(int flags); /* tools only (wrong results when != 0): 1 = no global loads in the tile loops */
 int hcp_debug_set_attention_config(int cfg); /* tools only: bit0/1/2 = 32 rows per wave in fwd / dQ / dK,dV; -1 = heuristic */
@@ -146,6 +149,11 @@ int hcp_transpose_bf16(const void* src, void* dst, int batch, int R, int C, hcpS
 int hcp_softmax_rows(const float* S, long lds, void* P, long ldp, int M, int N, float scale, hcpStream_t stream);
 int hcp_vae_latent_sample(const float* moments, const float* Wq, const float* bq, const float* noise, float* latents, int B, int L,
                           long hw, float scale, hcpStream_t stream);
+/* --- text encoder (CLIP, cfgs/te_struct.txt; text-encoder LoRA of cfgs/train/examples/lora_conventional.yaml:14-19): its linears,
+ * LayerNorms and (causal) attention are the entry points above; these two are its embedding lookup and MLP activation. */
+int hcp_quick_gelu(const void* x, const void* dy, void* out, long n, hcpStream_t stream);   /* dy NULL: forward; else dx */
+int hcp_embedding_bf16(const float* token_table, const long long* ids, const float* position_table, const long long* position_ids,
+                       void* out, long n, int C, int L, hcpStream_t stream);
 /* per-sample loss weights of the reference's timestep-aware criteria (hcpdiff/loss/min_snr_loss.py): kind 0 MinSNRLoss :21-25,
  * 1 SoftMinSNRLoss :31-35, 2 KDiffMinSNRLoss :39-43, 3 EDMLoss :47-52; snr = acp/(1-acp) as in :14-19.  w: float[B]. */
 int hcp_snr_loss_weight(const long long* timesteps, const float* alphas_cumprod, float* w, int B, int kind, float gamma,

@@ -55,8 +55,8 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
     bad = {
         "hcp_conv3x3_bf16": (N, 8, N, 0, 1, 4, 4, 4, 4, 0, 1, 0, 1, N, 8, N, 8, N, N, 0, N, 0, 0, N, N, N, 0, N),
         "hcp_gemm_lora_bf16": (N, 8, N, 8, N, N, N, N, 8, 8, 8, 8, N, N, 0, N, 0, N),
-        "hcp_attention_fwd": (N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, N),
-        "hcp_attention_bwd": (N, N, N, N, N, N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, N, 0, N),
+        "hcp_attention_fwd": (N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, 0, N),
+        "hcp_attention_bwd": (N, N, N, N, N, N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, 0, N, 0, N),
         "hcp_groupnorm_silu_fwd": (N, N, N, N, N, N, 1, 16, 30, 32, 1e-5, 1, N),          # C % G != 0
         "hcp_groupnorm_silu_bwd": (N, N, N, N, N, N, N, N, 1, 16, 32, 32, 1, N),
         "hcp_groupnorm_affine_grad": (N, N, N, N, N, N, N, 1, 16, 32, 32, 1, N),
@@ -73,6 +73,8 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
         "hcp_timestep_embedding": (N, N, 0, 3, 1e4, N),
         "hcp_add_noise": (N, N, N, N, N, 0, 0, N),
         "hcp_snr_loss_weight": (N, N, N, 0, 0, 5.0, N),
+        "hcp_quick_gelu": (N, N, N, 7, N),
+        "hcp_embedding_bf16": (N, N, N, N, N, 0, 8, 77, N),
         "hcp_transpose_bf16": (N, N, 0, 8, 8, N),
         "hcp_softmax_rows": (N, 8, N, 8, 0, 8, 1.0, N),
         "hcp_vae_latent_sample": (N, N, N, N, N, 1, 9, 16, 1.0, N),
@@ -86,5 +88,9 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
         assert rc < 0 and len(lib.hcp_last_error()) > 0, name
     # unsupported head dimension is reported, not mis-dispatched
     one = ctypes.c_void_p(16)
-    rc = lib.hcp_attention_fwd(one, one, one, one, one, 1, 1, 8, 8, 48, 0, 48, 0, 48, 0, 48, 0, 48, 0.1, None, 0, None)
+    rc = lib.hcp_attention_fwd(one, one, one, one, one, 1, 1, 8, 8, 48, 0, 48, 0, 48, 0, 48, 0, 48, 0.1, None, 0, 0, None)
+    assert rc < 0 and b"head_dim" in lib.hcp_last_error()
+    rc = lib.hcp_attention_fwd(one, one, one, one, one, 1, 1, 8, 16, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, None, 0, 1, None)   # causal cross-attention
+    assert rc < 0 and b"causal" in lib.hcp_last_error()
+    rc = lib.hcp_attention_fwd(one, one, one, one, one, 1, 1, 8, 8, 48, 0, 48, 0, 48, 0, 48, 0, 48, 0.1, None, 0, 0, None)
     assert rc < 0 and b"head_dim" in lib.hcp_last_error()

@@ -148,6 +148,39 @@ def test_attention_additive_key_mask(backend):
     assert dk.cpu().float()[0, 50:].abs().max().item() < 1e-6          # masked keys receive no gradient
 
 
+@pytest.mark.parametrize("B,H,N,D,with_bias", [(2, 2, 77, 64, False), (1, 1, 150, 40, True), (2, 12, 77, 64, False), (1, 20, 77, 64, True), (2, 4, 300, 80, False)])
+def test_attention_causal(backend, B, H, N, D, with_bias):
+    """causal=1: the CLIP text encoder's self-attention (77 tokens, 12 x 64; bigG: 20 x 64) — key k visible to query q iff k <= q —
+    alone and combined with an additive key mask; forward, lse and all three gradients vs an explicit masked softmax."""
+    if not backend.is_gpu and B * H * N > 400:
+        pytest.skip("large shape: GPU only")
+    torch.manual_seed(N + D)
+    q, k, v, do = rnd(B, N, H * D), rnd(B, N, H * D), rnd(B, N, H * D), rnd(B, N, H * D)
+    bias = None
+    if with_bias:
+        keep = torch.ones(B, N); keep[:, N - 9:] = 0; keep[:, 5] = 0               # key 0 stays visible: no fully masked row
+        bias = (1.0 - keep) * -10000.0
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    def heads(t):
+        return t.view(B, N, H, D).transpose(1, 2)
+    s = heads(qr) @ heads(kr).transpose(-1, -2) * D ** -0.5
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    s = s.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
+    o_ref = (torch.softmax(s, -1) @ heads(vr)).transpose(1, 2).reshape(B, N, H * D)
+    o_ref.backward(do.float())
+    to = backend.to
+    kb = to(bias) if bias is not None else None
+    o, lse = K.attention_fwd(to(q), to(k), to(v), H, key_bias=kb, causal=True)
+    assert relerr(o, o_ref) < 1.5e-2
+    assert (lse.cpu() - torch.logsumexp(s, -1).detach()).abs().max().item() < 2e-2
+    assert relerr(o[:, 0], v[:, 0]) < 1e-2                                                    # query 0 sees only key 0
+    dq, dk, dv = K.attention_bwd(to(q), to(k), to(v), o, to(do), lse, H, key_bias=kb, causal=True)
+    assert relerr(dq, qr.grad) < 2e-2 and relerr(dk, kr.grad) < 2e-2 and relerr(dv, vr.grad) < 2e-2
+    o2, _ = K.attention_fwd(to(q), to(k), to(v), H, key_bias=kb)
+    assert relerr(o2, o_ref) > 5e-2                                                          # the mask matters
+
+
 def attn_ref(q, k, v, H, do=None):
     B, Nq, C = q.shape; D = C // H
     q = q.float().requires_grad_(True); k = k.float().requires_grad_(True); v = v.float().requires_grad_(True)
@@ -347,6 +380,23 @@ def test_pointwise_misc(backend):
     lref.backward()
     loss, grad = K.mse_masked_mean(to(pred), to(noise), to(mask), weight=0.7)
     assert abs(loss.item() - lref.item()) < 1e-5 * max(1, abs(lref.item())) and relerr(grad, pr.grad) < 1e-5
+
+
+def test_quick_gelu_and_embedding(backend):
+    """CLIP text-encoder pointwise pieces: quick_gelu fwd / bwd vs autograd, embedding lookup (token + position) vs torch."""
+    torch.manual_seed(0)
+    to = backend.to
+    x = rnd(3, 77, 64, scale=2.0); dy = rnd(3, 77, 64)
+    xr = x.float().requires_grad_(True)
+    yr = xr * torch.sigmoid(1.702 * xr)
+    yr.backward(dy.float())
+    assert relerr(K.quick_gelu(to(x)), yr) < 1e-2 and relerr(K.quick_gelu(to(x), to(dy)), xr.grad) < 1e-2
+    tok, pos = torch.randn(50, 32), torch.randn(77, 32)
+    ids = torch.randint(0, 50, (2, 77))
+    ref = tok[ids] + pos[None]
+    assert relerr(K.embedding(to(tok), to(ids), to(pos)), ref) < 5e-3
+    pid = torch.randint(0, 77, (2, 77))
+    assert relerr(K.embedding(to(tok), to(ids), to(pos), to(pid)), tok[ids] + pos[pid]) < 5e-3
 
 
 @pytest.mark.parametrize("b,R,C", [(2, 10, 24), (1, 70, 130), (2, 4096, 512), (3, 77, 768)])
