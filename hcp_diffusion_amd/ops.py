@@ -420,23 +420,39 @@ geglu = _GegluFn.apply
 
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, heads, key_bias=None):
-        o, lse = K.attention_fwd(q, k, v, heads, key_bias=key_bias)
+    def forward(ctx, q, k, v, heads, key_bias=None, causal=False):
+        o, lse = K.attention_fwd(q, k, v, heads, key_bias=key_bias, causal=causal)
         ctx.save_for_backward(q, k, v, o, lse, key_bias)
-        ctx.heads = heads
+        ctx.heads, ctx.causal = heads, causal
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse, key_bias = ctx.saved_tensors
         dq, dk, dv = K.attention_bwd(q.contiguous(), k.contiguous(), v.contiguous(), o, do.contiguous(), lse, ctx.heads,
-                                     key_bias=key_bias)
-        return dq, dk, dv, None, None
+                                     key_bias=key_bias, causal=ctx.causal)
+        return dq, dk, dv, None, None, None
 
 
-def attention(q, k, v, heads, key_bias=None):
-    """key_bias: optional fp32 [B,Nk] additive key mask (constant: no gradient)."""
-    return _AttentionFn.apply(q, k, v, heads, key_bias)
+def attention(q, k, v, heads, key_bias=None, causal=False):
+    """key_bias: optional fp32 [B,Nk] additive key mask (constant: no gradient); causal: the text encoder's triangular mask."""
+    return _AttentionFn.apply(q, k, v, heads, key_bias, causal)
+
+
+class _QuickGeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return K.quick_gelu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.quick_gelu(x, dy.contiguous())
+
+
+def quick_gelu(x):
+    return _QuickGeluFn.apply(x)
 
 
 class _AttentionPackedFn(torch.autograd.Function):

@@ -44,7 +44,8 @@ class _OptState:
 class NativeTrainer:
     def __init__(self, unet, lora_cfg=None, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000,
-                 overlap_wgrad=False, grouped_wgrad=True, train_cfg=None, plugins=None, ema=None, loss_cfg=None):
+                 overlap_wgrad=False, grouped_wgrad=True, train_cfg=None, plugins=None, ema=None, loss_cfg=None, text_encoder=None,
+                 lora_te_cfg=None):
         """lora_cfg: the reference's ``lora_unet`` list ({layers, rank, alpha, lr, ...}); train_cfg: its ``unet`` list
         ({layers, lr}) of host modules to fine-tune in full (DreamBooth.yaml:6-10 uses ``layers: ['']`` = everything);
         plugins: [(plugin module, lr)] — trainable hook plugins such as controlnet.ControlNetHipPlugin (make_plugin,
@@ -52,7 +53,11 @@ class NativeTrainer:
         {decay_max, inv_gamma, power} (``model.ema``, train_ac.py:238-242): an EMA copy of every trainable bucket, updated by
         one kernel per bucket after the optimizer step (train_ac.py:503); loss_cfg: None = ``train.loss.criterion`` MSELoss
         (train_base.yaml), or {type: 'min_snr'|'soft_min_snr'|'kdiff_min_snr'|'edm', gamma} = the reference's timestep-aware
-        criteria (hcpdiff/loss/min_snr_loss.py, selected through ``need_timesteps`` in train_ac.py:509-510)."""
+        criteria (hcpdiff/loss/min_snr_loss.py, selected through ``need_timesteps`` in train_ac.py:509-510); text_encoder: a
+        text_encoder.NativeCLIPTextModel — batches may then carry ``prompt_ids`` [B,77] instead of ``encoder_hidden_states`` and the
+        prompt is encoded inside the step (TEUnetWrapper.forward, models/wrapper.py:14-30); lora_te_cfg: the reference's
+        ``lora_text_encoder`` list (lora_conventional.yaml:14-19) — its blocks form a second flat bucket that shares the step's
+        single global-norm clip (train_ac.py:485-490 clips TE_unet.trainable_parameters() together)."""
         self.unet = unet
         self.device = next(unet.parameters()).device
         unet.requires_grad_(False)            # config_model(): freeze host, eval (train_ac.py:264-268)
@@ -75,11 +80,21 @@ class NativeTrainer:
             self.host_buckets.append(_OptState(hb, plr * scale_lr_factor, self.device))
             self.plugins.append(plugin)
         self.param_groups, self.lora_group, self.bucket = make_lora(unet, lora_cfg) if lora_cfg else ([], None, None)
-        assert self.bucket is not None or self.host_buckets, "nothing to train: no LoRA layer matched and no host group given"
+        assert self.bucket is not None or self.host_buckets or lora_te_cfg, "nothing to train: no LoRA layer matched and no host group given"
         self._lora_state = _OptState(self.bucket, lr * scale_lr_factor, self.device) if self.bucket is not None else None
         if self._lora_state is not None:      # historical attribute names (tests / tools read them)
             st = self._lora_state
             self.exp_avg, self.exp_avg_sq, self.lr, self.step_count, self.sumsq = st.exp_avg, st.exp_avg_sq, st.lr, st.step_count, st.sumsq
+        self.text_encoder, self.lora_te_group, self.te_bucket, self._te_state = text_encoder, None, None, None
+        if text_encoder is not None:
+            text_encoder.requires_grad_(False)
+            text_encoder.eval()
+            if lora_te_cfg:
+                _, self.lora_te_group, self.te_bucket = make_lora(text_encoder, lora_te_cfg)
+                assert self.te_bucket is not None, "lora_text_encoder matched no layer"
+                self._te_state = _OptState(self.te_bucket, lora_te_cfg[0].get("lr", lr) * scale_lr_factor, self.device)
+        elif lora_te_cfg:
+            raise ValueError("lora_te_cfg needs the text_encoder module")
         self.ema_cfg = None
         if ema is not None:
             self.ema_cfg = {**dict(decay_max=0.9997, inv_gamma=1.0, power=2.0 / 3.0), **ema}
@@ -114,8 +129,13 @@ class NativeTrainer:
         t = torch.randint(0, self.num_train_timesteps, (latents.shape[0],), device=latents.device).long()
         return K.add_noise(latents, noise, t, self.acp), noise, t
 
-    def forward_backward(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None, plugin_input=None):
+    def forward_backward(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None, plugin_input=None, prompt_ids=None):
         noisy, noise, t = self.make_noise(latents)
+        if encoder_hidden_states is None:                                 # wrapper.py:20: the prompt is encoded inside the step
+            if self.text_encoder is None or prompt_ids is None:
+                raise ValueError("a batch needs encoder_hidden_states, or prompt_ids together with a text_encoder")
+            with torch.set_grad_enabled(self.te_bucket is not None):
+                encoder_hidden_states = self.text_encoder(prompt_ids)
         if plugin_input:                                                  # wrapper.py:15,25-28: feeders see the batch dict
             for feeder in getattr(self.unet, "input_feeder", []):
                 feeder(dict(noisy_latents=noisy, timesteps=t, encoder_hidden_states=encoder_hidden_states, **plugin_input))
@@ -137,7 +157,8 @@ class NativeTrainer:
         return loss
 
     def _states(self):
-        return ([self._lora_state] if self._lora_state is not None else []) + self.host_buckets
+        return (([self._lora_state] if self._lora_state is not None else []) + self.host_buckets +
+                ([self._te_state] if getattr(self, "_te_state", None) is not None else []))
 
     def all_reduce(self):
         if self.world > 1:                     # one collective per flat bucket (LoRA: 12 MB; SD1.5 full FT: 3.4 GB)
@@ -161,6 +182,8 @@ class NativeTrainer:
                 K.ema_update(st.ema, st.bucket.params, st.step_count, **self.ema_cfg)
         if self.bucket is not None:
             self.bucket.pack()                 # refresh the bf16 LoRA operands for the next forward
+        if self.te_bucket is not None:
+            self.te_bucket.pack()
         for st in self.host_buckets:
             st.bucket.repack()                 # ... and the bf16 host operands (one grouped launch)
 
@@ -172,6 +195,8 @@ class NativeTrainer:
             named = getattr(b, "named", None)
             if named is None:              # LoraBucket: names from the model
                 ids = {id(p): n for n, p in self.unet.named_parameters()}
+                if self.text_encoder is not None:
+                    ids.update({id(p): n for n, p in self.text_encoder.named_parameters()})
                 named = [(ids.get(id(p), f"lora.{i}"), p) for i, blk in enumerate(b.blocks) for p in (blk.layer.W_down, blk.layer.W_up)]
             base = b.params.data_ptr()
             for name, p in named:
@@ -186,6 +211,9 @@ class NativeTrainer:
         from .patch_api import PluginGroup
         ema = _EMAView(self.ema_state_dict(), self.unet) if self.ema_cfg else None
         paths = [ckpt_manager.save_model_with_lora(self.unet, self.lora_group, name=name, step=step, model_ema=ema)]
+        if self.lora_te_group is not None:     # train_ac.py:529-533: the text encoder's own file
+            te_ema = _EMAView(self.ema_state_dict(), self.text_encoder) if self.ema_cfg else None
+            paths.append(ckpt_manager.save_model_with_lora(self.text_encoder, self.lora_te_group, name="text_encoder", step=step, model_ema=te_ema))
         for plugin in self.plugins:
             pema = None
             if ema is not None:             # EMA names of a plugin bucket are relative to the plugin; a whole-model plugin's
@@ -198,12 +226,12 @@ class NativeTrainer:
             st.lr.fill_(lr)
 
     # ---- one optimisation step
-    def train_one_step(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None, plugin_input=None):
+    def train_one_step(self, latents, encoder_hidden_states=None, mask=None, added_cond_kwargs=None, plugin_input=None, prompt_ids=None):
         """latents [B,4,h,w] fp32 (cached VAE latents), encoder_hidden_states [B,L,D]; SDXL adds
         added_cond_kwargs={"text_embeds" [B,1280], "time_ids" [B,6]}; plugins read plugin_input (ControlNet: {"cond"}).
         Returns the loss as a device tensor (no host sync)."""
         return self.train_data_list([dict(latents=latents, encoder_hidden_states=encoder_hidden_states, mask=mask,
-                                          added_cond_kwargs=added_cond_kwargs, plugin_input=plugin_input)])
+                                          added_cond_kwargs=added_cond_kwargs, plugin_input=plugin_input, prompt_ids=prompt_ids)])
 
     @staticmethod
     def _tensors(batch):
@@ -229,8 +257,8 @@ class NativeTrainer:
                 lw = b.get("loss_weight", 1.0)
                 keep, self.loss_weight = self.loss_weight, self.loss_weight * lw
                 try:
-                    l = self.forward_backward(b["latents"], b["encoder_hidden_states"], b.get("mask"), b.get("added_cond_kwargs"),
-                                              b.get("plugin_input"))
+                    l = self.forward_backward(b["latents"], b.get("encoder_hidden_states"), b.get("mask"), b.get("added_cond_kwargs"),
+                                              b.get("plugin_input"), b.get("prompt_ids"))
                 finally:
                     self.loss_weight = keep
                 self.loss = l if self.loss is None else self.loss + l
@@ -262,8 +290,8 @@ class NativeTrainer:
                 lw = sb.get("loss_weight", 1.0)
                 keep, self.loss_weight = self.loss_weight, self.loss_weight * lw
                 try:
-                    l = self.forward_backward(sb["latents"], sb["encoder_hidden_states"], sb.get("mask"), sb.get("added_cond_kwargs"),
-                                              sb.get("plugin_input"))
+                    l = self.forward_backward(sb["latents"], sb.get("encoder_hidden_states"), sb.get("mask"), sb.get("added_cond_kwargs"),
+                                              sb.get("plugin_input"), sb.get("prompt_ids"))
                 finally:
                     self.loss_weight = keep
                 total = l if total is None else total + l

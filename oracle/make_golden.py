@@ -50,6 +50,9 @@ def parse_unet_struct(path):
         elif kind == "LayerNorm":
             c = int(re.match(r"\((\d+),\)", rest).group(1))
             shapes[full + ".weight"] = [c]; shapes[full + ".bias"] = [c]
+        elif kind == "Embedding":
+            n, c = map(int, re.match(r"(\d+), (\d+)", rest).groups())
+            shapes[full + ".weight"] = [n, c]
     return shapes
 
 
@@ -306,6 +309,13 @@ def minsnr_reference_vectors():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "te_struct":
+        ref = os.environ.get("HCP_REFERENCE_ROOT", "/root/reference")
+        shapes = parse_unet_struct(os.path.join(ref, "cfgs", "te_struct.txt"))
+        json.dump({"source": "reference cfgs/te_struct.txt", "n_params": sum(int(torch.tensor(s).prod()) for s in shapes.values()),
+                   "shapes": shapes}, open(os.path.join(GOLD, "te_struct.json"), "w"), indent=0)
+        print("te_struct.json:", len(shapes), "tensors")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "vae":
         torch.save(vae_full_vectors(), os.path.join(GOLD, "vae_full_oracle.pt"))
         print("vae_full_oracle.pt", os.path.getsize(os.path.join(GOLD, "vae_full_oracle.pt")))
