@@ -92,10 +92,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["sd15", "sdxl", "dreambooth", "controlnet"], default="sd15",
+    ap.add_argument("--workload", choices=["sd15", "sdxl", "dreambooth", "controlnet", "sd15te"], default="sd15",
                     help="sd15 = the headline metric (BASELINE.json configs[1]); sdxl = configs[3] (SDXL LoRA r16 1024px bs2); "
                          "dreambooth = configs[2] (SD1.5 full fine-tune, all 859.5 M parameters, bs2); controlnet = configs[4] (frozen SD1.5 + "
-                         "trainable ControlNet branch, bs4) — secondary lines")
+                         "trainable ControlNet branch, bs4); sd15te = the reference's default LoRA example, lora_unet r8 + "
+                         "lora_text_encoder r4 with the prompt encoded inside the step (lora_conventional.yaml) — secondary lines")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--rank-lora", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true")
@@ -125,6 +126,7 @@ def main():
     sdxl = args.workload == "sdxl"
     fullft = args.workload == "dreambooth"
     cnet = args.workload == "controlnet"
+    te = args.workload == "sd15te"
     args.batch = args.batch or (2 if (sdxl or fullft) else 4)
     args.rank_lora = args.rank_lora or (16 if sdxl else 8)
     torch.manual_seed(114514)                      # same weights on every rank (train_base.yaml:5)
@@ -155,16 +157,36 @@ def main():
                            train_cfg=[dict(layers=[""], lr=1e-6)])
         torch.manual_seed(114514 + rank)
     else:
+        text_encoder = None
+        if te:                                     # CLIP-L text encoder (cfgs/te_struct.txt), random init, lora_text_encoder rank 4 lr 1e-5
+            from hcp_diffusion_amd.text_encoder import NativeCLIPTextModel
+            with torch.device("meta"):
+                text_encoder = NativeCLIPTextModel()
+            text_encoder = text_encoder.to_empty(device=dev)
+            with torch.no_grad():
+                for name, p in text_encoder.named_parameters():
+                    if "embedding" in name:
+                        p.normal_(0, 0.02)
+                    elif p.dim() > 1:
+                        p.normal_(0, p[0].numel() ** -0.5)
+                    elif "norm" in name and name.endswith("weight"):
+                        p.fill_(1.0)
+                    else:
+                        p.zero_()
         tr = NativeTrainer(unet, [dict(layers=LORA_PATTERNS, rank=args.rank_lora, lr=1e-4)], lr=1e-4, weight_decay=1e-3,
                            scale_lr_factor=args.batch * world, use_graph=not args.no_graph, overlap_wgrad=args.overlap,
-                           grouped_wgrad=not args.no_grouped_wgrad)
+                           grouped_wgrad=not args.no_grouped_wgrad, text_encoder=text_encoder,
+                           lora_te_cfg=[dict(layers=[r"re:.*self_attn$", r"re:.*mlp$"], rank=4, lr=1e-5)] if te else None)
         torch.manual_seed(114514 + rank)           # set_seed(seed + local_rank), train_ac.py:128
+        buckets = [tr.bucket] + ([tr.te_bucket] if te else [])
         with torch.no_grad():                      # non-zero W_up so every LoRA path carries signal
-            for blk in tr.bucket.blocks:
-                blk.layer.W_up.normal_(0, 0.02)
-        if world > 1:                              # identical LoRA init on every rank (DDP broadcasts rank 0's)
-            torch.distributed.broadcast(tr.bucket.params, 0)
-        tr.bucket.pack()
+            for bk in buckets:
+                for blk in bk.blocks:
+                    blk.layer.W_up.normal_(0, 0.02)
+        for bk in buckets:
+            if world > 1:                          # identical LoRA init on every rank (DDP broadcasts rank 0's)
+                torch.distributed.broadcast(bk.params, 0)
+            bk.pack()
     B = args.batch
     added = None
     if sdxl:                                       # [2,4,128,128], ctx [2,77,2048], pooled [2,1280], crop_info [2,6]
@@ -176,17 +198,23 @@ def main():
         latents = torch.randn(B, 4, 64, 64, device=dev)
         ehs = torch.randn(B, 77, 768, device=dev).to(torch.bfloat16)
 
+    prompt_ids = None
+    if te:                                         # random token ids in [0, 49407], BOS / EOS at the ends; no precomputed states
+        prompt_ids = torch.randint(0, 49406, (B, 77), device=dev)
+        prompt_ids[:, 0] = 49406; prompt_ids[:, -1] = 49407
+        ehs = None
+
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        tr.train_one_step(latents, ehs, None, added, plugin_input)
+        tr.train_one_step(latents, ehs, None, added, plugin_input, prompt_ids)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tr.train_one_step(latents, ehs, None, added, plugin_input)
+        loss = tr.train_one_step(latents, ehs, None, added, plugin_input, prompt_ids)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev)
@@ -200,6 +228,7 @@ def main():
             "metric": ("training images/sec (whole node), SDXL LoRA 1024px bs=%d/GPU" % B) if sdxl else
                       ("training images/sec (whole node), SD1.5 full fine-tune (DreamBooth) 512px bs=%d/GPU" % B) if fullft else
                       ("training images/sec (whole node), SD1.5 + ControlNet branch training 512px bs=%d/GPU" % B) if cnet else
+                      ("training images/sec (whole node), SD1.5 LoRA on UNet + text encoder 512px bs=%d/GPU" % B) if te else
                       "training images/sec (whole node), SD1.5 LoRA 512px bs=4/GPU", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -209,6 +238,9 @@ def main():
                                     "512x512, 77-token context, random-init weights, cached latents, grad-ckpt off" % B if fullft else
                                     "frozen SD1.5 UNet + trainable ControlNet branch (361 M params, fp32 masters + AdamW), bf16 compute, "
                                     "bs=%d/GPU, 512x512 + control image [B,3,512,512], random-init weights, grad-ckpt off" % B if cnet else
+                                    "SD1.5 UNet LoRA rank=%d + CLIP-L text-encoder LoRA rank=4 (prompt encoded inside the step, gradient through "
+                                    "the cross-attention K/V projections), bf16, bs=%d/GPU, 512x512, random-init weights, cached latents, "
+                                    "grad-ckpt off" % (args.rank_lora, B) if te else
                                     "SD1.5 UNet LoRA rank=%d bf16, bs=%d/GPU, 512x512 (64x64 latents), 77-token context, "
                                     "random-init weights, cached latents, grad-ckpt off" % (args.rank_lora, B)),
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
