@@ -304,7 +304,7 @@ def minsnr_reference_vectors():
             per = crit(pr.float(), target.float(), t)                        # train_ac.py:510
             loss = (per * mask).mean()
             loss.backward()
-            out["cases"][(kind, gamma)] = dict(loss=float(loss), grad=pr.grad.clone(), weight=(per.detach() / ((pred - target) ** 2))[:, 0, 0, 0].clone())
+            out["cases"][(kind, gamma)] = dict(loss=float(loss.detach()), grad=pr.grad.clone(), weight=(per.detach() / ((pred - target) ** 2))[:, 0, 0, 0].clone())
     return out
 
 
