@@ -9,7 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hcp_diffusion_amd import kernels as K
 from hcp_diffusion_amd.trainer import NativeTrainer
 from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
-from oracle.unet_sd15 import TINY_CONFIG
+
+TINY_CONFIG = dict(block_out_channels=(80, 160, 160, 160), layers_per_block=1, num_attention_heads=2, cross_attention_dim=64,
+                   norm_num_groups=8)      # a small UNet with the SD1.5 head widths (40 / 80)
 
 dev = torch.device("cuda:0")
 PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
