@@ -13,7 +13,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
 
 
+class _Both:
+    """UNet + text-encoder LoRA buckets seen as one flat vector (mode 'lora_te')."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    grads = property(lambda self: torch.cat([self.a.grads, self.b.grads]))
+    params = property(lambda self: torch.cat([self.a.params, self.b.params]))
+
+
 def _bucket(tr):
+    if getattr(tr, "te_bucket", None) is not None:
+        return _Both(tr.bucket, tr.te_bucket)
     return tr.bucket if tr.bucket is not None else tr.host_buckets[0].bucket
 
 
@@ -27,12 +39,22 @@ def _make(tiny_cfg, mode="lora"):
     nat.load_state_dict(ora.state_dict())
     if mode == "fullft":                           # DreamBooth.yaml:6-10: every UNet parameter, one 3.4 GB-class bucket
         return NativeTrainer(nat, None, lr=1e-2, train_cfg=[dict(layers=[""])])
-    tr = NativeTrainer(nat, [dict(layers=PATS, rank=4)], lr=1e-2)
+    te = None
+    if mode == "lora_te":                          # lora_conventional.yaml as shipped: lora_unet + lora_text_encoder, two buckets
+        from hcp_diffusion_amd.text_encoder import NativeCLIPTextModel
+        from oracle.clip_ref import OracleCLIPTextModel
+        tcfg = dict(vocab_size=100, hidden_size=tiny_cfg["cross_attention_dim"], intermediate_size=128, num_hidden_layers=2,
+                    num_attention_heads=1, max_position_embeddings=77)
+        te = NativeCLIPTextModel(**tcfg)
+        te.load_state_dict(seeded_init_(OracleCLIPTextModel(**tcfg), 2).state_dict())
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=4)], lr=1e-2, text_encoder=te,
+                       lora_te_cfg=[dict(layers=[r"re:.*self_attn$", r"re:.*mlp$"], rank=4)] if te is not None else None)
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
-        for blk in tr.bucket.blocks:
-            blk.layer.W_up.copy_(torch.randn(blk.layer.W_up.shape, generator=g) * 0.05)
-    tr.bucket.pack()
+        for bk in [tr.bucket] + ([tr.te_bucket] if te is not None else []):
+            for blk in bk.blocks:
+                blk.layer.W_up.copy_(torch.randn(blk.layer.W_up.shape, generator=g) * 0.05)
+            bk.pack()
     return tr
 
 
@@ -42,20 +64,31 @@ def _data():
             torch.tensor([20, 700]))
 
 
+def _cfg(mode):
+    from oracle.unet_sd15 import MICRO_CONFIG      # two-level miniature: the DP contract does not need depth
+    return dict(MICRO_CONFIG, cross_attention_dim=64) if mode == "lora_te" else MICRO_CONFIG
+
+
+def _step(tr, x0, ehs, mode, sl=slice(None)):
+    if mode == "lora_te":                          # the prompt is encoded inside the step
+        ids = torch.randint(0, 100, (2, 77), generator=torch.Generator().manual_seed(3))
+        return tr.forward_backward(x0[sl].contiguous(), None, prompt_ids=ids[sl].contiguous())
+    return tr.forward_backward(x0[sl].contiguous(), ehs[sl].contiguous())
+
+
 def _worker(rank, world, port, out, mode):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from conftest import emu_cdll
     from hcp_diffusion_amd import kernels as K
-    from oracle.unet_sd15 import MICRO_CONFIG as TINY_CONFIG      # two-level miniature: the DP contract does not need depth
     K._set_backend_for_tests(emu_cdll())
-    tr = _make(TINY_CONFIG, mode)
+    tr = _make(_cfg(mode), mode)
     assert tr.world == world
     x0, ehs, noise, t = _data()
     sl = slice(rank, rank + 1)                     # rank r gets sample r of the global batch (strided sampler shard)
     tr.make_noise = lambda lat: (K.add_noise(lat, noise[sl], t[sl], tr.acp), noise[sl], t[sl])
-    tr.forward_backward(x0[sl].contiguous(), ehs[sl].contiguous())
+    _step(tr, x0, ehs, mode, sl)
     tr.all_reduce()
     g = _bucket(tr).grads.clone() / world
     tr.optimizer_step()
@@ -65,9 +98,9 @@ def _worker(rank, world, port, out, mode):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("mode", ["lora", "fullft"])
+@pytest.mark.parametrize("mode", ["lora", "fullft", "lora_te"])
 def test_two_rank_gloo_matches_single_process(tmp_path, mode):
-    port = 29500 + os.getpid() % 2000 + (7 if mode == "fullft" else 0)
+    port = 29500 + os.getpid() % 2000 + {"lora": 0, "fullft": 7, "lora_te": 13}[mode]
     mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["params"], r1["params"])
@@ -75,13 +108,12 @@ def test_two_rank_gloo_matches_single_process(tmp_path, mode):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import emu_cdll
     from hcp_diffusion_amd import kernels as K
-    from oracle.unet_sd15 import MICRO_CONFIG as TINY_CONFIG      # two-level miniature: the DP contract does not need depth
     K._set_backend_for_tests(emu_cdll())
     try:
-        tr = _make(TINY_CONFIG, mode)
+        tr = _make(_cfg(mode), mode)
         x0, ehs, noise, t = _data()
         tr.make_noise = lambda lat: (K.add_noise(lat, noise, t, tr.acp), noise, t)
-        tr.forward_backward(x0, ehs)
+        _step(tr, x0, ehs, mode)
         g = _bucket(tr).grads.clone()
         tr.optimizer_step()
         cos = torch.nn.functional.cosine_similarity(g, r0["grads"], dim=0).item()
