@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="LoRA wgrad kernels on a side stream (measured slower)")
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="one wgrad launch per layer instead of one grouped launch")
+    ap.add_argument("--grad-ckpt", action="store_true", help="enable_gradient_checkpointing() as the reference defaults to "
+                    "(train_base.yaml:69): +1 forward per step; a secondary line, the headline runs without (288 GB HBM)")
     ap.add_argument("--gn-target", type=int, default=None, help="A/B only: hcp_debug_set_gn_target (workgroups a GroupNorm launch aims for)")
     args = ap.parse_args()
 
@@ -141,6 +143,8 @@ def main():
                 p.fill_(1.0)
             else:
                 p.zero_()
+    if args.grad_ckpt:
+        unet.enable_gradient_checkpointing()
     plugin_input = None
     if cnet:                                       # cfgs/plugins/plugin_controlnet.yaml: frozen host + trainable branch, lr 1e-4
         from hcp_diffusion_amd.controlnet import make_controlnet
@@ -243,7 +247,8 @@ def main():
                                     "grad-ckpt off" % (args.rank_lora, B) if te else
                                     "SD1.5 UNet LoRA rank=%d bf16, bs=%d/GPU, 512x512 (64x64 latents), 77-token context, "
                                     "random-init weights, cached latents, grad-ckpt off" % (args.rank_lora, B)),
-                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                       "gradient_checkpointing": bool(args.grad_ckpt)},
             "final_loss": round(loss_v, 5),
             "step_mfma_frac": round(ips / world * (FLOP_PER_IMAGE_SDXL_LORA_NOCKPT if sdxl else FLOP_PER_IMAGE_FULLFT_NOCKPT if fullft
                                                    else FLOP_PER_IMAGE_CNET_NOCKPT if cnet
