@@ -54,6 +54,22 @@ def test_tiny_forward_vs_oracle_and_golden(backend):
     assert ((yn - yo).norm() / yo.norm()).item() < 2e-2
 
 
+@pytest.mark.parametrize("B,h,w,L", [(1, 8, 12, 77), (3, 12, 8, 9), (2, 16, 8, 154), (1, 96, 64, 77)])
+def test_forward_ragged_shapes_vs_oracle(backend, B, h, w, L):
+    """Aspect-ratio buckets give non-square latents (data/bucket.py), batch sizes of 1 and odd counts, prompts of 1 / N x 77 tokens
+    (tokenizer_repeats): the native forward against the oracle on shapes that are not multiples of any tile size."""
+    if not backend.is_gpu and h * w > 200:
+        pytest.skip("large shape: GPU only")
+    ora, nat = _pair(MICRO_CONFIG, backend.device)
+    g = torch.Generator().manual_seed(h * w + L)
+    x = torch.randn(B, 4, h, w, generator=g); t = torch.randint(0, 1000, (B,), generator=g); ehs = torch.randn(B, L, 32, generator=g)
+    with torch.no_grad():
+        yo = ora(x, t, ehs).sample
+        yn = nat(backend.to(x), backend.to(t), backend.to(ehs)).sample.cpu()
+    assert yn.shape == yo.shape == (B, 4, h, w)
+    assert ((yn - yo).norm() / yo.norm()).item() < 2e-2
+
+
 def test_tiny_forward_with_encoder_attention_mask(backend):
     """The call contract's `encoder_attention_mask=[B,L]` (models/wrapper.py:22-29; the reference pads L to a multiple of 8)."""
     ora, nat = _pair(TINY_CONFIG, backend.device)
