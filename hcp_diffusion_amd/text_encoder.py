@@ -38,9 +38,9 @@ class CLIPAttention(nn.Module):
         self.k_proj = HipLinear(c, c); self.v_proj = HipLinear(c, c); self.q_proj = HipLinear(c, c); self.out_proj = HipLinear(c, c)
         self.heads = heads
 
-    def forward(self, x, residual):
+    def forward(self, x, residual, key_bias=None):
         q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
-        return _call(self.out_proj, ops.attention(q, k, v, self.heads, causal=True), residual)
+        return _call(self.out_proj, ops.attention(q, k, v, self.heads, key_bias=key_bias, causal=True), residual)
 
 
 class CLIPMLP(nn.Module):
@@ -60,9 +60,9 @@ class CLIPEncoderLayer(nn.Module):
         self.mlp = CLIPMLP(c, inner)
         self.layer_norm2 = HipLayerNorm(c, eps=1e-5)
 
-    def forward(self, x):
+    def forward(self, x, key_bias=None):
         h, x = self.layer_norm1(x, fork=True)                 # fork: backward adds the residual-path gradient inside the LN kernel
-        x = self.self_attn(h, x)                              # residual add fused into the out_proj GEMM epilogue
+        x = self.self_attn(h, x, key_bias)                    # residual add fused into the out_proj GEMM epilogue
         h, x = self.layer_norm2(x, fork=True)
         return self.mlp(h, x)
 
@@ -103,20 +103,23 @@ class NativeCLIPTextModel(nn.Module):
         return self.text_model.final_layer_norm.weight.device
 
     def forward(self, input_ids, position_ids=None, attention_mask=None):
-        """int64 [B, L] token ids -> bf16 [B, L, C] conditioning states (TEEXHook's selection, N_repeats = 1)."""
-        if attention_mask is not None:
-            raise NotImplementedError("hcp_diffusion_amd: the text encoder takes no attention_mask (reference default "
-                                      "encoder_attention_mask: False); the UNet side supports it")
+        """int64 [B, L] token ids -> bf16 [B, L, C] conditioning states (TEEXHook's selection, N_repeats = 1).  attention_mask
+        [B, L] (1 = attend) is combined with the causal mask like transformers' CLIPTextTransformer does; token 0 must stay visible."""
         tm = self.text_model
         if input_ids.dim() != 2 or input_ids.shape[1] > self.config["max_position_embeddings"]:
             raise ValueError(f"expected token ids [B, L <= {self.config['max_position_embeddings']}], got {tuple(input_ids.shape)}")
+        if attention_mask is not None and tuple(attention_mask.shape) != tuple(input_ids.shape):
+            raise ValueError(f"attention_mask {tuple(attention_mask.shape)} does not match input_ids {tuple(input_ids.shape)}")
         emb = tm.embeddings
         if torch.is_grad_enabled() and (emb.token_embedding.weight.requires_grad or emb.position_embedding.weight.requires_grad):
             raise NotImplementedError("hcp_diffusion_amd: training the embedding tables (prompt tuning) is not implemented")
         x = K.embedding(emb.token_embedding.weight.detach(), input_ids.contiguous(), emb.position_embedding.weight.detach(), position_ids)
+        key_bias = None
+        if attention_mask is not None:       # [B, L], 1 = attend (wrapper.py:20 passes the tokenizer's mask when encoder_attention_mask is on)
+            key_bias = ((1.0 - attention_mask.to(torch.float32)) * -1.0e9).contiguous()       # additive on the keys, on top of the causal mask
         layers = tm.encoder.layers
         for layer in layers[:len(layers) - self.clip_skip]:
-            x = layer(x)
+            x = layer(x, key_bias)
         return tm.final_layer_norm(x) if self.clip_final_norm else x
 
     @classmethod

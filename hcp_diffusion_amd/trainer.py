@@ -129,20 +129,24 @@ class NativeTrainer:
         t = torch.randint(0, self.num_train_timesteps, (latents.shape[0],), device=latents.device).long()
         return K.add_noise(latents, noise, t, self.acp), noise, t
 
-    def forward_backward(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None, plugin_input=None, prompt_ids=None):
+    def forward_backward(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None, plugin_input=None, prompt_ids=None,
+                         attn_mask=None):
+        """attn_mask: the batch's ``attn_mask`` [B, L] (train_ac.py:473; wrapper.py:20,29 hands it to the text encoder as
+        attention_mask and to the UNet as encoder_attention_mask)."""
         noisy, noise, t = self.make_noise(latents)
         if encoder_hidden_states is None:                                 # wrapper.py:20: the prompt is encoded inside the step
             if self.text_encoder is None or prompt_ids is None:
                 raise ValueError("a batch needs encoder_hidden_states, or prompt_ids together with a text_encoder")
             with torch.set_grad_enabled(self.te_bucket is not None):
-                encoder_hidden_states = self.text_encoder(prompt_ids)
+                encoder_hidden_states = self.text_encoder(prompt_ids, attention_mask=attn_mask)
         if plugin_input:                                                  # wrapper.py:15,25-28: feeders see the batch dict
             for feeder in getattr(self.unet, "input_feeder", []):
                 feeder(dict(noisy_latents=noisy, timesteps=t, encoder_hidden_states=encoder_hidden_states, **plugin_input))
+        kw = {"encoder_attention_mask": attn_mask} if attn_mask is not None else {}
         if added_cond_kwargs:                                             # SDXL: wrapper.py:66-73
-            pred = self.unet(noisy, t, encoder_hidden_states, added_cond_kwargs=added_cond_kwargs).sample
+            pred = self.unet(noisy, t, encoder_hidden_states, added_cond_kwargs=added_cond_kwargs, **kw).sample
         else:
-            pred = self.unet(noisy, t, encoder_hidden_states).sample      # wrapper.py:29
+            pred = self.unet(noisy, t, encoder_hidden_states, **kw).sample      # wrapper.py:29
         sw = K.snr_loss_weight(t, self.acp, self.loss_kind, self.loss_gamma) if self.loss_kind else None
         loss, grad = K.mse_masked_mean(pred.detach(), noise, mask, weight=self.loss_weight, sample_weight=sw)    # loss.type == 'eps'
         ops.enable_wgrad_side_stream(self.overlap_wgrad)
@@ -258,7 +262,7 @@ class NativeTrainer:
                 keep, self.loss_weight = self.loss_weight, self.loss_weight * lw
                 try:
                     l = self.forward_backward(b["latents"], b.get("encoder_hidden_states"), b.get("mask"), b.get("added_cond_kwargs"),
-                                              b.get("plugin_input"), b.get("prompt_ids"))
+                                              b.get("plugin_input"), b.get("prompt_ids"), b.get("attn_mask"))
                 finally:
                     self.loss_weight = keep
                 self.loss = l if self.loss is None else self.loss + l
@@ -291,7 +295,7 @@ class NativeTrainer:
                 keep, self.loss_weight = self.loss_weight, self.loss_weight * lw
                 try:
                     l = self.forward_backward(sb["latents"], sb.get("encoder_hidden_states"), sb.get("mask"), sb.get("added_cond_kwargs"),
-                                              sb.get("plugin_input"), sb.get("prompt_ids"))
+                                              sb.get("plugin_input"), sb.get("prompt_ids"), sb.get("attn_mask"))
                 finally:
                     self.loss_weight = keep
                 total = l if total is None else total + l

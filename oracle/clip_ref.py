@@ -27,11 +27,13 @@ class CLIPAttention(nn.Module):
         self.k_proj = nn.Linear(c, c); self.v_proj = nn.Linear(c, c); self.q_proj = nn.Linear(c, c); self.out_proj = nn.Linear(c, c)
         self.heads = heads
 
-    def forward(self, x):
+    def forward(self, x, attention_mask=None):
         B, L, C = x.shape
         d = C // self.heads
         q, k, v = (p(x).view(B, L, self.heads, d).transpose(1, 2) for p in (self.q_proj, self.k_proj, self.v_proj))
         s = q @ k.transpose(-1, -2) * d ** -0.5
+        if attention_mask is not None:                       # [B, L], 1 = attend: additive on the keys, on top of the causal mask
+            s = s + ((1.0 - attention_mask.to(s.dtype)) * torch.finfo(s.dtype).min)[:, None, None, :]
         s = s.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool, device=x.device), 1), float("-inf"))
         return self.out_proj((torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, L, C))
 
@@ -54,8 +56,8 @@ class CLIPEncoderLayer(nn.Module):
         self.mlp = CLIPMLP(c, inner)
         self.layer_norm2 = nn.LayerNorm(c, eps=1e-5)
 
-    def forward(self, x):
-        x = x + self.self_attn(self.layer_norm1(x))
+    def forward(self, x, attention_mask=None):
+        x = x + self.self_attn(self.layer_norm1(x), attention_mask)
         return x + self.mlp(self.layer_norm2(x))
 
 
@@ -86,19 +88,19 @@ class OracleCLIPTextModel(nn.Module):
         self.config = {**CLIP_L_CONFIG, **cfg}
         self.text_model = _TextTransformer(**self.config)
 
-    def hidden_states(self, input_ids, position_ids=None):
+    def hidden_states(self, input_ids, position_ids=None, attention_mask=None):
         tm = self.text_model
         L = input_ids.shape[-1]
         pos = position_ids if position_ids is not None else torch.arange(L, device=input_ids.device)[None]
         x = tm.embeddings.token_embedding(input_ids) + tm.embeddings.position_embedding(pos)
         hs = [x]
         for layer in tm.encoder.layers:
-            x = layer(x)
+            x = layer(x, attention_mask)
             hs.append(x)
         return hs
 
-    def encode(self, input_ids, position_ids=None, clip_skip=0, final_norm=True):
-        h = self.hidden_states(input_ids, position_ids)[-clip_skip - 1]
+    def encode(self, input_ids, position_ids=None, clip_skip=0, final_norm=True, attention_mask=None):
+        h = self.hidden_states(input_ids, position_ids, attention_mask)[-clip_skip - 1]
         return self.text_model.final_layer_norm(h) if final_norm else h
 
     def forward(self, input_ids, position_ids=None):

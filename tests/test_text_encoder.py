@@ -51,6 +51,10 @@ def test_oracle_matches_installed_transformers_clip():
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
         assert torch.allclose(out.last_hidden_state, ours.encode(ids), rtol=1e-4, atol=1e-5)
         assert torch.allclose(ours.text_model.final_layer_norm(out.hidden_states[-2]), ours.encode(ids, clip_skip=1), rtol=1e-4, atol=1e-5)
+        mask = torch.ones(3, 77, dtype=torch.long); mask[0, 41:] = 0; mask[2, 60:] = 0          # padding masked out (tokenizer attention_mask)
+        masked = theirs(input_ids=ids, attention_mask=mask).last_hidden_state
+        assert torch.allclose(masked, ours.encode(ids, attention_mask=mask), rtol=1e-4, atol=1e-5)
+        assert not torch.allclose(masked[0], out.last_hidden_state[0], atol=1e-3)
 
 
 def _pair(dev, seed=5, **kw):
@@ -70,8 +74,13 @@ def test_tiny_text_encoder_forward_vs_oracle(backend, clip_skip):
         out = nat(backend.to(ids)).float().cpu()
     assert out.shape == ref.shape
     assert ((out - ref).norm() / ref.norm()).item() < 2e-2
-    with pytest.raises(NotImplementedError):
-        nat(backend.to(ids), attention_mask=torch.ones(2, 77))
+    mask = torch.ones(2, 77); mask[0, 50:] = 0
+    with torch.no_grad():
+        refm = ora.encode(ids, clip_skip=clip_skip, attention_mask=mask)
+        outm = nat(backend.to(ids), attention_mask=backend.to(mask)).float().cpu()
+    assert ((outm - refm).norm() / refm.norm()).item() < 2e-2 and ((refm - ref).norm() / ref.norm()).item() > 1e-2
+    with pytest.raises(ValueError):
+        nat(backend.to(ids), attention_mask=torch.ones(2, 70))
 
 
 def test_tiny_text_encoder_lora_gradients_vs_oracle(backend):
@@ -106,7 +115,8 @@ def test_tiny_text_encoder_lora_gradients_vs_oracle(backend):
     assert (gn.norm() / go.norm()).item() == pytest.approx(1.0, abs=3e-2)
 
 
-def test_unet_plus_text_encoder_lora_step_vs_oracle(backend):
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_unet_plus_text_encoder_lora_step_vs_oracle(backend, with_mask):
     """The reference's default LoRA example (lora_unet + lora_text_encoder, lora_conventional.yaml:7-19): the prompt is encoded
     inside the step, the UNet's cross-attention K/V projections hand a gradient back to the encoder's LoRA blocks, and ONE
     global-norm clip covers both buckets (train_ac.py:485-490).  Loss, both gradient sets and the updated parameters vs the
@@ -135,11 +145,14 @@ def test_unet_plus_text_encoder_lora_step_vs_oracle(backend):
     tr.bucket.pack(); tr.te_bucket.pack()
     x0 = torch.randn(2, 4, 8, 8, generator=gen); noise = torch.randn(2, 4, 8, 8, generator=gen)
     t = torch.tensor([100, 800]); ids = torch.randint(0, 100, (2, 77), generator=gen)
-    pred = ou(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ot.encode(ids)).sample
+    amask = None
+    if with_mask:                                    # the batch's attn_mask goes to BOTH models (wrapper.py:20,29)
+        amask = torch.ones(2, 77); amask[0, 30:] = 0; amask[1, 70:] = 0
+    pred = ou(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ot.encode(ids, attention_mask=amask), encoder_attention_mask=amask).sample
     lo = F.mse_loss(pred, noise)
     lo.backward()
     tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
-    ln = tr.forward_backward(x0.to(dev), None, prompt_ids=ids.to(dev))
+    ln = tr.forward_backward(x0.to(dev), None, prompt_ids=ids.to(dev), attn_mask=amask.to(dev) if with_mask else None)
     assert abs(lo.item() - ln.item()) / lo.item() < 2e-2
 
     def flat(wr, group, grads):
