@@ -11,7 +11,8 @@ Same module tree, parameter names and shapes as transformers' ``CLIPTextModel`` 
 LoRA blocks are the UNet's own ``LoraHipLayer`` (one flat bucket, grouped weight-gradient launch, fused clip + AdamW).
 Kernels: ``hcp_embedding_bf16``, LayerNorm, fused-LoRA GEMM, flash attention with ``causal=1`` (12 x 64 heads, 77 tokens),
 ``hcp_quick_gelu``.  Output selection follows ``TEEXHook.forward_hook`` (textencoder_ex.py:62-79) for N_repeats = 1:
-``final_layer_norm(hidden_states[-clip_skip-1])``.
+``final_layer_norm(hidden_states[-clip_skip-1])``; ``N_repeats`` > 1 (``tokenizer_repeats``) encodes [B, r x 77] ids as B r prompts and stitches
+the chunks back with one BOS and one EOS, as the hook does.
 """
 import json
 import os
@@ -89,14 +90,14 @@ class _TextTransformer(nn.Module):
 
 
 class NativeCLIPTextModel(nn.Module):
-    def __init__(self, clip_skip=0, clip_final_norm=True, **cfg):
+    def __init__(self, clip_skip=0, clip_final_norm=True, N_repeats=1, **cfg):
         super().__init__()
         keys = tuple(CLIP_L_CONFIG)
         self.config = {**CLIP_L_CONFIG, **{k: v for k, v in cfg.items() if k in keys}}
         if self.config["hidden_size"] // self.config["num_attention_heads"] not in (40, 64, 80, 160):
             raise NotImplementedError("hcp_diffusion_amd: text-encoder head width must be one of 40/64/80/160")
         self.text_model = _TextTransformer(**self.config)
-        self.clip_skip, self.clip_final_norm = clip_skip, clip_final_norm
+        self.clip_skip, self.clip_final_norm, self.N_repeats = clip_skip, clip_final_norm, N_repeats
 
     @property
     def device(self):
@@ -106,6 +107,13 @@ class NativeCLIPTextModel(nn.Module):
         """int64 [B, L] token ids -> bf16 [B, L, C] conditioning states (TEEXHook's selection, N_repeats = 1).  attention_mask
         [B, L] (1 = attend) is combined with the causal mask like transformers' CLIPTextTransformer does; token 0 must stay visible."""
         tm = self.text_model
+        B, r = input_ids.shape[0], self.N_repeats
+        if r > 1:                                                 # TEEXHook.forward_hook_input (textencoder_ex.py:57-59): 'b (r w) -> (b r) w'
+            if input_ids.dim() != 2 or input_ids.shape[1] % r:
+                raise ValueError(f"token ids [B, {r} x L] expected for N_repeats={r}, got {tuple(input_ids.shape)}")
+            input_ids = input_ids.reshape(B * r, -1)
+            attention_mask = attention_mask.reshape(B * r, -1) if attention_mask is not None else None
+            position_ids = position_ids.reshape(B * r, -1) if position_ids is not None else None
         if input_ids.dim() != 2 or input_ids.shape[1] > self.config["max_position_embeddings"]:
             raise ValueError(f"expected token ids [B, L <= {self.config['max_position_embeddings']}], got {tuple(input_ids.shape)}")
         if attention_mask is not None and tuple(attention_mask.shape) != tuple(input_ids.shape):
@@ -120,7 +128,11 @@ class NativeCLIPTextModel(nn.Module):
         layers = tm.encoder.layers
         for layer in layers[:len(layers) - self.clip_skip]:
             x = layer(x, key_bias)
-        return tm.final_layer_norm(x) if self.clip_final_norm else x
+        x = tm.final_layer_norm(x) if self.clip_final_norm else x
+        if r > 1:       # textencoder_ex.py:68-72: one BOS (first chunk), every chunk's inner tokens, one EOS (last chunk) -> [B, r*(L-2)+2, C]
+            x = x.reshape(B, r, *x.shape[1:])
+            x = torch.cat([x[:, 0, :1, :], x[:, :, 1:-1, :].flatten(1, 2), x[:, -1, -1:, :]], dim=1)
+        return x
 
     @classmethod
     def from_pretrained(cls, path, subfolder="text_encoder", device="cuda", **kw):

@@ -99,9 +99,20 @@ class OracleCLIPTextModel(nn.Module):
             hs.append(x)
         return hs
 
-    def encode(self, input_ids, position_ids=None, clip_skip=0, final_norm=True, attention_mask=None):
+    def encode(self, input_ids, position_ids=None, clip_skip=0, final_norm=True, attention_mask=None, n_repeats=1):
+        """TEEXHook (textencoder_ex.py:57-72): ids [B, r*77] are encoded as B*r prompts of 77 tokens (forward_hook_input :57-59), the
+        selected hidden state goes through final_layer_norm (:63-65), then the r chunks are stitched back together keeping ONE BOS
+        (first chunk) and ONE EOS (last chunk): [B, r*75 + 2, C] (:68-72)."""
+        B = input_ids.shape[0]
+        if n_repeats > 1:
+            input_ids = input_ids.reshape(B * n_repeats, -1)
+            attention_mask = attention_mask.reshape(B * n_repeats, -1) if attention_mask is not None else None
         h = self.hidden_states(input_ids, position_ids, attention_mask)[-clip_skip - 1]
-        return self.text_model.final_layer_norm(h) if final_norm else h
+        h = self.text_model.final_layer_norm(h) if final_norm else h
+        if n_repeats > 1:
+            h = h.reshape(B, n_repeats, *h.shape[1:])
+            h = torch.cat([h[:, 0, :1, :], h[:, :, 1:-1, :].flatten(1, 2), h[:, -1, -1:, :]], dim=1)
+        return h
 
     def forward(self, input_ids, position_ids=None):
         return self.encode(input_ids, position_ids)

@@ -83,6 +83,25 @@ def test_tiny_text_encoder_forward_vs_oracle(backend, clip_skip):
         nat(backend.to(ids), attention_mask=torch.ones(2, 70))
 
 
+def test_text_encoder_prompt_repeats(backend):
+    """tokenizer_repeats = 2 (TEEXHook, textencoder_ex.py:57-72): [B, 2 x 77] ids -> [B, 2 x 75 + 2, C] with one BOS and one EOS;
+    the native model against the oracle restatement, and the stitching against its definition."""
+    ora, _ = _pair(backend.device)
+    nat = NativeCLIPTextModel(**TINY_CLIP_CONFIG, N_repeats=2)
+    nat.load_state_dict(ora.state_dict()); nat.to(backend.device)
+    g = torch.Generator().manual_seed(8)
+    ids = torch.randint(0, 100, (2, 154), generator=g)
+    with torch.no_grad():
+        ref = ora.encode(ids, n_repeats=2)
+        parts = ora.encode(ids.reshape(4, 77)).reshape(2, 2, 77, -1)
+        out = nat(backend.to(ids)).float().cpu()
+    assert ref.shape == out.shape == (2, 152, 128)
+    assert torch.equal(ref[:, 0], parts[:, 0, 0]) and torch.equal(ref[:, -1], parts[:, 1, -1]) and torch.equal(ref[:, 76], parts[:, 1, 1])
+    assert ((out - ref).norm() / ref.norm()).item() < 2e-2
+    with pytest.raises(ValueError):
+        nat(backend.to(ids[:, :153]))
+
+
 def test_tiny_text_encoder_lora_gradients_vs_oracle(backend):
     """lora_text_encoder (rank 4 on self_attn + mlp Linears): gradients of a scalar loss on the conditioning states w.r.t. every
     W_down / W_up vs autograd through the oracle + the reference's LoRA restatement (cosine >= 0.995)."""
