@@ -200,3 +200,37 @@ def test_ckpt_fixture_is_reproducible_from_reference(tmp_path):
     assert set(new) == set(old) == {"lora"} and set(new["lora"]) == set(old["lora"])
     assert all(torch.equal(new["lora"][k], old["lora"][k]) for k in old["lora"])
     assert torch.equal(torch.load(tmp_path / "ref_lora_ckpt_expect.pt")["pred"], torch.load(os.path.join(GOLD, "ref_lora_ckpt_expect.pt"))["pred"])
+
+
+def test_text_encoder_lora_ckpt_round_trip(backend, tmp_path):
+    """Trainer.save_model writes the text encoder's LoRA to its own ``text_encoder-{step}`` file (train_ac.py:529-533); the loader
+    rebuilds the blocks on a fresh encoder and the conditioning states are bit-identical."""
+    from hcp_diffusion_amd.text_encoder import NativeCLIPTextModel
+    from oracle.clip_ref import OracleCLIPTextModel
+    tcfg = dict(vocab_size=100, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=1, max_position_embeddings=77)
+    tcfg["hidden_size"] = 64                                            # one 64-wide head; MICRO UNet with a matching context width
+    ucfg = dict(MICRO_CONFIG, cross_attention_dim=64)
+    te_sd = seeded_init_(OracleCLIPTextModel(**tcfg), 2).state_dict()
+    def fresh_te():
+        m = NativeCLIPTextModel(**tcfg); m.load_state_dict(te_sd); return m.to(backend.device)
+    nat = seeded_init_(NativeUNet2DConditionModel(**ucfg), 1).to(backend.device)
+    te = fresh_te()
+    te_cfg = [dict(layers=[r"re:.*self_attn$", r"re:.*mlp$"], rank=4, alpha=2.0)]
+    tr = NativeTrainer(nat, [dict(layers=[r"re:.*\.attn.?$"], rank=4)], lr=1e-3, text_encoder=te, lora_te_cfg=te_cfg)
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for blk in tr.te_bucket.blocks:
+            blk.layer.W_up.copy_(torch.randn(blk.layer.W_up.shape, generator=g) * 0.05)
+    tr.te_bucket.pack()
+    mgr = CkptManagerNative()
+    mgr.set_save_dir(str(tmp_path))
+    paths = tr.save_model(mgr, step=9)
+    assert [os.path.basename(p) for p in paths] == ["unet-9.safetensors", "text_encoder-9.safetensors"]
+    sd = mgr.load_ckpt(paths[1])["lora"]
+    assert len(sd) == 2 * 6 * 3 and "text_model.encoder.layers.1.mlp.fc2.___.layer.W_up" in sd
+    te2 = fresh_te()
+    te2.requires_grad_(False)
+    group, _ = NativeModelLoader(te2).load_lora([dict(path=paths[1], alpha=2.0)])
+    ids = backend.to(torch.randint(0, 100, (2, 77), generator=g))
+    with torch.no_grad():
+        assert torch.equal(te(ids), te2(ids))
