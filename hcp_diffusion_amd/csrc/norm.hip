@@ -254,6 +254,10 @@ HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row
+// NV = 16-byte vectors per lane (C <= 512 NV): the row is loaded ONCE into registers — mean, variance and the normalised output
+// (backward: both reductions and dx) come from there; the first version re-read the row from L1/L2 for every pass, three
+// dependent memory round trips per wave for a 640-byte row.
+template <int NV>
 HCP_KERNEL(256) ln_fwd_kernel(const hcp_bf16* x, const float* gamma, const float* beta, hcp_bf16* y, float* stats,
                               int M, int C, float eps) {
     const int lane = threadIdx.x & 63;
@@ -261,37 +265,43 @@ HCP_KERNEL(256) ln_fwd_kernel(const hcp_bf16* x, const float* gamma, const float
     const bool live = row < M;
     const hcp_bf16* xr = x + (size_t)(live ? row : 0) * C;
     const int nch = C / 8;
-    float s = 0.f;
-    for (int j = lane; j < nch; j += 64) {
-        hcp_bf16x8 v = *(const hcp_bf16x8*)(xr + j * 8);
+    hcp_bf16x8 v[NV];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += hcp_bf2f((unsigned short)v[i]);
-    }
+    for (int u = 0; u < NV; ++u) { const int j = lane + 64 * u; v[u] = j < nch ? *(const hcp_bf16x8*)(xr + j * 8) : hcp_zero8(); }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += hcp_bf2f((unsigned short)v[u][i]);
     const float mean = hcp_wave_sum(s) / C;
     float q = 0.f;
-    for (int j = lane; j < nch; j += 64) {
-        hcp_bf16x8 v = *(const hcp_bf16x8*)(xr + j * 8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { float d = hcp_bf2f((unsigned short)v[i]) - mean; q += d * d; }
-    }
+    for (int u = 0; u < NV; ++u)
+        if (lane + 64 * u < nch) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { float d = hcp_bf2f((unsigned short)v[u][i]) - mean; q += d * d; }
+        }
     const float rstd = 1.0f / sqrtf(hcp_wave_sum(q) / C + eps);
     if (!live) return;
     if (lane == 0) { stats[(size_t)row * 2] = mean; stats[(size_t)row * 2 + 1] = rstd; }
     hcp_bf16* yr = y + (size_t)row * C;
-    for (int j = lane; j < nch; j += 64) {
-        hcp_bf16x8 v = *(const hcp_bf16x8*)(xr + j * 8);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int j = lane + 64 * u;
+        if (j >= nch) continue;
         hcp_f32x4 g0 = *(const hcp_f32x4*)(gamma + j * 8), g1 = *(const hcp_f32x4*)(gamma + j * 8 + 4);
         hcp_f32x4 b0 = *(const hcp_f32x4*)(beta + j * 8), b1 = *(const hcp_f32x4*)(beta + j * 8 + 4);
         hcp_bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float g = i < 4 ? g0[i] : g1[i - 4], bb = i < 4 ? b0[i] : b1[i - 4];
-            o[i] = (short)hcp_f2bf((hcp_bf2f((unsigned short)v[i]) - mean) * rstd * g + bb);
+            o[i] = (short)hcp_f2bf((hcp_bf2f((unsigned short)v[u][i]) - mean) * rstd * g + bb);
         }
         *(hcp_bf16x8*)(yr + j * 8) = o;
     }
 }
 
+template <int NV>
 HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float* gamma, const float* stats,
                               const hcp_bf16* addend, hcp_bf16* dx, int M, int C) {
     const int lane = threadIdx.x & 63;
@@ -300,29 +310,39 @@ HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float
     const size_t off = (size_t)(live ? row : 0) * C;
     const float mean = stats[(size_t)(live ? row : 0) * 2], rstd = stats[(size_t)(live ? row : 0) * 2 + 1];
     const int nch = C / 8;
+    hcp_bf16x8 v[NV], d[NV], ad[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int j = lane + 64 * u;
+        const bool ok = j < nch;
+        v[u] = ok ? *(const hcp_bf16x8*)(x + off + j * 8) : hcp_zero8();
+        d[u] = ok ? *(const hcp_bf16x8*)(dy + off + j * 8) : hcp_zero8();                   // dy = 0: padding lanes add nothing
+        ad[u] = (ok && addend) ? *(const hcp_bf16x8*)(addend + off + j * 8) : hcp_zero8();
+    }
     float s1 = 0.f, s2 = 0.f;
-    for (int j = lane; j < nch; j += 64) {
-        hcp_bf16x8 v = *(const hcp_bf16x8*)(x + off + j * 8);
-        hcp_bf16x8 d = *(const hcp_bf16x8*)(dy + off + j * 8);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int j = lane + 64 * u;
+        if (j >= nch) continue;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float xh = (hcp_bf2f((unsigned short)v[i]) - mean) * rstd;
-            float dxh = hcp_bf2f((unsigned short)d[i]) * gamma[j * 8 + i];
+            float xh = (hcp_bf2f((unsigned short)v[u][i]) - mean) * rstd;
+            float dxh = hcp_bf2f((unsigned short)d[u][i]) * gamma[j * 8 + i];
             s1 += dxh; s2 += dxh * xh;
         }
     }
     const float c1 = hcp_wave_sum(s1) / C, c2 = hcp_wave_sum(s2) / C;
     if (!live) return;
-    for (int j = lane; j < nch; j += 64) {
-        hcp_bf16x8 v = *(const hcp_bf16x8*)(x + off + j * 8);
-        hcp_bf16x8 d = *(const hcp_bf16x8*)(dy + off + j * 8);
-        hcp_bf16x8 ad = addend ? *(const hcp_bf16x8*)(addend + off + j * 8) : hcp_zero8();
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int j = lane + 64 * u;
+        if (j >= nch) continue;
         hcp_bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float xh = (hcp_bf2f((unsigned short)v[i]) - mean) * rstd;
-            float dxh = hcp_bf2f((unsigned short)d[i]) * gamma[j * 8 + i];
-            o[i] = (short)hcp_f2bf(rstd * (dxh - c1 - xh * c2) + (addend ? hcp_bf2f((unsigned short)ad[i]) : 0.f));
+            float xh = (hcp_bf2f((unsigned short)v[u][i]) - mean) * rstd;
+            float dxh = hcp_bf2f((unsigned short)d[u][i]) * gamma[j * 8 + i];
+            o[i] = (short)hcp_f2bf(rstd * (dxh - c1 - xh * c2) + hcp_bf2f((unsigned short)ad[u][i]));
         }
         *(hcp_bf16x8*)(dx + off + j * 8) = o;
     }
@@ -449,20 +469,24 @@ HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* g
 
 HCP_API int hcp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int C,
                               float eps, hipStream_t stream) {
-    HCP_REQUIRE(M > 0 && C > 0 && C % 8 == 0, "hcp_layernorm_fwd: bad shape M=%d C=%d", M, C);
+    HCP_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 4096, "hcp_layernorm_fwd: bad shape M=%d C=%d (C: multiple of 8 up to 4096)", M, C);
     HCP_REQUIRE(x && gamma && beta && y && stats, "hcp_layernorm_fwd: null pointer");
-    HCP_LAUNCH(ln_fwd_kernel, dim3(hcp_cdiv(M, 4)), dim3(256), 0, stream, (const hcp_bf16*)x, gamma, beta, (hcp_bf16*)y,
-               stats, M, C, eps);
+#define HCP_LN_FWD(NV_) HCP_LAUNCH(ln_fwd_kernel<NV_>, dim3(hcp_cdiv(M, 4)), dim3(256), 0, stream, (const hcp_bf16*)x, gamma, beta, \
+                                   (hcp_bf16*)y, stats, M, C, eps)
+    if (C <= 512) HCP_LN_FWD(1); else if (C <= 1024) HCP_LN_FWD(2); else if (C <= 2048) HCP_LN_FWD(4); else HCP_LN_FWD(8);
+#undef HCP_LN_FWD
     HCP_LAUNCH_CHECK("layernorm_fwd");
 }
 
 // dx = layer_norm_backward(dy) [+ addend]   (addend: gradient arriving on the residual path of a pre-norm block)
 HCP_API int hcp_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, const void* addend,
                               void* dx, int M, int C, hipStream_t stream) {
-    HCP_REQUIRE(M > 0 && C > 0 && C % 8 == 0, "hcp_layernorm_bwd: bad shape M=%d C=%d", M, C);
+    HCP_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 4096, "hcp_layernorm_bwd: bad shape M=%d C=%d (C: multiple of 8 up to 4096)", M, C);
     HCP_REQUIRE(x && dy && gamma && stats && dx, "hcp_layernorm_bwd: null pointer");
-    HCP_LAUNCH(ln_bwd_kernel, dim3(hcp_cdiv(M, 4)), dim3(256), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy, gamma,
-               stats, (const hcp_bf16*)addend, (hcp_bf16*)dx, M, C);
+#define HCP_LN_BWD(NV_) HCP_LAUNCH(ln_bwd_kernel<NV_>, dim3(hcp_cdiv(M, 4)), dim3(256), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy, \
+                                   gamma, stats, (const hcp_bf16*)addend, (hcp_bf16*)dx, M, C)
+    if (C <= 512) HCP_LN_BWD(1); else if (C <= 1024) HCP_LN_BWD(2); else if (C <= 2048) HCP_LN_BWD(4); else HCP_LN_BWD(8);
+#undef HCP_LN_BWD
     HCP_LAUNCH_CHECK("layernorm_bwd");
 }
 

@@ -303,7 +303,7 @@ def test_groupnorm_statistics_many_chunks_large_mean(backend, B, H, W, C):
     assert relerr(y.permute(0, 3, 1, 2), yr) < 1e-2
 
 
-@pytest.mark.parametrize("M,C", [(10, 320), (7, 640), (5, 1280), (16384, 320), (1024, 1280)])
+@pytest.mark.parametrize("M,C", [(10, 320), (7, 640), (5, 1280), (6, 768), (3, 2048), (2, 2560), (9, 8), (16384, 320), (1024, 1280), (308, 768)])
 def test_layernorm(backend, M, C):
     if not backend.is_gpu and M > 100:
         pytest.skip("large shape: GPU only")
