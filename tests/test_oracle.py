@@ -147,3 +147,25 @@ def test_minsnr_golden_is_reproducible_from_reference():
     new, old = minsnr_reference_vectors(), torch.load(os.path.join(GOLD, "minsnr_reference.pt"))
     for k, case in old["cases"].items():
         assert new["cases"][k]["loss"] == case["loss"] and torch.equal(new["cases"][k]["grad"], case["grad"])
+
+
+SELECTORS = [[""], [r"re:.*\.attn.?$", r"re:.*\.ff$"], [r"re:.*attn2\.to_k$", r"re:.*attn2\.to_v$"], [r"re:.*\.to_k$", r"re:.*\.to_v$"],
+             [r"re:.*\.resnets$", r"re:.*\.proj_in$", r"re:.*\.proj_out$", r"re:.*\.conv$"], ["down_blocks.0", "down_blocks.3", "mid_block"],
+             [r"re:.*\.resnets\.0\.conv1$"], [r"re:down_blocks\.[01]\..*\.to_q$", "conv_in"]]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("patterns", SELECTORS)
+def test_layer_selectors_match_the_reference_implementation(patterns):
+    """hcp_diffusion_amd.lora.get_match_layers == the reference's own get_match_layers (utils/cfg_net_tools.py:30-75, run
+    unmodified through the import shims) on the native UNet's module names, for every selector the reference's configs use
+    (cfgs/train/examples/*.yaml, cfgs/plugins/*.yaml) — same layers, same order."""
+    from hcp_diffusion_amd.lora import get_match_layers
+    from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
+    from oracle.ref_shims import load_reference_ckpt
+    from oracle.unet_sd15 import TINY_CONFIG
+    _, tools = load_reference_ckpt()
+    with torch.device("meta"):
+        named = dict(NativeUNet2DConditionModel(**TINY_CONFIG).named_modules())
+    ours, theirs = get_match_layers(patterns, named), tools.get_match_layers(patterns, named)
+    assert list(ours) == list(theirs) and len(ours) > 0
