@@ -169,3 +169,27 @@ def test_layer_selectors_match_the_reference_implementation(patterns):
         named = dict(NativeUNet2DConditionModel(**TINY_CONFIG).named_modules())
     ours, theirs = get_match_layers(patterns, named), tools.get_match_layers(patterns, named)
     assert list(ours) == list(theirs) and len(ours) > 0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("rank,alpha,auto", [(4, 1.0, True), (8, 2.0, True), (16, 0.5, False), (0.1, 1.0, True), (0.004, 3.0, True)])
+def test_lora_hyperparameters_match_the_reference_layer(rank, alpha, auto):
+    """rank (int, or a float fraction of out_features: lora_base_patch.py:105-106), the alpha buffer (alpha / rank when
+    alpha_auto_scale, :59) and the factor shapes of the native block == the reference's own LoraLayer on the same host sizes,
+    for Linear and 3x3 Conv2d hosts."""
+    from hcp_diffusion_amd.layers import HipConv2d, HipLinear
+    from hcp_diffusion_amd.lora import LoraHipLayer
+    from oracle.ref_shims import load_reference_lora
+    layers, _ = load_reference_lora()
+    ref_cls = layers.lora_layer_map["lora"]
+    for make_ref, make_nat in ((lambda: torch.nn.Linear(320, 640), lambda: HipLinear(320, 640)),
+                               (lambda: torch.nn.Conv2d(64, 128, 3, padding=1), lambda: HipConv2d(64, 128, 3, padding=1))):
+        pr, pn = torch.nn.Module(), torch.nn.Module()
+        pr.host, pn.host = make_ref(), make_nat()
+        a = ref_cls.wrap_layer(0, pr.host, rank=rank, alpha=alpha, alpha_auto_scale=auto, parent_block=pr, host_name="host")
+        b = LoraHipLayer.wrap_layer(0, pn.host, rank=rank, alpha=alpha, alpha_auto_scale=auto, parent_block=pn, host_name="host")
+        assert int(a.layer.rank) == int(b.rank) >= 1
+        assert float(a.alpha) == pytest.approx(float(b.alpha), rel=1e-7)
+        assert tuple(a.layer.W_down.shape) == tuple(b.layer.W_down.shape) and tuple(a.layer.W_up.shape) == tuple(b.layer.W_up.shape)
+        assert sorted(a.state_dict()) == sorted(b.state_dict()) and a.name == b.name == "lora_block_0"
+        assert type(pr.host).__name__ == "LoraPatchContainer" and pn.host._host is not None       # both replaced the host in its parent
