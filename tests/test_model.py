@@ -569,6 +569,29 @@ def test_ema_matches_reference_schedule(backend):
     assert sd[name].shape == dict(nat.named_parameters())[name].shape and len(sd) == 2 * len(tr.bucket.blocks)
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+def test_ema_matches_the_reference_class(backend):
+    """The same three optimizer steps tracked by the reference's OWN ModelEMA (hcpdiff/utils/ema.py, loaded as a file: it only
+    imports torch / numpy) and by hcp_ema_update: every averaged LoRA tensor agrees to fp32 rounding."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_hcp_ref_ema", "/root/reference/hcpdiff/utils/ema.py")
+    ref_ema = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref_ema)
+    _, nat = _pair(MICRO_CONFIG, backend.device)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=4)], lr=1e-2, ema=dict(decay_max=0.95, inv_gamma=2.0, power=0.75))
+    theirs = ref_ema.ModelEMA(nat, decay_max=0.95, inv_gamma=2.0, power=0.75)       # snapshots the requires_grad parameters (= the LoRA factors)
+    theirs.train_params = {k: v.clone() for k, v in theirs.train_params.items()}    # its p.data.to('cpu') copies from a GPU model but ALIASES a CPU one
+    g = torch.Generator().manual_seed(3)
+    for _ in range(3):
+        tr.bucket.grads.copy_(backend.to(torch.randn(tr.bucket.numel, generator=g)))
+        tr.optimizer_step()
+        theirs.update(nat)
+    ours, ref = tr.ema_state_dict(), theirs.state_dict()
+    lora_names = [n for n in ref if "lora_block_" in n and not n.endswith("alpha")]
+    assert sorted(lora_names) == sorted(ours)
+    for n in lora_names:
+        assert torch.allclose(ours[n].cpu(), ref[n].cpu(), rtol=1e-5, atol=1e-7), n
+
+
 @pytest.mark.parametrize("cfg_name", ["sd15", "sdxl"])
 def test_from_pretrained_reads_diffusers_layout(tmp_path, cfg_name):
     """`model.unet: {_target_: ...NativeUNet2DConditionModel.from_pretrained, path, subfolder: unet}`:
