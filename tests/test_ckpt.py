@@ -234,3 +234,27 @@ def test_text_encoder_lora_ckpt_round_trip(backend, tmp_path):
     ids = backend.to(torch.randint(0, 100, (2, 77), generator=g))
     with torch.no_grad():
         assert torch.equal(te(ids), te2(ids))
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("fmt", ["safetensors", "ckpt"])
+def test_reference_auto_manager_reads_native_files(backend, tmp_path, fmt):
+    """Both containers through the reference's OWN auto_manager (ckpt_manager/__init__.py): a natively written file yields the same
+    nested dict (sections, keys, tensors) as CkptManagerNative.load_ckpt — and a file the reference's manager writes from that dict
+    is read back natively."""
+    from oracle.ref_shims import load_reference_ckpt
+    load_reference_ckpt()
+    import hcpdiff.ckpt_manager as ref_mgr
+    nat, tr = _trained_native(backend, LORA_CFG, ema=dict(decay_max=0.9))
+    mgr = CkptManagerNative(fmt=fmt)
+    mgr.set_save_dir(str(tmp_path))
+    (path,) = tr.save_model(mgr, step=2)
+    theirs, ours = ref_mgr.auto_manager(path).load_ckpt(path), mgr.load_ckpt(path)
+    assert set(theirs) == set(ours) >= {"lora", "lora_ema"}
+    for sec in ours:
+        assert set(theirs[sec]) == set(ours[sec])
+        assert all(torch.equal(theirs[sec][k], ours[sec][k]) for k in ours[sec])
+    back = str(tmp_path / f"back.{fmt}")
+    ref_mgr.auto_manager(back)._save_ckpt({k: v for k, v in theirs.items() if v}, save_path=back)
+    again = mgr.load_ckpt(back)
+    assert all(torch.equal(again["lora"][k], ours["lora"][k]) for k in ours["lora"])
