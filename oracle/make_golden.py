@@ -283,6 +283,72 @@ def vae_full_vectors():
     return out
 
 
+CNET_CONFIG = dict(block_out_channels=(16, 32, 32, 32), layers_per_block=2, num_attention_heads=1, cross_attention_dim=16, norm_num_groups=4)
+
+
+def controlnet_reference_vectors():
+    """The reference's OWN ControlNetPlugin (hcpdiff/models/controlnet.py: construction :11-62, hooks :64-82, forward :88-183, hook
+    registration of MultiPluginBlock plugin.py:175-201), executed unmodified on top of the oracle UNet — a small UNet with SD1.5's
+    block layout (4 down blocks x 2 layers: the plugin's residual indices are hard-coded for it).  The oracle's blocks are given the
+    keyword names diffusers uses at the plugin's call sites (hidden_states= / temb= / encoder_hidden_states= ...) for the duration of
+    the run; nothing else is adapted.  Output: the UNet prediction with the branch attached, the 13 residuals, and the plugin's
+    state_dict (so that OracleControlNet can be loaded with identical weights)."""
+    import importlib
+    from oracle.ref_shims import load_reference_ckpt
+    from oracle import unet_sd15 as U
+    _, tools = load_reference_ckpt()
+    diffusers = sys.modules["diffusers"]             # the shim package ref_shims registered (the real one is not installed)
+    if not hasattr(diffusers, "UNet2DConditionModel"):
+        diffusers.UNet2DConditionModel = type("UNet2DConditionModel", (), {})
+    cn = importlib.import_module("hcpdiff.models.controlnet")
+
+    def block_fwd(orig):
+        def fwd(self, *a, hidden_states=None, temb=None, encoder_hidden_states=None, attention_mask=None, cross_attention_kwargs=None):
+            a = list(a)
+            h = hidden_states if hidden_states is not None else a.pop(0)
+            t = temb if temb is not None else a.pop(0)
+            c = encoder_hidden_states if encoder_hidden_states is not None else (a.pop(0) if a else None)
+            return orig(self, h, t, c)
+        return fwd
+
+    saved = {cls: cls.forward for cls in (U.DownBlock, U.MidBlock, U.TimestepEmbedding)}
+    U.DownBlock.forward, U.MidBlock.forward = block_fwd(saved[U.DownBlock]), block_fwd(saved[U.MidBlock])
+    U.TimestepEmbedding.forward = lambda self, x, cond=None, _o=saved[U.TimestepEmbedding]: _o(self, x)
+    try:
+        host = U.seeded_init_(U.OracleUNet2DConditionModel(**CNET_CONFIG), 1)
+        host.class_embedding, host.dtype = None, torch.float32
+        for blk in host.down_blocks:
+            blk.has_cross_attention = blk.has_attn
+        named = dict(host.named_modules())
+        metas = lambda pats: [{**m, "layer": named[m["layer"]]} for m in tools.get_match_layers(pats, named, return_metas=True)]
+        plug = cn.ControlNetPlugin("controlnet1", metas(["pre_hook:", "pre_hook:conv_in"]),
+                                   metas([f"down_blocks.{i}" for i in range(4)] + ["mid_block", "pre_hook:up_blocks.3.resnets.2"]),
+                                   host_model=host, cond_block_channels=(3, 4, 8, 8, 16, 16), layers_per_block=2, block_out_channels=CNET_CONFIG["block_out_channels"])
+        g = torch.Generator().manual_seed(21)
+        with torch.no_grad():                       # non-zero "zero convs" and a branch that differs from the host, as after training
+            for n, p in plug.named_parameters():
+                if n.startswith(("controlnet_", "cond_head")):
+                    p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.05))
+                else:
+                    p.add_(torch.randn(p.shape, generator=g) * 0.02)
+        x = torch.randn(2, 4, 8, 8, generator=g); t = torch.tensor([40, 900]); ehs = torch.randn(2, 10, 16, generator=g)
+        cond = torch.rand(2, 3, 64, 64, generator=g)
+        for feeder in host.input_feeder:
+            feeder(dict(cond=cond))
+        with torch.no_grad():
+            pred = host(x, t, ehs).sample
+            residuals = [r.clone() for r in plug.feat_to]
+        sd = {k: v.clone() for k, v in plug.state_dict().items()}
+        plug.remove()
+        with torch.no_grad():
+            pred_plain = host(x, t, ehs).sample
+        return dict(x=x, t=t, ehs=ehs, cond=cond, pred=pred, pred_without_branch=pred_plain, residuals=residuals, plugin_state=sd, host_seed=1,
+                    config=CNET_CONFIG, cond_block_channels=(3, 4, 8, 8, 16, 16))
+    finally:
+        for cls, f in saved.items():
+            cls.forward = f
+
+
 def minsnr_reference_vectors():
     """Outputs of the REFERENCE's MinSNRLoss / SoftMinSNRLoss / KDiffMinSNRLoss / EDMLoss (min_snr_loss.py) wrapped in
     Trainer.get_loss's reduction (train_ac.py:506-515) on seeded inputs, SD beta schedule."""
@@ -309,6 +375,10 @@ def minsnr_reference_vectors():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "controlnet":
+        torch.save(controlnet_reference_vectors(), os.path.join(GOLD, "controlnet_reference.pt"))
+        print("controlnet_reference.pt", os.path.getsize(os.path.join(GOLD, "controlnet_reference.pt")))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "te_struct":
         ref = os.environ.get("HCP_REFERENCE_ROOT", "/root/reference")
         shapes = parse_unet_struct(os.path.join(ref, "cfgs", "te_struct.txt"))

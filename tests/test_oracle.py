@@ -193,3 +193,33 @@ def test_lora_hyperparameters_match_the_reference_layer(rank, alpha, auto):
         assert tuple(a.layer.W_down.shape) == tuple(b.layer.W_down.shape) and tuple(a.layer.W_up.shape) == tuple(b.layer.W_up.shape)
         assert sorted(a.state_dict()) == sorted(b.state_dict()) and a.name == b.name == "lora_block_0"
         assert type(pr.host).__name__ == "LoraPatchContainer" and pn.host._host is not None       # both replaced the host in its parent
+
+
+def test_controlnet_restatement_matches_reference_plugin_code():
+    """OracleControlNet + the oracle UNet's `control_residuals` routing == the reference's OWN ControlNetPlugin (construction, hook
+    layout with its hard-coded residual indices, forward) run on top of the oracle UNet (tests/golden/controlnet_reference.pt,
+    oracle/make_golden.py controlnet): the 13 residuals and the final prediction, fp32."""
+    from oracle.unet_sd15 import OracleControlNet
+    from oracle.unet_sd15 import seeded_init_
+    g = torch.load(os.path.join(GOLD, "controlnet_reference.pt"))
+    host = seeded_init_(OracleUNet2DConditionModel(**g["config"]), g["host_seed"])
+    cn = OracleControlNet(host, cond_block_channels=g["cond_block_channels"], layers_per_block=2, block_out_channels=g["config"]["block_out_channels"])
+    missing, unexpected = cn.load_state_dict(g["plugin_state"], strict=False)
+    assert not missing and not unexpected                                   # same parameter names as the reference class
+    with torch.no_grad():
+        res = cn(g["x"], g["t"], g["ehs"], g["cond"])
+        assert len(res) == len(g["residuals"]) == 13
+        for a, b in zip(res, g["residuals"]):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+        pred = host(g["x"], g["t"], g["ehs"], control_residuals=res).sample
+        plain = host(g["x"], g["t"], g["ehs"]).sample
+    assert torch.allclose(pred, g["pred"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(plain, g["pred_without_branch"], rtol=1e-5, atol=1e-6)
+    assert ((g["pred"] - g["pred_without_branch"]).norm() / g["pred"].norm()).item() > 0.05       # the branch matters
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+def test_controlnet_golden_is_reproducible_from_reference():
+    from oracle.make_golden import controlnet_reference_vectors
+    new, old = controlnet_reference_vectors(), torch.load(os.path.join(GOLD, "controlnet_reference.pt"))
+    assert torch.equal(new["pred"], old["pred"]) and all(torch.equal(a, b) for a, b in zip(new["residuals"], old["residuals"]))
