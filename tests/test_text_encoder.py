@@ -229,3 +229,36 @@ def test_clip_l_full_size_forward_and_lora_grads_vs_oracle():
     go = torch.cat([p.grad.flatten() for w in wr.values() for p in (w.lora_block_0.layer.W_down, w.lora_block_0.layer.W_up)])
     gn = torch.cat([p.grad.flatten().float().cpu() for path in wr for p in (group.plugin_dict[path].layer.W_down, group.plugin_dict[path].layer.W_up)])
     assert F.cosine_similarity(go, gn, dim=0).item() > 0.99
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("n_repeats,clip_skip,final_norm", [(1, 0, True), (2, 1, True), (3, 0, False), (2, 2, True)])
+def test_output_selection_matches_the_reference_teexhook(n_repeats, clip_skip, final_norm):
+    """oracle.encode(clip_skip, final_norm, n_repeats) == the reference's OWN TEEXHook (hcpdiff/models/textencoder_ex.py:19-79: input
+    re-chunking pre-hook, hidden_states[-clip_skip-1] + final_layer_norm, BOS / EOS stitching) hooked onto the oracle text model
+    exposed with the transformers output fields the hook reads."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_hcp_ref_teex", "/root/reference/hcpdiff/models/textencoder_ex.py")
+    teex = importlib.util.module_from_spec(spec); spec.loader.exec_module(teex)
+    ora = seeded_init_(OracleCLIPTextModel(**TINY_CLIP_CONFIG), 5)
+
+    class _Out(dict):
+        pooler_output = None
+
+    class HFLike(torch.nn.Module):                      # CLIPTextModel's surface as the hook uses it: .text_model.final_layer_norm, output fields
+        def __init__(self, m):
+            super().__init__()
+            self.m, self.text_model = m, m.text_model
+
+        def forward(self, input_ids, **kw):
+            hs = self.m.hidden_states(input_ids)
+            return _Out(hidden_states=hs, last_hidden_state=self.text_model.final_layer_norm(hs[-1]))
+
+    host = HFLike(ora).eval()
+    teex.TEEXHook(host, tokenizer=None, N_repeats=n_repeats, clip_skip=clip_skip, clip_final_norm=final_norm, device="cpu")
+    ids = torch.randint(0, 100, (2, 77 * n_repeats), generator=torch.Generator().manual_seed(n_repeats))
+    with torch.no_grad():
+        ref, pooled = host(ids)
+        ours = ora.encode(ids, clip_skip=clip_skip, final_norm=final_norm, n_repeats=n_repeats)
+    assert pooled is None and ref.shape == ours.shape == (2, 75 * n_repeats + 2, 128)
+    assert torch.equal(ref, ours)
