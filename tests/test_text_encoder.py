@@ -262,3 +262,48 @@ def test_output_selection_matches_the_reference_teexhook(n_repeats, clip_skip, f
         ours = ora.encode(ids, clip_skip=clip_skip, final_norm=final_norm, n_repeats=n_repeats)
     assert pooled is None and ref.shape == ours.shape == (2, 75 * n_repeats + 2, 128)
     assert torch.equal(ref, ours)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_step_composition_matches_the_reference_wrapper(with_mask):
+    """The reference's OWN TEUnetWrapper.forward (hcpdiff/models/wrapper.py:14-30, with pad_attn_bias from utils/utils.py:154-162 and
+    TEEXHook on the text model) run over the oracle text encoder + oracle UNet == the composition NativeTrainer.forward_backward
+    restates: states = TE(ids, attention_mask=m); pred = unet(x, t, states, encoder_attention_mask=m).  (With a mask the wrapper pads
+    77 -> 80 keys with mask 0: the padded keys carry no weight, so the unpadded call must agree.)"""
+    import importlib
+    import importlib.util
+    from oracle.ref_shims import load_reference_lora
+    from oracle.unet_sd15 import MICRO_CONFIG, OracleUNet2DConditionModel
+    load_reference_lora()                                    # registers the hcpdiff stub packages (hcpdiff.utils.pad_attn_bias)
+    wrapper = importlib.import_module("hcpdiff.models.wrapper")
+    spec = importlib.util.spec_from_file_location("_hcp_ref_teex2", "/root/reference/hcpdiff/models/textencoder_ex.py")
+    teex = importlib.util.module_from_spec(spec); spec.loader.exec_module(teex)
+    tcfg = dict(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1, max_position_embeddings=77)
+    ot = seeded_init_(OracleCLIPTextModel(**tcfg), 2)
+    ou = seeded_init_(OracleUNet2DConditionModel(**dict(MICRO_CONFIG, cross_attention_dim=64)), 1)
+
+    class _Out(dict):
+        pooler_output = None
+
+    class HFLike(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m, self.text_model = m, m.text_model
+
+        def forward(self, input_ids, position_ids=None, attention_mask=None, output_hidden_states=True):
+            hs = self.m.hidden_states(input_ids, position_ids, attention_mask)
+            return _Out(hidden_states=hs, last_hidden_state=self.text_model.final_layer_norm(hs[-1]))
+
+    te = HFLike(ot).eval()
+    teex.TEEXHook(te, tokenizer=None, N_repeats=1, clip_skip=0, device="cpu")
+    w = wrapper.TEUnetWrapper(ou, te)
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, 100, (2, 77), generator=g); x = torch.randn(2, 4, 8, 8, generator=g); t = torch.tensor([10, 600])
+    m = None
+    if with_mask:
+        m = torch.ones(2, 77); m[0, 33:] = 0; m[1, 70:] = 0
+    with torch.no_grad():
+        ref = w(ids, x, t, attn_mask=m)
+        ours = ou(x, t, ot.encode(ids, attention_mask=m), encoder_attention_mask=m).sample
+    assert torch.allclose(ref, ours, rtol=1e-5, atol=1e-6)
