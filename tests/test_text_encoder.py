@@ -307,3 +307,31 @@ def test_step_composition_matches_the_reference_wrapper(with_mask):
         ref = w(ids, x, t, attn_mask=m)
         ours = ou(x, t, ot.encode(ids, attention_mask=m), encoder_attention_mask=m).sample
     assert torch.allclose(ref, ours, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+def test_sdxl_call_contract_matches_the_reference_wrapper():
+    """SDXLTEUnetWrapper.forward (models/wrapper.py:57-74): added_cond_kwargs = {text_embeds: pooled_output[-1], time_ids: crop_info} —
+    the contract NativeTrainer / bench.py feed the SDXL UNet with.  The reference wrapper over the oracle SDXL-structured UNet and a
+    stand-in text encoder == the direct oracle call."""
+    import importlib
+    from oracle.ref_shims import load_reference_lora
+    from oracle.unet_sd15 import TINY_SDXL_CONFIG, OracleUNet2DConditionModel
+    load_reference_lora()
+    wrapper = importlib.import_module("hcpdiff.models.wrapper")
+    ou = seeded_init_(OracleUNet2DConditionModel(**TINY_SDXL_CONFIG), 1)
+    g = torch.Generator().manual_seed(5)
+    ctx_dim = TINY_SDXL_CONFIG["cross_attention_dim"]
+    pooled_dim = TINY_SDXL_CONFIG["projection_class_embeddings_input_dim"] - 6 * TINY_SDXL_CONFIG["addition_time_embed_dim"]
+    ehs = torch.randn(2, 77, ctx_dim, generator=g); pooled = torch.randn(2, pooled_dim, generator=g)
+
+    class TE(torch.nn.Module):
+        def forward(self, prompt_ids, position_ids=None, attention_mask=None, output_hidden_states=True):
+            return ehs, [torch.zeros_like(pooled), pooled]               # (states, per-encoder pooled outputs): the wrapper takes the last
+
+    x = torch.randn(2, 4, 8, 8, generator=g); t = torch.tensor([5, 500])
+    crop = torch.tensor([[64.0, 64.0, 0.0, 0.0, 64.0, 64.0]] * 2)
+    with torch.no_grad():
+        ref = wrapper.SDXLTEUnetWrapper(ou, TE())(torch.zeros(2, 77, dtype=torch.long), x, t, crop_info=crop)
+        ours = ou(x, t, ehs, added_cond_kwargs=dict(text_embeds=pooled, time_ids=crop)).sample
+    assert torch.equal(ref, ours)
