@@ -223,3 +223,26 @@ def test_controlnet_golden_is_reproducible_from_reference():
     from oracle.make_golden import controlnet_reference_vectors
     new, old = controlnet_reference_vectors(), torch.load(os.path.join(GOLD, "controlnet_reference.pt"))
     assert torch.equal(new["pred"], old["pred"]) and all(torch.equal(a, b) for a, b in zip(new["residuals"], old["residuals"]))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("patterns", [[""], [r"re:down_blocks\.0\..*"], [r"re:.*\.attn1$", "mid_block.resnets.0", "conv_out"]])
+def test_full_finetune_parameter_selection_matches_the_reference(backend, patterns):
+    """`unet: [{lr, layers}]` (DreamBooth.yaml:6-10): the parameters NativeTrainer(train_cfg=...) trains == the parameter group the
+    reference's own make_hcpdiff builds for the same selectors (utils/cfg_net_tools.py:97-105, LoraBlock.extract_param_without_lora)."""
+    from hcp_diffusion_amd.trainer import NativeTrainer
+    from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
+    from oracle.make_golden import _Item
+    from oracle.ref_shims import load_reference_ckpt
+    from oracle.unet_sd15 import MICRO_CONFIG
+    _, tools = load_reference_ckpt()
+    a = NativeUNet2DConditionModel(**MICRO_CONFIG).to(backend.device)
+    b = NativeUNet2DConditionModel(**MICRO_CONFIG)
+    b.requires_grad_(False)
+    tr = NativeTrainer(a, None, train_cfg=[dict(layers=patterns, lr=1e-5)])
+    ours = sorted(n for n, _ in tr.host_buckets[0].bucket.named)
+    groups, _ = tools.make_hcpdiff(b, [_Item(layers=patterns, lr=1e-5)], None)
+    ids = {id(p): n for n, p in b.named_parameters()}
+    theirs = sorted(ids[id(p)] for p in groups[0]["params"])
+    assert ours == theirs and len(ours) > 0
+    assert sorted(n for n, p in b.named_parameters() if p.requires_grad) == theirs      # and it switched exactly those to requires_grad
