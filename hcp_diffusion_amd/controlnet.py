@@ -25,7 +25,7 @@ from torch import nn
 from . import kernels as K
 from . import ops
 from .layers import HipConv2d
-from .patch_api import BasePluginBlock, PatchPluginContainer
+from .patch_api import BasePluginBlock, MultiPluginBlock, PatchPluginContainer
 
 BF16 = torch.bfloat16
 
@@ -55,10 +55,12 @@ class _SiLU(nn.Module):
         return ops.silu(x)
 
 
-class ControlNetHipPlugin(BasePluginBlock):
+class ControlNetHipPlugin(MultiPluginBlock):
     def __init__(self, name, from_layers, to_layers, host_model=None, cond_block_channels=(3, 16, 32, 96, 256, 320),
                  layers_per_block=2, block_out_channels=(320, 640, 1280, 1280)):
-        super().__init__(name)
+        # a MultiPluginBlock by ROLE (make_plugin's issubclass dispatch, cfg_net_tools.py:148): its own __init__ would register the
+        # reference's hook lambdas (plugin.py:189-201); this class registers kwargs-aware hooks below instead
+        BasePluginBlock.__init__(self, name)
         assert host_model is not None
         assert len(from_layers) == 2 and len(to_layers) == len(block_out_channels) + 2, "ControlNet hook layout: see plugin_controlnet.yaml"
         self.host_model = weakref.ref(host_model)

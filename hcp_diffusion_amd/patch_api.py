@@ -14,7 +14,7 @@ import weakref
 from torch import nn
 
 try:  # pragma: no cover - only on a machine with the reference installed
-    from hcpdiff.models.plugin import BasePluginBlock, PatchPluginBlock, PatchPluginContainer, PluginGroup  # noqa: F401
+    from hcpdiff.models.plugin import BasePluginBlock, MultiPluginBlock, PatchPluginBlock, PatchPluginContainer, PluginGroup  # noqa: F401
     USING_REFERENCE_PLUGIN_API = True
 except Exception:  # noqa: BLE001
     USING_REFERENCE_PLUGIN_API = False
@@ -33,6 +33,10 @@ except Exception:  # noqa: BLE001
 
         def get_trainable_parameters(self):
             return self.parameters()
+
+    class MultiPluginBlock(BasePluginBlock):
+        """Role marker of a whole-model plugin (reference plugin.py:175-222): make_plugin builds subclasses with
+        (name, host_model, from_layers, to_layers) (cfg_net_tools.py:148-162)."""
 
     class PatchPluginContainer(nn.Module):
         """Takes the host's place inside its parent; plugins become children named ``plugin_names[i]``."""
