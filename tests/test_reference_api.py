@@ -46,6 +46,17 @@ y = u(x, t, ehs).sample
 y.square().mean().backward()
 grads = [p.grad for p in groups[0]["params"]]
 assert all(gr is not None and torch.isfinite(gr).all() for gr in grads) and sum(float(gr.abs().sum()) for gr in grads) > 0
+# --- checkpoint: the reference's CkptManagerSafe saves this group; the native loader rebuilds identical blocks on a fresh UNet
+import tempfile, os
+from hcpdiff.ckpt_manager import CkptManagerSafe
+from hcp_diffusion_amd.ckpt import NativeModelLoader
+d = tempfile.mkdtemp()
+mgr = CkptManagerSafe(); mgr.set_save_dir(d)
+mgr.save_model_with_lora(u, group, name="unet", step=1)
+u2 = seeded_init_(NativeUNet2DConditionModel(**MICRO_CONFIG), 1); u2.requires_grad_(False)
+g2, _ = NativeModelLoader(u2).load_lora([dict(path=os.path.join(d, "unet-1.safetensors"), alpha=1.0)])
+with torch.no_grad():
+    assert torch.equal(u2(x, t, ehs).sample, y.detach())
 group.remove()                                            # PluginGroup.remove -> PatchPluginBlock.remove restores the plain hosts
 assert type(u.down_blocks[0].attentions[0].transformer_blocks[0].attn1.to_q).__name__ == "HipLinear"
 # --- seam 3: the reference's make_plugin builds the native ControlNet (cfg_net_tools.py:130-162, plugin_controlnet.yaml)
