@@ -29,6 +29,10 @@ CLIP_L_CONFIG = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, 
                      max_position_embeddings=77)
 
 
+class _Config(dict):
+    __getattr__ = dict.__getitem__          # transformers configs answer cfg.hidden_size as well as cfg['hidden_size']
+
+
 def _call(m, x, residual=None):
     return m(x, residual=residual) if residual is not None else m(x)
 
@@ -93,7 +97,7 @@ class NativeCLIPTextModel(nn.Module):
     def __init__(self, clip_skip=0, clip_final_norm=True, N_repeats=1, **cfg):
         super().__init__()
         keys = tuple(CLIP_L_CONFIG)
-        self.config = {**CLIP_L_CONFIG, **{k: v for k, v in cfg.items() if k in keys}}
+        self.config = _Config({**CLIP_L_CONFIG, **{k: v for k, v in cfg.items() if k in keys}})
         if self.config["hidden_size"] // self.config["num_attention_heads"] not in (40, 64, 80, 160):
             raise NotImplementedError("hcp_diffusion_amd: text-encoder head width must be one of 40/64/80/160")
         self.text_model = _TextTransformer(**self.config)

@@ -31,6 +31,31 @@ SD_VAE_CONFIG = dict(in_channels=3, latent_channels=4, block_out_channels=(128, 
                      scaling_factor=0.18215)
 
 
+class _Config(dict):
+    """diffusers configs answer both ``cfg['k']`` and ``cfg.k``; the reference reads ``vae.config.scaling_factor`` (pair_dataset.py:75)."""
+    __getattr__ = dict.__getitem__
+
+
+class _LatentDist:
+    """What ``vae.encode(image).latent_dist`` must offer the reference: ``.sample()`` (data/pair_dataset.py:74, train_ac.py:431) and
+    ``.mode()``; both are one pass of hcp_vae_latent_sample over the encoder's fp32 moments (quant_conv folded in), UNSCALED as in
+    diffusers — the caller multiplies by ``vae.config.scaling_factor``."""
+
+    def __init__(self, vae, moments):
+        self._vae, self._moments = vae, moments
+
+    def sample(self, generator=None, noise=None):
+        return self._vae._draw(self._moments, generator, noise, True, 1.0)
+
+    def mode(self):
+        return self._vae._draw(self._moments, None, None, False, 1.0)
+
+
+class _EncoderOutput:
+    def __init__(self, latent_dist):
+        self.latent_dist = latent_dist
+
+
 def _gn(m, x, silu):
     g, b = m.f32_params()
     return K.groupnorm_fwd(x, g, b, m.num_groups, m.eps, silu)[0]
@@ -143,7 +168,7 @@ class NativeVAEEncoder(nn.Module):
     def __init__(self, in_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2, norm_num_groups=32,
                  scaling_factor=0.18215, **unused):
         super().__init__()
-        self.config = dict(in_channels=in_channels, latent_channels=latent_channels, block_out_channels=tuple(block_out_channels),
+        self.config = _Config(in_channels=in_channels, latent_channels=latent_channels, block_out_channels=tuple(block_out_channels),
                            layers_per_block=layers_per_block, norm_num_groups=norm_num_groups, scaling_factor=scaling_factor)
         self.encoder = VaeEncoderNet(in_channels, latent_channels, block_out_channels, layers_per_block, norm_num_groups)
         self.quant_conv = HipConv2d(2 * latent_channels, 2 * latent_channels, 1)
@@ -153,22 +178,37 @@ class NativeVAEEncoder(nn.Module):
     def device(self):
         return self.quant_conv.weight.device
 
-    @torch.no_grad()
-    def encode(self, image, generator=None, noise=None, sample=True):
-        """``vae.encode(image).latent_dist.sample() * scaling_factor`` -> fp32 [B, L, H/8, W/8].  The draw uses ``noise`` if
-        given, else torch.randn with ``generator`` (the reference draws from torch's global generator); sample=False returns
-        the distribution's mode."""
+    @property
+    def dtype(self):                                   # train_ac.py:431 casts the image to vae.dtype before encode
+        return self.quant_conv.weight.dtype
+
+    def _check(self, image):
         if image.dim() != 4 or image.shape[1] != self.config["in_channels"]:
             raise ValueError(f"expected an image batch [B,{self.config['in_channels']},H,W], got {tuple(image.shape)}")
         if max(image.shape[2:]) > 1024 or image.shape[2] % 8 or image.shape[3] % 8:
             raise NotImplementedError("hcp_diffusion_amd: VAE encode takes image sides that are multiples of 8 up to 1024 px")
-        mom = self.encoder(image)
+
+    def _draw(self, mom, generator, noise, sample, scale):
         B, L2, h, w = mom.shape
         if sample and noise is None:
             noise = torch.randn((B, L2 // 2, h, w), dtype=torch.float32, device=mom.device, generator=generator)
         wq = self.quant_conv.weight.detach().float().reshape(L2, L2).contiguous()
-        return K.vae_latent_sample(mom, wq, self.quant_conv.bias.detach().float().contiguous(), noise if sample else None,
-                                   self.config["scaling_factor"])
+        return K.vae_latent_sample(mom, wq, self.quant_conv.bias.detach().float().contiguous(), noise if sample else None, scale)
+
+    @torch.no_grad()
+    def encode(self, image):
+        """The diffusers call contract the reference uses: ``vae.encode(image).latent_dist.sample()`` (unscaled fp32 [B, L, H/8, W/8];
+        data/pair_dataset.py:74, train_ac.py:431) — ``PairDataset.cache_latents`` / ``Trainer.get_latents`` run unchanged on this class."""
+        self._check(image)
+        return _EncoderOutput(_LatentDist(self, self.encoder(image)))
+
+    @torch.no_grad()
+    def encode_latents(self, image, generator=None, noise=None, sample=True):
+        """``vae.encode(image).latent_dist.sample() * vae.config.scaling_factor`` in one call (the scale rides in the sampling kernel).
+        The draw uses ``noise`` if given, else torch.randn with ``generator`` (the reference draws from torch's global generator);
+        sample=False returns the distribution's mode."""
+        self._check(image)
+        return self._draw(self.encoder(image), generator, noise, sample, self.config["scaling_factor"])
 
     @classmethod
     def from_pretrained(cls, path, subfolder="vae", device="cuda"):
@@ -199,7 +239,7 @@ def build_latent_cache(vae, items, cache_path=None, generator=None):
     for name, image, mask in items:
         if name in latents:
             continue
-        z = vae.encode(image.unsqueeze(0).to(vae.device), generator=generator).squeeze(0)
+        z = vae.encode_latents(image.unsqueeze(0).to(vae.device), generator=generator).squeeze(0)
         if mask is None:
             mask = torch.ones((z.shape[1], z.shape[2]))
         latents[name] = {"img": z.cpu(), "mask": mask}

@@ -39,8 +39,13 @@ def test_tiny_vae_encode_vs_oracle(backend, hw):
     noise = torch.randn(2, 4, hw[0] // 2, hw[1] // 2, generator=g)
     with torch.no_grad():
         zo, zo_mode = ora.encode(img, noise), ora.encode(img, None)
-    zn = nat.encode(backend.to(img), noise=backend.to(noise)).cpu()
-    zn_mode = nat.encode(backend.to(img), sample=False).cpu()
+    zn = nat.encode_latents(backend.to(img), noise=backend.to(noise)).cpu()
+    zn_mode = nat.encode_latents(backend.to(img), sample=False).cpu()
+    # the diffusers contract the reference calls (pair_dataset.py:74-75): encode(...).latent_dist.sample() * config.scaling_factor
+    dist = nat.encode(backend.to(img)).latent_dist
+    assert torch.allclose(dist.sample(noise=backend.to(noise)).cpu() * nat.config.scaling_factor, zn, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(dist.mode().cpu() * nat.config.scaling_factor, zn_mode, rtol=1e-6, atol=1e-7)
+    assert dist.sample().shape == zn.shape
     assert zn.shape == zo.shape and zn.dtype == torch.float32
     assert ((zn - zo).norm() / zo.norm()).item() < 2e-2
     assert ((zn_mode - zo_mode).norm() / zo_mode.norm()).item() < 2e-2
@@ -91,5 +96,5 @@ def test_sd_vae_full_size_encode_vs_golden(side):
     gen = torch.Generator().manual_seed(g["input_seed"])
     img = torch.rand(1, 3, side, side, generator=gen) * 2 - 1
     noise = torch.randn(1, 4, side // 8, side // 8, generator=gen)
-    z = nat.encode(img.cuda(), noise=noise.cuda()).cpu()
+    z = nat.encode_latents(img.cuda(), noise=noise.cuda()).cpu()
     assert ((z - g["latents"]).norm() / g["latents"].norm()).item() < 2e-2

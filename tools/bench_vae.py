@@ -20,11 +20,11 @@ def main():
     for batch in ([int(sys.argv[2])] if len(sys.argv) > 2 else [1, 4, 16]):
         img = torch.rand(batch, 3, side, side, device=dev) * 2 - 1
         for _ in range(2):
-            vae.encode(img)
+            vae.encode_latents(img)
         torch.cuda.synchronize()
         t0 = time.time(); n = 5
         for _ in range(n):
-            vae.encode(img)
+            vae.encode_latents(img)
         torch.cuda.synchronize()
         dt = (time.time() - t0) / n
         # encoder forward at 512 px ~ 566 GFLOP/image (convs 9*2*Cin*Cout*HW per layer + attention), for orientation only
