@@ -107,9 +107,12 @@ class NativeCLIPTextModel(nn.Module):
     def device(self):
         return self.text_model.final_layer_norm.weight.device
 
-    def forward(self, input_ids, position_ids=None, attention_mask=None):
-        """int64 [B, L] token ids -> bf16 [B, L, C] conditioning states (TEEXHook's selection, N_repeats = 1).  attention_mask
-        [B, L] (1 = attend) is combined with the causal mask like transformers' CLIPTextTransformer does; token 0 must stay visible."""
+    def forward(self, input_ids, position_ids=None, attention_mask=None, output_hidden_states=None):
+        """int64 [B, L] token ids -> bf16 [B, L, C] conditioning states (TEEXHook's selection).  attention_mask [B, L] (1 = attend) is
+        combined with the causal mask like transformers' CLIPTextTransformer does; token 0 must stay visible.
+        Called the way the reference's wrapper calls its hooked text encoder — ``TE(ids, position_ids=..., attention_mask=...,
+        output_hidden_states=True)[0]`` (models/wrapper.py:20,64) — it answers with the hook's tuple ``(states, pooled_output)``
+        (pooled_output None: CLIP-L's pooled vector is not used by the SD1.x path)."""
         tm = self.text_model
         B, r = input_ids.shape[0], self.N_repeats
         if r > 1:                                                 # TEEXHook.forward_hook_input (textencoder_ex.py:57-59): 'b (r w) -> (b r) w'
@@ -136,7 +139,7 @@ class NativeCLIPTextModel(nn.Module):
         if r > 1:       # textencoder_ex.py:68-72: one BOS (first chunk), every chunk's inner tokens, one EOS (last chunk) -> [B, r*(L-2)+2, C]
             x = x.reshape(B, r, *x.shape[1:])
             x = torch.cat([x[:, 0, :1, :], x[:, :, 1:-1, :].flatten(1, 2), x[:, -1, -1:, :]], dim=1)
-        return x
+        return (x, None) if output_hidden_states is not None else x
 
     @classmethod
     def from_pretrained(cls, path, subfolder="text_encoder", device="cuda", **kw):

@@ -335,3 +335,35 @@ def test_sdxl_call_contract_matches_the_reference_wrapper():
         ref = wrapper.SDXLTEUnetWrapper(ou, TE())(torch.zeros(2, 77, dtype=torch.long), x, t, crop_info=crop)
         ours = ou(x, t, ehs, added_cond_kwargs=dict(text_embeds=pooled, time_ids=crop)).sample
     assert torch.equal(ref, ours)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+def test_native_models_inside_the_reference_wrapper(backend):
+    """Drop-in check of seam 1 + the text encoder: the reference's OWN TEUnetWrapper (models/wrapper.py:6-30) constructed over the
+    NATIVE text encoder and NATIVE UNet, called the way Trainer.forward calls it (train_ac.py:454), gives the same prediction as the
+    native trainer's own composition — and tracks the oracle pair."""
+    import importlib
+    from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
+    from oracle.ref_shims import load_reference_lora
+    from oracle.unet_sd15 import MICRO_CONFIG, OracleUNet2DConditionModel
+    load_reference_lora()
+    wrapper = importlib.import_module("hcpdiff.models.wrapper")
+    dev = backend.device
+    tcfg = dict(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1, max_position_embeddings=77)
+    ucfg = dict(MICRO_CONFIG, cross_attention_dim=64)
+    ot = seeded_init_(OracleCLIPTextModel(**tcfg), 2); ou = seeded_init_(OracleUNet2DConditionModel(**ucfg), 1)
+    nt = NativeCLIPTextModel(**tcfg); nt.load_state_dict(ot.state_dict()); nt.to(dev)
+    nu = NativeUNet2DConditionModel(**ucfg); nu.load_state_dict(ou.state_dict()); nu.to(dev)
+    w = wrapper.TEUnetWrapper(nu, nt)
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, 100, (2, 77), generator=g); x = torch.randn(2, 4, 8, 8, generator=g); t = torch.tensor([10, 600])
+    m = torch.ones(2, 77); m[0, 33:] = 0
+    to = backend.to
+    with torch.no_grad():
+        for mask in (None, m):
+            ref = w(to(ids), to(x), to(t), attn_mask=to(mask) if mask is not None else None)
+            ours = nu(to(x), to(t), nt(to(ids), attention_mask=to(mask) if mask is not None else None),
+                      encoder_attention_mask=to(mask) if mask is not None else None).sample
+            assert torch.allclose(ref.float().cpu(), ours.float().cpu(), rtol=1e-3, atol=1e-3)       # (the wrapper pads 77 -> 80 masked keys)
+            oracle = ou(x, t, ot.encode(ids, attention_mask=mask), encoder_attention_mask=mask).sample
+            assert ((ref.float().cpu() - oracle).norm() / oracle.norm()).item() < 2e-2
