@@ -108,16 +108,31 @@ def main():
     ap.add_argument("--gn-target", type=int, default=None, help="A/B only: hcp_debug_set_gn_target (workgroups a GroupNorm launch aims for)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher — one process per GPU, as the reference's
+        # `accelerate launch -m hcpdiff.train_ac` does (README.md:85-92, train_ac.py:117-128)
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product path has no CPU fallback)"
+    assert torch.cuda.device_count() >= (args.gpus if world > 1 else 1), \
+        f"--gpus {args.gpus} but only {torch.cuda.device_count()} visible"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)       # nccl == RCCL on ROCm
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        assert torch.distributed.get_world_size() == args.gpus
 
     from hcp_diffusion_amd.trainer import NativeTrainer
     from hcp_diffusion_amd.unet import SDXL_CONFIG, NativeUNet2DConditionModel

@@ -63,7 +63,6 @@ _PROTOTYPES = {
     "hcp_debug_gemm_table_stats": (I, [P, P]),
     # ema, p, n, step, inv_gamma, power, decay_max, stream
     "hcp_ema_update": (I, [P, P, L, P, F, F, F, P]),
-    "hcp_debug_set_attention_ablation": (I, [I]),
     "hcp_pack_piece_bytes": (I, []),
     # pieces, count, total_tiles, stream
     "hcp_pack_weights": (I, [P, I, I, P]),

@@ -89,6 +89,33 @@ HCP_DEVICE hcp_bf16x8 hcp_buf_load16(hcp_rsrc rsrc, unsigned voffset) {
     u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffset, 0, 0);
     return __builtin_bit_cast(hcp_bf16x8, v);
 }
+// LDS-DMA the compiler does not see (inline asm): hipcc drains every builtin LDS-DMA with s_waitcnt vmcnt(0) in front of the
+// next ds_read_b64_tr_b16 (it cannot prove the transpose read does not alias the DMA's destination), which serialises the
+// "fill the other buffer while this one is consumed" pipeline of the attention kernels.  Issued through asm the copy is
+// invisible to the waitcnt pass; completion is the caller's hcp_dma_wait_all() + workgroup barrier before the first read
+// (guide §5.7 item 1: LDS-DMA has no VGPR destination, so hiding it is register-safe; an extra in-flight load can only make
+// a compiler-counted vmcnt(N) wait longer, never shorter, because loads return in order).
+// desc = {base lo, base hi (stride 0), num_records bytes, 0x00020000}; a lane whose voffset >= num_records writes ZEROS;
+// a lane that is masked off by the surrounding `if` writes NOTHING (its 16 LDS bytes keep their contents).
+typedef unsigned int hcp_desc4 __attribute__((ext_vector_type(4)));
+HCP_DEVICE hcp_desc4 hcp_make_desc(const void* base, unsigned nbytes) {
+    const unsigned long long a = (unsigned long long)base;
+    hcp_desc4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    d[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    d[2] = __builtin_amdgcn_readfirstlane(nbytes);
+    d[3] = 0x00020000u;
+    return d;
+}
+HCP_DEVICE void hcp_dma16(hcp_desc4 desc, unsigned voffset, void* lds_wave_base) {
+    // a generic pointer into LDS is {shared aperture, LDS byte address}: the low 32 bits are what M0 wants
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voffset), "s"(desc), "s"(la) : "memory");
+}
+template <int P> HCP_DEVICE void hcp_setprio() { __builtin_amdgcn_s_setprio(P); }
+HCP_DEVICE void hcp_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 HCP_DEVICE int hcp_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }   // value known to be wave-uniform -> SGPR
 // "This register is consumed here": makes the compiler retire the global load that produces `v` BEFORE a loop instead of at the
 // loop's first use — otherwise its conservative s_waitcnt vmcnt(0) at the loop head also drains the tile prefetch issued a few

@@ -78,7 +78,6 @@ int hcp_attention_bwd(const void* Q, const void* K, const void* V, const void* O
                       const float* key_bias, long key_bias_bs, int causal, void* workspace, size_t workspace_bytes,
                       hcpStream_t stream);
 
-int hcp_debug_set_attention_ablation(int flags); /* tools only (wrong results when != 0): 1 = no global loads in the tile loops */
 int hcp_debug_set_attention_config(int cfg); /* tools only: bit0/1/2 = 32 rows per wave in fwd / dQ / dK,dV; -1 = heuristic */
 
 /* GroupNorm (+SiLU) over NHWC; stats[B,G,2] = (mean, rstd).  Replaces F.group_norm + SiLU

@@ -115,6 +115,14 @@ HCP_DEVICE hcp_bf16x8 hcp_buf_load16(hcp_rsrc rsrc, unsigned voffset) {
     if (voffset < rsrc.nbytes && voffset + 16 <= rsrc.nbytes) memcpy(&v, rsrc.base + voffset, 16);
     return v;
 }
+struct hcp_desc4 { const unsigned char* base; unsigned nbytes; };
+HCP_DEVICE hcp_desc4 hcp_make_desc(const void* base, unsigned nbytes) { hcp_desc4 d; d.base = (const unsigned char*)base; d.nbytes = nbytes; return d; }
+HCP_DEVICE void hcp_dma16(hcp_desc4 d, unsigned voffset, void* lds_wave_base) {
+    unsigned char* dst = (unsigned char*)lds_wave_base + 16 * hcp_emu::g_cur->lane;
+    if (voffset >= d.nbytes || voffset + 16 > d.nbytes) memset(dst, 0, 16); else memcpy(dst, d.base + voffset, 16);
+}
+template <int P> HCP_DEVICE void hcp_setprio() {}
+HCP_DEVICE void hcp_dma_wait_all() {}
 HCP_DEVICE int hcp_uniform(int v) { return v; }
 HCP_DEVICE void hcp_force_ready(hcp_bf16x8&) {}
 HCP_DEVICE void hcp_force_ready(float&) {}

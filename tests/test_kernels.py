@@ -214,10 +214,11 @@ def test_attention_fwd_bwd(backend, case):
     assert relerr(dq, dq_ref) < 2e-2 and relerr(dk, dk_ref) < 2e-2 and relerr(dv, dv_ref) < 2e-2
 
 
-@pytest.mark.parametrize("cfg", [0, 7])
+@pytest.mark.parametrize("cfg", [0, 7, 8, 15])
 def test_attention_rows_per_wave_variants(backend, cfg):
-    """16- and 32-rows-per-wave instantiations of forward / dQ / dK,dV agree with the reference (forced via the tools hook)."""
-    B, H, Nq, Nk, D = (1, 2, 150, 200, 40) if not backend.is_gpu else (2, 4, 1000, 1100, 64)
+    """16- and 32-rows-per-wave and 4- / 8-wave-workgroup instantiations of forward / dQ / dK,dV agree with the reference
+    (forced via the tools hook)."""
+    B, H, Nq, Nk, D = (1, 2, 150, 200, 40) if not backend.is_gpu else ((2, 4, 1000, 1100, 64) if cfg < 8 else (2, 4, 1000, 1100, 40))
     torch.manual_seed(cfg)
     q, k, v, do = rnd(B, Nq, H * D), rnd(B, Nk, H * D), rnd(B, Nk, H * D), rnd(B, Nq, H * D)
     o_ref, lse_ref, dq_ref, dk_ref, dv_ref = attn_ref(q, k, v, H, do)
