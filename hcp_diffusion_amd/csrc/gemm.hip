@@ -413,9 +413,17 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
     const int nk = nprim + (has_ext ? 1 : 0);
 
     // ---- loop-invariant per-lane byte offsets (HCP_BUF_OOB = this lane contributes zeros)
+    // Register diet of the conv gathers (every VGPR over the occupancy step became a scratch reload INSIDE the loop, and an
+    // ordinary load behind the tile's LDS-DMA makes its s_waitcnt drain the DMA queue too — guide §5 trap (b): the phases
+    // then run back to back): one pixel index per row instead of two byte offsets, all 3x3 validity masks in one register
+    // (9 bits per row), one shared 16-byte chunk term (the swizzle term (r >> 1) & 7 is the same for rows RPP apart).
     const int Ctot = p.cv.C1 + p.cv.C2;
-    unsigned va[A_IT], va2[A_IT], vb[B_IT];
-    int a_msk[A_IT];
+    static_assert(MODE == 0 || RPP % 16 == 0, "conv gather: rows RPP apart share their swizzle term");
+    unsigned va[A_IT], vb[B_IT];                          // MODE 0: byte offset of the row; conv: pixel index of the row (or ~0u)
+    unsigned a_msk[(A_IT + 2) / 3];                       // conv: word i/3, bit 9*(i%3) + tap = tap valid for row i
+#pragma unroll
+    for (int i = 0; i < (A_IT + 2) / 3; ++i) a_msk[i] = 0;
+    const unsigned a_chunk = (unsigned)(((kc ^ ((lrow >> 1) & 7)) << 3) * 2);
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int r = lrow + RPP * i, n = n0 + r;
@@ -425,7 +433,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
     for (int i = 0; i < A_IT; ++i) {
         const int r = lrow + RPP * i, m = m0 + r;
         const int chunk = (kc ^ ((r >> 1) & 7)) << 3;
-        va[i] = HCP_BUF_OOB; va2[i] = HCP_BUF_OOB; a_msk[i] = 0;
+        va[i] = HCP_BUF_OOB;
         if (r < BM && m < p.M) {
             if (MODE == 0) {
                 va[i] = (unsigned)(((size_t)m * p.lda + chunk) * 2);
@@ -435,18 +443,17 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
                 const int py = rem / p.cv.Wo, px = rem - py * p.cv.Wo;
                 const int s = MODE == 1 ? p.cv.stride : 1;
                 const int pix = (b * p.cv.Hs + py * s) * p.cv.Ws + px * s;
-                va[i] = (unsigned)(((size_t)pix * p.cv.C1 + chunk) * 2);
-                va2[i] = (unsigned)(((size_t)pix * p.cv.C2 + chunk) * 2);
-                int msk = 0;
+                va[i] = (unsigned)pix;
+                unsigned msk = 0;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int sy = MODE == 1 ? py * s + ky - p.cv.pad : py + 1 - ky;
                         const int sx = MODE == 1 ? px * s + kx - p.cv.pad : px + 1 - kx;
-                        if (sy >= 0 && sy < p.cv.Hs && sx >= 0 && sx < p.cv.Ws) msk |= 1 << (ky * 3 + kx);
+                        if (sy >= 0 && sy < p.cv.Hs && sx >= 0 && sx < p.cv.Ws) msk |= 1u << (ky * 3 + kx);
                     }
-                a_msk[i] = msk;
+                a_msk[i / 3] |= msk << (9 * (i % 3));
             }
         }
     }
@@ -486,7 +493,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i)
                 if ((i + 1) * RPP <= BM || wave * 8 + RPP * i < BM) {
-                    const unsigned v = ((a_msk[i] >> tap) & 1) ? (first ? va[i] : va2[i]) : HCP_BUF_OOB;
+                    const unsigned v = ((a_msk[i / 3] >> (9 * (i % 3) + tap)) & 1) ? va[i] * (unsigned)(2 * (first ? p.cv.C1 : p.cv.C2)) + a_chunk : HCP_BUF_OOB;
                     hcp_buf_glds16(ra, v, la + (wave * 8 + RPP * i) * BK);
                 }
             cb += BK;
@@ -522,29 +529,27 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
 
     // fragment addresses (elements) inside a stage: row R = base + 16*i, slot (ks*4 + fg) ^ ((R >> 1) & 7) — the swizzle term only
     // depends on fr because every 16-row block starts at a multiple of 16
-    int a_rd[2], b_rd[2], l_rd[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int q = ks * 4 + fg;
-        a_rd[ks] = (wm * WTM + fr) * BK + ((q ^ ((fr >> 1) & 7)) << 3);
-        b_rd[ks] = A_ELEMS + (wn * WTN + fr) * BK + ((q ^ ((fr >> 1) & 7)) << 3);
-        l_rd[ks] = A_ELEMS + B_ELEMS + (wn * 16 + fr) * BK + ((q ^ ((fr >> 1) & 7)) << 3);
-    }
+    // (slot of k-step 1 = slot of k-step 0 XOR 4, i.e. element offset XOR 32: one register per operand, the other is one v_xor away)
+    const int sw0 = (fg ^ ((fr >> 1) & 7)) << 3;
+    const int a_rd0 = (wm * WTM + fr) * BK + sw0;
+    const int b_rd0 = A_ELEMS + (wn * WTN + fr) * BK + sw0;
+    const int l_rd0 = A_ELEMS + B_ELEMS + (wn * 16 + fr) * BK + sw0;
     auto compute = [&](int stage) {
         const hcp_bf16* st = lds + stage * BUF_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             hcp_bf16x8 fa[TM], fb[TN];
+            const int a_rd = a_rd0 ^ (ks * 32), b_rd = b_rd0 ^ (ks * 32);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const hcp_bf16x8*)(st + a_rd[ks] + i * 16 * BK);
+            for (int i = 0; i < TM; ++i) fa[i] = *(const hcp_bf16x8*)(st + a_rd + i * 16 * BK);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const hcp_bf16x8*)(st + b_rd[ks] + j * 16 * BK);
+            for (int j = 0; j < TN; ++j) fb[j] = *(const hcp_bf16x8*)(st + b_rd + j * 16 * BK);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fb[j], fa[i], acc[i][j]);
             if (LORA) {                                    // this wave's 16 of the 32 rank slots: T += A L^T from the same A fragments
-                const hcp_bf16x8 fl = *(const hcp_bf16x8*)(st + l_rd[ks]);
+                const hcp_bf16x8 fl = *(const hcp_bf16x8*)(st + (l_rd0 ^ (ks * 32)));
 #pragma unroll
                 for (int i = 0; i < TM; ++i) tacc[i] = hcp_mfma16(fl, fa[i], tacc[i]);
             }
