@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="one wgrad launch per layer instead of one grouped launch")
     ap.add_argument("--grad-ckpt", action="store_true", help="enable_gradient_checkpointing() as the reference defaults to "
                     "(train_base.yaml:69): +1 forward per step; a secondary line, the headline runs without (288 GB HBM)")
+    ap.add_argument("--comm", choices=["torch", "abi"], default=os.environ.get("HCP_COMM", "torch"),
+                    help="gradient exchange: torch.distributed (backend nccl = RCCL) or RCCL through the C ABI (hcp_allreduce_flat / "
+                         "hcp_reduce_scatter_flat / hcp_allgather_flat, csrc/comm.hip)")
     ap.add_argument("--gn-target", type=int, default=None, help="A/B only: hcp_debug_set_gn_target (workgroups a GroupNorm launch aims for)")
     args = ap.parse_args()
 
@@ -134,8 +137,10 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=dev)       # nccl == RCCL on ROCm
         assert torch.distributed.get_world_size() == args.gpus
 
+    from hcp_diffusion_amd.comm import make_comm
     from hcp_diffusion_amd.trainer import NativeTrainer
     from hcp_diffusion_amd.unet import SDXL_CONFIG, NativeUNet2DConditionModel
+    comm = make_comm(dev, kind=args.comm) if world > 1 else None
     if args.gn_target is not None:
         from hcp_diffusion_amd import kernels as _K
         assert _K.lib().hcp_debug_set_gn_target(args.gn_target) == 0
@@ -168,12 +173,12 @@ def main():
             for m in list(plug.controlnet_down_blocks) + [plug.controlnet_mid_block, plug.cond_head[-1]]:
                 m.weight.normal_(0, 0.02)          # time the steady state ("after some training") instead
         tr = NativeTrainer(unet, None, lr=1e-4, weight_decay=1e-3, scale_lr_factor=args.batch * world, use_graph=not args.no_graph,
-                           plugins=[(plug, 1e-4)])
+                           plugins=[(plug, 1e-4)], comm=comm)
         torch.manual_seed(114514 + rank)
         plugin_input = dict(cond=torch.rand(args.batch, 3, 512, 512, device=dev))
     elif fullft:                                   # cfgs/train/examples/DreamBooth.yaml:6-10: unet: [{lr: 1e-6, layers: ['']}]
         tr = NativeTrainer(unet, None, lr=1e-6, weight_decay=1e-3, scale_lr_factor=args.batch * world, use_graph=not args.no_graph,
-                           train_cfg=[dict(layers=[""], lr=1e-6)])
+                           train_cfg=[dict(layers=[""], lr=1e-6)], comm=comm)
         torch.manual_seed(114514 + rank)
     else:
         text_encoder = None
@@ -195,7 +200,7 @@ def main():
         tr = NativeTrainer(unet, [dict(layers=LORA_PATTERNS, rank=args.rank_lora, lr=1e-4)], lr=1e-4, weight_decay=1e-3,
                            scale_lr_factor=args.batch * world, use_graph=not args.no_graph, overlap_wgrad=args.overlap,
                            grouped_wgrad=not args.no_grouped_wgrad, text_encoder=text_encoder,
-                           lora_te_cfg=[dict(layers=[r"re:.*self_attn$", r"re:.*mlp$"], rank=4, lr=1e-5)] if te else None)
+                           lora_te_cfg=[dict(layers=[r"re:.*self_attn$", r"re:.*mlp$"], rank=4, lr=1e-5)] if te else None, comm=comm)
         torch.manual_seed(114514 + rank)           # set_seed(seed + local_rank), train_ac.py:128
         buckets = [tr.bucket] + ([tr.te_bucket] if te else [])
         with torch.no_grad():                      # non-zero W_up so every LoRA path carries signal
@@ -262,7 +267,9 @@ def main():
                                     "grad-ckpt off" % (args.rank_lora, B) if te else
                                     "SD1.5 UNet LoRA rank=%d bf16, bs=%d/GPU, 512x512 (64x64 latents), 77-token context, "
                                     "random-init weights, cached latents, grad-ckpt off" % (args.rank_lora, B)),
-                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                       "global_batch": B * world, "parallelism": f"dp{world}", "rccl_ranks": world,
+                       "comm": ("RCCL via " + ("C ABI (hcp_allreduce_flat)" if args.comm == "abi" else "torch.distributed")) if world > 1 else "none",
+                       "hip_graph": not args.no_graph,
                        "gradient_checkpointing": bool(args.grad_ckpt)},
             "final_loss": round(loss_v, 5),
             "step_mfma_frac": round(ips / world * (FLOP_PER_IMAGE_SDXL_LORA_NOCKPT if sdxl else FLOP_PER_IMAGE_FULLFT_NOCKPT if fullft

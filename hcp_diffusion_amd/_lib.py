@@ -90,6 +90,15 @@ _PROTOTYPES = {
     "hcp_sumsq_f32": (I, [P, L, P, P]),
     # p, g, m, v, n, lr, beta1, beta2, eps, wd, sumsq, grad_scale, max_norm, step, stream
     "hcp_adamw_clip_fused": (I, [P, P, P, P, L, P, F, F, F, F, P, F, F, P, P]),
+    # data-parallel exchange (RCCL, csrc/comm.hip)
+    "hcp_comm_unique_id": (I, [P]),
+    "hcp_comm_init": (I, [I, I, P, ctypes.POINTER(P)]),
+    "hcp_comm_destroy": (I, [P]),
+    "hcp_comm_rank": (I, [P]),
+    "hcp_comm_world": (I, [P]),
+    "hcp_allreduce_flat": (I, [P, P, c_size_t, I, P]),
+    "hcp_reduce_scatter_flat": (I, [P, P, P, c_size_t, I, P]),
+    "hcp_allgather_flat": (I, [P, P, P, c_size_t, I, P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -10,7 +10,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(__file__).resolve().parent / "libhcp_mi355x.so"
-SOURCES = ["runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "pointwise.hip", "lora.hip", "optim.hip", "wgrad.hip", "pack.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "pointwise.hip", "lora.hip", "optim.hip", "wgrad.hip", "pack.hip", "comm.hip"]
 
 
 def _hipcc():
@@ -51,7 +51,7 @@ def build_product(force: bool = False, verbose: bool = False) -> Path:
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
     if force or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH)] + [str(o) for o in objs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH)] + [str(o) for o in objs] + ["-ldl"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout.decode()}")

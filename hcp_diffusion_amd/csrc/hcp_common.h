@@ -20,6 +20,7 @@ extern "C" int hcp_set_error(const char* fmt, ...);
 #if defined(HCP_EMU)
 #define HCP_LAUNCH_CHECK(name) return 0
 static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline int hcp_memcpy_async(void* d, const void* s, size_t n, hipStream_t) { memmove(d, s, n); return 0; }
 #else
 #define HCP_LAUNCH_CHECK(name)                                                        \
     do {                                                                              \
@@ -29,6 +30,9 @@ static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t) { mems
     } while (0)
 static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t s) {
     return hipMemsetAsync(p, v, n, s) == hipSuccess ? 0 : -1;
+}
+static inline int hcp_memcpy_async(void* d, const void* src, size_t n, hipStream_t s) {
+    return hipMemcpyAsync(d, src, n, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -24,8 +24,9 @@ def _is_conv3(p):
 
 
 class HostBucket:
-    def __init__(self, model, params):
-        """params: list of (name, parameter) to train (all on one device, fp32)."""
+    def __init__(self, model, params, pad_multiple=1):
+        """params: list of (name, parameter) to train (all on one device, fp32); pad_multiple: the flat buffers' length is
+        rounded up to a multiple of it (sharded optimizer: equal slices per rank; the tail stays zero)."""
         assert params, "no trainable host parameter selected"
         dev = params[0][1].device
         offs, n = [], 0
@@ -34,6 +35,7 @@ class HostBucket:
                 raise TypeError("hcp_diffusion_amd: full fine-tuning keeps fp32 master parameters (reference: fp32 params + autocast)")
             offs.append(n)
             n += (p.numel() + 3) // 4 * 4                      # 16-byte aligned segments
+        n = (n + pad_multiple - 1) // pad_multiple * pad_multiple
         self.numel = n
         self.params = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)

@@ -550,25 +550,41 @@ def lora_wgrad_grouped(items):
     dev = items[0][1].device
     src = torch.frombuffer(buf, dtype=torch.uint8)
     if dev.type == "cuda":
-        # persistent pinned staging buffer + device table (no allocation while a hipGraph is being captured)
-        key = (dev.index, len(buf))
-        slot = _WGTAB.get(key)
-        if slot is None:
-            slot = {"host": torch.empty(len(buf), dtype=torch.uint8).pin_memory(),
-                    "table": torch.empty(len(buf), dtype=torch.uint8, device=dev), "event": None}
-            _WGTAB[key] = slot
+        # Pinned staging buffer + device table from a pool (no allocation while a hipGraph is being captured).  A captured
+        # H2D copy re-reads its HOST buffer on every replay, so a slot used under capture is frozen for good, and within one
+        # step (wgrad_staging_begin_step) every call takes its own slot: two same-length launches in one capture (two
+        # datasets per step, or per-layer launches) must not share a staging buffer.
+        pool = _WGTAB.setdefault((dev.index, len(buf)), {"slots": [], "cursor": 0})
         capturing = torch.cuda.is_current_stream_capturing()
+        slots, i = pool["slots"], pool["cursor"]
+        if i > 4096 and not capturing:            # nobody marks step boundaries: recycle
+            i = 0
+        while i < len(slots) and slots[i]["frozen"]:
+            i += 1
+        if i == len(slots):                       # the eager warm-up steps before a capture grow the pool to what a step needs
+            slots.append({"host": torch.empty(len(buf), dtype=torch.uint8).pin_memory(),
+                          "table": torch.empty(len(buf), dtype=torch.uint8, device=dev), "event": None, "frozen": False})
+        slot = slots[i]
+        pool["cursor"] = i + 1
         if slot["event"] is not None and not capturing:
-            slot["event"].synchronize()           # the previous step's H2D copy has consumed the staging buffer
+            slot["event"].synchronize()           # the previous use's H2D copy has consumed the staging buffer
         slot["host"].copy_(src)
         slot["table"].copy_(slot["host"], non_blocking=True)
-        if not capturing:
+        if capturing:
+            slot["frozen"] = True
+        else:
             slot["event"] = torch.cuda.Event(); slot["event"].record()
         host, table = slot["host"], slot["table"]
     else:
         host, table = src, src.clone()
     _chk(L.hcp_lora_wgrad_grouped(_p(table), len(items), begin, _stream(table)), "hcp_lora_wgrad_grouped")
     return host, table
+
+
+def wgrad_staging_begin_step():
+    """Step boundary for lora_wgrad_grouped's staging pool: the next calls start again from the first free slot."""
+    for pool in _WGTAB.values():
+        pool["cursor"] = 0
 
 
 def lora_pack(desc_tensor, count):

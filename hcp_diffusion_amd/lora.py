@@ -442,7 +442,7 @@ def make_lora(model, cfg_lora):
         item = dict(item)
         layers = item.pop("layers")
         cls = lora_layer_map[item.pop("type", "lora_hip")]
-        lr = item.pop("lr", 1e-4)
+        lr = item.pop("lr", None)             # None: the trainer's default lr
         params = []
         for layer_name in get_match_layers(layers, named):
             parent_name, _, host_name = layer_name.rpartition(".")

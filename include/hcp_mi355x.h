@@ -188,6 +188,23 @@ int hcp_adamw_clip_fused(float* p, float* g, float* m, float* v, long n, const f
 int hcp_ema_update(float* ema, const float* p, long n, const int* step, float inv_gamma, float power, float decay_max,
                    hcpStream_t stream);
 
+/* ---- data-parallel exchange: RCCL over xGMI on flat buffers (csrc/comm.hip).  Replaces accelerator.backward's DDP gradient
+ * all-reduce (reference train_ac.py:117-123,175,482).  One process per GPU; `comm` is an opaque handle owned by the caller;
+ * every collective is stream-ordered, allocates nothing, never synchronises and can be captured into a hipGraph.
+ * dtype: 0 = fp32, 1 = bf16.  RCCL is dlopen'ed on first use (the copy PyTorch-ROCm already mapped, if any). */
+#define HCP_COMM_UNIQUE_ID_BYTES 128
+int hcp_comm_unique_id(void* out128);                                   /* rank 0: create the 128-byte rendezvous token */
+int hcp_comm_init(int rank, int world, const void* unique_id128, void** comm_out);   /* collective over all ranks */
+int hcp_comm_destroy(void* comm);
+int hcp_comm_rank(const void* comm);
+int hcp_comm_world(const void* comm);
+/* buf[i] <- sum over ranks, in place (one call per flat gradient bucket; 1/world is applied by hcp_adamw_clip_fused) */
+int hcp_allreduce_flat(void* comm, void* buf, size_t count, int dtype, hcpStream_t stream);
+/* recv[0..n) <- sum over ranks of send[rank*n .. rank*n+n)   (send: world*n elements) */
+int hcp_reduce_scatter_flat(void* comm, const void* send, void* recv, size_t recv_count, int dtype, hcpStream_t stream);
+/* recv[r*n .. r*n+n) <- rank r's send[0..n)   (recv: world*n elements; send may be its own slot of recv) */
+int hcp_allgather_flat(void* comm, const void* send, void* recv, size_t send_count, int dtype, hcpStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,8 +37,8 @@ def _make(tiny_cfg, mode="lora"):
     ora = seeded_init_(OracleUNet2DConditionModel(**tiny_cfg), 1)
     nat = NativeUNet2DConditionModel(**tiny_cfg)
     nat.load_state_dict(ora.state_dict())
-    if mode == "fullft":                           # DreamBooth.yaml:6-10: every UNet parameter, one 3.4 GB-class bucket
-        return NativeTrainer(nat, None, lr=1e-2, train_cfg=[dict(layers=[""])])
+    if mode in ("fullft", "fullft_sharded"):       # DreamBooth.yaml:6-10: every UNet parameter, one 3.4 GB-class bucket
+        return NativeTrainer(nat, None, lr=1e-2, train_cfg=[dict(layers=[""])], shard_optimizer=(mode == "fullft_sharded"))
     te = None
     if mode == "lora_te":                          # lora_conventional.yaml as shipped: lora_unet + lora_text_encoder, two buckets
         from hcp_diffusion_amd.text_encoder import NativeCLIPTextModel
@@ -90,7 +90,10 @@ def _worker(rank, world, port, out, mode):
     tr.make_noise = lambda lat: (K.add_noise(lat, noise[sl], t[sl], tr.acp), noise[sl], t[sl])
     _step(tr, x0, ehs, mode, sl)
     tr.all_reduce()
-    g = _bucket(tr).grads.clone() / world
+    g = _bucket(tr).grads.clone() / world          # sharded buckets are exchanged inside optimizer_step: still the local gradient here
+    if mode == "fullft_sharded":
+        st = tr.host_buckets[0]
+        assert st.shard and st.exp_avg.numel() * world == st.bucket.params.numel()      # moments exist for this rank's slice only
     tr.optimizer_step()
     torch.save({"grads": g, "params": _bucket(tr).params.clone()}, os.path.join(out, f"rank{rank}.pt"))
     dist.barrier()
@@ -98,12 +101,18 @@ def _worker(rank, world, port, out, mode):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("mode", ["lora", "fullft", "lora_te"])
+@pytest.mark.parametrize("mode", ["lora", "fullft", "fullft_sharded", "lora_te"])
 def test_two_rank_gloo_matches_single_process(tmp_path, mode):
-    port = 29500 + os.getpid() % 2000 + {"lora": 0, "fullft": 7, "lora_te": 13}[mode]
+    """fullft_sharded: reduce-scatter -> AdamW on this rank's slice -> all-gather (the path full fine-tune / ControlNet buckets take
+    under data parallelism) must leave both ranks with bit-identical parameters that equal the single-process step."""
+    port = 29500 + os.getpid() % 2000 + {"lora": 0, "fullft": 7, "lora_te": 13, "fullft_sharded": 19}[mode]
     mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
-    assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["params"], r1["params"])
+    assert torch.equal(r0["params"], r1["params"])
+    if mode == "fullft_sharded":                   # local (un-exchanged) gradients differ per rank; their mean is the global gradient
+        r0["grads"] = r0["grads"] + r1["grads"]
+    else:
+        assert torch.equal(r0["grads"], r1["grads"])
     # single process on the concatenated batch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import emu_cdll
@@ -116,8 +125,12 @@ def test_two_rank_gloo_matches_single_process(tmp_path, mode):
         _step(tr, x0, ehs, mode)
         g = _bucket(tr).grads.clone()
         tr.optimizer_step()
+        n = min(g.numel(), r0["grads"].numel())                     # (a sharded bucket is padded to a multiple of world * 64)
+        g, r0["grads"] = g[:n], r0["grads"][:n]
         cos = torch.nn.functional.cosine_similarity(g, r0["grads"], dim=0).item()
         assert cos > 0.9999, cos                                    # same math, different bf16 rounding order only
         assert ((g - r0["grads"]).norm() / g.norm()).item() < 1e-2
+        dp = (_bucket(tr).params[:n] - r0["params"][:n]).abs().max().item()
+        assert dp < 2.5e-2, dp                                      # lr 1e-2: one AdamW step moves a parameter by <= lr; sign flips of tiny gradients aside
     finally:
         K._set_backend_for_tests(None)

@@ -1,0 +1,197 @@
+"""NativeTrainer behaviours added in round 2: per-item learning rates (cfg_net_tools.py:108-123), gradient accumulation
+(train_ac.py:119,468), loss.type 'sample' (train_ac.py:458-465), and — on the GPU — hipGraph mode: the capture must not
+perturb the training state, two datasets per step must replay their own descriptor tables, and a new latent shape
+(aspect-ratio bucket, data/bucket.py:167-204) gets its own captured graph."""
+import pytest
+import torch
+
+from hcp_diffusion_amd import kernels as K
+from hcp_diffusion_amd.trainer import NativeTrainer
+from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
+from oracle.unet_sd15 import MICRO_CONFIG, OracleUNet2DConditionModel, seeded_init_
+
+PATS_A, PATS_F = [r"re:.*\.attn.?$"], [r"re:.*\.ff$"]
+
+
+def _native(dev):
+    torch.manual_seed(0)
+    ora = seeded_init_(OracleUNet2DConditionModel(**MICRO_CONFIG), 1)
+    nat = NativeUNet2DConditionModel(**MICRO_CONFIG)
+    nat.load_state_dict(ora.state_dict())
+    return nat.to(dev)
+
+
+def _trainer(dev, lora_cfg=None, **kw):
+    tr = NativeTrainer(_native(dev), lora_cfg or [dict(layers=PATS_A + PATS_F, rank=4)], lr=kw.pop("lr", 1e-2), **kw)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for blk in tr.bucket.blocks:
+            blk.layer.W_up.copy_((torch.randn(blk.layer.W_up.shape, generator=g) * 0.05).to(dev))
+    tr.bucket.pack()
+    return tr
+
+
+def _batch(dev, seed, hw=(8, 8), B=1, L=24):
+    g = torch.Generator().manual_seed(seed)
+    return dict(latents=torch.randn(B, 4, *hw, generator=g).to(dev), encoder_hidden_states=torch.randn(B, L, 32, generator=g).to(dev))
+
+
+def _fix_noise(tr, dev, seed=11):
+    """Deterministic make_noise (same draw in every call for a given latent shape)."""
+    cache = {}                                                        # device tensors made once per shape: capture-safe afterwards
+
+    def mk(lat):
+        key = tuple(lat.shape)
+        if key not in cache:
+            g = torch.Generator().manual_seed(seed + lat.shape[2] * 131 + lat.shape[3])
+            cache[key] = (torch.randn(lat.shape, generator=g).to(dev), torch.randint(0, 1000, (lat.shape[0],), generator=g).to(dev))
+        n, t = cache[key]
+        return K.add_noise(lat, n, t, tr.acp), n, t
+    tr.make_noise = mk
+
+
+def test_per_item_learning_rates(backend):
+    """Two lora_unet items with different lr: each item's parameters move with ITS lr (one AdamW param group per item)."""
+    dev = backend.device
+    tr = _trainer(dev, [dict(layers=PATS_A, rank=4, lr=1e-2), dict(layers=PATS_F, rank=4, lr=1e-4)], lr=1e-3)
+    st = tr._lora_state
+    assert len(st.segments) == 2 and st.base_lrs == [1e-2, 1e-4]
+    _fix_noise(tr, dev)
+    p0 = tr.bucket.params.clone()
+    b = _batch(dev, 1)
+    tr.train_one_step(b["latents"], b["encoder_hidden_states"])
+    d = (tr.bucket.params - p0).abs()
+    (o0, n0), (o1, n1) = st.segments
+    m0, m1 = d[o0:o0 + n0].max().item(), d[o1:o1 + n1].max().item()
+    assert 0.5e-2 < m0 < 1.3e-2 and 0.5e-4 < m1 < 1.3e-4, (m0, m1)      # first AdamW step moves a parameter by ~lr
+    tr.set_lr_factor(0.5)                                             # scheduler: every group keeps its own base lr
+    assert abs(st.lrs[0].item() - 0.5e-2) < 1e-9 and abs(st.lrs[1].item() - 0.5e-4) < 1e-9
+
+
+def test_gradient_accumulation_matches_one_big_step(backend):
+    """accelerator.accumulate (train_ac.py:119,468): two micro-steps of one sample each == one step on both samples (mean loss)."""
+    dev = backend.device
+    b1, b2 = _batch(dev, 1), _batch(dev, 2)
+    n = [torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(7 + i)).to(dev) for i in range(2)]
+    t = [torch.tensor([100]).to(dev), torch.tensor([700]).to(dev)]
+    tr = _trainer(dev, gradient_accumulation_steps=2)
+    seq = iter([0, 1])
+    tr.make_noise = lambda lat: (lambda i: (K.add_noise(lat, n[i], t[i], tr.acp), n[i], t[i]))(next(seq))
+    p0 = tr.bucket.params.clone()
+    tr.train_one_step(b1["latents"], b1["encoder_hidden_states"])
+    assert torch.equal(tr.bucket.params, p0) and tr.bucket.grads.abs().max().item() > 0     # no optimizer step yet
+    tr.train_one_step(b2["latents"], b2["encoder_hidden_states"])
+    assert tr.bucket.grads.abs().max().item() == 0.0 and not torch.equal(tr.bucket.params, p0)
+    ref = _trainer(dev)
+    nn_, tt = torch.cat(n), torch.cat(t)
+    ref.make_noise = lambda lat: (K.add_noise(lat, nn_, tt, ref.acp), nn_, tt)
+    ref.train_one_step(torch.cat([b1["latents"], b2["latents"]]), torch.cat([b1["encoder_hidden_states"], b2["encoder_hidden_states"]]))
+    assert ((tr.bucket.params - ref.bucket.params).abs().max() / ref.bucket.params.abs().max()).item() < 2e-3
+
+
+def test_loss_type_sample_is_the_reweighted_eps_loss(backend):
+    """loss.type 'sample' (train_ac.py:460-463): MSE between the x0 recovered from the prediction and from the true noise
+    = (1 - acp_t) / acp_t * MSE(eps_hat, eps) per sample."""
+    dev = backend.device
+    b = _batch(dev, 3, B=2)
+    tr_e, tr_s = _trainer(dev), _trainer(dev, loss_type="sample")
+    for tr in (tr_e, tr_s):
+        _fix_noise(tr, dev)
+    tr_e.forward_backward(b["latents"][:1], b["encoder_hidden_states"][:1])
+    ls = tr_s.forward_backward(b["latents"][:1], b["encoder_hidden_states"][:1])
+    _, _, t = tr_e.make_noise(b["latents"][:1])
+    a = tr_e.acp[t].item()
+    w = (1 - a) / a
+    ge, gs = w * tr_e.bucket.grads, tr_s.bucket.grads                # (same bf16 backward on a rescaled dL/dpred: equal to rounding)
+    assert torch.nn.functional.cosine_similarity(ge, gs, dim=0).item() > 0.9999 and abs(gs.norm().item() / ge.norm().item() - 1) < 1e-2
+    assert ls.item() > 0
+    with pytest.raises(ValueError):
+        NativeTrainer(_native(dev), [dict(layers=PATS_A, rank=4)], loss_type="v")
+
+
+def test_train_one_step_takes_attn_mask_and_leaves_the_batch_alone(backend):
+    dev = backend.device
+    tr = _trainer(dev)
+    _fix_noise(tr, dev)
+    b = _batch(dev, 4, B=2)
+    lat16 = b["latents"].half()
+    batch = dict(latents=lat16, encoder_hidden_states=b["encoder_hidden_states"])
+    tr.train_data_list([batch])
+    assert batch["latents"] is lat16                                  # the caller's dict is not rewritten
+    mask = torch.ones(2, 24); mask[:, 20:] = 0
+    l1 = tr.train_one_step(b["latents"], b["encoder_hidden_states"], attn_mask=backend.to(mask))
+    assert torch.isfinite(l1).all()
+
+
+# ------------------------------------------------------------------------------------------------ hipGraph mode (GPU)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    K._set_backend_for_tests(None)
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+def test_graph_capture_does_not_perturb_training_state():
+    """The first step in hipGraph mode is the FIRST optimisation step: parameters, moments, step counters and the RNG stream
+    after it equal eager mode's (the capture's warm-up steps are rolled back)."""
+    dev = _gpu()
+    b = _batch(dev, 1, B=2)
+    outs = []
+    for use_graph in (False, True):
+        tr = _trainer(dev, use_graph=use_graph, ema=dict(decay_max=0.99))
+        torch.manual_seed(123); torch.cuda.manual_seed(123)           # make_noise draws from torch's generators
+        for _ in range(2):
+            tr.train_one_step(b["latents"], b["encoder_hidden_states"])
+        torch.cuda.synchronize()
+        outs.append((tr.bucket.params.clone(), tr.exp_avg.clone(), tr.step_count.item(), tr._lora_state.ema.clone(), torch.rand(1, device=dev).item()))
+    (pe, me, se, ee, re_), (pg, mg, sg, eg, rg) = outs
+    assert se == sg == 2
+    assert ((pe - pg).abs().max() / pe.abs().max()).item() < 1e-5 and ((me - mg).abs().max() / me.abs().max()).item() < 1e-4
+    assert ((ee - eg).abs().max() / ee.abs().max()).item() < 1e-5
+    assert re_ == rg                                                  # same position in the device RNG stream
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grouped", [True, False])
+def test_graph_two_datasets_equal_eager(grouped):
+    """DreamBooth instance + class batch in one captured step: both forward/backward passes replay their OWN LoRA weight-gradient
+    descriptor tables (same byte length: the staging buffers must not be shared), with one grouped launch or one per layer."""
+    dev = _gpu()
+    data = [dict(**_batch(dev, 1)), dict(**_batch(dev, 2), loss_weight=0.5)]
+    res = []
+    for use_graph in (False, True):
+        tr = _trainer(dev, use_graph=use_graph, grouped_wgrad=grouped)
+        _fix_noise(tr, dev)
+        tr.optimizer_step_real, grads = tr.optimizer_step, []
+        for step in range(3):
+            tr.optimizer_step = lambda: None
+            tr._opt_graph = None
+            tr.train_data_list([dict(d) for d in data])
+            torch.cuda.synchronize()
+            grads.append(tr.bucket.grads.clone())
+            tr.bucket.grads.zero_()
+        res.append(grads)
+    for ge, gg in zip(*res):
+        assert ((ge - gg).norm() / ge.norm()).item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_graph_cache_per_latent_shape():
+    """Aspect-ratio buckets: steps alternate between two resolutions (and context lengths); each gets its own captured graph and
+    the trajectory equals eager mode's."""
+    dev = _gpu()
+    shapes = [((8, 8), 24), ((8, 16), 24), ((16, 8), 48)]
+    batches = [_batch(dev, 10 + i, hw=hw, B=2, L=L) for i, (hw, L) in enumerate(shapes)]
+    order = [0, 1, 0, 2, 1, 0]
+    outs = []
+    for use_graph in (False, True):
+        tr = _trainer(dev, use_graph=use_graph, lr=1e-3)
+        _fix_noise(tr, dev)
+        for i in order:
+            tr.train_one_step(batches[i]["latents"], batches[i]["encoder_hidden_states"])
+        torch.cuda.synchronize()
+        outs.append(tr.bucket.params.clone())
+        if use_graph:
+            assert len(tr._graph_cache) == 3
+    assert ((outs[0] - outs[1]).abs().max() / outs[0].abs().max()).item() < 1e-4
