@@ -29,32 +29,81 @@ MFMA_BF16_PEAK = 2.5e15                   # MI355X_MICROARCH.md: dense bf16 MFMA
 LORA_PATTERNS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]      # cfgs/train/examples/lora_conventional.yaml:10-12
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """Oracle (fp32 PyTorch CPU restatement + merged-weight LoRA, as the reference computes it) on the host cores:
-    ONE training step at batch 1 (fwd + bwd + clip + AdamW), no gradient checkpointing."""
-    import torch.nn.functional as F
+def _wrap_lora_for_baseline(m, rank):
+    """LoRA on the oracle UNet: the REFERENCE's own LoraLayer / LoraPatchContainer (executed from /root/reference through
+    oracle/ref_shims.py) where that tree exists (the build container), else the pinned restatement oracle/lora_ref.py."""
+    from oracle.ref_shims import reference_available
+    if reference_available():
+        import re
+        from oracle.ref_shims import load_reference_lora
+        layers, _ = load_reference_lora()
+        named = dict(m.named_modules())
+        params = []
+        for pat in LORA_PATTERNS:
+            rx = re.compile(pat[3:])
+            for name in [n for n in named if rx.match(n)]:
+                parent_name, _, host_name = name.rpartition(".")
+                made = layers.LoraLayer.wrap_model(0, named[name], parent_block=named[parent_name], host_name=host_name, rank=rank, dropout=0.0)
+                for blk in made.values():
+                    blk.requires_grad_(True)
+                    params += list(blk.parameters())
+        return params, "the reference's own LoraPatchContainer (hcpdiff/models/lora_base_patch.py via oracle/ref_shims.py)"
     from oracle.lora_ref import wrap_lora
-    from oracle.unet_sd15 import OracleUNet2DConditionModel, add_noise, ddpm_alphas_cumprod
+    wr = wrap_lora(m, LORA_PATTERNS, rank=rank)
+    return [p for w in wr.values() for p in w.lora_block_0.parameters()], "merged-weight LoRA restatement (oracle/lora_ref.py)"
+
+
+def cpu_baseline(batch=4, steps=3, grad_ckpt=True, budget_s=240.0):
+    """The reference-equivalent CPU path: oracle UNet (fp32 PyTorch restatement of diffusers) + merged-weight
+    LoRA as the reference computes it + MSE + clip_grad_norm_ + torch AdamW, batch 4, gradient checkpointing as
+    train_base.yaml:69 (per ResnetBlock2D / Transformer2DModel, non-reentrant: train_ac.py:44-47), on the host cores:
+    one warm-up step at batch 1, then up to `steps` timed steps (fewer if the time budget runs out)."""
+    import torch.nn.functional as F
+    from torch.utils.checkpoint import checkpoint
+    from oracle.unet_sd15 import OracleUNet2DConditionModel, ResnetBlock2D, Transformer2DModel, add_noise, ddpm_alphas_cumprod
     torch.manual_seed(0)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
     m = OracleUNet2DConditionModel()
     m.requires_grad_(False)
-    wr = wrap_lora(m, LORA_PATTERNS, rank=8)
-    params = [p for w in wr.values() for p in w.lora_block_0.parameters()]
+    params, lora_kind = _wrap_lora_for_baseline(m, 8)
+    if grad_ckpt:
+        for mod in m.modules():
+            if isinstance(mod, (ResnetBlock2D, Transformer2DModel)):
+                mod.forward = (lambda f: (lambda *a: checkpoint(f, *a, use_reentrant=False)))(mod.forward)
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-3)
-    x0 = torch.randn(1, 4, 64, 64); ehs = torch.randn(1, 77, 768)
     acp = ddpm_alphas_cumprod()
-    t0 = time.time()
-    noise = torch.randn_like(x0); t = torch.randint(0, 1000, (1,))
-    pred = m(add_noise(x0, noise, t, acp), t, ehs).sample
-    F.mse_loss(pred, noise).backward()
-    torch.nn.utils.clip_grad_norm_(params, 1.0)
-    opt.step()
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 LoRA(r=8) training step at batch 1, 512px latents, fp32 oracle, no grad-ckpt ({dt:.1f} s)"}
+
+    def step(B):
+        x0 = torch.randn(B, 4, 64, 64); ehs = torch.randn(B, 77, 768)
+        noise = torch.randn_like(x0); t = torch.randint(0, 1000, (B,))
+        xt = add_noise(x0, noise, t, acp).requires_grad_(grad_ckpt)   # non-reentrant checkpoints need a graph-connected input
+        pred = m(xt, t, ehs).sample
+        F.mse_loss(pred, noise).backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step(); opt.zero_grad(set_to_none=True)
+    step(1)                                        # warm-up (thread pool, allocator)
+    t0, done = time.time(), 0
+    while done < steps and (done == 0 or (time.time() - t0) * (done + 1) / done < budget_s):
+        step(batch); done += 1
+    dt = (time.time() - t0) / done
+    return {"value": round(batch / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} LoRA(r=8) training steps at batch {batch} after 1 warm-up step, 512px latents, fp32 oracle UNet + {lora_kind}, "
+                      f"gradient checkpointing {'on' if grad_ckpt else 'off'}, torch {torch.__version__} CPU kernels ({dt:.1f} s/step)"}
+
+
+def _pmc_record(kernel_key):
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/pmc_roofline.json, written by
+    tools/pmc_roofline.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs; rocprofv3 cannot nest inside this process)."""
+    path = os.path.join(ROOT, "profiles", "pmc_roofline.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        rec = json.load(open(path)).get(kernel_key)
+    except (OSError, ValueError):
+        return None
+    return rec
 
 
 def dominant_kernel_roofline(dev):
@@ -77,14 +126,40 @@ def dominant_kernel_roofline(dev):
     dt = e0.elapsed_time(e1) * 1e-3 / n
     flops = 2.0 * B * H * H * C * 9 * C
     ach = flops / dt / 1e12
-    return {"bound": "mfma", "kernel": "gemm_v2_kernel<128,160,4,2,MODE=1> implicit-GEMM conv3x3 C320->320 @64x64, B=4 (no split-K)", "achieved": round(ach, 1),
-            "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4),
-            # HBM bytes per launch from the committed PMC passes (profiles/r1_pmc_attention_conv_final.md: FETCH_SIZE x 2 gfx950
-            # correction 35.6 MB + WRITE_SIZE 10.5 MB) vs 22.8 MB algorithmic: the 3x3 halo rows are re-fetched by workgroups
-            # on other XCDs.  (The first version of this kernel moved 130.6 MB: 84 MB of split-K slabs, now gone.)
-            # Not re-measured by this run (rocprofv3 cannot nest).
-            "traffic": 46.1e6, "traffic_unit": "bytes/launch (PMC, profiles/r1_pmc_attention_conv_final.md)", "algorithmic_bytes": 22.8e6,
-            "avg_launch_us": round(dt * 1e6, 1)}
+    out = {"bound": "mfma", "kernel": "implicit-GEMM conv3x3 C320->320 @64x64, B=4 (gemm_v2_kernel, MODE=1)", "achieved": round(ach, 1),
+           "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4),
+           "algorithmic_bytes": 22.8e6, "avg_launch_us": round(dt * 1e6, 1), "traffic": None}
+    rec = _pmc_record("conv3x3_c320_64x64_b4")
+    if rec:                                        # FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE, bytes per launch
+        out["traffic"] = rec["hbm_bytes_per_launch"]
+        out["traffic_source"] = f"profiles/pmc_roofline.json ({rec.get('source', '?')}, kernel sources at git {rec.get('git', '?')})"
+    return out
+
+
+def attention_roofline(dev):
+    """Secondary roofline line, the north-star's named kernel: self-attention forward at the 64x64 level (B4 H8 N4096 d40)."""
+    from hcp_diffusion_amd import kernels as K
+    B, H, N, D = 4, 8, 4096, 40
+    q, k, v = [torch.randn(B, N, H * D, device=dev).to(torch.bfloat16) for _ in range(3)]
+    for _ in range(3):
+        K.attention_fwd(q, k, v, H)
+    torch.cuda.synchronize()
+    n = 30
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        K.attention_fwd(q, k, v, H)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = e0.elapsed_time(e1) * 1e-3 / n
+    flops = 4.0 * B * H * N * N * D
+    out = {"kernel": "attn2_fwd_kernel<40,2,8 waves> B4 H8 N4096 d40", "achieved": round(flops / dt / 1e12, 1), "unit": "TFLOP/s",
+           "frac": round(flops / dt / MFMA_BF16_PEAK, 4), "avg_launch_us": round(dt * 1e6, 1)}
+    rec = _pmc_record("attn_fwd_b4_h8_n4096_d40")
+    if rec:
+        out["mfma_busy"] = rec.get("mfma_busy"); out["traffic"] = rec.get("hbm_bytes_per_launch")
+        out["traffic_source"] = f"profiles/pmc_roofline.json ({rec.get('source', '?')})"
+    return out
 
 
 def main():
@@ -108,7 +183,6 @@ def main():
     ap.add_argument("--comm", choices=["torch", "abi"], default=os.environ.get("HCP_COMM", "torch"),
                     help="gradient exchange: torch.distributed (backend nccl = RCCL) or RCCL through the C ABI (hcp_allreduce_flat / "
                          "hcp_reduce_scatter_flat / hcp_allgather_flat, csrc/comm.hip)")
-    ap.add_argument("--gn-target", type=int, default=None, help="A/B only: hcp_debug_set_gn_target (workgroups a GroupNorm launch aims for)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -141,9 +215,6 @@ def main():
     from hcp_diffusion_amd.trainer import NativeTrainer
     from hcp_diffusion_amd.unet import SDXL_CONFIG, NativeUNet2DConditionModel
     comm = make_comm(dev, kind=args.comm) if world > 1 else None
-    if args.gn_target is not None:
-        from hcp_diffusion_amd import kernels as _K
-        assert _K.lib().hcp_debug_set_gn_target(args.gn_target) == 0
 
     sdxl = args.workload == "sdxl"
     fullft = args.workload == "dreambooth"
@@ -277,6 +348,7 @@ def main():
                                                    else FLOP_PER_IMAGE_LORA_NOCKPT) / MFMA_BF16_PEAK, 4),
         }
         out["roofline"] = dominant_kernel_roofline(dev)
+        out["roofline_attention"] = attention_roofline(dev)
         if world == 1 and not args.no_cpu_baseline and args.workload == "sd15":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

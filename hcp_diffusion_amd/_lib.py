@@ -23,10 +23,6 @@ _PROTOTYPES = {
     # A, lda, B, ldb, L, E, Tout, D, ldd, M, N, K, bias, residual, ldr, workspace, workspace_bytes, stream
     "hcp_gemm_lora_bf16": (I, [P, I, P, I, P, P, P, P, I, I, I, I, P, P, I, P, c_size_t, P]),
     "hcp_gemm_workspace_bytes": (c_size_t, [I, I]),
-    "hcp_debug_set_gemm_config": (I, [I]),
-    "hcp_debug_set_gemm_glds": (I, [I]),
-    "hcp_debug_set_gn_target": (I, [I]),
-    "hcp_debug_set_gemm_ablation": (I, [I]),
     # X1, C1, X2, C2, B, Hs, Ws, Ho, Wo, mode, stride, upsample, Wp, Cout, D, ldd, bias, rowbias, rowbias_ld,
     # residual, ldr, out_f32, workspace, workspace_bytes, stream
     "hcp_conv3x3_bf16": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, P, I, P, I, P, P, I, P, I, I, P, P, P, c_size_t, P]),
@@ -34,7 +30,6 @@ _PROTOTYPES = {
     "hcp_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P, L, I, P]),
     # Q, K, V, O, dO, lse, delta, dQ, dK, dV, B, H, Nq, Nk, D, strides..., scale, workspace, workspace_bytes, stream
     "hcp_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, I, L, I, L, I, L, I, F, P, L, I, P, c_size_t, P]),
-    "hcp_debug_set_attention_config": (I, [I]),
     "hcp_groupnorm_workspace_bytes": (c_size_t, [I, I, I, I]),
     # x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, stream
     "hcp_groupnorm_silu_fwd": (I, [P, P, P, P, P, P, I, I, I, I, F, I, P]),
@@ -59,8 +54,6 @@ _PROTOTYPES = {
     "hcp_wgrad_conv3x3_bf16": (I, [P, I, P, I, P, I, P, I, I, I, I, I, I, I, I, I, P, c_size_t, P]),
     # Y, ldy, out, ldo, M, N, rows_per_group, stream
     "hcp_colsum_bf16": (I, [P, I, P, I, I, I, I, P]),
-    "hcp_debug_set_wgrad_tile": (I, [I]),
-    "hcp_debug_gemm_table_stats": (I, [P, P]),
     # ema, p, n, step, inv_gamma, power, decay_max, stream
     "hcp_ema_update": (I, [P, P, L, P, F, F, F, P]),
     "hcp_pack_piece_bytes": (I, []),
@@ -101,7 +94,20 @@ _PROTOTYPES = {
     "hcp_allgather_flat": (I, [P, P, P, c_size_t, I, P]),
 }
 
+# hcp_debug_* tuning hooks: exported by the -DHCP_TOOLS builds only (libhcp_mi355x_tools.so, tests/emu)
+_TOOLS_PROTOTYPES = {
+    "hcp_debug_set_gemm_config": (I, [I]),
+    "hcp_debug_set_gemm_glds": (I, [I]),
+    "hcp_debug_set_gn_target": (I, [I]),
+    "hcp_debug_set_gemm_ablation": (I, [I]),
+    "hcp_debug_set_attention_config": (I, [I]),
+    "hcp_debug_set_wgrad_tile": (I, [I]),
+    "hcp_debug_gemm_table_stats": (I, [P, P]),
+}
+
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+TOOLS_SYMBOLS = tuple(_TOOLS_PROTOTYPES)
+TOOLS_LIB_PATH = Path(__file__).resolve().parent / "libhcp_mi355x_tools.so"
 
 
 class HcpError(RuntimeError):
@@ -109,12 +115,34 @@ class HcpError(RuntimeError):
 
 
 def bind(cdll):
-    """Attach argtypes/restype for every exported symbol; raises AttributeError if one is missing."""
+    """Attach argtypes/restype for every exported symbol; raises AttributeError if one is missing.  The tuning hooks are
+    bound when the library has them (tools / interpreter builds)."""
     for name, (res, args) in _PROTOTYPES.items():
         fn = getattr(cdll, name)
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _TOOLS_PROTOTYPES.items():
+        fn = getattr(cdll, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     return cdll
+
+
+_tools = None
+
+
+def load_tools():
+    """TOOLS / TESTS ONLY: the -DHCP_TOOLS build (hcp_debug_* hooks).  Pass the result to kernels._set_backend_for_tests()."""
+    global _tools
+    if _tools is None:
+        import torch  # noqa: F401
+        if not TOOLS_LIB_PATH.exists():
+            raise HcpError(f"{TOOLS_LIB_PATH} not found: build it with `python -m hcp_diffusion_amd.build`")
+        _tools = ctypes.CDLL(str(TOOLS_LIB_PATH))
+        for name in _TOOLS_PROTOTYPES:
+            getattr(_tools, name)                      # all hooks must be there
+    return _tools
 
 
 _lib = None

@@ -239,6 +239,15 @@ class NativeModelLoader:
             rest = {k.replace("___", name): v for k, v in state.items() if not k.startswith(".___.")}
             if rest:
                 self.host.load_state_dict(rest, strict=False)
+            # every remaining cfg key is a hyper-parameter of the plugin(s) (cfg_net_tools.py:307-315: e.g. a ControlNet's scale)
+            hyper = {k: v for k, v in dict(item).items() if k not in ("path", "layers")}
+            if hyper:
+                targets = [multi] if multi is not None else [self.named_modules[k.split("___", 1)[0] + name] for k in
+                                                             {k.split("___", 1)[0] for k in state if not k.startswith(".___.")}]
+                for tgt in targets:
+                    if not hasattr(tgt, "set_hyper_params"):
+                        raise ValueError(f"plugin {name!r}: cfg keys {sorted(hyper)} given but {type(tgt).__name__} has no set_hyper_params")
+                    tgt.set_hyper_params(**hyper)
 
     def load_all(self, cfg_merge, load_ema=False):
         self.load_part(cfg_merge.get("part", []), base_model_alpha=cfg_merge.get("base_model_alpha", 0.0), load_ema=load_ema)

@@ -49,7 +49,7 @@ HCP_KERNEL(256) attn_dkv_convert_kernel(AttnParams p, int B, int C) {
     }
 }
 
-int g_attn_cfg = -1;   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32, bit3 fwd 8-wave workgroups; -1 = heuristic
+HCP_TUNABLE(int, g_attn_cfg, -1);   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32, bit3 fwd 8-wave workgroups; -1 = heuristic
 
 template <int D, int QT, int NW>
 int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
@@ -148,8 +148,10 @@ int attn_check(const AttnParams& p, int B, int D) {
 
 }  // namespace
 
-// TOOLS ONLY: bit0 forward / bit1 dQ / bit2 dK,dV use 32 rows per wave; -1 restores the heuristic.
+#if defined(HCP_TOOLS)
+// TOOLS ONLY: bit0 forward / bit1 dQ / bit2 dK,dV use 32 rows per wave, bit3 forward 8-wave workgroups; -1 restores the heuristic.
 HCP_API int hcp_debug_set_attention_config(int cfg) { g_attn_cfg = cfg; return 0; }
+#endif
 
 // O[b,q,h,:] = softmax_k(scale * Q[b,q,h,:].K[b,k,h,:]) V[b,k,h,:];  lse[b,h,q] = logsumexp of the scaled scores.
 // All tensors bf16, token-major: element (b, n, h, c) at  base + b*bs + n*rs + h*D + c.

@@ -681,10 +681,10 @@ HCP_KERNEL(256) splitk_reduce_kernel(GemmParams p) {
     }
 }
 
-int g_force_cfg = -1;   // tools/tune: force a tile configuration (see hcp_debug_set_gemm_config)
-int g_dbg_ablate = 0;   // tools only, see GemmParams::dbg
-int g_use_glds = 1;     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
-int g_use_v2 = 1;       // 1: buffer-addressed v2 main loop where its requirements hold (default), 0: gemm_glds_kernel everywhere
+HCP_TUNABLE(int, g_force_cfg, -1);   // tools/tune: force a tile configuration (see hcp_debug_set_gemm_config)
+HCP_TUNABLE(int, g_dbg_ablate, 0);   // tools only, see GemmParams::dbg
+HCP_TUNABLE(int, g_use_glds, 1);     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
+HCP_TUNABLE(int, g_use_v2, 1);       // 1: buffer-addressed v2 main loop where its requirements hold (default), 0: gemm_glds_kernel everywhere
 
 template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false, int NSTAGE = 2>
 int launch_cfg(GemmParams& p, hipStream_t stream) {
@@ -788,7 +788,9 @@ const TunedEntry kTuned[] = {
 #include "gemm_tuned.inc"
 };
 
+#if defined(HCP_TOOLS)
 long g_table_hits = 0, g_table_misses = 0;   // tools: how much of a workload the measured dispatch table covers
+#endif
 
 bool lookup_tuned(const GemmParams& p, int mode, int* cfg, int* split) {
     bool hit = false;
@@ -798,7 +800,9 @@ bool lookup_tuned(const GemmParams& p, int mode, int* cfg, int* split) {
             *cfg = e.cfg; *split = e.split; hit = true; break;
         }
     }
+#if defined(HCP_TOOLS)
     (hit ? g_table_hits : g_table_misses) += 1;
+#endif
     return hit;
 }
 
@@ -830,6 +834,7 @@ int check_common(const GemmParams& p) {
 
 }  // namespace
 
+#if defined(HCP_TOOLS)
 // TOOLS ONLY: dispatch-table lookups since the last call (hits, misses); resets the counters.
 HCP_API int hcp_debug_gemm_table_stats(long* hits, long* misses) {
     if (hits) *hits = g_table_hits;
@@ -843,6 +848,7 @@ HCP_API int hcp_debug_set_gemm_config(int cfg) { g_force_cfg = cfg; return 0; }
 HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = 1; g_use_v2 = on == 1; return 0; }
 // TOOLS ONLY: ablation of the 2-stage LDS-DMA loop (results are wrong when != 0): 1 no DMA after tile 0, 2 no MFMA, 4 no LDS reads.
 HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; return 0; }
+#endif
 
 // Bytes of fp32 split-K workspace that lets every launch of this shape use its preferred decomposition.
 HCP_API size_t hcp_gemm_workspace_bytes(int M, int N) { return (size_t)16 * M * N * sizeof(float); }

@@ -10,6 +10,15 @@
 
 #define HCP_API extern "C" __attribute__((visibility("default")))
 
+// Tuning / ablation hooks (hcp_debug_*) are process-global knobs for tools and variant-coverage tests.  They exist only in
+// builds made with -DHCP_TOOLS (libhcp_mi355x_tools.so, the interpreter build of tests/emu): in the product library every
+// knob is a compile-time constant — no mutable global state behind the ABI, and the ablation branches fold away.
+#if defined(HCP_TOOLS)
+#define HCP_TUNABLE(type, name, value) type name = value
+#else
+#define HCP_TUNABLE(type, name, value) constexpr type name = value
+#endif
+
 extern "C" int hcp_set_error(const char* fmt, ...);
 
 #define HCP_REQUIRE(cond, ...)                         \

@@ -14,7 +14,7 @@ struct GNGeom { int TX, R, threads, nchunk, rows_per_chunk; };
 // Thread (cx, ry) owns channels [8cx, 8cx+8) and rows ry, ry+R, ...; a chunk is >= 4R rows (every thread has >= 4 independent
 // 16-byte loads in flight) and is sized so that the launch has about g_gn_target_wgs workgroups (2 per CU): enough to fill the
 // chip, few enough that the per-sample partial table every apply workgroup merges stays ~100 entries per group.
-int g_gn_target_wgs = 512;
+HCP_TUNABLE(int, g_gn_target_wgs, 512);
 GNGeom gn_geom(int B, int HW, int C) {
     GNGeom g;
     g.TX = C / 8;
@@ -421,12 +421,14 @@ int gn_check(int B, int HW, int C, int G) {
 
 }  // namespace
 
+#if defined(HCP_TOOLS)
 // TOOLS ONLY (tools/bench_norm.py): workgroups a GroupNorm launch aims for (default 512).  Changes the workspace size.
 HCP_API int hcp_debug_set_gn_target(int workgroups) {
     HCP_REQUIRE(workgroups >= 1 && workgroups <= 65536, "hcp_debug_set_gn_target: bad arguments");
     g_gn_target_wgs = workgroups;
     return 0;
 }
+#endif
 
 // Workspace (bytes) both GroupNorm entry points need: [B][nchunk][G][2] fp32 partials + [B][G][2] merged sums.
 HCP_API size_t hcp_groupnorm_workspace_bytes(int B, int HW, int C, int G) {

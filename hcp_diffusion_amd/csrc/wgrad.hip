@@ -247,8 +247,8 @@ HCP_KERNEL(256) colsum_kernel(const hcp_bf16* Y, int ldy, float* out, int ldo, i
     }
 }
 
-int g_force_wx = 0;     // tools/tests: 64 or 128 forces the X-tile width, 0 = heuristic
-int g_force_split = 0;  // tools/tests: > 0 forces the number of token splits
+HCP_TUNABLE(int, g_force_wx, 0);     // tools/tests: 64 or 128 forces the X-tile width, 0 = heuristic
+HCP_TUNABLE(int, g_force_split, 0);  // tools/tests: > 0 forces the number of token splits
 
 template <bool CONV>
 int launch_wgrad(WgradParams& p, float* ws, size_t ws_bytes, hipStream_t stream) {
@@ -283,8 +283,10 @@ int launch_wgrad(WgradParams& p, float* ws, size_t ws_bytes, hipStream_t stream)
 
 }  // namespace
 
+#if defined(HCP_TOOLS)
 // TOOLS / TESTS ONLY: cfg = X-tile width (64 / 128 / 0 = heuristic) + 256 * forced token splits (0 = heuristic).
 HCP_API int hcp_debug_set_wgrad_tile(int cfg) { g_force_wx = cfg & 255; g_force_split = cfg >> 8; return 0; }
+#endif
 
 // dW[N,K] (fp32, leading dim ldw) += dY[M,N]^T X[M,K]     (nn.Linear / 1x1 conv weight gradient)
 // workspace: optional fp32 scratch for the token-split partial sums (any size; more allows more parallelism)

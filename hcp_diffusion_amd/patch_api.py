@@ -34,6 +34,10 @@ except Exception:  # noqa: BLE001
         def get_trainable_parameters(self):
             return self.parameters()
 
+        def set_hyper_params(self, **kwargs):          # reference plugin.py:39-41
+            for k, v in kwargs.items():
+                setattr(self, k, v)
+
     class MultiPluginBlock(BasePluginBlock):
         """Role marker of a whole-model plugin (reference plugin.py:175-222): make_plugin builds subclasses with
         (name, host_model, from_layers, to_layers) (cfg_net_tools.py:148-162)."""

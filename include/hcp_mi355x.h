@@ -43,11 +43,6 @@ int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const voi
                        size_t workspace_bytes, hcpStream_t stream);
 /* fp32 split-K scratch (optional: workspace may be NULL, then small-M problems run unsplit). */
 size_t hcp_gemm_workspace_bytes(int M, int N);
-int hcp_debug_gemm_table_stats(long* hits, long* misses); /* tools only: dispatch-table lookups since the last call; resets */
-int hcp_debug_set_gemm_config(int cfg); /* tools/tune_gemm.py only: force tile id + 16*nsplit, -1 = heuristic */
-int hcp_debug_set_gemm_ablation(int flags); /* tools only (wrong results when != 0): 1 no DMA, 2 no MFMA, 4 no LDS reads */
-int hcp_debug_set_gn_target(int workgroups);   /* tools only: workgroups a GroupNorm launch aims for (default 512) */
-int hcp_debug_set_gemm_glds(int on);    /* tools only: 1 = default (v2 main loop where eligible), 0/2 = first LDS-DMA loop everywhere */
 
 /* 3x3 convolution over NHWC bf16 as an implicit GEMM.  mode 0: forward, Wp = [Cout][3][3][C1+C2];
  * mode 1: data gradient, X1 = dY, Wp = [Cin][3][3][Cout].  pad 1 = padding 1 (every conv of the UNet); pad 0 (forward only) = taps
@@ -78,7 +73,6 @@ int hcp_attention_bwd(const void* Q, const void* K, const void* V, const void* O
                       const float* key_bias, long key_bias_bs, int causal, void* workspace, size_t workspace_bytes,
                       hcpStream_t stream);
 
-int hcp_debug_set_attention_config(int cfg); /* tools only: bit0/1/2 = 32 rows per wave in fwd / dQ / dK,dV; -1 = heuristic */
 
 /* GroupNorm (+SiLU) over NHWC; stats[B,G,2] = (mean, rstd).  Replaces F.group_norm + SiLU
  * (unet_struct.txt:13,93,97,929).  Backward returns dx only (affine parameters frozen). */
@@ -119,7 +113,6 @@ int hcp_wgrad_conv3x3_bf16(const void* dY, int ldy, const void* X1, int C1, cons
                            size_t workspace_bytes, hcpStream_t stream);
 /* out[g][n] += sum of rows of group g of Y (bias gradients; per-sample time-embedding row-bias gradient) */
 int hcp_colsum_bf16(const void* Y, int ldy, float* out, int ldo, int M, int N, int rows_per_group, hcpStream_t stream);
-int hcp_debug_set_wgrad_tile(int wx);
 /* After the optimizer step of a full fine-tune: refresh every layer's bf16 operand copies (row-major + transposed) from
  * the fp32 masters in ONE grouped launch.  pieces = device array of 56-byte descriptors
  * {const float* src; bf16* dst_rm; bf16* dst_tr; int rows, cols, src_ld, rm_ld, tr_ld, tile0, tiles_c; float scale;} sorted by tile0. */
@@ -187,6 +180,18 @@ int hcp_adamw_clip_fused(float* p, float* g, float* m, float* v, long n, const f
 /* ModelEMA.update (reference hcpdiff/utils/ema.py:17-27) over a flat bucket: ema <- lerp(ema, p, 1 - decay(step)) */
 int hcp_ema_update(float* ema, const float* p, long n, const int* step, float inv_gamma, float power, float decay_max,
                    hcpStream_t stream);
+
+/* ---- tuning / ablation hooks: ONLY in builds made with -DHCP_TOOLS (libhcp_mi355x_tools.so, used by tools/*.py and by the
+ * tests that force kernel variants).  They set process-global knobs and are therefore not part of the product ABI. */
+#ifdef HCP_TOOLS
+int hcp_debug_gemm_table_stats(long* hits, long* misses); /* tools only: dispatch-table lookups since the last call; resets */
+int hcp_debug_set_gemm_config(int cfg); /* tools/tune_gemm.py only: force tile id + 16*nsplit, -1 = heuristic */
+int hcp_debug_set_gemm_ablation(int flags); /* tools only (wrong results when != 0): 1 no DMA, 2 no MFMA, 4 no LDS reads */
+int hcp_debug_set_gn_target(int workgroups);   /* tools only: workgroups a GroupNorm launch aims for (default 512) */
+int hcp_debug_set_gemm_glds(int on);    /* tools only: 1 = default (v2 main loop where eligible), 0/2 = first LDS-DMA loop everywhere */
+int hcp_debug_set_attention_config(int cfg); /* tools only: bit0/1/2 = 32 rows per wave in fwd / dQ / dK,dV; -1 = heuristic */
+int hcp_debug_set_wgrad_tile(int wx);
+#endif
 
 /* ---- data-parallel exchange: RCCL over xGMI on flat buffers (csrc/comm.hip).  Replaces accelerator.backward's DDP gradient
  * all-reduce (reference train_ac.py:117-123,175,482).  One process per GPU; `comm` is an opaque handle owned by the caller;

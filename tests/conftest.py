@@ -52,3 +52,19 @@ def backend(request):
         kernels._set_backend_for_tests(emu_cdll())
     yield Backend(request.param)
     kernels._set_backend_for_tests(None)
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def tbackend(request):
+    """Like `backend`, for the tests that force kernel variants through the hcp_debug_* hooks: on the GPU those exist only in the
+    tuning build (libhcp_mi355x_tools.so: same kernel sources, -DHCP_TOOLS); the interpreter build always has them."""
+    from hcp_diffusion_amd import _lib, kernels
+    if request.param == "gpu":
+        if not torch.cuda.is_available():
+            pytest.skip("no GPU visible")
+        kernels._set_backend_for_tests(_lib.load_tools())
+        assert kernels.lib().hcp_is_emulated() == 0
+    else:
+        kernels._set_backend_for_tests(emu_cdll())
+    yield Backend(request.param)
+    kernels._set_backend_for_tests(None)

@@ -34,7 +34,7 @@ def build_emu(force=False):
         obj = bdir / (s.stem + ".o")
         objs.append(obj)
         if force or not obj.exists() or any(d.stat().st_mtime > obj.stat().st_mtime for d in [s] + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [HERE / "hcp_emu.h"]):
-            cmd = [_cxx(), "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DHCP_EMU", "-ffp-contract=off",
+            cmd = [_cxx(), "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DHCP_EMU", "-DHCP_TOOLS", "-ffp-contract=off",
                    "-fvisibility=hidden", "-Wno-unused-function", "-Wno-unknown-attributes",
                    f"-I{HERE}", f"-I{CSRC}", "-c", str(s), "-o", str(obj)]
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -10,14 +10,21 @@ from hcp_diffusion_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
+def header_symbols(tools=False):
+    """Symbols the header declares: the product ABI, or (tools=True) the hooks inside its `#ifdef HCP_TOOLS` block."""
     src = open(os.path.join(ROOT, "include", "hcp_mi355x.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    blocks = re.findall(r"#ifdef HCP_TOOLS(.*?)#endif", src, flags=re.S)
+    if tools:
+        src = "\n".join(blocks)
+    else:
+        src = re.sub(r"#ifdef HCP_TOOLS.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(hcp_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_and_binding_agree():
     assert header_symbols() == sorted(_lib.EXPORTED_SYMBOLS)
+    assert header_symbols(tools=True) == sorted(_lib.TOOLS_SYMBOLS)
 
 
 def test_product_library_exports_every_declared_symbol():
@@ -27,6 +34,19 @@ def test_product_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} missing from libhcp_mi355x.so"
     lib.hcp_is_emulated.restype = ctypes.c_int
     assert lib.hcp_is_emulated() == 0 and lib.hcp_abi_version() == 1
+
+
+def test_product_library_has_no_tuning_hooks_but_the_tools_build_does():
+    """No process-global mutable knob behind the product ABI: hcp_debug_* exist only in the -DHCP_TOOLS build."""
+    import subprocess
+    from hcp_diffusion_amd.build import build_product, build_tools
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
+        return {l.split()[-1] for l in out.splitlines() if l.strip()}
+    prod, tools = exported(build_product()), exported(build_tools())
+    assert not [s for s in prod if s.startswith("hcp_debug_")]
+    assert sorted(s for s in prod if s.startswith("hcp_")) == header_symbols()
+    assert set(header_symbols(tools=True)) <= tools and set(header_symbols()) <= tools
 
 
 def test_product_path_fails_loudly_without_gpu_tensors():
@@ -78,7 +98,6 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
         "hcp_transpose_bf16": (N, N, 0, 8, 8, N),
         "hcp_softmax_rows": (N, 8, N, 8, 0, 8, 1.0, N),
         "hcp_vae_latent_sample": (N, N, N, N, N, 1, 9, 16, 1.0, N),
-        "hcp_debug_set_gn_target": (0,),
         "hcp_mse_masked_mean": (N, N, N, 1, N, N, N, 0, 0, 0, 1.0, N),
         "hcp_copy2d_bf16": (N, 8, N, 8, 0, 7, N),
     }

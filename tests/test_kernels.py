@@ -215,14 +215,14 @@ def test_attention_fwd_bwd(backend, case):
 
 
 @pytest.mark.parametrize("cfg", [0, 7, 8, 15])
-def test_attention_rows_per_wave_variants(backend, cfg):
+def test_attention_rows_per_wave_variants(tbackend, cfg):
     """16- and 32-rows-per-wave and 4- / 8-wave-workgroup instantiations of forward / dQ / dK,dV agree with the reference
     (forced via the tools hook)."""
-    B, H, Nq, Nk, D = (1, 2, 150, 200, 40) if not backend.is_gpu else ((2, 4, 1000, 1100, 64) if cfg < 8 else (2, 4, 1000, 1100, 40))
+    B, H, Nq, Nk, D = (1, 2, 150, 200, 40) if not tbackend.is_gpu else ((2, 4, 1000, 1100, 64) if cfg < 8 else (2, 4, 1000, 1100, 40))
     torch.manual_seed(cfg)
     q, k, v, do = rnd(B, Nq, H * D), rnd(B, Nk, H * D), rnd(B, Nk, H * D), rnd(B, Nq, H * D)
     o_ref, lse_ref, dq_ref, dk_ref, dv_ref = attn_ref(q, k, v, H, do)
-    to = backend.to
+    to = tbackend.to
     K.lib().hcp_debug_set_attention_config(cfg)
     try:
         o, lse = K.attention_fwd(to(q), to(k), to(v), H)
@@ -532,14 +532,14 @@ def test_adamw_clip(backend):
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 2 + 16 * 2, 3 + 16 * 4, 1 + 16 * 3, 8 + 16 * 2, 11 + 16 * 2])
-def test_gemm_every_tile_config_and_splitk(backend, cfg):
+def test_gemm_every_tile_config_and_splitk(tbackend, cfg):
     """Each tile shape / split-K decomposition the dispatcher can pick gives the same answer (forced via the tuning hook)."""
     torch.manual_seed(cfg)
-    M, N, Kd, K2 = (200, 328, 512, 32) if not backend.is_gpu else (1000, 1288, 2304, 32)
+    M, N, Kd, K2 = (200, 328, 512, 32) if not tbackend.is_gpu else (1000, 1288, 2304, 32)
     a, b, a2, b2 = rnd(M, Kd), rnd(N, Kd), rnd(M, K2), rnd(N, K2)
     bias = torch.randn(N); res = rnd(M, N)
     ref = a.float() @ b.float().T + a2.float() @ b2.float().T + bias + res.float()
-    to = backend.to
+    to = tbackend.to
     K.lib().hcp_debug_set_gemm_config(cfg)
     try:
         out = K.gemm(to(a), to(b), a2=to(a2), b2=to(b2), bias=to(bias), residual=to(res), out_f32=True)
@@ -582,8 +582,8 @@ WGL_CASES_GPU = WGL_CASES_EMU + [(16384, 320, 320), (4096, 640, 2560), (308, 320
 
 @pytest.mark.parametrize("wx", [0, 64, 128, 128 + 256 * 1, 64 + 256 * 3])      # X-tile width + 256 * forced token splits
 @pytest.mark.parametrize("case", range(len(WGL_CASES_GPU)))
-def test_wgrad_linear(backend, case, wx):
-    if not backend.is_gpu and case >= len(WGL_CASES_EMU):
+def test_wgrad_linear(tbackend, case, wx):
+    if not tbackend.is_gpu and case >= len(WGL_CASES_EMU):
         pytest.skip("large shape: GPU only")
     M, N, Kd = WGL_CASES_GPU[case]
     torch.manual_seed(case)
@@ -592,7 +592,7 @@ def test_wgrad_linear(backend, case, wx):
     x = rnd(M, Kd)
     dw0 = torch.randn(N, Kd)
     ref = dw0 + dy[:, :N].float().T @ x.float()
-    to = backend.to
+    to = tbackend.to
     dw = to(dw0.clone())
     K.lib().hcp_debug_set_wgrad_tile(wx)
     try:

@@ -7,6 +7,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from hcp_diffusion_amd import kernels as K
+from hcp_diffusion_amd import _lib
+K._set_backend_for_tests(_lib.load_tools())      # tuning build: the hcp_debug_* hooks do not exist in the product library
 from tune_gemm_common import timeit, rnd, CFG_NAMES
 
 B, H, C = 4, 64, 320

@@ -15,6 +15,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hcp_diffusion_amd import kernels as K
+from hcp_diffusion_amd import _lib
+K._set_backend_for_tests(_lib.load_tools())      # tuning build: the hcp_debug_* hooks do not exist in the product library
 from hcp_diffusion_amd.trainer import NativeTrainer
 from hcp_diffusion_amd.unet import SDXL_CONFIG, NativeUNet2DConditionModel
 

@@ -8,6 +8,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hcp_diffusion_amd import kernels as K
+from hcp_diffusion_amd import _lib
+K._set_backend_for_tests(_lib.load_tools())      # tuning build: the hcp_debug_* hooks do not exist in the product library
 
 BF = torch.bfloat16
 dev = torch.device("cuda:0")

@@ -7,6 +7,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hcp_diffusion_amd import kernels as K
+from hcp_diffusion_amd import _lib
+K._set_backend_for_tests(_lib.load_tools())      # tuning build: the hcp_debug_* hooks do not exist in the product library
 from tune_gemm_common import timeit, rnd, CFG_NAMES
 
 SHAPES = [(16384, 320, 320), (16384, 2560, 320), (16384, 320, 1280), (16384, 320, 2560), (16384, 1280, 320),
