@@ -180,6 +180,10 @@ def main():
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="one wgrad launch per layer instead of one grouped launch")
     ap.add_argument("--grad-ckpt", action="store_true", help="enable_gradient_checkpointing() as the reference defaults to "
                     "(train_base.yaml:69): +1 forward per step; a secondary line, the headline runs without (288 GB HBM)")
+    ap.add_argument("--seam", action="store_true", help="secondary line: time the step the way the REFERENCE's Trainer drives the native "
+                    "modules (train_ac.py:467-504 restated: eager module calls, torch autograd, clip_grad_norm_, optimizer.step(), "
+                    "zero_grad, loss.item() every step) instead of NativeTrainer's captured step; sd15 workload, 1 GPU")
+    ap.add_argument("--seam-optimizer", choices=["fused", "torch"], default="fused")
     ap.add_argument("--comm", choices=["torch", "abi"], default=os.environ.get("HCP_COMM", "torch"),
                     help="gradient exchange: torch.distributed (backend nccl = RCCL) or RCCL through the C ABI (hcp_allreduce_flat / "
                          "hcp_reduce_scatter_flat / hcp_allgather_flat, csrc/comm.hip)")
@@ -304,6 +308,43 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.seam:
+        # What the reference's Trainer does with the native modules behind its seams (tests/test_reference_trainer.py runs its
+        # real code on the CPU interpreter; /root/reference does not exist on the GPU box, so the loop is restated here):
+        # TEUnetWrapper-style module call, MSE(reduction none).mean(), loss.backward(), accelerator.clip_grad_norm_,
+        # optimizer.step(), zero_grad(set_to_none=False), loss.item().
+        assert args.workload == "sd15" and world == 1
+        from hcp_diffusion_amd.optim import FusedAdamW
+        from hcp_diffusion_amd.scheduler import NativeDDPMScheduler
+        sched = NativeDDPMScheduler()
+        params = [p for blk in tr.bucket.blocks for p in (blk.layer.W_down, blk.layer.W_up)]
+        opt = (FusedAdamW if args.seam_optimizer == "fused" else torch.optim.AdamW)([dict(params=params, lr=1e-4 * B)], weight_decay=1e-3)
+        crit = torch.nn.MSELoss(reduction="none")
+
+        def seam_step():
+            noise = torch.randn_like(latents)
+            t = torch.randint(0, 1000, (B,), device=dev).long()
+            pred = unet(sched.add_noise(latents, noise, t), t, ehs).sample
+            loss = crit(pred.float(), noise.float()).mean()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(unet.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=False)
+            return loss.item()
+        for _ in range(args.warmup):
+            seam_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lv = seam_step()
+        sync()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "training images/sec, SD1.5 LoRA 512px bs=4, native modules driven the reference trainer's way (eager seam)",
+                          "value": round(B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "optimizer": args.seam_optimizer, "final_loss": round(lv, 5),
+                          "config": {"workload": "SD1.5 UNet LoRA rank=%d bf16 bs=%d, eager, clip_grad_norm_ + %s AdamW + loss.item() per step" %
+                                     (args.rank_lora, B, args.seam_optimizer)}}), flush=True)
+        return
     for _ in range(args.warmup):
         tr.train_one_step(latents, ehs, None, added, plugin_input, prompt_ids)
     sync()

@@ -387,14 +387,28 @@ class LoraBucket:
         if self._conv_pieces is not None:                  # conv (LoCon) blocks: the grouped convert/transpose kernel
             K.pack_weights(self._conv_pieces, len(self._conv_rows), self._conv_tiles)
         self._packed_version = self.params._version
+        for b in self.blocks:                              # each factor's own counter too: an optimizer steps through the Parameters,
+            b._pk_ver = (b.layer.W_down._version, b.layer.W_up._version)   # whose `.data` views do not share the bucket's version counter
+
+    def _stale(self, blocks):
+        """Has anything written the fp32 factors since the bf16 operands were derived?  The flat buffer's counter sees in-place
+        writes to `params` (NativeTrainer's fused kernel is followed by an explicit pack()); the factors' own counters see a
+        torch / reference-trainer optimizer stepping W_down / W_up in place (train_ac.py:491) — found by driving the reference's
+        Trainer.train_one_step over these blocks: without this check step 2 ran on step-1 operands."""
+        if self._packed_version != self.params._version:
+            return True
+        for b in blocks:
+            if b is not None and getattr(b, "_pk_ver", None) != (b.layer.W_down._version, b.layer.W_up._version):
+                return True
+        return False
 
     def packed_for(self, blk):
-        if self._packed_version != self.params._version:
+        if self._stale((blk,)):
             self.pack()
         return self._ops[id(blk)]
 
     def packed_group(self, group):
-        if self._packed_version != self.params._version:
+        if self._stale(group.blocks):
             self.pack()
         return group.ops
 

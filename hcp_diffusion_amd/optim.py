@@ -1,0 +1,80 @@
+"""Seam 4 (``train.optimizer``, train_base.yaml:37-40 -> train_ac.py:370: ``cfg.train.optimizer(params=params_group)``): a
+``torch.optim.Optimizer`` whose step is the fused AdamW kernel (csrc/optim.hip).
+
+The reference trainer clips with ``accelerator.clip_grad_norm_`` before ``optimizer.step()`` (train_ac.py:485-491), so the step
+here is plain AdamW (decoupled weight decay, bias correction as torch.optim.AdamW).  Parameters whose storage is adjacent — all
+``W_down`` / ``W_up`` of a native LoRA model live in ONE flat bucket, a fully fine-tuned UNet's in another — are stepped with one
+launch per contiguous run per param group instead of one per tensor (320 launches -> 1 for the conventional LoRA config).
+The kernel leaves the consumed gradients zeroed (the reference's ``zero_grad`` that follows is then a no-op on values)."""
+import torch
+
+from . import kernels as K
+
+
+def _dense_flat(t):
+    """1-D view over the dense storage range of a contiguous / channels_last tensor (element order is irrelevant to AdamW)."""
+    if not (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
+        raise ValueError("FusedAdamW: parameters and gradients must be dense (contiguous or channels_last)")
+    return t.as_strided((t.numel(),), (1,), t.storage_offset())
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._runs = {}            # group index -> (signature, [run])
+
+    def _build_runs(self, group):
+        items = []
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+                raise TypeError("FusedAdamW keeps fp32 master parameters (the reference: fp32 params under autocast)")
+            items.append((p.untyped_storage().data_ptr(), p.storage_offset(), p.numel(), p,
+                          p.grad.untyped_storage().data_ptr(), p.grad.storage_offset()))
+        items.sort(key=lambda it: (it[0], it[1]))
+        runs, cur = [], None
+        for sp, so, n, p, gp, go in items:
+            if cur and cur["sp"] == sp and cur["gp"] == gp and cur["so"] + cur["n"] == so and cur["go"] + cur["n"] == go:
+                cur["n"] += n
+            else:
+                cur = dict(sp=sp, gp=gp, so=so, go=go, n=n, p=p)
+                runs.append(cur)
+        out = []
+        for r in runs:
+            p, n = r["p"], r["n"]
+            pf = _dense_flat(p).as_strided((n,), (1,), r["so"])
+            gf = _dense_flat(p.grad).as_strided((n,), (1,), r["go"])
+            out.append(dict(p=pf, g=gf, m=torch.zeros_like(pf), v=torch.zeros_like(pf),
+                            lr=torch.zeros(1, dtype=torch.float32, device=pf.device), step=torch.zeros(1, dtype=torch.int32, device=pf.device)))
+        return out
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for gi, group in enumerate(self.param_groups):
+            sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in group["params"] if p.grad is not None)
+            cached = self._runs.get(gi)
+            if cached is None or cached[0] != sig:
+                if cached is not None:
+                    raise RuntimeError("FusedAdamW: the set of parameters with gradients (or their storage) changed between steps; "
+                                       "the flat AdamW moments cannot follow")
+                cached = (sig, self._build_runs(group))
+                self._runs[gi] = cached
+            b1, b2 = group["betas"]
+            for r in cached[1]:
+                r["lr"].fill_(group["lr"])
+                K.adamw_clip_fused(r["p"], r["g"], r["m"], r["v"], r["lr"], r["step"], beta1=b1, beta2=b2, eps=group["eps"],
+                                   weight_decay=group["weight_decay"], sumsq_t=None, grad_scale=1.0, max_norm=0.0)
+        self._bump_versions()
+        return loss
+
+    def _bump_versions(self):
+        """The kernel wrote through raw pointers: advance the parameters' autograd version counters, as the in-place torch ops of
+        torch.optim.AdamW would have (the native layers key their bf16 operand caches on them).  No kernel, no data touched."""
+        ps = [p for group in self.param_groups for p in group["params"] if p.grad is not None]
+        if hasattr(torch._C._autograd, "_unsafe_set_version_counter"):
+            torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
+        else:                                              # older torch: an in-place op on an empty slice bumps the counter
+            for p in ps:
+                p[:0].add_(0)

@@ -142,9 +142,10 @@ class NativeCLIPTextModel(nn.Module):
         return (x, None) if output_hidden_states is not None else x
 
     @classmethod
-    def from_pretrained(cls, path, subfolder="text_encoder", device="cuda", **kw):
+    def from_pretrained(cls, path=None, subfolder="text_encoder", device="cuda", pretrained_model_name_or_path=None, **kw):
         """A diffusers / transformers directory (config.json + model.safetensors) by parameter name."""
         from safetensors.torch import load_file
+        path = path if path is not None else pretrained_model_name_or_path
         root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
         cfg = json.load(open(os.path.join(root, "config.json")))
         model = cls(**kw, **{k: cfg[k] for k in CLIP_L_CONFIG if k in cfg})

@@ -414,8 +414,10 @@ class NativeUNet2DConditionModel(nn.Module):
         return cls(**dict(config or {}, **kw))
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, **kw):
-        """Load diffusers-format weights (config.json + *.safetensors) — names are identical by construction."""
+    def from_pretrained(cls, path=None, subfolder=None, pretrained_model_name_or_path=None, **kw):
+        """Load diffusers-format weights (config.json + *.safetensors) — names are identical by construction.
+        (``pretrained_model_name_or_path``: diffusers' own keyword, as the YAML overlays of cfgs/train/mi355x pass it.)"""
+        path = path if path is not None else pretrained_model_name_or_path
         import json
         import os
         root = os.path.join(path, subfolder) if subfolder else path

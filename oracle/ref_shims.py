@@ -97,3 +97,53 @@ def load_reference_ckpt():
     ckpt = importlib.import_module("hcpdiff.ckpt_manager")          # its real 4-line __init__ runs
     tools = importlib.import_module("hcpdiff.utils.cfg_net_tools")
     return ckpt.CkptManagerSafe, tools
+
+
+def load_reference_trainer():
+    """(train_ac module, train_ac_single module) of the reference, executed where they lie, with every dependency that the
+    inner loop does NOT touch replaced by an empty stand-in: diffusers / hydra / loguru (not installable here) and the
+    reference's own data, logger, visualizer and config-converter packages (host-side I/O, out of scope of the hot path).
+    What stays REAL: hcpdiff/train_ac.py itself (Trainer.train_one_step / forward / make_noise / get_loss / get_latents,
+    train_ac.py:428-515), hcpdiff/train_ac_single.py (TrainerSingleCard.init_context builds a real accelerate.Accelerator),
+    hcpdiff/models/wrapper.py (TEUnetWrapper), hcpdiff/models/cfg_context.py, hcpdiff/utils/cfg_net_tools.py (make_hcpdiff)."""
+    load_reference_ckpt()
+    d = sys.modules["diffusers"]
+    for name in ("AutoencoderKL", "UNet2DConditionModel", "DDPMScheduler", "SchedulerMixin"):
+        if not hasattr(d, name):
+            setattr(d, name, type(name, (), {}))
+    if "diffusers.utils" not in sys.modules:
+        du = types.ModuleType("diffusers.utils"); du.__path__ = []
+        dui = types.ModuleType("diffusers.utils.import_utils"); dui.is_xformers_available = lambda: False
+        sys.modules["diffusers.utils"] = du; sys.modules["diffusers.utils.import_utils"] = dui
+        d.utils = du; du.import_utils = dui
+
+    def stub(modname, **attrs):
+        if modname not in sys.modules:
+            m = types.ModuleType(modname); m.__path__ = []
+            sys.modules[modname] = m
+        for k, v in attrs.items():
+            setattr(sys.modules[modname], k, v)
+        return sys.modules[modname]
+
+    def placeholder(name):
+        return type(name, (), {})
+
+    stub("hydra", utils=stub("hydra.utils", instantiate=lambda *a, **k: (_ for _ in ()).throw(RuntimeError("hydra is shimmed"))))
+    if "loguru" not in sys.modules:
+        import logging
+        stub("loguru", logger=logging.getLogger("hcpdiff-shim"))
+    sys.modules["omegaconf"].OmegaConf = getattr(sys.modules["omegaconf"], "OmegaConf", placeholder("OmegaConf"))
+    stub("hcpdiff.data", RatioBucket=placeholder("RatioBucket"), DataGroup=placeholder("DataGroup"), get_sampler=lambda *a, **k: None)
+    stub("hcpdiff.deprecated"); stub("hcpdiff.deprecated.cfg_converter", TrainCFGConverter=placeholder("TrainCFGConverter"))
+    stub("hcpdiff.loggers", LoggerGroup=placeholder("LoggerGroup"))
+    stub("hcpdiff.visualizer", Visualizer=placeholder("Visualizer"))
+    stub("hcpdiff.models.compose", ComposeEmbPTHook=placeholder("ComposeEmbPTHook"), ComposeTEEXHook=placeholder("ComposeTEEXHook"),
+         SDXLTextEncoder=placeholder("SDXLTextEncoder"))
+    models = sys.modules["hcpdiff.models"]
+    ctx = importlib.import_module("hcpdiff.models.cfg_context")
+    wrapper = importlib.import_module("hcpdiff.models.wrapper")
+    models.CFGContext, models.DreamArtistPTContext = ctx.CFGContext, ctx.DreamArtistPTContext
+    models.TEUnetWrapper, models.SDXLTEUnetWrapper = wrapper.TEUnetWrapper, wrapper.SDXLTEUnetWrapper
+    train_ac = importlib.import_module("hcpdiff.train_ac")
+    single = importlib.import_module("hcpdiff.train_ac_single")
+    return train_ac, single

@@ -1,0 +1,109 @@
+"""The reference's OWN inner loop — hcpdiff/train_ac.py Trainer.train_one_step / forward / make_noise / get_loss / get_latents
+(train_ac.py:428-515) on a TrainerSingleCard (train_ac_single.py:11-30, real accelerate.Accelerator) — drives the native modules:
+native UNet + native CLIP text encoder inside the reference's TEUnetWrapper, LoRA built by the reference's make_hcpdiff with
+``type: lora_hip`` (BASELINE.json configs[0]: rank 4 on attn + ff, 10 steps, plumbing on the CPU interpreter), the native noise
+scheduler (seam 4) and either torch AdamW or the native FusedAdamW.  Its losses must equal NativeTrainer's step for step.
+Runs in a fresh interpreter (the reference's modules must be importable before hcp_diffusion_amd.patch_api binds); only where
+/root/reference exists."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, types, torch
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+from oracle.ref_shims import load_reference_trainer
+train_ac, single = load_reference_trainer()              # BEFORE the package: patch_api must find hcpdiff importable
+import hcp_diffusion_amd.patch_api as pa
+assert pa.USING_REFERENCE_PLUGIN_API
+import hcpdiff.utils.cfg_net_tools as tools
+from hcpdiff.models import TEUnetWrapper, CFGContext
+from conftest import emu_cdll
+from hcp_diffusion_amd import kernels as K
+K._set_backend_for_tests(emu_cdll())
+from hcp_diffusion_amd.lora import LoraBucket
+from hcp_diffusion_amd.optim import FusedAdamW
+from hcp_diffusion_amd.scheduler import NativeDDPMScheduler
+from hcp_diffusion_amd.text_encoder import NativeCLIPTextModel
+from hcp_diffusion_amd.trainer import NativeTrainer
+from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
+from oracle.clip_ref import OracleCLIPTextModel
+from oracle.make_golden import _Item
+from oracle.unet_sd15 import MICRO_CONFIG, seeded_init_
+
+PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
+UCFG = dict(MICRO_CONFIG, cross_attention_dim=64)
+TCFG = dict(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1, max_position_embeddings=77)
+STEPS, B = 10, 2
+
+def models():
+    u = seeded_init_(NativeUNet2DConditionModel(**UCFG), 1); u.requires_grad_(False); u.eval()
+    te = NativeCLIPTextModel(**TCFG); te.load_state_dict(seeded_init_(OracleCLIPTextModel(**TCFG), 2).state_dict()); te.requires_grad_(False); te.eval()
+    return u, te
+
+def init_up(plugin_dict):                                # by layer path: the two builders may enumerate the blocks in different orders
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for path in sorted(plugin_dict):
+            blk = plugin_dict[path]
+            blk.layer.W_up.copy_(torch.randn(blk.layer.W_up.shape, generator=g) * 0.05)
+            blk.layer.W_down.copy_(torch.randn(blk.layer.W_down.shape, generator=g) * blk.layer.W_down.shape[1] ** -0.5)
+
+g = torch.Generator().manual_seed(9)
+data = [dict(img=torch.randn(B, 4, 8, 8, generator=g), prompt=torch.randint(0, 100, (B, 77), generator=g)) for _ in range(STEPS)]
+
+def reference_run(opt_cls):
+    u, te = models()
+    t = single.TrainerSingleCard.__new__(single.TrainerSingleCard)        # the constructor's data / logger / hydra plumbing is out of scope
+    ns = types.SimpleNamespace
+    t.cfgs = ns(seed=114514, mixed_precision="no",
+                train=ns(gradient_accumulation_steps=1, max_grad_norm=1.0, set_grads_to_none=False, loss=ns(type="eps")))
+    t.init_context(None)                                              # train_ac_single.py:12-22: a real accelerate.Accelerator, set_seed
+    assert type(t.accelerator).__name__ == "Accelerator" and t.world_size == 1
+    t.weight_dtype = torch.float32                                    # (device is the Trainer property over accelerator.device)
+    # make_hcpdiff (cfg_net_tools.py:90-128) builds the native LoRA blocks and the optimizer's param groups
+    groups, lora_unet = tools.make_hcpdiff(u, None, [_Item(layers=PATS, rank=4, type="lora_hip", lr=1e-3)])
+    init_up(lora_unet.plugin_dict)
+    LoraBucket(list(lora_unet.plugin_dict.values()))
+    t.TE_unet = TEUnetWrapper(u, te)                                  # models/wrapper.py:14-30
+    t.noise_scheduler = NativeDDPMScheduler()                         # seam 4
+    t.cfg_context = CFGContext()
+    t.criterion = torch.nn.MSELoss(reduction="none")                  # train_base.yaml:31-34
+    t.embedding_hook = ns(emb_train=[])
+    t.train_loader_group = ns(get_dataset=lambda idx: ns(latents=True), get_loss_weights=lambda idx: 1.0)    # cached latents
+    t.optimizer = opt_cls(groups, weight_decay=1e-3)
+    t.lr_scheduler = None
+    torch.manual_seed(1234)
+    losses = [t.train_one_step([dict(d)]) for d in data]              # train_ac.py:467-504, unmodified
+    return losses, {k: torch.cat([b.layer.W_down.detach().flatten(), b.layer.W_up.detach().flatten()]) for k, b in lora_unet.plugin_dict.items()}
+
+def native_run():
+    u, te = models()
+    tr = NativeTrainer(u, [dict(layers=PATS, rank=4, lr=1e-3)], lr=1e-3, weight_decay=1e-3, text_encoder=te)
+    init_up(tr.lora_group.plugin_dict); tr.bucket.pack()
+    torch.manual_seed(1234)
+    losses = [tr.train_one_step(d["img"], None, prompt_ids=d["prompt"]).item() for d in data]
+    return losses, {k: torch.cat([b.layer.W_down.detach().flatten(), b.layer.W_up.detach().flatten()]) for k, b in tr.lora_group.plugin_dict.items()}
+
+ln, pn = native_run()
+for opt_cls in (torch.optim.AdamW, FusedAdamW):
+    lr_, pr = reference_run(opt_cls)
+    assert len(lr_) == STEPS
+    for a, b in zip(lr_, ln):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (opt_cls.__name__, lr_, ln)
+    assert set(pr) == set(pn)
+    worst = max(((pr[k] - pn[k]).abs().max() / pn[k].abs().max()).item() for k in pn)
+    assert worst < 2e-3, (opt_cls.__name__, worst)        # 10 AdamW steps at lr 1e-3 on bf16-rounded gradients
+assert ln[0] != ln[-1]
+print("REFERENCE_TRAINER_OK", ln[0], ln[-1])
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+def test_reference_trainer_steps_the_native_modules():
+    r = subprocess.run([sys.executable, "-c", SCRIPT.replace("ROOT", repr(ROOT))], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "REFERENCE_TRAINER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
