@@ -64,6 +64,7 @@ _PROTOTYPES = {
     # x, dy, stats, dgamma, dbeta, M, C, stream
     "hcp_layernorm_affine_grad": (I, [P, P, P, P, P, I, I, P]),
     "hcp_add_noise": (I, [P, P, P, P, P, I, L, P]),
+    "hcp_cfg_ddim_step": (I, [P, P, P, L, I, F, F, F, P]),
     "hcp_snr_loss_weight": (I, [P, P, P, I, I, F, P]),
     "hcp_quick_gelu": (I, [P, P, P, L, P]),
     "hcp_embedding_bf16": (I, [P, P, P, P, P, L, I, I, P]),

@@ -156,6 +156,21 @@ HCP_KERNEL(256) add_noise_kernel(const float* x0, const float* noise, const long
     }
 }
 
+// One sampler step with classifier-free guidance, fused (inference / in-training previews; reference utils/pipe_hook.py:120-140:
+// noise_pred = uncond + scale (text - uncond), then scheduler.step):
+//   eps = eps2[b] + g (eps2[B + b] - eps2[b])            eps2 = the UNet's output on the batch [uncond ; cond] (g = 1, eps2 of B rows: no CFG)
+//   x0  = (x - sqrt(1 - a_t) eps) / sqrt(a_t)            (epsilon prediction)
+//   out = sqrt(a_prev) x0 + sqrt(1 - a_prev) eps         (DDIM, eta = 0; a_prev = 1 on the final step)
+HCP_KERNEL(256) cfg_ddim_kernel(const float* x, const float* eps2, float* out, long n, long cond_off, float guidance, float a_t, float a_prev) {
+    const float sa = sqrtf(a_t), sb = sqrtf(1.0f - a_t), pa = sqrtf(a_prev), pb = sqrtf(1.0f - a_prev);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float eu = eps2[i];
+        const float e = cond_off ? eu + guidance * (eps2[cond_off + i] - eu) : eu;
+        const float x0 = (x[i] - sb * e) / sa;
+        out[i] = pa * x0 + pb * e;
+    }
+}
+
 // Per-sample loss weight from the noise level of the sample's timestep (reference hcpdiff/loss/min_snr_loss.py):
 //   snr = acp/(1-acp) (= (alpha/sigma)^2, :14-19), sigma^2 = 1-acp
 //   kind 0 MinSNRLoss      min(gamma/snr, 1)                                   (:21-25)
@@ -368,6 +383,16 @@ HCP_API int hcp_add_noise(const float* x0, const float* noise, const long long* 
     HCP_LAUNCH(add_noise_kernel, dim3(pw_grid((long)B * per_sample)), dim3(PW_THREADS), 0, stream, x0, noise, timesteps,
                alphas_cumprod, xt, B, per_sample);
     HCP_LAUNCH_CHECK("add_noise");
+}
+// x [n] fp32, eps2 [2n] (classifier-free guidance: uncond rows first) or [n] (guided == 0), out [n]; may run in place (out == x).
+HCP_API int hcp_cfg_ddim_step(const float* x, const float* eps2, float* out, long n, int guided, float guidance_scale,
+                              float alpha_cumprod_t, float alpha_cumprod_prev, hipStream_t stream) {
+    HCP_REQUIRE(x && eps2 && out && n > 0, "hcp_cfg_ddim_step: bad arguments");
+    HCP_REQUIRE(alpha_cumprod_t > 0.f && alpha_cumprod_t <= 1.f && alpha_cumprod_prev > 0.f && alpha_cumprod_prev <= 1.f,
+                "hcp_cfg_ddim_step: alphas_cumprod must lie in (0, 1]");
+    HCP_LAUNCH(cfg_ddim_kernel, dim3(pw_grid(n)), dim3(PW_THREADS), 0, stream, x, eps2, out, n, guided ? n : 0L, guidance_scale,
+               alpha_cumprod_t, alpha_cumprod_prev);
+    HCP_LAUNCH_CHECK("cfg_ddim_step");
 }
 // w[b] = loss weight of sample b from its timestep (kinds above); w feeds hcp_mse_masked_mean's sample_weight.
 HCP_API int hcp_snr_loss_weight(const long long* timesteps, const float* alphas_cumprod, float* w, int B, int kind, float gamma,

@@ -422,6 +422,17 @@ def add_noise(x0, noise, t, alphas_cumprod):
     return xt
 
 
+def cfg_ddim_step(x, eps2, a_t, a_prev, guidance_scale=1.0, out=None):
+    """One DDIM (eta = 0) step with classifier-free guidance: eps2 is the UNet output on [uncond ; cond] (2B rows) or on B rows."""
+    assert x.dtype == torch.float32 and eps2.dtype == torch.float32 and x.is_contiguous() and eps2.is_contiguous()
+    guided = eps2.numel() == 2 * x.numel()
+    assert guided or eps2.numel() == x.numel()
+    out = torch.empty_like(x) if out is None else out
+    _chk(lib().hcp_cfg_ddim_step(_p(x), _p(eps2), _p(out), x.numel(), 1 if guided else 0, float(guidance_scale), float(a_t), float(a_prev),
+                                 _stream(x)), "hcp_cfg_ddim_step")
+    return out
+
+
 def quick_gelu(x, dy=None):
     """quick_gelu(x) = x * sigmoid(1.702 x) (dy None) or dy * quick_gelu'(x); bf16, any shape with numel % 8 == 0."""
     assert x.dtype == BF16 and x.is_contiguous() and (dy is None or (dy.dtype == BF16 and dy.is_contiguous() and dy.shape == x.shape))

@@ -181,6 +181,12 @@ int hcp_adamw_clip_fused(float* p, float* g, float* m, float* v, long n, const f
 int hcp_ema_update(float* ema, const float* p, long n, const int* step, float inv_gamma, float power, float decay_max,
                    hcpStream_t stream);
 
+/* One DDIM (eta = 0) sampler step with classifier-free guidance fused in (reference utils/pipe_hook.py:120-140 + scheduler.step):
+ * eps = eps2[:n] + g (eps2[n:] - eps2[:n]) when guided (eps2 = UNet output on [uncond ; cond]), else eps2[:n];
+ * out = sqrt(a_prev) (x - sqrt(1 - a_t) eps) / sqrt(a_t) + sqrt(1 - a_prev) eps.  fp32, out may alias x. */
+int hcp_cfg_ddim_step(const float* x, const float* eps2, float* out, long n, int guided, float guidance_scale,
+                      float alpha_cumprod_t, float alpha_cumprod_prev, hcpStream_t stream);
+
 /* ---- tuning / ablation hooks: ONLY in builds made with -DHCP_TOOLS (libhcp_mi355x_tools.so, used by tools/*.py and by the
  * tests that force kernel variants).  They set process-global knobs and are therefore not part of the product ABI. */
 #ifdef HCP_TOOLS

@@ -92,6 +92,7 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
         "hcp_ema_update": (N, N, 0, N, 1.0, 0.6, 0.99, N),
         "hcp_timestep_embedding": (N, N, 0, 3, 1e4, N),
         "hcp_add_noise": (N, N, N, N, N, 0, 0, N),
+        "hcp_cfg_ddim_step": (N, N, N, 0, 1, 7.5, 0.5, 0.6, N),
         "hcp_snr_loss_weight": (N, N, N, 0, 0, 5.0, N),
         "hcp_quick_gelu": (N, N, N, 7, N),
         "hcp_embedding_bf16": (N, N, N, N, N, 0, 8, 77, N),
