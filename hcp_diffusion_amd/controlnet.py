@@ -109,11 +109,21 @@ class ControlNetHipPlugin(MultiPluginBlock):
         if block is None:
             return None
         block = deepcopy(block)
+        # remove_all_hooks + remove_layers(block, BasePluginBlock) (controlnet.py:38-44): the branch is a copy of the PLAIN host
+        # layers.  (The reference's remove_layers indexes a dict with a list, net_utils.py:141, so there a LoRA-wrapped host ends
+        # in a TypeError; its evident intent — drop the plugin blocks, keep the hosts — is what happens here: every patch
+        # container in the copy is replaced by the host layer it wraps.)
+        if isinstance(block, PatchPluginContainer):
+            block = block._host
+        for _ in range(8):                                  # containers never nest deeper than this
+            swaps = [(parent, name, child._host) for parent in block.modules() for name, child in parent.named_children()
+                     if isinstance(child, PatchPluginContainer)]
+            if not swaps:
+                break
+            for parent, name, host in swaps:
+                setattr(parent, name, host)
         for m in block.modules():
             m._forward_hooks.clear(); m._forward_pre_hooks.clear(); m._backward_hooks.clear()
-            if isinstance(m, PatchPluginContainer):
-                raise NotImplementedError("hcp_diffusion_amd: build the ControlNet branch before wrapping the host with LoRA "
-                                          "(the reference strips plugin layers from the copy; not implemented here)")
             if hasattr(m, "_groups"):
                 m._groups = {}
         return block

@@ -34,15 +34,30 @@ class LoraHipContainer(PatchPluginContainer):
                 self._multi = MultiLora([self[n] for n in self.plugin_names], tuple(self.plugin_names))
             if kwargs:
                 raise NotImplementedError(f"LoraHipContainer: unsupported call arguments {list(kwargs)}")
+            last = self[self.plugin_names[-1]]         # the reference applies the LAST block's dropout (lora_base_patch.py:35)
+            if last.dropout.p > 0.0 and last.training:
+                return self._dropped(ops.linear(x, self._host, self._multi, None), last, residual)
             return ops.linear(x, self._host, self._multi, residual)
         blk = self[self.plugin_names[0]]
+        drop = blk.dropout.p > 0.0 and blk.training
         if blk.host_type == "conv":                    # 3x3 host: same keyword surface as HipConv2d.forward
             host = self._host
-            return ops.conv3x3(x, host, x2=kwargs.pop("x2", None), rowbias=kwargs.pop("rowbias", None), residual=residual,
-                               stride=host.stride[0], upsample=kwargs.pop("upsample", False), lora=blk, **kwargs)
+            y = ops.conv3x3(x, host, x2=kwargs.pop("x2", None), rowbias=kwargs.pop("rowbias", None), residual=None if drop else residual,
+                            stride=host.stride[0], upsample=kwargs.pop("upsample", False), lora=blk, **kwargs)
+            return self._dropped(y, blk, residual) if drop else y
         if kwargs:
             raise NotImplementedError(f"LoraHipContainer: unsupported call arguments {list(kwargs)}")
+        if drop:
+            return self._dropped(ops.linear(x, self._host, blk, None), blk, residual)
         return ops.linear(x, self._host, blk, residual)
+
+    @staticmethod
+    def _dropped(y, blk, residual):
+        """``dropout(layer(x, W_host + dW, bias))`` (lora_base_patch.py:74): the reference drops the WHOLE layer output, host path
+        included, with torch's dropout (its Philox stream, its 1/(1-p) scaling) — reproduced with the same op; a residual that
+        the native caller wanted fused into the GEMM epilogue is added afterwards (it is not part of the layer's output)."""
+        y = blk.dropout(y)
+        return y if residual is None else ops.add(y, residual)
 
 
 class _Factors(nn.Module):
@@ -100,8 +115,10 @@ class LoraHipLayer(PatchPluginBlock):
         if not isinstance(host, (HipLinear, HipConv2d)):
             raise NotImplementedError(f"lora_hip: host {type(host).__name__} is not a native Linear / Conv2d layer")
         conv3 = isinstance(host, HipConv2d) and host.kernel_size == (3, 3)
-        if bias or dropout != 0.0:
-            raise NotImplementedError("lora_hip: bias=True / dropout>0 are not implemented (reference defaults are off)")
+        if bias:
+            # unreachable in the reference as well: LinearLayer / Conv2dLayer.reset_parameters do `if self.bias:` on the [out]-element
+            # Parameter (lora_layers_patch.py:41,85) -> "Boolean value of Tensor with more than one value is ambiguous"
+            raise NotImplementedError("lora_hip: bias=True (the reference's own LoraLayer raises on it: lora_layers_patch.py:41)")
         out_f, in_f = host.weight.shape[0], host.weight.shape[1]
         if conv3 and (in_f % 8 or out_f % 8 or type(host) is not HipConv2d):
             raise NotImplementedError("lora_hip: conv LoRA needs channel counts that are multiples of 8 (conv_in / conv_out are excluded)")
@@ -132,9 +149,26 @@ class LoraHipLayer(PatchPluginBlock):
         return None
 
     def init_weights(self, svd_init=False):
-        if svd_init:
-            raise NotImplementedError("lora_hip: svd_init")
-        self.layer.reset_parameters()
+        """svd_init (lora_base_patch.py:76-82): the factors start as the rank-r truncated SVD of the host weight, U S -> W_up,
+        V^T -> W_down, both clamped at the 0.99 quantile of their joint value distribution (utils/utils.py:17-41).  The reference's
+        own patch-LoRA cannot run this path (its feed_svd writes ``lora_up`` / ``lora_down``, attributes its layers do not have,
+        lora_base_patch.py:108-110, and low_rank_approximate unpacks a flattened conv weight into four dims, utils.py:19-20): what
+        is implemented is what those lines evidently mean.  A one-off host call (torch.linalg.svd), like checkpoint loading."""
+        if not svd_init:
+            self.layer.reset_parameters()
+            return
+        with torch.no_grad():
+            w = self.host().weight.detach().float()
+            w2 = w.flatten(1)                                            # conv: [out, in*kh*kw]
+            U, S, Vh = torch.linalg.svd(w2, full_matrices=False)
+            U = U[:, :self.rank] @ torch.diag(S[:self.rank])
+            Vh = Vh[:self.rank]
+            dist = torch.cat([U.flatten(), Vh.flatten()])
+            if dist.numel() > (1 << 24):                                 # torch.quantile's input limit: a strided subsample
+                dist = dist[::(dist.numel() >> 24) + 1]
+            hi = torch.quantile(dist, 0.99)
+            self.layer.W_up.copy_(U.clamp(-hi, hi).reshape(self.layer.W_up.shape))
+            self.layer.W_down.copy_(Vh.clamp(-hi, hi).reshape(self.layer.W_down.shape))      # conv: [r, in*kh*kw] -> [r, in, kh, kw]
 
     def reparameterization_to_host(self, alpha=None, base_alpha=1.0):
         alpha = self.alpha if alpha is None else alpha

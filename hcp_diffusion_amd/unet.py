@@ -143,6 +143,8 @@ def _fusable_linear(m):
         return None
     if blk is not None and blk.wide:                   # rank > 32 runs as its own skinny GEMM, not in a shared slot group
         return None
+    if blk is not None and blk.dropout.p > 0.0:        # dropout acts on this layer's whole output (lora_base_patch.py:74): own call
+        return None
     return host, blk
 
 

@@ -642,3 +642,67 @@ def test_lora_rank_above_one_slot_group(backend, rank):
     rel = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
     assert rel(y.detach(), yr.detach()) < 2e-2 and rel(xn.grad, xr.grad) < 2e-2
     assert rel(blk.layer.W_down.grad, wd.grad) < 2e-2 and rel(blk.layer.W_up.grad, wu.grad) < 2e-2
+
+
+def test_lora_dropout_and_svd_init(backend):
+    """dropout > 0: the reference drops the whole layer output (lora_base_patch.py:74) — eval mode is the identity, train mode
+    zeroes ~p of the outputs and rescales the rest by 1/(1-p), gradients flow through the kept ones only.  svd_init: the factors
+    start as the clamped rank-r SVD of the host weight (lora_base_patch.py:76-82, utils/utils.py:17-41 — the Linear branch of the
+    reference's own low_rank_approximate is the oracle where the reference tree exists)."""
+    from hcp_diffusion_amd.layers import HipLinear
+    dev = backend.device
+    torch.manual_seed(3)
+    lin = HipLinear(64, 96, bias=True).to(dev)
+    parent = torch.nn.Module(); parent.proj = lin
+    blk = LoraHipLayer.wrap_layer(0, lin, rank=4, dropout=0.5, parent_block=parent, host_name="proj")
+    with torch.no_grad():
+        blk.layer.W_up.normal_(0, 0.05)
+    x = backend.to(torch.randn(2, 40, 64).to(torch.bfloat16))
+    parent.proj.eval(); blk.eval()
+    y_eval = parent.proj(x).float()
+    blk.dropout.p = 0.0
+    y_ref = parent.proj(x).float()
+    assert torch.equal(y_eval, y_ref)
+    blk.dropout.p = 0.5
+    blk.train()
+    xg = x.clone().requires_grad_(True)
+    y = parent.proj(xg)
+    yf = y.float()
+    dropped = (yf == 0).float().mean().item()
+    assert 0.4 < dropped < 0.6
+    kept = yf != 0
+    assert ((yf[kept] - 2.0 * y_ref[kept]).abs().max() / y_ref.abs().max()).item() < 2e-2
+    y.float().sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad.float()).all() and blk.layer.W_up.grad.abs().sum().item() > 0
+    # svd_init
+    lin2 = HipLinear(64, 96, bias=False).to(dev)
+    parent2 = torch.nn.Module(); parent2.proj = lin2
+    blk2 = LoraHipLayer.wrap_layer(1, lin2, rank=8, svd_init=True, parent_block=parent2, host_name="proj")
+    w = lin2.weight.detach().float().cpu()
+    U, S, Vh = torch.linalg.svd(w, full_matrices=False)
+    best = (U[:, :8] * S[:8]) @ Vh[:8]
+    approx = (blk2.layer.W_up.detach().float().cpu().reshape(96, 8) @ blk2.layer.W_down.detach().float().cpu().reshape(8, 64))
+    assert ((approx - best).norm() / best.norm()).item() < 0.15         # the 0.99-quantile clamp trims the largest entries only
+    if os.path.isdir("/root/reference/hcpdiff"):
+        from oracle.ref_shims import load_reference_lora
+        load_reference_lora()
+        from hcpdiff.utils.utils import low_rank_approximate
+        Ur, Vr = low_rank_approximate(w, 8)
+        # singular vectors are defined up to sign per component: compare the products
+        assert ((approx - Ur @ Vr).norm() / (Ur @ Vr).norm()).item() < 1e-4
+
+
+def test_controlnet_branch_from_a_lora_wrapped_host(backend):
+    """copy_block (controlnet.py:38-44): the branch copies the PLAIN host layers even when the host already carries LoRA blocks."""
+    from hcp_diffusion_amd.controlnet import make_controlnet
+    from hcp_diffusion_amd.lora import LoraHipContainer
+    dev = backend.device
+    _, nat = _pair(MICRO_CONFIG, dev)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=4)], lr=1e-3)
+    assert any(isinstance(m, LoraHipContainer) for m in nat.modules())
+    plug = make_controlnet(nat, block_out_channels=MICRO_CONFIG["block_out_channels"], layers_per_block=MICRO_CONFIG["layers_per_block"],
+                           cond_block_channels=(3, 8, 8, 16, 16, MICRO_CONFIG["block_out_channels"][0]))
+    assert not any(isinstance(m, LoraHipContainer) for m in plug.modules())
+    assert not any("lora_block" in n for n, _ in plug.named_parameters())
+    n_host = sum(p.numel() for n, p in nat.down_blocks.named_parameters() if "lora_block" not in n)
+    assert sum(p.numel() for p in plug.down_blocks.parameters()) == n_host
