@@ -198,6 +198,77 @@ def sd15_full_vectors():
     return dict(pred=pred.detach(), loss=float(loss), n_lora=len(wr), fingerprint=grad_fingerprint([(n, p.grad) for n, p in lora_named]))
 
 
+def sd15_b4_inputs():
+    """The benchmark batch (BASELINE.json configs[1]): B=4, 64x64 latents, 77x768 context, timesteps of SURVEY.md §8(c)."""
+    g2 = torch.Generator().manual_seed(4242)
+    x0 = torch.randn(4, 4, 64, 64, generator=g2); ehs = torch.randn(4, 77, 768, generator=g2)
+    noise = torch.randn(4, 4, 64, 64, generator=g2); t = torch.tensor([10, 250, 500, 999])
+    return x0, ehs, noise, t
+
+
+SD15_BOUNDARIES = ["conv_in", "down_blocks.0", "down_blocks.1", "down_blocks.2", "down_blocks.3", "mid_block",
+                   "up_blocks.0", "up_blocks.1", "up_blocks.2", "up_blocks.3", "conv_norm_out"]
+
+
+def boundary_sample(name, y_nchw, n=8192, seed=31):
+    """A seeded sample of a block-boundary activation [B,C,H,W] (logical NCHW coordinates, so the native channels-last tensors are
+    sampled at the same elements): (values fp32 [n], L2 norm of the whole tensor)."""
+    import zlib
+    y = y_nchw.detach().float().cpu()
+    gen = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
+    idx = torch.randint(0, y.numel(), (min(n, y.numel()),), generator=gen)
+    return y.reshape(-1)[idx].clone(), float(y.norm())
+
+
+def quantize_grads(named_grads):
+    """int8 with one absmax scale per tensor: a 3 MB fixture of the FULL flat LoRA gradient (cosine error of the code ~1e-5)."""
+    q, scales = [], []
+    for _, g in named_grads:
+        g = g.detach().float().cpu().flatten()
+        s_ = float(g.abs().max()) / 127.0 or 1.0
+        q.append(torch.clamp((g / s_).round(), -127, 127).to(torch.int8)); scales.append(s_)
+    return torch.cat(q), torch.tensor(scales)
+
+
+def dequantize_grads(q, scales, named_params):
+    out, off = [], 0
+    for (_, p), s_ in zip(named_params, scales.tolist()):
+        n = p.numel()
+        out.append(q[off:off + n].float() * s_); off += n
+    return torch.cat(out)
+
+
+def sd15_full_b4_vectors():
+    """Full SD1.5 architecture at the BENCHMARK batch (B=4): prediction, loss, a sample of every block-boundary activation and the
+    full flat LoRA gradient (int8, per-tensor scale) of the fp32 oracle."""
+    import torch.nn.functional as F
+    from oracle.lora_ref import wrap_lora
+    from oracle.unet_sd15 import OracleUNet2DConditionModel, add_noise, ddpm_alphas_cumprod, seeded_init_
+    with torch.device("meta"):
+        m = OracleUNet2DConditionModel()
+    m = seeded_init_(m.to_empty(device="cpu"), 1)
+    m.requires_grad_(False)
+    wrap_lora(m, [r"re:.*\.attn.?$", r"re:.*\.ff$"], rank=8)
+    lora_named = [(n, p) for n, p in m.named_parameters() if "lora_block_" in n]
+    sd15_lora_init_(lora_named)
+    x0, ehs, noise, t = sd15_b4_inputs()
+    named = dict(m.named_modules())
+    bounds, hooks = {}, []
+    for name in SD15_BOUNDARIES:
+        def hook(mod, args, out, name=name):
+            y = out[0] if isinstance(out, tuple) else out
+            bounds[name] = boundary_sample(name, y)
+        hooks.append(named[name].register_forward_hook(hook))
+    pred = m(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ehs).sample
+    for h in hooks:
+        h.remove()
+    loss = F.mse_loss(pred, noise)
+    loss.backward()
+    q, scales = quantize_grads([(n, p.grad) for n, p in lora_named])
+    return dict(pred=pred.detach(), loss=float(loss), boundaries=bounds, grad_q=q, grad_scales=scales, grad_names=[n for n, _ in lora_named],
+                grad_norm=float(torch.cat([p.grad.flatten() for _, p in lora_named]).norm()))
+
+
 def sdxl_full_inputs():
     """SDXL-base shapes at batch 1 / 512 px (64x64 latents keep the CPU oracle to minutes; every layer shape except the
     token count equals BASELINE.json configs[3])."""
@@ -413,5 +484,6 @@ if __name__ == "__main__":
         sys.exit(0)
     torch.save(tiny_unet_vectors(), os.path.join(GOLD, "tiny_unet_oracle.pt"))
     torch.save(sd15_full_vectors(), os.path.join(GOLD, "sd15_full_oracle.pt"))
+    torch.save(sd15_full_b4_vectors(), os.path.join(GOLD, "sd15_full_b4_oracle.pt"))
     for f in os.listdir(GOLD):
         print(f, os.path.getsize(os.path.join(GOLD, f)))

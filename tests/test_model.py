@@ -121,7 +121,7 @@ def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42, poole
 def test_tiny_lora_train_step_vs_oracle(backend):
     lo, ln, go, tr, wr = _train_step_pair(TINY_CONFIG, backend, 4, (2, 4, 8, 8), 77, 64)
     assert abs(lo - ln) / abs(lo) < 2e-2
-    assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.995
+    assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.999
     # fused clip + AdamW + re-pack against torch's clip_grad_norm_ + AdamW on the oracle's (near identical) gradients
     params = [p for w in wr.values() for p in (w.lora_block_0.layer.W_down, w.lora_block_0.layer.W_up)]
     for p, gslice in zip(params, torch.split(tr.bucket.grads.cpu(), [p.numel() for p in params])):
@@ -140,7 +140,7 @@ def test_tiny_lora_train_step_min_snr_loss(backend):
     under oracle/loss_ref.get_loss (itself pinned to the reference classes); the weights differ from 1 for this batch."""
     lo, ln, go, tr, _ = _train_step_pair(MICRO_CONFIG, backend, 4, (2, 4, 8, 8), 77, 32, loss_cfg=dict(type="min_snr", gamma=5.0))
     assert abs(lo - ln) / abs(lo) < 2e-2
-    assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.995
+    assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.999
     with pytest.raises(ValueError):
         NativeTrainer(tr.unet, None, train_cfg=[dict(layers=[""])], loss_cfg=dict(type="huber"))
 
@@ -168,7 +168,7 @@ def test_tiny_sdxl_lora_train_step_vs_oracle(backend):
     text_time additional embedding, rank-16 LoRA as in BASELINE.json configs[3])."""
     lo, ln, go, tr, wr = _train_step_pair(TINY_SDXL_CONFIG, backend, 16, (2, 4, 8, 8), 77, 64, pooled_dim=64)
     assert abs(lo - ln) / abs(lo) < 2e-2
-    assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.995
+    assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.999
 
 
 def _full_ft_pair(cfg, backend, shape, ctx_len, ctx_dim, pooled_dim=None, seed=11):
@@ -292,6 +292,56 @@ def test_sd15_full_size_forward_and_lora_grads_vs_golden():
     assert num / (da * db) > 0.99                                # projections agree in sign and size across 320 tensors
     bad = [n for n in fp if g["fingerprint"][n][0] > 1e-7 and abs(fp[n][0] - g["fingerprint"][n][0]) / g["fingerprint"][n][0] > 0.1]
     assert len(bad) <= 3, bad                                    # per-tensor gradient norms within 10% (bf16 pipeline)
+
+
+@pytest.mark.gpu
+def test_sd15_full_size_batch4_blocks_and_full_lora_gradient_vs_golden():
+    """The BENCHMARK shape (BASELINE.json configs[1]: SD1.5, B=4, 64x64 latents, LoRA r=8, timesteps 10/250/500/999) against the fp32
+    oracle (tests/golden/sd15_full_b4_oracle.pt, oracle/make_golden.sd15_full_b4_vectors), at the tolerances SURVEY.md §8(c) states:
+    every block-boundary activation rel-L2 <= 1e-2 (seeded 8192-element samples), prediction rel-L2 <= 2e-2, loss <= 1e-2 relative,
+    cosine of the FULL flat LoRA gradient (2,992,128 elements) >= 0.999."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle.make_golden import SD15_BOUNDARIES, boundary_sample, dequantize_grads, sd15_b4_inputs, sd15_lora_init_
+    K._set_backend_for_tests(None)
+    dev = torch.device("cuda:0")
+    g = torch.load(os.path.join(GOLD, "sd15_full_b4_oracle.pt"))
+    with torch.device("meta"):
+        nat = NativeUNet2DConditionModel()
+    nat = seeded_init_(nat.to_empty(device=dev), 1)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=8)], lr=1e-4)
+    lora_named = [(n, p) for n, p in nat.named_parameters() if "lora_block_" in n]
+    assert [n for n, _ in lora_named] == g["grad_names"]
+    sd15_lora_init_(lora_named)
+    tr.bucket.pack()
+    x0, ehs, noise, t = sd15_b4_inputs()
+    named = dict(nat.named_modules())
+    got, hooks = {}, []
+    for name in SD15_BOUNDARIES:
+        def hook(mod, args, out, name=name):
+            got[name] = out[0] if isinstance(out, tuple) else out
+        hooks.append(named[name].register_forward_hook(hook))
+    with torch.no_grad():
+        pred = nat(K.add_noise(x0.to(dev), noise.to(dev), t.to(dev), tr.acp), t.to(dev), ehs.to(dev)).sample.cpu()
+    for h in hooks:
+        h.remove()
+    worst = {}
+    for name in SD15_BOUNDARIES:
+        y = got[name].permute(0, 3, 1, 2)              # native activations are [B,H,W,C]; the samples are taken at logical NCHW positions
+        smp, nrm = boundary_sample(name, y.float().contiguous())
+        ref, ref_n = g["boundaries"][name]
+        worst[name] = ((smp - ref).norm() / ref.norm()).item()
+        assert abs(nrm - ref_n) / ref_n < 1e-2, (name, nrm, ref_n)
+    assert max(worst.values()) < 1e-2, worst
+    assert ((pred - g["pred"]).norm() / g["pred"].norm()).item() < 2e-2
+    tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
+    loss = tr.forward_backward(x0.to(dev), ehs.to(dev)).item()
+    assert abs(loss - g["loss"]) / g["loss"] < 1e-2
+    flat = torch.cat([p.grad.detach().float().flatten().cpu() for _, p in lora_named])
+    ref = dequantize_grads(g["grad_q"], g["grad_scales"], lora_named)
+    cos = F.cosine_similarity(flat, ref, dim=0).item()
+    print(f"[b4] worst block rel-L2 {max(worst.values()):.2e}, LoRA gradient cosine {cos:.5f}, norm {flat.norm().item():.5f} vs {g['grad_norm']:.5f}")
+    assert cos > 0.999 and abs(flat.norm().item() - g["grad_norm"]) / g["grad_norm"] < 2e-2
 
 
 @pytest.mark.gpu
