@@ -310,8 +310,9 @@ def test_sd15_full_size_batch4_blocks_and_full_lora_gradient_vs_golden():
         nat = NativeUNet2DConditionModel()
     nat = seeded_init_(nat.to_empty(device=dev), 1)
     tr = NativeTrainer(nat, [dict(layers=PATS, rank=8)], lr=1e-4)
-    lora_named = [(n, p) for n, p in nat.named_parameters() if "lora_block_" in n]
-    assert [n for n, _ in lora_named] == g["grad_names"]
+    by_name = {n: p for n, p in nat.named_parameters() if "lora_block_" in n}
+    assert sorted(by_name) == sorted(g["grad_names"])
+    lora_named = [(n, by_name[n]) for n in g["grad_names"]]             # the oracle's enumeration order (the flat gradient's layout)
     sd15_lora_init_(lora_named)
     tr.bucket.pack()
     x0, ehs, noise, t = sd15_b4_inputs()
