@@ -328,6 +328,11 @@ def test_sd15_full_size_batch4_blocks_and_full_lora_gradient_vs_golden():
         h.remove()
     worst = {}
     for name in SD15_BOUNDARIES:
+        if name == "conv_norm_out":                    # the native module returns GroupNorm+SiLU fused (one kernel): compare after SiLU
+            ref, ref_n = g["boundaries"][name]
+            smp, _ = boundary_sample(name, got[name].permute(0, 3, 1, 2).float().contiguous())
+            worst[name] = ((smp - F.silu(ref)).norm() / F.silu(ref).norm()).item()
+            continue
         y = got[name].permute(0, 3, 1, 2)              # native activations are [B,H,W,C]; the samples are taken at logical NCHW positions
         smp, nrm = boundary_sample(name, y.float().contiguous())
         ref, ref_n = g["boundaries"][name]
