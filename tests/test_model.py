@@ -348,7 +348,7 @@ def test_sd15_full_size_batch4_blocks_and_full_lora_gradient_vs_golden():
     assert abs(loss - g["loss"]) / g["loss"] < 1e-2
     flat = torch.cat([p.grad.detach().float().flatten().cpu() for _, p in lora_named])
     ref = dequantize_grads(g["grad_q"], g["grad_scales"], lora_named)
-    cos = F.cosine_similarity(flat, ref, dim=0).item()
+    cos = (flat.double() @ ref.double() / (flat.double().norm() * ref.double().norm())).item()      # fp64: 3M-term dot product
     print(f"[b4] worst block rel-L2 {max(worst.values()):.2e}, LoRA gradient cosine {cos:.5f}, norm {flat.norm().item():.5f} vs {g['grad_norm']:.5f}")
     assert cos > 0.999 and abs(flat.norm().item() - g["grad_norm"]) / g["grad_norm"] < 2e-2
 
