@@ -51,6 +51,7 @@ struct GemmParams {
     // fused LoRA (LORA kernels): T = A L^T is accumulated next to the main tile from the same A tiles, rounded to
     // bf16, then D += T E^T as one extra k-step.  L [32,K] (ldl = K), E [N,32], Tout [M,32] (optional, for wgrad).
     const hcp_bf16* L; const hcp_bf16* E; hcp_bf16* Tout;
+    int loaders;                    // 1: launch the loader-wave variant of the v2 kernel where one is instantiated (dispatch table / tools)
     int dbg;                        // tools/ablate_gemm.py: 1 = skip the DMA after the first tile, 2 = skip the MFMAs, 4 = skip LDS reads + MFMAs
     ConvDesc cv;
 };
@@ -382,10 +383,18 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
 //   * LDS fragment addresses are two precomputed VGPRs per operand (the XOR swizzle does not depend on the 16-row block);
 //   * the rank-32 K-extension tile and the epilogue are outside the loop; no ablation hooks.
 // Requirements (else the dispatcher keeps the kernel above): K % 64 == 0; conv gathers in their FAST form.
-template <int BM, int BN, int WGM, int WGN, int MODE, bool LORA = false>
-HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
+// NLD > 0: wave specialisation.  NLD extra "loader" waves issue ALL of the tile's LDS-DMA instructions; the WGM x WGN compute waves
+// only read fragments and issue MFMAs.  An LDS-DMA instruction costs its issuing wave ~100+ cycles of in-order issue time (the
+// per-CU global->LDS path moves ~40-60 B/clk), so with every wave loading AND computing, each K tile serialises
+// [5 DMA issues] -> [LDS reads + 20 MFMAs] inside every wave (measured: DMA ~14 us + LDS ~10 us + MFMA ~12 us of a 44 us
+// convolution, back to back).  With loaders the two phases belong to different waves and overlap inside ONE workgroup —
+// which is what shapes with a single workgroup per CU (grid <= 256, the common case at 64x64 resolution) need.
+template <int BM, int BN, int WGM, int WGN, int MODE, bool LORA = false, int NLD = 0>
+HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
     static_assert(!LORA || (MODE == 0 && WGN == 2), "fused LoRA: plain GEMM, two waves across N");
-    constexpr int NT = 64 * WGM * WGN;
+    constexpr int NC = WGM * WGN;                       // compute waves
+    constexpr int NT = 64 * (NLD ? NLD : NC);           // threads that issue DMA: the loaders, or everybody
+    constexpr int NTC = 64 * NC;                        // compute threads
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int RPP = NT / 8;
@@ -395,10 +404,15 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
     hcp_bf16* lds = (hcp_bf16*)smem;
     constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, L_ELEMS = LORA ? 32 * BK : 0, BUF_ELEMS = A_ELEMS + B_ELEMS + L_ELEMS;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = hcp_uniform(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int tid_all = threadIdx.x;
+    const int lane = tid_all & 63;
+    const int wave_all = hcp_uniform(tid_all >> 6);
+    const bool is_loader = NLD > 0 && wave_all >= NC;
+    // DMA geometry is indexed by the issuing thread: loader-local when loaders exist
+    const int tid = NLD ? (is_loader ? tid_all - NTC : tid_all % NT) : tid_all;
+    const int wave = NLD ? (is_loader ? wave_all - NC : 0) : wave_all;
+    const int cwave = is_loader ? 0 : wave_all;         // compute-wave index (tile position)
+    const int wm = cwave / WGN, wn = cwave % WGN;
     const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.y;
@@ -556,12 +570,24 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
         }
     };
 
-    if (nprim > 0) issue(0); else if (has_ext) issue_ext(0);
+    if (NLD == 0 || is_loader) { if (nprim > 0) issue(0); else if (has_ext) issue_ext(0); }
     HCP_SYNC();
+    if (NLD > 0 && is_loader) {
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nprim) issue(cur ^ 1);
+            else if (t + 1 == nprim && has_ext) issue_ext(cur ^ 1);
+            HCP_SYNC();                                     // (the barrier's fence drains this wave's DMA of tile t+1)
+        }
+        if (LORA) HCP_SYNC();                               // the compute waves' epilogue barrier
+        return;
+    }
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nprim) issue(cur ^ 1);
-        else if (t + 1 == nprim && has_ext) issue_ext(cur ^ 1);
+        if (NLD == 0) {
+            if (t + 1 < nprim) issue(cur ^ 1);
+            else if (t + 1 == nprim && has_ext) issue_ext(cur ^ 1);
+        }
         compute(cur);
         HCP_SYNC();                                         // drains the DMA of tile t+1 and fences the LDS reads of tile t
     }
@@ -580,7 +606,7 @@ HCP_KERNEL(64 * WGM * WGN) gemm_v2_kernel(GemmParams p) {
             *(hcp_bf16x4*)(lt + ml * TS2 + wn * 16 + 4 * fg) = o;
             if (tile_n == 0 && p.Tout && m0 + ml < p.M) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * 32 + wn * 16 + 4 * fg) = o;
         }
-        for (int c = tid; c < BN * 4; c += NT) {
+        for (int c = tid_all; c < BN * 4; c += NTC) {
             const int r = c >> 2, q = c & 3;
             hcp_bf16x8 v = hcp_zero8();
             if (n0 + r < p.N) v = *(const hcp_bf16x8*)(p.E + (size_t)(n0 + r) * 32 + q * 8);
@@ -686,7 +712,9 @@ HCP_TUNABLE(int, g_dbg_ablate, 0);   // tools only, see GemmParams::dbg
 HCP_TUNABLE(int, g_use_glds, 1);     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
 HCP_TUNABLE(int, g_use_v2, 1);       // 1: buffer-addressed v2 main loop where its requirements hold (default), 0: gemm_glds_kernel everywhere
 
-template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false, int NSTAGE = 2>
+HCP_TUNABLE(int, g_force_loaders, -1);   // tools: -1 = as dispatched, 0 = no loader waves, 4 = loader-wave variant where instantiated
+
+template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false, int NSTAGE = 2, int NLD = 0>
 int launch_cfg(GemmParams& p, hipStream_t stream) {
     p.tiles_m = hcp_cdiv(p.M, BM);
     const int tiles_n = hcp_cdiv(p.N, BN);
@@ -697,7 +725,11 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
             size_t smem = (size_t)2 * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
             const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);
             if (LORA && smem < tail) smem = tail;
-            HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN), smem, stream, p);
+            if (NLD > 0 && p.loaders) {
+                HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * (WGM * WGN + NLD)), smem, stream, p);
+            } else {
+                HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN), smem, stream, p);
+            }
             if (p.nsplit > 1) {
                 long nv = (long)p.M * (p.N / 4);
                 int g = (int)((nv + 255) / 256); if (g > 2048) g = 2048;
@@ -741,10 +773,10 @@ int launch_by_id(int id, GemmParams& p, hipStream_t stream) {
         case 9: return launch_cfg<128, 160, 2, 2, MODE, FAST, false, 3>(p, stream);
         case 10: return launch_cfg<256, 160, 4, 2, MODE, FAST, false, 3>(p, stream);
         case 11: return launch_cfg<128, 320, 4, 4, MODE, FAST>(p, stream);
-        case 12: return launch_cfg<256, 160, 8, 2, MODE, FAST>(p, stream);
-        case 13: return launch_cfg<128, 160, 4, 2, MODE, FAST>(p, stream);
-        case 14: return launch_cfg<64, 160, 4, 2, MODE, FAST>(p, stream);
-        case 15: return launch_cfg<128, 128, 4, 2, MODE, FAST>(p, stream);
+        case 12: return launch_cfg<256, 160, 8, 2, MODE, FAST>(p, stream);            // 16 waves already: no room for loader waves
+        case 13: return launch_cfg<128, 160, 4, 2, MODE, FAST, false, 2, 4>(p, stream);
+        case 14: return launch_cfg<64, 160, 4, 2, MODE, FAST, false, 2, 4>(p, stream);
+        case 15: return launch_cfg<128, 128, 4, 2, MODE, FAST, false, 2, 4>(p, stream);
         default: return launch_cfg<128, 320, 2, 4, MODE, FAST>(p, stream);
     }
 }
@@ -760,9 +792,9 @@ int launch_lora_by_id(int id, GemmParams& p, hipStream_t stream) {
         case 8: return launch_cfg<128, 160, 4, 2, 0, false, true, 3>(p, stream);
         case 9: return launch_cfg<128, 160, 2, 2, 0, false, true, 3>(p, stream);
         case 12: return launch_cfg<256, 160, 8, 2, 0, false, true>(p, stream);
-        case 13: return launch_cfg<128, 160, 4, 2, 0, false, true>(p, stream);
-        case 14: return launch_cfg<64, 160, 4, 2, 0, false, true>(p, stream);
-        case 15: return launch_cfg<128, 128, 4, 2, 0, false, true>(p, stream);
+        case 13: return launch_cfg<128, 160, 4, 2, 0, false, true, 2, 4>(p, stream);
+        case 14: return launch_cfg<64, 160, 4, 2, 0, false, true, 2, 4>(p, stream);
+        case 15: return launch_cfg<128, 128, 4, 2, 0, false, true, 2, 4>(p, stream);
         default: return launch_cfg<64, 160, 2, 2, 0, false, true>(p, stream);
     }
 }
@@ -783,8 +815,9 @@ int choose_cfg(const GemmParams& p, int* nsplit_out) {
     return id;
 }
 
-struct TunedEntry { int mode, M, N, K, has_k2, stride, up, cfg, split; };
+struct TunedEntry { int mode, M, N, K, has_k2, stride, up, cfg, split, loaders; };   // (loaders: 0 when the entry omits it)
 const TunedEntry kTuned[] = {
+#include "gemm_tuned_loaders.inc"
 #include "gemm_tuned.inc"
 };
 
@@ -792,12 +825,12 @@ const TunedEntry kTuned[] = {
 long g_table_hits = 0, g_table_misses = 0;   // tools: how much of a workload the measured dispatch table covers
 #endif
 
-bool lookup_tuned(const GemmParams& p, int mode, int* cfg, int* split) {
+bool lookup_tuned(const GemmParams& p, int mode, int* cfg, int* split, int* loaders = nullptr) {
     bool hit = false;
     for (const TunedEntry& e : kTuned) {
         if (e.mode == mode && e.M == p.M && e.N == p.N && e.K == p.K && e.has_k2 == (p.K2 > 0) &&
             (mode == 0 || mode == 3 || (e.stride == p.cv.stride && e.up == p.cv.up))) {     // 0 / 3: plain GEMMs carry no conv geometry
-            *cfg = e.cfg; *split = e.split; hit = true; break;
+            *cfg = e.cfg; *split = e.split; if (loaders) *loaders = e.loaders; hit = true; break;
         }
     }
 #if defined(HCP_TOOLS)
@@ -809,9 +842,10 @@ bool lookup_tuned(const GemmParams& p, int mode, int* cfg, int* split) {
 template <int MODE, bool FAST>
 int dispatch_gemm(GemmParams& p, float* ws, size_t ws_bytes, hipStream_t stream) {
     int nsplit = 1;
-    int id = 0;
-    if (!lookup_tuned(p, MODE, &id, &nsplit)) id = choose_cfg(p, &nsplit);
+    int id = 0, ld = 0;
+    if (!lookup_tuned(p, MODE, &id, &nsplit, &ld)) id = choose_cfg(p, &nsplit);
     if (g_force_cfg >= 0) { id = g_force_cfg % 16; nsplit = g_force_cfg / 16 > 0 ? g_force_cfg / 16 : 1; }
+    p.loaders = g_force_loaders >= 0 ? g_force_loaders : ld;
     if (nsplit > 1 && (size_t)nsplit * p.M * p.N * sizeof(float) > ws_bytes) nsplit = 1;
     const int nk1 = hcp_cdiv(p.K, BK);
     p.nsplit = nsplit;
@@ -848,6 +882,8 @@ HCP_API int hcp_debug_set_gemm_config(int cfg) { g_force_cfg = cfg; return 0; }
 HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = 1; g_use_v2 = on == 1; return 0; }
 // TOOLS ONLY: ablation of the 2-stage LDS-DMA loop (results are wrong when != 0): 1 no DMA after tile 0, 2 no MFMA, 4 no LDS reads.
 HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; return 0; }
+// TOOLS ONLY: -1 = as the dispatch table says, 0 = never, 1 = the loader-wave variant wherever one is instantiated (tile ids 12-15).
+HCP_API int hcp_debug_set_gemm_loaders(int mode) { g_force_loaders = mode; return 0; }
 #endif
 
 // Bytes of fp32 split-K workspace that lets every launch of this shape use its preferred decomposition.
@@ -924,9 +960,9 @@ HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, c
     HCP_REQUIRE(A && B && D && L && E, "hcp_gemm_lora_bf16: null operand");
     HCP_REQUIRE(lda % 8 == 0, "hcp_gemm_lora_bf16: lda (%d) must be a multiple of 8", lda);
     if (int e = check_common(p)) return e;
-    int id = 4, nsplit = 1;
+    int id = 4, nsplit = 1, ld = 0;
     GemmParams q = p; q.K2 = 32;
-    if (!lookup_tuned(q, 3, &id, &nsplit)) {
+    if (!lookup_tuned(q, 3, &id, &nsplit, &ld)) {
         // unseen shape: deep-K / small-M problems want split-K (two launches); otherwise fuse with a narrow-M tile
         if (p.K >= 4096 && p.M <= 4096) id = -1;
         else if ((long)p.M * p.N >= (long)4096 * 2560 && p.N % 160 == 0) id = 6;
@@ -934,6 +970,7 @@ HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, c
         else id = 2;
     }
     if (g_force_cfg >= 0) id = g_force_cfg % 16;
+    p.loaders = g_force_loaders >= 0 ? g_force_loaders : ld;
     if (id == 7 || id == 10 || id == 11) id = 6;
     if (id < 0) {
         // two-launch form: T = A L^T, then D = A B^T + T E^T with the measured tile / split-K choice
