@@ -388,6 +388,24 @@ def main():
                                                    else FLOP_PER_IMAGE_CNET_NOCKPT if cnet
                                                    else FLOP_PER_IMAGE_LORA_NOCKPT) / MFMA_BF16_PEAK, 4),
         }
+        if world == 1 and args.workload == "sd15" and not args.grad_ckpt and not args.no_graph:
+            # the reference's default (train_base.yaml:69 gradient_checkpointing: True) timed beside the headline: same
+            # trainer, every ResnetBlock2D / Transformer2DModel segment recomputed in backward, graphs re-captured
+            unet.enable_gradient_checkpointing()
+            tr._graph_cache.clear()
+            k2 = max(5, min(args.steps, 20))
+            for _ in range(3):
+                tr.train_one_step(latents, ehs, None, added, plugin_input, prompt_ids)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                tr.train_one_step(latents, ehs, None, added, plugin_input, prompt_ids)
+            sync()
+            d2 = time.perf_counter() - t1
+            out["grad_ckpt_on"] = {"value": round(B * k2 / d2, 2), "unit": "images/sec", "ms_per_step": round(d2 / k2 * 1e3, 3),
+                                   "steps": k2, "note": "same workload with enable_gradient_checkpointing() (+1 forward per step)"}
+            unet.disable_gradient_checkpointing()
+            tr._graph_cache.clear()
         out["roofline"] = dominant_kernel_roofline(dev)
         out["roofline_attention"] = attention_roofline(dev)
         if world == 1 and not args.no_cpu_baseline and args.workload == "sd15":

@@ -389,9 +389,13 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
 // [5 DMA issues] -> [LDS reads + 20 MFMAs] inside every wave (measured: DMA ~14 us + LDS ~10 us + MFMA ~12 us of a 44 us
 // convolution, back to back).  With loaders the two phases belong to different waves and overlap inside ONE workgroup —
 // which is what shapes with a single workgroup per CU (grid <= 256, the common case at 64x64 resolution) need.
-template <int BM, int BN, int WGM, int WGN, int MODE, bool LORA = false, int NLD = 0>
+// NST (loader-wave variant only): depth of the LDS ring.  The loaders keep NST-1 K tiles in flight (counted vmcnt waits, barriers
+// that do not drain the DMA queue), so a short-K problem is no longer a chain of one memory latency per K tile: the bytes in
+// flight per CU are what hides the latency, and with one workgroup per CU only a deeper ring raises them.
+template <int BM, int BN, int WGM, int WGN, int MODE, bool LORA = false, int NLD = 0, int NST = 2>
 HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
     static_assert(!LORA || (MODE == 0 && WGN == 2), "fused LoRA: plain GEMM, two waves across N");
+    static_assert(NST == 2 || NLD > 0, "deeper rings need the loader waves (nobody else may hold DMA across a barrier)");
     constexpr int NC = WGM * WGN;                       // compute waves
     constexpr int NT = 64 * (NLD ? NLD : NC);           // threads that issue DMA: the loaders, or everybody
     constexpr int NTC = 64 * NC;                        // compute threads
@@ -570,26 +574,43 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         }
     };
 
-    if (NLD == 0 || is_loader) { if (nprim > 0) issue(0); else if (has_ext) issue_ext(0); }
-    HCP_SYNC();
     if (NLD > 0 && is_loader) {
+        // every loader wave issues the same IPT instructions per tile (whole 8-row groups: static_assert below), so "tile t+1
+        // has landed" = at most IPT * (tiles issued after it) of this wave's loads are still in flight (loads return in order)
+        static_assert(NLD == 0 || (BM % RPP == 0 && BN % RPP == 0), "loader waves: whole row groups");
+        constexpr int IPT = A_IT + B_IT + (LORA ? 1 : 0);
+        int issued = 0, wbuf = 0;
+        auto issue_next = [&]() {
+            if (issued < nprim) issue(wbuf); else issue_ext(wbuf);
+            ++issued; wbuf = wbuf + 1 == NST ? 0 : wbuf + 1;
+        };
+        auto wait_newer = [&](int newer) {                  // newer = tiles issued after the one that must be complete
+            if (NST > 3 && newer >= 2) hcp_wait_vmcnt_c<2 * IPT>();
+            else if (NST > 2 && newer >= 1) hcp_wait_vmcnt_c<IPT>();
+            else hcp_wait_vmcnt_c<0>();
+        };
+        for (int i = 0; i < NST - 1 && issued < nk; ++i) issue_next();
+        wait_newer(issued - 1);
+        hcp_barrier_keep_dma();                             // tile 0 is in LDS
         for (int t = 0; t < nk; ++t) {
-            const int cur = t & 1;
-            if (t + 1 < nprim) issue(cur ^ 1);
-            else if (t + 1 == nprim && has_ext) issue_ext(cur ^ 1);
-            HCP_SYNC();                                     // (the barrier's fence drains this wave's DMA of tile t+1)
+            // ring slot of tile t+NST-1 = slot of tile t-1: its readers passed the barrier that ended iteration t-1
+            if (issued < nk) issue_next();
+            wait_newer(issued - (t + 2));
+            hcp_barrier_keep_dma();                         // tile t+1 is in LDS, tile t is consumed
         }
         if (LORA) HCP_SYNC();                               // the compute waves' epilogue barrier
         return;
     }
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
+    if (NLD == 0) { if (nprim > 0) issue(0); else if (has_ext) issue_ext(0); }
+    HCP_SYNC();
+    for (int t = 0, cur = 0; t < nk; ++t) {
         if (NLD == 0) {
             if (t + 1 < nprim) issue(cur ^ 1);
             else if (t + 1 == nprim && has_ext) issue_ext(cur ^ 1);
         }
         compute(cur);
         HCP_SYNC();                                         // drains the DMA of tile t+1 and fences the LDS reads of tile t
+        cur = cur + 1 == NST ? 0 : cur + 1;
     }
 
     if (LORA) {
@@ -712,7 +733,7 @@ HCP_TUNABLE(int, g_dbg_ablate, 0);   // tools only, see GemmParams::dbg
 HCP_TUNABLE(int, g_use_glds, 1);     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
 HCP_TUNABLE(int, g_use_v2, 1);       // 1: buffer-addressed v2 main loop where its requirements hold (default), 0: gemm_glds_kernel everywhere
 
-HCP_TUNABLE(int, g_force_loaders, -1);   // tools: -1 = as dispatched, 0 = no loader waves, 4 = loader-wave variant where instantiated
+HCP_TUNABLE(int, g_force_loaders, -1);   // tools: -1 = as dispatched, 0 = no loader waves, 1 / 3 / 4 = loader-wave variant with a 2 / 3 / 4 tile ring
 
 template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false, int NSTAGE = 2, int NLD = 0>
 int launch_cfg(GemmParams& p, hipStream_t stream) {
@@ -722,11 +743,22 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
     if constexpr (NSTAGE == 2 && (MODE == 0 || FAST)) {
         if (g_use_v2 && g_use_glds && !p.dbg && p.K % BK == 0 && (p.K2 == 0 || p.K2 == 32) &&
             (size_t)p.M * p.lda * 2 < (1ul << 31) && (size_t)p.N * p.ldb * 2 < (1ul << 31)) {
-            size_t smem = (size_t)2 * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
+            constexpr size_t stage = (size_t)(BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
+            size_t smem = 2 * stage;
             const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);
             if (LORA && smem < tail) smem = tail;
-            if (NLD > 0 && p.loaders) {
-                HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * (WGM * WGN + NLD)), smem, stream, p);
+            [[maybe_unused]] const dim3 grid(p.tiles_m * tiles_n, p.nsplit);
+            if constexpr (NLD > 0) {
+                // p.loaders: 1 (or 2) = two-stage ring, 3 / 4 = deeper ring where it fits the 160 KB of LDS
+                if (p.loaders == 4 && 4 * stage <= 160 * 1024) {
+                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD, (4 * stage <= 160 * 1024 ? 4 : 2)>), grid, dim3(64 * (WGM * WGN + NLD)), 4 * stage, stream, p);
+                } else if (p.loaders >= 3 && 3 * stage <= 160 * 1024) {
+                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD, (3 * stage <= 160 * 1024 ? 3 : 2)>), grid, dim3(64 * (WGM * WGN + NLD)), 3 * stage, stream, p);
+                } else if (p.loaders) {
+                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD>), grid, dim3(64 * (WGM * WGN + NLD)), smem, stream, p);
+                } else {
+                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA>), grid, dim3(64 * WGM * WGN), smem, stream, p);
+                }
             } else {
                 HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA>), dim3(p.tiles_m * tiles_n, p.nsplit), dim3(64 * WGM * WGN), smem, stream, p);
             }
@@ -828,6 +860,7 @@ long g_table_hits = 0, g_table_misses = 0;   // tools: how much of a workload th
 bool lookup_tuned(const GemmParams& p, int mode, int* cfg, int* split, int* loaders = nullptr) {
     bool hit = false;
     for (const TunedEntry& e : kTuned) {
+        if (g_force_loaders == 0 && e.loaders) continue;     // tools: "no loader waves" = the dispatch before the loader table
         if (e.mode == mode && e.M == p.M && e.N == p.N && e.K == p.K && e.has_k2 == (p.K2 > 0) &&
             (mode == 0 || mode == 3 || (e.stride == p.cv.stride && e.up == p.cv.up))) {     // 0 / 3: plain GEMMs carry no conv geometry
             *cfg = e.cfg; *split = e.split; if (loaders) *loaders = e.loaders; hit = true; break;

@@ -144,6 +144,10 @@ HCP_DEVICE void hcp_wait_vmcnt(int n) {
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
+template <int N> HCP_DEVICE void hcp_wait_vmcnt_c() {         // compile-time count (the field is 6 bits wide on gfx9)
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 // Workgroup barrier WITHOUT the vmcnt(0) drain __syncthreads() implies while LDS-DMA is in flight: own LDS reads are
 // retired (lgkmcnt(0)), DMA completion is the caller's counted hcp_wait_vmcnt.
 HCP_DEVICE void hcp_barrier_keep_dma() {

@@ -129,6 +129,7 @@ HCP_DEVICE void hcp_force_ready(float&) {}
 #define HCP_DEVICE_GLOBAL static
 HCP_DEVICE void hcp_wait_vmcnt(int) {}                       // DMA is synchronous in the interpreter
 HCP_DEVICE void hcp_barrier_keep_dma() { hcp_emu::yield_barrier(); }
+template <int N> HCP_DEVICE void hcp_wait_vmcnt_c() {}
 HCP_DEVICE bool hcp_all(bool pred) {
     int v = pred ? 1 : 0;
     for (int m = 32; m >= 1; m >>= 1) v &= hcp_shfl_xor_i(v, m);

@@ -681,10 +681,12 @@ def test_pack_weights_grouped(backend):
             assert pk.w.cpu()[..., ci:].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("stages", [1, 3, 4])
 @pytest.mark.parametrize("cfg", [13, 14, 15])
-def test_gemm_loader_wave_variants(tbackend, cfg):
-    """The wave-specialised v2 kernel (4 loader waves + 8 compute waves): plain GEMM with K-extension, fused-LoRA GEMM, forward
-    convolution (concat input, stride 2) and data gradient, split-K on and off — forced through the tuning hooks."""
+def test_gemm_loader_wave_variants(tbackend, cfg, stages):
+    """The wave-specialised v2 kernel (4 loader waves + 8 compute waves; LDS ring of 2 / 3 / 4 K tiles): plain GEMM with
+    K-extension, fused-LoRA GEMM, forward convolution (concat input, stride 2) and data gradient, split-K on and off — forced
+    through the tuning hooks."""
     to = tbackend.to
     L = K.lib()
     torch.manual_seed(cfg)
@@ -703,7 +705,7 @@ def test_gemm_loader_wave_variants(tbackend, cfg):
     wd = rnd(Cout, C1, 3, 3) * 0.1
     ref_d = F.conv_transpose2d(dy.permute(0, 3, 1, 2).float(), wd.float(), stride=1, padding=1).permute(0, 2, 3, 1)
     try:
-        L.hcp_debug_set_gemm_loaders(1)
+        L.hcp_debug_set_gemm_loaders(stages)
         for split in (1, 2):
             L.hcp_debug_set_gemm_config(cfg + 16 * split)
             out = K.gemm(to(a), to(b), a2=to(a2), b2=to(b2), bias=to(bias))

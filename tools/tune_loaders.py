@@ -28,16 +28,17 @@ def sweep_loaders(fn, nk1, cfgs=(13, 14, 15), splits=(1, 2, 4, 8)):
     K.lib().hcp_debug_set_gemm_config(-1)
     cur = round(A.timeit(fn), 1)
     res = {}
-    K.lib().hcp_debug_set_gemm_loaders(1)
-    for cid in cfgs:
-        for s in splits:
-            if s > 1 and nk1 // s < 4:
-                continue
-            K.lib().hcp_debug_set_gemm_config(cid + 16 * s)
-            try:
-                res[(cid, s)] = round(A.timeit(fn), 1)
-            except Exception:  # noqa: BLE001
-                pass
+    for st in (1, 3, 4):                       # LDS ring of 2 / 3 / 4 K tiles
+        K.lib().hcp_debug_set_gemm_loaders(st)
+        for cid in cfgs:
+            for s in splits:
+                if s > 1 and nk1 // s < 4:
+                    continue
+                K.lib().hcp_debug_set_gemm_config(cid + 16 * s)
+                try:
+                    res[(cid, s, st)] = round(A.timeit(fn), 1)
+                except Exception:  # noqa: BLE001
+                    pass
     K.lib().hcp_debug_set_gemm_config(-1)
     K.lib().hcp_debug_set_gemm_loaders(-1)
     return cur, res
@@ -79,12 +80,12 @@ def main():
         total += cur * cnt
         if not res:
             continue
-        us, (cid, s) = min((v, k) for k, v in res.items())
-        ent.update(cfg=cid, split=s, us=us, cur=cur, count=cnt)
+        us, (cid, s, st) = min((v, k) for k, v in res.items())
+        ent.update(cfg=cid, split=s, stages=st, us=us, cur=cur, count=cnt, us_2stage=min(v for k, v in res.items() if k[2] == 1))
         out.append(ent)
         if us < 0.97 * cur:
             saved += (cur - us) * cnt
-        print(f"{key} x{cnt}: dispatched {cur} us | loaders best {us} us ({LOADER_CFGS[cid]}/s{s}){'  <-- wins' if us < 0.97 * cur else ''}", flush=True)
+        print(f"{key} x{cnt}: dispatched {cur} us | loaders best {us} us ({LOADER_CFGS[cid]}/s{s}/ring{st}; 2-tile ring {ent['us_2stage']}){'  <-- wins' if us < 0.97 * cur else ''}", flush=True)
     print(f"GEMM-family time per step {total / 1e3:.2f} ms; loader variants would save {saved / 1e3:.2f} ms", flush=True)
     root = os.environ.get("GRAFT_REPO_ROOT", ROOT)
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
