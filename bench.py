@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--rank-lora", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ckpt-line", action="store_true", help="skip the secondary grad-ckpt-on measurement (profiling runs)")
     ap.add_argument("--overlap", action="store_true", help="LoRA wgrad kernels on a side stream (measured slower)")
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="one wgrad launch per layer instead of one grouped launch")
     ap.add_argument("--grad-ckpt", action="store_true", help="enable_gradient_checkpointing() as the reference defaults to "
@@ -388,7 +389,7 @@ def main():
                                                    else FLOP_PER_IMAGE_CNET_NOCKPT if cnet
                                                    else FLOP_PER_IMAGE_LORA_NOCKPT) / MFMA_BF16_PEAK, 4),
         }
-        if world == 1 and args.workload == "sd15" and not args.grad_ckpt and not args.no_graph:
+        if world == 1 and args.workload == "sd15" and not args.grad_ckpt and not args.no_graph and not args.no_ckpt_line:
             # the reference's default (train_base.yaml:69 gradient_checkpointing: True) timed beside the headline: same
             # trainer, every ResnetBlock2D / Transformer2DModel segment recomputed in backward, graphs re-captured
             unet.enable_gradient_checkpointing()

@@ -574,7 +574,44 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         }
     };
 
+    // Loader-wave variant: everything the tail needs is requested BEFORE the main loop instead of after it (each was one more
+    // exposed memory latency on a kernel that is a chain of them): the compute waves fetch their bias / residual fragments now
+    // (their wait folds into the wait for K tile 0), the loaders DMA the tile's E rows into their own LDS area.
+    constexpr bool EARLY = NLD > 0;
+    constexpr int ES = EARLY ? 32 : 40;                     // row stride (elements) of the E image: DMA rows are unpadded
+    hcp_bf16* const le_early = lds + NST * BUF_ELEMS;
+    hcp_f32x4 bias_v[TN];
+    hcp_bf16x4 res_v[TM][TN];
+    auto load_epilogue_operands = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + 4 * fg;
+            hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bias_v[j] = (p.bias && n < p.N) ? *(const hcp_f32x4*)(p.bias + n) : z;
+        }
+        if (p.residual) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * WTM + i * 16 + fr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WTN + j * 16 + 4 * fg;
+                    hcp_bf16x4 z = {0, 0, 0, 0};
+                    res_v[i][j] = (m < p.M && n < p.N) ? *(const hcp_bf16x4*)(p.residual + (size_t)m * p.ldr + n) : z;
+                }
+            }
+        }
+    };
+    if (EARLY && !is_loader && p.nsplit == 1) load_epilogue_operands();
+
     if (NLD > 0 && is_loader) {
+        if (LORA) {                                         // E rows n0 .. n0+BN, 64 bytes each: 16 rows per DMA instruction
+            const hcp_rsrc re = hcp_make_rsrc(p.E);
+            for (int g = wave; g < BN / 16; g += NLD) {
+                const int n = n0 + g * 16 + (lane >> 2);
+                hcp_buf_glds16(re, n < p.N ? (unsigned)(((size_t)n * 32 + (lane & 3) * 8) * 2) : HCP_BUF_OOB, le_early + g * 16 * 32);
+            }
+        }
         // every loader wave issues the same IPT instructions per tile (whole 8-row groups: static_assert below), so "tile t+1
         // has landed" = at most IPT * (tiles issued after it) of this wave's loads are still in flight (loads return in order)
         static_assert(NLD == 0 || (BM % RPP == 0 && BN % RPP == 0), "loader waves: whole row groups");
@@ -617,7 +654,7 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         // T (bf16-rounded) and E = alpha * W_up rows of this N tile meet in LDS; one extra k-step adds T E^T
         constexpr int TS2 = 40;
         hcp_bf16* lt = lds;
-        hcp_bf16* le = lds + BM * TS2;
+        hcp_bf16* le = EARLY ? le_early : lds + BM * TS2;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             hcp_bf16x4 o;
@@ -627,18 +664,20 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
             *(hcp_bf16x4*)(lt + ml * TS2 + wn * 16 + 4 * fg) = o;
             if (tile_n == 0 && p.Tout && m0 + ml < p.M) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * 32 + wn * 16 + 4 * fg) = o;
         }
-        for (int c = tid_all; c < BN * 4; c += NTC) {
-            const int r = c >> 2, q = c & 3;
-            hcp_bf16x8 v = hcp_zero8();
-            if (n0 + r < p.N) v = *(const hcp_bf16x8*)(p.E + (size_t)(n0 + r) * 32 + q * 8);
-            *(hcp_bf16x8*)(le + r * TS2 + q * 8) = v;
+        if (!EARLY) {
+            for (int c = tid_all; c < BN * 4; c += NTC) {
+                const int r = c >> 2, q = c & 3;
+                hcp_bf16x8 v = hcp_zero8();
+                if (n0 + r < p.N) v = *(const hcp_bf16x8*)(p.E + (size_t)(n0 + r) * 32 + q * 8);
+                *(hcp_bf16x8*)(le + r * TS2 + q * 8) = v;
+            }
         }
         HCP_SYNC();
         hcp_bf16x8 ft[TM], fe[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) ft[i] = *(const hcp_bf16x8*)(lt + (wm * WTM + i * 16 + fr) * TS2 + fg * 8);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fe[j] = *(const hcp_bf16x8*)(le + (wn * WTN + j * 16 + fr) * TS2 + fg * 8);
+        for (int j = 0; j < TN; ++j) fe[j] = *(const hcp_bf16x8*)(le + (wn * WTN + j * 16 + fr) * ES + fg * 8);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -660,26 +699,7 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
     }
     // epilogue: ALL of the lane's bias / row-bias / residual loads are issued before the first store (one vmcnt wait instead
     // of one per 16x16 block: with K = 320 the serialized form cost as much as the whole main loop)
-    hcp_f32x4 bias_v[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WTN + j * 16 + 4 * fg;
-        hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        bias_v[j] = (p.bias && n < p.N) ? *(const hcp_f32x4*)(p.bias + n) : z;
-    }
-    hcp_bf16x4 res_v[TM][TN];
-    if (p.residual) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + fr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WTN + j * 16 + 4 * fg;
-                hcp_bf16x4 z = {0, 0, 0, 0};
-                res_v[i][j] = (m < p.M && n < p.N) ? *(const hcp_bf16x4*)(p.residual + (size_t)m * p.ldr + n) : z;
-            }
-        }
-    }
+    if (!EARLY) load_epilogue_operands();
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * 16 + fr;
@@ -744,18 +764,19 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
         if (g_use_v2 && g_use_glds && !p.dbg && p.K % BK == 0 && (p.K2 == 0 || p.K2 == 32) &&
             (size_t)p.M * p.lda * 2 < (1ul << 31) && (size_t)p.N * p.ldb * 2 < (1ul << 31)) {
             constexpr size_t stage = (size_t)(BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
+            constexpr size_t eimg = (LORA && NLD > 0) ? (size_t)BN * 32 * sizeof(hcp_bf16) : 0;   // loader variant: the E rows, behind the ring
             size_t smem = 2 * stage;
             const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);
             if (LORA && smem < tail) smem = tail;
             [[maybe_unused]] const dim3 grid(p.tiles_m * tiles_n, p.nsplit);
             if constexpr (NLD > 0) {
                 // p.loaders: 1 (or 2) = two-stage ring, 3 / 4 = deeper ring where it fits the 160 KB of LDS
-                if (p.loaders == 4 && 4 * stage <= 160 * 1024) {
-                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD, (4 * stage <= 160 * 1024 ? 4 : 2)>), grid, dim3(64 * (WGM * WGN + NLD)), 4 * stage, stream, p);
-                } else if (p.loaders >= 3 && 3 * stage <= 160 * 1024) {
-                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD, (3 * stage <= 160 * 1024 ? 3 : 2)>), grid, dim3(64 * (WGM * WGN + NLD)), 3 * stage, stream, p);
+                if (p.loaders == 4 && 4 * stage + eimg <= 160 * 1024) {
+                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD, (4 * stage + eimg <= 160 * 1024 ? 4 : 2)>), grid, dim3(64 * (WGM * WGN + NLD)), 4 * stage + eimg, stream, p);
+                } else if (p.loaders >= 3 && 3 * stage + eimg <= 160 * 1024) {
+                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD, (3 * stage + eimg <= 160 * 1024 ? 3 : 2)>), grid, dim3(64 * (WGM * WGN + NLD)), 3 * stage + eimg, stream, p);
                 } else if (p.loaders) {
-                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD>), grid, dim3(64 * (WGM * WGN + NLD)), smem, stream, p);
+                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD>), grid, dim3(64 * (WGM * WGN + NLD)), smem + eimg, stream, p);
                 } else {
                     HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA>), grid, dim3(64 * WGM * WGN), smem, stream, p);
                 }

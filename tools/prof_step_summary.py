@@ -1,0 +1,54 @@
+"""Per-STEP kernel table from a rocprofv3 --kernel-trace csv:  python tools/prof_step_summary.py <dir> <out.md> [steps] [anchor-regex]
+
+The trace also holds weight initialisation, warm-up and graph capture; the table keeps only the LAST `steps` training steps (cut at
+the optimizer kernel that ends each step) and divides by `steps`, so "calls" and "ms" are per step of the replayed hipGraph."""
+import collections
+import csv
+import glob
+import re
+import sys
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    anchor = re.compile(sys.argv[4] if len(sys.argv) > 4 else r"adamw")
+    f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+    rows = []
+    for r in csv.DictReader(open(f)):
+        n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        n = re.sub(r"^void ", "", n)
+        n = re.sub(r"\(.*", "", n)[:100]
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n))
+    rows.sort()
+    ends = [i for i, r in enumerate(rows) if anchor.search(r[2])]
+    # several optimizer launches may end one step (one per bucket): a step boundary = the last anchor of a run
+    bounds = [i for k, i in enumerate(ends) if k + 1 == len(ends) or ends[k + 1] - i > 50]
+    assert len(bounds) > steps, f"only {len(bounds)} steps in the trace"
+    lo, hi = bounds[-steps - 1] + 1, bounds[-1] + 1
+    sel = rows[lo:hi]
+    wall = (sel[-1][1] - sel[0][0]) / steps / 1e6
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for s, e, n in sel:
+        agg[n][0] += 1; agg[n][1] += (e - s) / 1e3
+    tot = sum(v[1] for v in agg.values())
+    fam = collections.defaultdict(lambda: [0, 0.0])
+    for n, (c, t) in agg.items():
+        k = ("attention" if "attn" in n else "gemm / implicit conv" if "gemm_" in n else "split-K reduce" if "splitk" in n else
+             "GroupNorm" if n.startswith("gn_") else "LayerNorm" if n.startswith("ln_") else "GEGLU" if "geglu" in n else
+             "weight gradients" if "wgrad" in n else "optimizer" if "adamw" in n else "torch (at::)" if "at::" in n else "other")
+        fam[k][0] += c; fam[k][1] += t
+    L = [f"last {steps} steps of the trace: {len(sel) / steps:.0f} dispatches per step, kernel time {tot / steps / 1e3:.3f} ms per step, "
+         f"first start -> last end {wall:.3f} ms per step (profiler attached)", "",
+         "| family | launches / step | ms / step | % |", "|---|---|---|---|"]
+    for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        L.append(f"| {k} | {c / steps:.0f} | {t / steps / 1e3:.3f} | {100 * t / tot:.1f} |")
+    L += ["", "| kernel | launches / step | ms / step | avg us | % |", "|---|---|---|---|---|"]
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        L.append(f"| {n} | {c / steps:.1f} | {t / steps / 1e3:.3f} | {t / c:.1f} | {100 * t / tot:.1f} |")
+    open(out, "w").write("\n".join(L) + "\n")
+    print("\n".join(L[:16]))
+
+
+if __name__ == "__main__":
+    main()
