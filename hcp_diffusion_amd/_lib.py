@@ -41,6 +41,7 @@ _PROTOTYPES = {
     "hcp_geglu_bwd": (I, [P, P, P, L, I, P]),
     "hcp_add_bf16": (I, [P, P, P, L, P]),
     "hcp_copy2d_bf16": (I, [P, I, P, I, L, I, P]),
+    "hcp_concat2_bf16": (I, [P, I, P, I, P, L, I, P]),
     "hcp_silu_fwd": (I, [P, P, L, P]),
     "hcp_silu_bwd": (I, [P, P, P, L, P]),
     "hcp_nchw_to_nhwc_bf16": (I, [P, I, P, I, I, I, I, P]),

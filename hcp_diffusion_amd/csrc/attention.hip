@@ -15,21 +15,43 @@ namespace {
 using namespace hcp_attn;
 
 // ------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+// One thread per 16-byte chunk of a (row, head) slice (D/8 chunks: 5 / 8 / 10 / 20), partial dot products meet in LDS; the block size
+// is a multiple of the chunk count so no slice straddles two workgroups.  (The first version — one thread per (row, head) walking
+// its whole slice — launched 32 workgroups for the 16x16 level and took 12.9 us for 5 MB.)
 template <int D>
-HCP_KERNEL(256) attn_delta_kernel(AttnParams p, int B) {
+HCP_KERNEL(320) attn_delta_kernel(AttnParams p, int B) {
+    constexpr int NCH = D / 8;
+    constexpr int NT = (NCH == 8) ? 256 : 320;               // 320 = 64 x 5 = 32 x 10 = 16 x 20
+    constexpr int SL = NT / NCH;                             // slices per workgroup
+    HCP_DYN_SMEM(smem);
+    float* s_part = (float*)smem;                              // [NT]
+    const int tid = threadIdx.x;
     const long total = (long)B * p.Nq * p.H;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int h = (int)(i % p.H); long r = i / p.H; const int q = (int)(r % p.Nq); const int b = (int)(r / p.Nq);
-        const hcp_bf16* o = p.O + (size_t)b * p.o_bs + (size_t)q * p.o_rs + h * D;
-        const hcp_bf16* d = p.dO + (size_t)b * p.o_bs + (size_t)q * p.o_rs + h * D;
+    const long nblk = (total + SL - 1) / SL;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long sl = blk * SL + tid / NCH;                // (b, q, h) slice of this thread
+        const int c = tid % NCH;
         float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < D / 8; ++c) {
-            hcp_bf16x8 a = *(const hcp_bf16x8*)(o + c * 8), g = *(const hcp_bf16x8*)(d + c * 8);
+        if (sl < total) {
+            const int h = (int)(sl % p.H); long r = sl / p.H; const int q = (int)(r % p.Nq); const int b = (int)(r / p.Nq);
+            const size_t off = (size_t)b * p.o_bs + (size_t)q * p.o_rs + h * D + c * 8;
+            const hcp_bf16x8 a = *(const hcp_bf16x8*)(p.O + off), g = *(const hcp_bf16x8*)(p.dO + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc += hcp_bf2f((unsigned short)a[e]) * hcp_bf2f((unsigned short)g[e]);
         }
-        p.delta[((size_t)b * p.H + h) * p.Nq + q] = acc;
+        s_part[tid] = acc;
+        HCP_SYNC();
+        if (tid < SL) {
+            const long s2 = blk * SL + tid;
+            if (s2 < total) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) t += s_part[tid * NCH + k];
+                const int h = (int)(s2 % p.H); long r = s2 / p.H; const int q = (int)(r % p.Nq); const int b = (int)(r / p.Nq);
+                p.delta[((size_t)b * p.H + h) * p.Nq + q] = t;
+            }
+        }
+        HCP_SYNC();
     }
 }
 
@@ -60,9 +82,10 @@ int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
 }
 template <int D>
 int launch_delta(AttnParams& p, int B, hipStream_t stream) {
+    constexpr int NCH = D / 8, NT = (NCH == 8) ? 256 : 320, SL = NT / NCH;
     long tot = (long)B * p.Nq * p.H;
-    int g = (int)((tot + 255) / 256); if (g > 4096) g = 4096;
-    HCP_LAUNCH((attn_delta_kernel<D>), dim3(g), dim3(256), 0, stream, p, B);
+    long g = (tot + SL - 1) / SL; if (g > 8192) g = 8192;
+    HCP_LAUNCH((attn_delta_kernel<D>), dim3((int)g), dim3(NT), NT * sizeof(float), stream, p, B);
     HCP_LAUNCH_CHECK("attn_delta");
 }
 template <int D, int QT>

@@ -417,6 +417,26 @@ HCP_API int hcp_mse_masked_mean(const float* pred, const float* target, const fl
 
 // dst[m, :C] = src[m, :C]; row strides sld/dld in elements (all multiples of 8). Used for the up-block skip concat
 // (torch.cat(dim=1) in diffusers' UpBlock2D/CrossAttnUpBlock2D) and its backward split.
+// The up-path skip concat (torch.cat([h, skip], dim=1) in every up-block ResnetBlock2D) and its gradient split as ONE launch each:
+// joint [M][C1+C2] <-> a [M][C1], b [M][C2]; split = 0: joint <- (a | b), split = 1: (a, b) <- joint.
+HCP_KERNEL(256) concat2_kernel(hcp_bf16* a, int c1, hcp_bf16* b, int c2, hcp_bf16* joint, long M, int split) {
+    const int cv = (c1 + c2) / 8, c1v = c1 / 8;
+    const long total = M * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cv; const int c = (int)(i - r * cv);
+        hcp_bf16* part = c < c1v ? a + r * c1 + (long)c * 8 : b + r * c2 + (long)(c - c1v) * 8;
+        hcp_bf16* j = joint + r * (c1 + c2) + (long)c * 8;
+        if (split) *(hcp_bf16x8*)part = *(const hcp_bf16x8*)j;
+        else *(hcp_bf16x8*)j = *(const hcp_bf16x8*)part;
+    }
+}
+HCP_API int hcp_concat2_bf16(void* a, int c1, void* b, int c2, void* joint, long M, int split, hipStream_t stream) {
+    HCP_REQUIRE(a && b && joint && M > 0 && c1 > 0 && c2 > 0 && c1 % 8 == 0 && c2 % 8 == 0, "hcp_concat2_bf16: bad arguments");
+    HCP_LAUNCH(concat2_kernel, dim3(pw_grid(M * ((c1 + c2) / 8))), dim3(PW_THREADS), 0, stream, (hcp_bf16*)a, c1, (hcp_bf16*)b, c2,
+               (hcp_bf16*)joint, M, split);
+    HCP_LAUNCH_CHECK("concat2");
+}
+
 HCP_API int hcp_copy2d_bf16(const void* src, int sld, void* dst, int dld, long M, int C, hipStream_t stream) {
     HCP_REQUIRE(src && dst && M > 0 && C > 0 && C % 8 == 0 && sld % 8 == 0 && dld % 8 == 0, "hcp_copy2d_bf16: bad arguments");
     HCP_LAUNCH(copy2d_kernel, dim3(pw_grid(M * (C / 8))), dim3(PW_THREADS), 0, stream, (const hcp_bf16*)src, sld,

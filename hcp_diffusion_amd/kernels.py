@@ -344,8 +344,7 @@ def concat_channels(a, b):
     M = a.numel() // c1
     out = torch.empty(a.shape[:-1] + (c1 + c2,), dtype=BF16, device=a.device)
     o2 = out.view(M, c1 + c2)
-    _chk(lib().hcp_copy2d_bf16(_p(a), c1, _p(o2), c1 + c2, M, c1, _stream(a)), "hcp_copy2d_bf16")
-    _chk(lib().hcp_copy2d_bf16(_p(b), c2, o2[:, c1:].data_ptr(), c1 + c2, M, c2, _stream(a)), "hcp_copy2d_bf16")
+    _chk(lib().hcp_concat2_bf16(_p(a), c1, _p(b), c2, _p(o2), M, 0, _stream(a)), "hcp_concat2_bf16")
     return out
 
 
@@ -356,8 +355,7 @@ def split_channels(d, c1):
     d2 = d.view(M, c)
     a = torch.empty(d.shape[:-1] + (c1,), dtype=BF16, device=d.device)
     b = torch.empty(d.shape[:-1] + (c2,), dtype=BF16, device=d.device)
-    _chk(lib().hcp_copy2d_bf16(_p(d2), c, _p(a), c1, M, c1, _stream(d)), "hcp_copy2d_bf16")
-    _chk(lib().hcp_copy2d_bf16(d2[:, c1:].data_ptr(), c, _p(b), c2, M, c2, _stream(d)), "hcp_copy2d_bf16")
+    _chk(lib().hcp_concat2_bf16(_p(a), c1, _p(b), c2, _p(d2), M, 1, _stream(d)), "hcp_concat2_bf16")
     return a, b
 
 

@@ -95,6 +95,9 @@ int hcp_geglu_bwd(const void* h, const void* dy, void* dh, long M, int F, hcpStr
 
 int hcp_add_bf16(const void* a, const void* b, void* out, long n, hcpStream_t stream);
 int hcp_copy2d_bf16(const void* src, int sld, void* dst, int dld, long M, int C, hcpStream_t stream); /* skip concat/split */
+/* torch.cat([h, skip], dim=1) of the up-block ResnetBlock2D and its gradient split in one launch: joint [M][c1+c2] <-> a [M][c1], b [M][c2];
+ * split = 0 writes joint, split = 1 writes a and b (c1, c2 multiples of 8). */
+int hcp_concat2_bf16(void* a, int c1, void* b, int c2, void* joint, long M, int split, hcpStream_t stream);
 int hcp_silu_fwd(const void* x, void* y, long n, hcpStream_t stream);
 int hcp_silu_bwd(const void* x, const void* dy, void* dx, long n, hcpStream_t stream);
 int hcp_nchw_to_nhwc_bf16(const void* src, int src_is_f32, void* dst, int B, int C, int HW, int Cpad, hcpStream_t stream);

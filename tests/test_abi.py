@@ -101,6 +101,7 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
         "hcp_vae_latent_sample": (N, N, N, N, N, 1, 9, 16, 1.0, N),
         "hcp_mse_masked_mean": (N, N, N, 1, N, N, N, 0, 0, 0, 1.0, N),
         "hcp_copy2d_bf16": (N, 8, N, 8, 0, 7, N),
+        "hcp_concat2_bf16": (N, 8, N, 8, N, 4, 0, N),
     }
     for name, args in bad.items():
         assert name in _lib.EXPORTED_SYMBOLS, name

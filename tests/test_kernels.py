@@ -345,6 +345,18 @@ def test_geglu(backend, M, Fd):
     assert relerr(dh, hr.grad) < 1e-2
 
 
+def test_concat_split_channels_one_launch(backend):
+    """torch.cat([h, skip], -1) of the up-block resnets and its gradient split: exact copies, one hcp_concat2_bf16 launch each."""
+    to = backend.to
+    torch.manual_seed(3)
+    for c1, c2 in ((16, 8), (40, 24), (8, 320)):
+        a, b = rnd(2, 3, 5, c1), rnd(2, 3, 5, c2)
+        j = K.concat_channels(to(a), to(b))
+        assert torch.equal(j.cpu(), torch.cat([a, b], -1))
+        ga, gb = K.split_channels(j, c1)
+        assert torch.equal(ga.cpu(), a) and torch.equal(gb.cpu(), b)
+
+
 def test_pointwise_misc(backend):
     torch.manual_seed(0)
     to = backend.to
