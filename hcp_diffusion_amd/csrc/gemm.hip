@@ -558,10 +558,29 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         for (int ks = 0; ks < 2; ++ks) {
             hcp_bf16x8 fa[TM], fb[TN];
             const int a_rd = a_rd0 ^ (ks * 32), b_rd = b_rd0 ^ (ks * 32);
+#if defined(HCP_TOOLS)
+            if (p.dbg & 32) {                               // ablation: no LDS reads (operands = loop-invariant registers)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const hcp_bf16x8*)(st + a_rd + i * 16 * BK);
+                for (int i = 0; i < TM; ++i) { hcp_f32x4 z = {(float)tid_all, (float)i, 1.f, 2.f}; fa[i] = __builtin_bit_cast(hcp_bf16x8, z); }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const hcp_bf16x8*)(st + b_rd + j * 16 * BK);
+                for (int j = 0; j < TN; ++j) { hcp_f32x4 z = {(float)lane, (float)j, 3.f, 4.f}; fb[j] = __builtin_bit_cast(hcp_bf16x8, z); }
+            } else
+#endif
+            {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *(const hcp_bf16x8*)(st + a_rd + i * 16 * BK);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *(const hcp_bf16x8*)(st + b_rd + j * 16 * BK);
+            }
+#if defined(HCP_TOOLS)
+            if (p.dbg & 16) {                               // ablation: no MFMA (keep the fragment reads alive)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[j]));
+                continue;
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -631,6 +650,9 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         hcp_barrier_keep_dma();                             // tile 0 is in LDS
         for (int t = 0; t < nk; ++t) {
             // ring slot of tile t+NST-1 = slot of tile t-1: its readers passed the barrier that ended iteration t-1
+#if defined(HCP_TOOLS)
+            if (p.dbg & 8) issued = nk;                     // ablation: no DMA after the prologue (results are wrong)
+#endif
             if (issued < nk) issue_next();
             wait_newer(issued - (t + 2));
             hcp_barrier_keep_dma();                         // tile t+1 is in LDS, tile t is consumed
@@ -761,7 +783,7 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
     const int tiles_n = hcp_cdiv(p.N, BN);
     p.dbg = g_dbg_ablate;
     if constexpr (NSTAGE == 2 && (MODE == 0 || FAST)) {
-        if (g_use_v2 && g_use_glds && !p.dbg && p.K % BK == 0 && (p.K2 == 0 || p.K2 == 32) &&
+        if (g_use_v2 && g_use_glds && !(p.dbg & 7) && p.K % BK == 0 && (p.K2 == 0 || p.K2 == 32) &&
             (size_t)p.M * p.lda * 2 < (1ul << 31) && (size_t)p.N * p.ldb * 2 < (1ul << 31)) {
             constexpr size_t stage = (size_t)(BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
             constexpr size_t eimg = (LORA && NLD > 0) ? (size_t)BN * 32 * sizeof(hcp_bf16) : 0;   // loader variant: the E rows, behind the ring
@@ -934,7 +956,8 @@ HCP_API int hcp_debug_gemm_table_stats(long* hits, long* misses) {
 HCP_API int hcp_debug_set_gemm_config(int cfg) { g_force_cfg = cfg; return 0; }
 // TOOLS ONLY: 1 = default (v2 main loop where its requirements hold), 0 / 2 = the first LDS-DMA loop (gemm_glds_kernel) everywhere.
 HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = 1; g_use_v2 = on == 1; return 0; }
-// TOOLS ONLY: ablation of the 2-stage LDS-DMA loop (results are wrong when != 0): 1 no DMA after tile 0, 2 no MFMA, 4 no LDS reads.
+// TOOLS ONLY: ablation (results are wrong when != 0).  First LDS-DMA loop: 1 no DMA after tile 0, 2 no MFMA, 4 no LDS reads;
+// v2 loop (tools build only): 8 no DMA after the ring prologue, 16 no MFMA, 32 no LDS fragment reads.
 HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; return 0; }
 // TOOLS ONLY: -1 = as the dispatch table says, 0 = never, 1 = the loader-wave variant wherever one is instantiated (tile ids 12-15).
 HCP_API int hcp_debug_set_gemm_loaders(int mode) { g_force_loaders = mode; return 0; }
