@@ -15,6 +15,7 @@ struct GNGeom { int TX, R, threads, nchunk, rows_per_chunk; };
 // 16-byte loads in flight) and is sized so that the launch has about g_gn_target_wgs workgroups (2 per CU): enough to fill the
 // chip, few enough that the per-sample partial table every apply workgroup merges stays ~100 entries per group.
 HCP_TUNABLE(int, g_gn_target_wgs, 512);
+HCP_TUNABLE(int, g_gn_slab, 1);      // tools: 0 = always the two-launch row-chunk path (A/B measurements; hcp_debug_set_gn_target(-1 / -2))
 GNGeom gn_geom(int B, int HW, int C) {
     GNGeom g;
     g.TX = C / 8;
@@ -253,6 +254,155 @@ HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float
     }
 }
 
+// ------------------------------------------------------------------ GroupNorm, one launch: a (sample, group) slab per workgroup
+// Below the 64x64 level a group's slab — HW rows x Cg channels — is at most 128 KB: ONE workgroup loads it into registers once
+// (8-byte pieces of 4 channels: Cg is 20 / 40 / 60 / 80 there), reduces in the block, and writes the result from the same
+// registers.  One read of x instead of two, exact two-pass variance for free, and above all ONE launch instead of two at the
+// ~5 us floor each (45 of the SD1.5 step's 61 GroupNorms qualify).  The slab's rows are only Cg*2 = 40..160 contiguous bytes,
+// but neighbouring groups' workgroups consume the rest of every line at the same time, so HBM traffic stays 1x.
+HCP_DEVICE float gn_block_sum(float v, float* s_red, int tid, int nthreads) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += hcp_shfl_xor(v, off);
+    HCP_SYNC();                                          // s_red may still be read from the previous reduction
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    HCP_SYNC();
+    float t = 0.f;
+    for (int w = 0; w < nthreads / 64; ++w) t += s_red[w];
+    return t;
+}
+// chunk c of the slab -> element offset inside the sample (row = c / cpr through a host-computed reciprocal: exact for c < 2^16)
+HCP_DEVICE size_t gn_slab_off(int c, int cpr, unsigned cpr_magic, int C, int* ch_in_group) {
+    const int row = cpr_magic ? (int)(((unsigned long long)(unsigned)c * cpr_magic) >> 32) : c;      // (magic 0: one chunk per row)
+    *ch_in_group = (c - row * cpr) * 4;
+    return (size_t)row * C + (size_t)*ch_in_group;
+}
+
+template <int NCH>
+HCP_KERNEL(1024) gn_slab_fwd(const hcp_bf16* x, const float* gamma, const float* beta, float* stats, hcp_bf16* y, int HW, int C,
+                             int G, int cpr, unsigned cpr_magic, int silu, float eps) {
+    HCP_DYN_SMEM(smem);
+    float* s_red = (float*)smem;                          // [waves]
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int Cg = C / G, total = HW * cpr;
+    const size_t base = (size_t)b * HW * C + (size_t)g * Cg;
+    hcp_bf16x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * NT;
+        hcp_bf16x4 z = {0, 0, 0, 0};
+        int cg;
+        v[i] = c < total ? *(const hcp_bf16x4*)(x + base + gn_slab_off(c, cpr, cpr_magic, C, &cg)) : z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += hcp_bf2f((unsigned short)v[i][e]);
+    }
+    const float n = (float)HW * Cg;
+    const float mean = gn_block_sum(s, s_red, tid, NT) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (tid + i * NT < total) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = hcp_bf2f((unsigned short)v[i][e]) - mean; q += d * d; }
+        }
+    const float rstd = 1.0f / sqrtf(gn_block_sum(q, s_red, tid, NT) / n + eps);
+    if (tid == 0) { stats[((size_t)b * G + g) * 2] = mean; stats[((size_t)b * G + g) * 2 + 1] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * NT;
+        if (c >= total) continue;
+        int cg;
+        const size_t off = gn_slab_off(c, cpr, cpr_magic, C, &cg);
+        const hcp_f32x4 ga = *(const hcp_f32x4*)(gamma + g * Cg + cg), be = *(const hcp_f32x4*)(beta + g * Cg + cg);
+        hcp_bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = rstd * ga[e];
+            float z = hcp_bf2f((unsigned short)v[i][e]) * a + (be[e] - mean * a);
+            if (silu) z = hcp_silu(z);
+            o[e] = (short)hcp_f2bf(z);
+        }
+        *(hcp_bf16x4*)(y + base + off) = o;
+    }
+}
+
+template <int NCH>
+HCP_KERNEL(1024) gn_slab_bwd(const hcp_bf16* x, const hcp_bf16* dy, const float* gamma, const float* beta, const float* stats,
+                             const hcp_bf16* addend, hcp_bf16* dx, int HW, int C, int G, int cpr, unsigned cpr_magic, int silu) {
+    HCP_DYN_SMEM(smem);
+    float* s_red = (float*)smem;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int Cg = C / G, total = HW * cpr;
+    const size_t base = (size_t)b * HW * C + (size_t)g * Cg;
+    const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
+    // the lane's chunks of x and dy stay in registers as loaded (bf16: 4 VGPRs per chunk); xhat / dxhat are recomputed in the second pass
+    hcp_bf16x4 v[NCH], d[NCH];
+    float s1 = 0.f, s2 = 0.f;
+    auto terms = [&](int i, int cg, float (&h)[4], float (&dh)[4]) {
+        const hcp_f32x4 ga = *(const hcp_f32x4*)(gamma + g * Cg + cg), be = *(const hcp_f32x4*)(beta + g * Cg + cg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (hcp_bf2f((unsigned short)v[i][e]) - mean) * rstd;
+            float dz = hcp_bf2f((unsigned short)d[i][e]);
+            if (silu) { const float z = h[e] * ga[e] + be[e]; const float sg = hcp_sigmoid(z); dz *= sg * (1.f + z * (1.f - sg)); }
+            dh[e] = dz * ga[e];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * NT;
+        hcp_bf16x4 z = {0, 0, 0, 0};
+        v[i] = z; d[i] = z;
+        if (c < total) {
+            int cg;
+            const size_t off = gn_slab_off(c, cpr, cpr_magic, C, &cg);
+            v[i] = *(const hcp_bf16x4*)(x + base + off); d[i] = *(const hcp_bf16x4*)(dy + base + off);
+            float h[4], dh[4];
+            terms(i, cg, h, dh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1 += dh[e]; s2 += dh[e] * h[e]; }
+        }
+    }
+    const float n = (float)HW * Cg;
+    const float c1 = gn_block_sum(s1, s_red, tid, NT) / n;
+    const float c2 = gn_block_sum(s2, s_red, tid, NT) / n;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * NT;
+        if (c >= total) continue;
+        int cg;
+        const size_t off = gn_slab_off(c, cpr, cpr_magic, C, &cg);
+        hcp_bf16x4 ad = {0, 0, 0, 0};
+        if (addend) ad = *(const hcp_bf16x4*)(addend + base + off);
+        float h[4], dh[4];
+        terms(i, cg, h, dh);
+        hcp_bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = (short)hcp_f2bf(rstd * (dh[e] - c1 - h[e] * c2) + (addend ? hcp_bf2f((unsigned short)ad[e]) : 0.f));
+        *(hcp_bf16x4*)(dx + base + off) = o;
+    }
+}
+
+// slab path geometry: threads per workgroup and chunks per thread (0 = use the two-launch path)
+struct GNSlab { int nt, nch, cpr; unsigned magic; };
+GNSlab gn_slab_geom(int HW, int C, int G) {
+    GNSlab r = {0, 0, 0, 0};
+    const int Cg = C / G;
+    if (Cg % 4) return r;
+    const long total = (long)HW * (Cg / 4);
+    if (total > 16384) return r;                              // 128 KB of bf16 per slab
+    r.cpr = Cg / 4;
+    r.magic = r.cpr == 1 ? 0u : (unsigned)(((1ull << 32) + r.cpr - 1) / r.cpr);
+    r.nt = total <= 256 * 8 ? 256 : 1024;
+    int nch = 1;
+    while ((long)nch * r.nt < total) nch *= 2;
+    r.nch = nch;
+    return r;
+}
+
 // ------------------------------------------------------------------ LayerNorm: one wave per row
 // NV = 16-byte vectors per lane (C <= 512 NV): the row is loaded ONCE into registers — mean, variance and the normalised output
 // (backward: both reductions and dx) come from there; the first version re-read the row from L1/L2 for every pass, three
@@ -424,6 +574,7 @@ int gn_check(int B, int HW, int C, int G) {
 #if defined(HCP_TOOLS)
 // TOOLS ONLY (tools/bench_norm.py): workgroups a GroupNorm launch aims for (default 512).  Changes the workspace size.
 HCP_API int hcp_debug_set_gn_target(int workgroups) {
+    if (workgroups == -1 || workgroups == -2) { g_gn_slab = workgroups == -1 ? 0 : 1; return 0; }   // -1: slab path off, -2: on
     HCP_REQUIRE(workgroups >= 1 && workgroups <= 65536, "hcp_debug_set_gn_target: bad arguments");
     g_gn_target_wgs = workgroups;
     return 0;
@@ -443,6 +594,20 @@ HCP_API int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const floa
                                    void* workspace, int B, int HW, int C, int G, float eps, int silu, hipStream_t stream) {
     if (int e = gn_check(B, HW, C, G)) return e;
     HCP_REQUIRE(x && gamma && beta && y && stats && workspace, "hcp_groupnorm_silu_fwd: null pointer");
+    const GNSlab sl = gn_slab_geom(HW, C, G);
+    if (sl.nch && g_gn_slab) {
+        const hcp_bf16* xp = (const hcp_bf16*)x; hcp_bf16* yp = (hcp_bf16*)y;
+        const dim3 grid(G, B), blk(sl.nt);
+        const size_t sm = 32 * sizeof(float);
+        switch (sl.nch) {
+            case 1: HCP_LAUNCH((gn_slab_fwd<1>), grid, blk, sm, stream, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps); break;
+            case 2: HCP_LAUNCH((gn_slab_fwd<2>), grid, blk, sm, stream, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps); break;
+            case 4: HCP_LAUNCH((gn_slab_fwd<4>), grid, blk, sm, stream, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps); break;
+            case 8: HCP_LAUNCH((gn_slab_fwd<8>), grid, blk, sm, stream, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps); break;
+            default: HCP_LAUNCH((gn_slab_fwd<16>), grid, blk, sm, stream, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps); break;
+        }
+        HCP_LAUNCH_CHECK("groupnorm_fwd (slab)");
+    }
     GNGeom g = gn_geom(B, HW, C);
     size_t sm1 = (size_t)2 * g.R * C * sizeof(float);
     HCP_LAUNCH(gn_fwd_partial, dim3(g.nchunk, B), dim3(g.threads), sm1, stream, (const hcp_bf16*)x, (float*)workspace, HW, C,
@@ -459,6 +624,20 @@ HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* g
                                    int G, int silu, hipStream_t stream) {
     if (int e = gn_check(B, HW, C, G)) return e;
     HCP_REQUIRE(x && dy && gamma && beta && stats && dx && workspace, "hcp_groupnorm_silu_bwd: null pointer");
+    const GNSlab sl = gn_slab_geom(HW, C, G);
+    if (sl.nch && g_gn_slab) {
+        const hcp_bf16 *xp = (const hcp_bf16*)x, *dp = (const hcp_bf16*)dy, *ap = (const hcp_bf16*)addend; hcp_bf16* op = (hcp_bf16*)dx;
+        const dim3 grid(G, B), blk(sl.nt);
+        const size_t sm = 32 * sizeof(float);
+        switch (sl.nch) {
+            case 1: HCP_LAUNCH((gn_slab_bwd<1>), grid, blk, sm, stream, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu); break;
+            case 2: HCP_LAUNCH((gn_slab_bwd<2>), grid, blk, sm, stream, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu); break;
+            case 4: HCP_LAUNCH((gn_slab_bwd<4>), grid, blk, sm, stream, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu); break;
+            case 8: HCP_LAUNCH((gn_slab_bwd<8>), grid, blk, sm, stream, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu); break;
+            default: HCP_LAUNCH((gn_slab_bwd<16>), grid, blk, sm, stream, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu); break;
+        }
+        HCP_LAUNCH_CHECK("groupnorm_bwd (slab)");
+    }
     GNGeom g = gn_geom(B, HW, C);
     size_t sm1 = (size_t)2 * g.R * C * sizeof(float);
     HCP_LAUNCH(gn_bwd_partial, dim3(g.nchunk, B), dim3(g.threads), sm1, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy,

@@ -245,7 +245,8 @@ def test_attention_strided_qkv(backend):
     assert relerr(o, o_ref) < 1e-2
 
 
-GN_CASES_EMU = [(2, 8, 8, 64, True, 1e-5), (1, 5, 7, 320, False, 1e-6), (2, 4, 4, 96, True, 1e-5)]
+GN_CASES_EMU = [(2, 8, 8, 64, True, 1e-5), (1, 5, 7, 320, False, 1e-6), (2, 4, 4, 96, True, 1e-5),
+                (2, 4, 4, 128, True, 1e-5), (1, 5, 7, 640, False, 1e-6), (1, 6, 6, 1280, True, 1e-5)]   # Cg % 4 == 0: the one-launch slab kernels
 GN_CASES_GPU = GN_CASES_EMU + [(4, 64, 64, 320, True, 1e-5), (4, 32, 32, 960, True, 1e-5), (4, 8, 8, 2560, True, 1e-5),
                                (4, 16, 16, 1280, False, 1e-6), (2, 64, 64, 640, True, 1e-5), (4, 32, 32, 1920, True, 1e-5)]
 
@@ -280,6 +281,36 @@ def test_groupnorm_silu(backend, case):
     skip = rnd(B, C, H, W)                                   # fused residual-path gradient
     dx2 = K.groupnorm_bwd(to(nhwc(x)), to(nhwc(dy)), to(gamma), to(beta), stats, 32, silu, addend=to(nhwc(skip)))
     assert relerr(dx2.permute(0, 3, 1, 2), xr.grad + skip.float()) < 1e-2
+
+
+@pytest.mark.parametrize("B,H,W,C,silu", [(2, 3, 5, 640, True), (1, 4, 4, 2560, False), (4, 16, 16, 1280, True), (4, 32, 32, 1920, True),
+                                          (4, 32, 32, 640, False), (4, 8, 8, 2560, True)])
+def test_groupnorm_slab_path_matches_row_chunk_path(tbackend, B, H, W, C, silu):
+    """GroupNorm below the 64x64 level runs as ONE launch (a (sample, group) slab per workgroup, registers hold it between the
+    passes); the two-launch row-chunk path is the same function: statistics to 1e-5 relative, outputs / gradients to bf16 rounding."""
+    if not tbackend.is_gpu and H * W > 64:
+        pytest.skip("large shape: GPU only")
+    to = tbackend.to
+    torch.manual_seed(C + H)
+    x = (torch.randn(B, H, W, C) * 1.5 + 0.4).to(BF); dy = rnd(B, H, W, C); skip = rnd(B, H, W, C)
+    gamma, beta = torch.randn(C) * 0.5 + 1, torch.randn(C) * 0.3
+    res = []
+    try:
+        for mode in (-1, -2):                                # -1: slab path off, -2: on
+            K.lib().hcp_debug_set_gn_target(mode)
+            y, st = K.groupnorm_fwd(to(x), to(gamma), to(beta), 32, 1e-5, silu)
+            dx = K.groupnorm_bwd(to(x), to(dy), to(gamma), to(beta), st, 32, silu, addend=to(skip))
+            res.append((y.cpu().float(), st.cpu(), dx.cpu().float()))
+    finally:
+        K.lib().hcp_debug_set_gn_target(-2)
+    (y0, s0, d0), (y1, s1, d1) = res
+    assert ((s0 - s1).abs() / (s0.abs() + 1)).max().item() < 1e-5
+    assert relerr(y1, y0) < 4e-3 and relerr(d1, d0) < 4e-3
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.group_norm(xr, 32, gamma, beta, 1e-5)
+    yr = F.silu(yr) if silu else yr
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    assert relerr(y1.permute(0, 3, 1, 2), yr) < 1e-2 and relerr(d1.permute(0, 3, 1, 2), xr.grad + skip.float().permute(0, 3, 1, 2)) < 1e-2
 
 
 @pytest.mark.parametrize("B,H,W,C", [(1, 10, 10, 320), (2, 12, 14, 1280), (4, 64, 64, 320), (2, 128, 128, 320), (4, 32, 32, 1920)])
