@@ -255,10 +255,10 @@ HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float
 }
 
 // ------------------------------------------------------------------ GroupNorm, one launch: a (sample, group) slab per workgroup
-// Below the 64x64 level a group's slab — HW rows x Cg channels — is at most 128 KB: ONE workgroup loads it into registers once
-// (8-byte pieces of 4 channels: Cg is 20 / 40 / 60 / 80 there), reduces in the block, and writes the result from the same
-// registers.  One read of x instead of two, exact two-pass variance for free, and above all ONE launch instead of two at the
-// ~5 us floor each (45 of the SD1.5 step's 61 GroupNorms qualify).  The slab's rows are only Cg*2 = 40..160 contiguous bytes,
+// Wherever a group's slab — HW rows x Cg channels — is at most 128 KB (everything below the 64x64 level, and C = 320 at 64x64), ONE
+// workgroup loads it into registers once (8-byte pieces of 4 channels where Cg % 4 == 0, else 4-byte pieces of 2), reduces in
+// the block, and writes the result from the same registers.  One read of x instead of two, exact two-pass variance for free,
+// and above all ONE launch instead of two at the ~5 us floor each.  The slab's rows are only Cg*2 = 20..160 contiguous bytes,
 // but neighbouring groups' workgroups consume the rest of every line at the same time, so HBM traffic stays 1x.
 HCP_DEVICE float gn_block_sum(float v, float* s_red, int tid, int nthreads) {
 #pragma unroll
@@ -271,31 +271,39 @@ HCP_DEVICE float gn_block_sum(float v, float* s_red, int tid, int nthreads) {
     return t;
 }
 // chunk c of the slab -> element offset inside the sample (row = c / cpr through a host-computed reciprocal: exact for c < 2^16)
+template <int CE>
 HCP_DEVICE size_t gn_slab_off(int c, int cpr, unsigned cpr_magic, int C, int* ch_in_group) {
     const int row = cpr_magic ? (int)(((unsigned long long)(unsigned)c * cpr_magic) >> 32) : c;      // (magic 0: one chunk per row)
-    *ch_in_group = (c - row * cpr) * 4;
+    *ch_in_group = (c - row * cpr) * CE;
     return (size_t)row * C + (size_t)*ch_in_group;
 }
+// a chunk = CE channels: 4 (8 bytes) where Cg % 4 == 0, else 2 (4 bytes: Cg = 10 / 30, i.e. C = 320 / 960)
+template <int CE> struct GNChunk;
+typedef float hcp_f32x2 __attribute__((ext_vector_type(2)));
+template <> struct GNChunk<4> { typedef hcp_bf16x4 T; typedef hcp_f32x4 F; };
+template <> struct GNChunk<2> { typedef hcp_bf16x2 T; typedef hcp_f32x2 F; };
 
-template <int NCH>
+template <int NCH, int CE>
 HCP_KERNEL(1024) gn_slab_fwd(const hcp_bf16* x, const float* gamma, const float* beta, float* stats, hcp_bf16* y, int HW, int C,
                              int G, int cpr, unsigned cpr_magic, int silu, float eps) {
+    typedef typename GNChunk<CE>::T V;
     HCP_DYN_SMEM(smem);
     float* s_red = (float*)smem;                          // [waves]
     const int tid = threadIdx.x, NT = blockDim.x;
     const int g = blockIdx.x, b = blockIdx.y;
     const int Cg = C / G, total = HW * cpr;
     const size_t base = (size_t)b * HW * C + (size_t)g * Cg;
-    hcp_bf16x4 v[NCH];
+    V v[NCH];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + i * NT;
-        hcp_bf16x4 z = {0, 0, 0, 0};
         int cg;
-        v[i] = c < total ? *(const hcp_bf16x4*)(x + base + gn_slab_off(c, cpr, cpr_magic, C, &cg)) : z;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s += hcp_bf2f((unsigned short)v[i][e]);
+        for (int e = 0; e < CE; ++e) v[i][e] = 0;
+        if (c < total) v[i] = *(const V*)(x + base + gn_slab_off<CE>(c, cpr, cpr_magic, C, &cg));
+#pragma unroll
+        for (int e = 0; e < CE; ++e) s += hcp_bf2f((unsigned short)v[i][e]);
     }
     const float n = (float)HW * Cg;
     const float mean = gn_block_sum(s, s_red, tid, NT) / n;
@@ -304,7 +312,7 @@ HCP_KERNEL(1024) gn_slab_fwd(const hcp_bf16* x, const float* gamma, const float*
     for (int i = 0; i < NCH; ++i)
         if (tid + i * NT < total) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = hcp_bf2f((unsigned short)v[i][e]) - mean; q += d * d; }
+            for (int e = 0; e < CE; ++e) { const float d = hcp_bf2f((unsigned short)v[i][e]) - mean; q += d * d; }
         }
     const float rstd = 1.0f / sqrtf(gn_block_sum(q, s_red, tid, NT) / n + eps);
     if (tid == 0) { stats[((size_t)b * G + g) * 2] = mean; stats[((size_t)b * G + g) * 2 + 1] = rstd; }
@@ -313,23 +321,25 @@ HCP_KERNEL(1024) gn_slab_fwd(const hcp_bf16* x, const float* gamma, const float*
         const int c = tid + i * NT;
         if (c >= total) continue;
         int cg;
-        const size_t off = gn_slab_off(c, cpr, cpr_magic, C, &cg);
-        const hcp_f32x4 ga = *(const hcp_f32x4*)(gamma + g * Cg + cg), be = *(const hcp_f32x4*)(beta + g * Cg + cg);
-        hcp_bf16x4 o;
+        const size_t off = gn_slab_off<CE>(c, cpr, cpr_magic, C, &cg);
+        typedef typename GNChunk<CE>::F FV;
+        const FV ga = *(const FV*)(gamma + g * Cg + cg), be = *(const FV*)(beta + g * Cg + cg);   // (one vector load each, not CE scalar ones)
+        V o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < CE; ++e) {
             const float a = rstd * ga[e];
             float z = hcp_bf2f((unsigned short)v[i][e]) * a + (be[e] - mean * a);
             if (silu) z = hcp_silu(z);
             o[e] = (short)hcp_f2bf(z);
         }
-        *(hcp_bf16x4*)(y + base + off) = o;
+        *(V*)(y + base + off) = o;
     }
 }
 
-template <int NCH>
+template <int NCH, int CE>
 HCP_KERNEL(1024) gn_slab_bwd(const hcp_bf16* x, const hcp_bf16* dy, const float* gamma, const float* beta, const float* stats,
                              const hcp_bf16* addend, hcp_bf16* dx, int HW, int C, int G, int cpr, unsigned cpr_magic, int silu) {
+    typedef typename GNChunk<CE>::T V;
     HCP_DYN_SMEM(smem);
     float* s_red = (float*)smem;
     const int tid = threadIdx.x, NT = blockDim.x;
@@ -337,13 +347,14 @@ HCP_KERNEL(1024) gn_slab_bwd(const hcp_bf16* x, const hcp_bf16* dy, const float*
     const int Cg = C / G, total = HW * cpr;
     const size_t base = (size_t)b * HW * C + (size_t)g * Cg;
     const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
-    // the lane's chunks of x and dy stay in registers as loaded (bf16: 4 VGPRs per chunk); xhat / dxhat are recomputed in the second pass
-    hcp_bf16x4 v[NCH], d[NCH];
+    // the lane's chunks of x and dy stay in registers as loaded (bf16); xhat / dxhat are recomputed in the second pass
+    V v[NCH], d[NCH];
     float s1 = 0.f, s2 = 0.f;
-    auto terms = [&](int i, int cg, float (&h)[4], float (&dh)[4]) {
-        const hcp_f32x4 ga = *(const hcp_f32x4*)(gamma + g * Cg + cg), be = *(const hcp_f32x4*)(beta + g * Cg + cg);
+    auto terms = [&](int i, int cg, float (&h)[CE], float (&dh)[CE]) {
+        typedef typename GNChunk<CE>::F FV;
+        const FV ga = *(const FV*)(gamma + g * Cg + cg), be = *(const FV*)(beta + g * Cg + cg);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < CE; ++e) {
             h[e] = (hcp_bf2f((unsigned short)v[i][e]) - mean) * rstd;
             float dz = hcp_bf2f((unsigned short)d[i][e]);
             if (silu) { const float z = h[e] * ga[e] + be[e]; const float sg = hcp_sigmoid(z); dz *= sg * (1.f + z * (1.f - sg)); }
@@ -353,16 +364,16 @@ HCP_KERNEL(1024) gn_slab_bwd(const hcp_bf16* x, const hcp_bf16* dy, const float*
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + i * NT;
-        hcp_bf16x4 z = {0, 0, 0, 0};
-        v[i] = z; d[i] = z;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { v[i][e] = 0; d[i][e] = 0; }
         if (c < total) {
             int cg;
-            const size_t off = gn_slab_off(c, cpr, cpr_magic, C, &cg);
-            v[i] = *(const hcp_bf16x4*)(x + base + off); d[i] = *(const hcp_bf16x4*)(dy + base + off);
-            float h[4], dh[4];
+            const size_t off = gn_slab_off<CE>(c, cpr, cpr_magic, C, &cg);
+            v[i] = *(const V*)(x + base + off); d[i] = *(const V*)(dy + base + off);
+            float h[CE], dh[CE];
             terms(i, cg, h, dh);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s1 += dh[e]; s2 += dh[e] * h[e]; }
+            for (int e = 0; e < CE; ++e) { s1 += dh[e]; s2 += dh[e] * h[e]; }
         }
     }
     const float n = (float)HW * Cg;
@@ -373,28 +384,32 @@ HCP_KERNEL(1024) gn_slab_bwd(const hcp_bf16* x, const hcp_bf16* dy, const float*
         const int c = tid + i * NT;
         if (c >= total) continue;
         int cg;
-        const size_t off = gn_slab_off(c, cpr, cpr_magic, C, &cg);
-        hcp_bf16x4 ad = {0, 0, 0, 0};
-        if (addend) ad = *(const hcp_bf16x4*)(addend + base + off);
-        float h[4], dh[4];
-        terms(i, cg, h, dh);
-        hcp_bf16x4 o;
+        const size_t off = gn_slab_off<CE>(c, cpr, cpr_magic, C, &cg);
+        V ad;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < CE; ++e) ad[e] = 0;
+        if (addend) ad = *(const V*)(addend + base + off);
+        float h[CE], dh[CE];
+        terms(i, cg, h, dh);
+        V o;
+#pragma unroll
+        for (int e = 0; e < CE; ++e)
             o[e] = (short)hcp_f2bf(rstd * (dh[e] - c1 - h[e] * c2) + (addend ? hcp_bf2f((unsigned short)ad[e]) : 0.f));
-        *(hcp_bf16x4*)(dx + base + off) = o;
+        *(V*)(dx + base + off) = o;
     }
 }
 
 // slab path geometry: threads per workgroup and chunks per thread (0 = use the two-launch path)
-struct GNSlab { int nt, nch, cpr; unsigned magic; };
+struct GNSlab { int nt, nch, ce, cpr; unsigned magic; };
 GNSlab gn_slab_geom(int HW, int C, int G) {
-    GNSlab r = {0, 0, 0, 0};
+    GNSlab r = {0, 0, 0, 0, 0};
     const int Cg = C / G;
-    if (Cg % 4) return r;
-    const long total = (long)HW * (Cg / 4);
-    if (total > 16384) return r;                              // 128 KB of bf16 per slab
-    r.cpr = Cg / 4;
+    if (Cg % 2) return r;
+    const int ce = Cg % 4 == 0 ? 4 : 2;
+    if ((long)HW * Cg > 65536) return r;                      // 128 KB of bf16 per slab: <= 64 elements per thread and tensor
+    if (ce == 2 && HW > 1024) return r;                       // C = 320 at 64x64: rows of 20 bytes, measured 0.95 ms/step SLOWER than two launches
+    const long total = (long)HW * (Cg / ce);
+    r.ce = ce; r.cpr = Cg / ce;
     r.magic = r.cpr == 1 ? 0u : (unsigned)(((1ull << 32) + r.cpr - 1) / r.cpr);
     r.nt = total <= 256 * 8 ? 256 : 1024;
     int nch = 1;
@@ -402,6 +417,25 @@ GNSlab gn_slab_geom(int HW, int C, int G) {
     r.nch = nch;
     return r;
 }
+
+// instantiated (chunks per thread, channels per chunk): 8-byte chunks up to 16 per thread, 4-byte chunks up to 32
+#define HCP_GN_SLAB_SWITCH(KERNEL, ...)                                                                              \
+    do {                                                                                                             \
+        const int key_ = sl.nch * 8 + sl.ce;                                                                         \
+        switch (key_) {                                                                                              \
+            case 1 * 8 + 4: HCP_LAUNCH((KERNEL<1, 4>), grid, blk, sm, stream, __VA_ARGS__); break;                   \
+            case 2 * 8 + 4: HCP_LAUNCH((KERNEL<2, 4>), grid, blk, sm, stream, __VA_ARGS__); break;                   \
+            case 4 * 8 + 4: HCP_LAUNCH((KERNEL<4, 4>), grid, blk, sm, stream, __VA_ARGS__); break;                   \
+            case 8 * 8 + 4: HCP_LAUNCH((KERNEL<8, 4>), grid, blk, sm, stream, __VA_ARGS__); break;                   \
+            case 16 * 8 + 4: HCP_LAUNCH((KERNEL<16, 4>), grid, blk, sm, stream, __VA_ARGS__); break;                 \
+            case 1 * 8 + 2: HCP_LAUNCH((KERNEL<1, 2>), grid, blk, sm, stream, __VA_ARGS__); break;                   \
+            case 2 * 8 + 2: HCP_LAUNCH((KERNEL<2, 2>), grid, blk, sm, stream, __VA_ARGS__); break;                   \
+            case 4 * 8 + 2: HCP_LAUNCH((KERNEL<4, 2>), grid, blk, sm, stream, __VA_ARGS__); break;                   \
+            case 8 * 8 + 2: HCP_LAUNCH((KERNEL<8, 2>), grid, blk, sm, stream, __VA_ARGS__); break;                   \
+            case 16 * 8 + 2: HCP_LAUNCH((KERNEL<16, 2>), grid, blk, sm, stream, __VA_ARGS__); break;                 \
+            default: HCP_LAUNCH((KERNEL<32, 2>), grid, blk, sm, stream, __VA_ARGS__); break;                         \
+        }                                                                                                            \
+    } while (0)
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row
 // NV = 16-byte vectors per lane (C <= 512 NV): the row is loaded ONCE into registers — mean, variance and the normalised output
@@ -599,13 +633,7 @@ HCP_API int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const floa
         const hcp_bf16* xp = (const hcp_bf16*)x; hcp_bf16* yp = (hcp_bf16*)y;
         const dim3 grid(G, B), blk(sl.nt);
         const size_t sm = 32 * sizeof(float);
-        switch (sl.nch) {
-            case 1: HCP_LAUNCH((gn_slab_fwd<1>), grid, blk, sm, stream, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps); break;
-            case 2: HCP_LAUNCH((gn_slab_fwd<2>), grid, blk, sm, stream, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps); break;
-            case 4: HCP_LAUNCH((gn_slab_fwd<4>), grid, blk, sm, stream, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps); break;
-            case 8: HCP_LAUNCH((gn_slab_fwd<8>), grid, blk, sm, stream, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps); break;
-            default: HCP_LAUNCH((gn_slab_fwd<16>), grid, blk, sm, stream, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps); break;
-        }
+        HCP_GN_SLAB_SWITCH(gn_slab_fwd, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps);
         HCP_LAUNCH_CHECK("groupnorm_fwd (slab)");
     }
     GNGeom g = gn_geom(B, HW, C);
@@ -629,13 +657,7 @@ HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* g
         const hcp_bf16 *xp = (const hcp_bf16*)x, *dp = (const hcp_bf16*)dy, *ap = (const hcp_bf16*)addend; hcp_bf16* op = (hcp_bf16*)dx;
         const dim3 grid(G, B), blk(sl.nt);
         const size_t sm = 32 * sizeof(float);
-        switch (sl.nch) {
-            case 1: HCP_LAUNCH((gn_slab_bwd<1>), grid, blk, sm, stream, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu); break;
-            case 2: HCP_LAUNCH((gn_slab_bwd<2>), grid, blk, sm, stream, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu); break;
-            case 4: HCP_LAUNCH((gn_slab_bwd<4>), grid, blk, sm, stream, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu); break;
-            case 8: HCP_LAUNCH((gn_slab_bwd<8>), grid, blk, sm, stream, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu); break;
-            default: HCP_LAUNCH((gn_slab_bwd<16>), grid, blk, sm, stream, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu); break;
-        }
+        HCP_GN_SLAB_SWITCH(gn_slab_bwd, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu);
         HCP_LAUNCH_CHECK("groupnorm_bwd (slab)");
     }
     GNGeom g = gn_geom(B, HW, C);

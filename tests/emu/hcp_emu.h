@@ -57,6 +57,7 @@ typedef void* hipStream_t;
 
 typedef short hcp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short hcp_bf16x4 __attribute__((ext_vector_type(4)));
+typedef short hcp_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float hcp_f32x4 __attribute__((ext_vector_type(4)));
 typedef float hcp_f32x16 __attribute__((ext_vector_type(16)));
 

@@ -283,8 +283,9 @@ def test_groupnorm_silu(backend, case):
     assert relerr(dx2.permute(0, 3, 1, 2), xr.grad + skip.float()) < 1e-2
 
 
-@pytest.mark.parametrize("B,H,W,C,silu", [(2, 3, 5, 640, True), (1, 4, 4, 2560, False), (4, 16, 16, 1280, True), (4, 32, 32, 1920, True),
-                                          (4, 32, 32, 640, False), (4, 8, 8, 2560, True)])
+@pytest.mark.parametrize("B,H,W,C,silu", [(2, 3, 5, 640, True), (1, 4, 4, 2560, False), (2, 3, 5, 320, True), (4, 16, 16, 1280, True),
+                                          (4, 32, 32, 1920, True), (4, 32, 32, 640, False), (4, 8, 8, 2560, True), (4, 64, 64, 320, True),
+                                          (4, 32, 32, 960, True), (2, 64, 64, 320, False)])
 def test_groupnorm_slab_path_matches_row_chunk_path(tbackend, B, H, W, C, silu):
     """GroupNorm below the 64x64 level runs as ONE launch (a (sample, group) slab per workgroup, registers hold it between the
     passes); the two-launch row-chunk path is the same function: statistics to 1e-5 relative, outputs / gradients to bf16 rounding."""
