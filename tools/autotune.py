@@ -104,6 +104,7 @@ def trace(workload, B):
 
 def sweep(fn, nk1, cfgs=range(len(CFG_NAMES))):
     res = {}
+    K.lib().hcp_debug_set_gemm_loaders(0)        # the MAIN table: no loader waves (tools/tune_loaders.py sweeps those on top of it)
     for cid in cfgs:
         for s in (1, 2, 4, 8, 16):
             if s > 1 and nk1 // s < 4:
@@ -114,7 +115,9 @@ def sweep(fn, nk1, cfgs=range(len(CFG_NAMES))):
             except Exception:  # noqa: BLE001
                 pass
     K.lib().hcp_debug_set_gemm_config(-1)
-    return res, round(timeit(fn), 1)
+    heur = round(timeit(fn), 1)                  # what the main table / heuristic picks today (still without loaders)
+    K.lib().hcp_debug_set_gemm_loaders(-1)
+    return res, heur
 
 
 def choose(res):
@@ -150,6 +153,7 @@ def main():
             def two():
                 t = K.gemm(a, l)
                 return K.gemm(a, b, a2=t, b2=e)
+            K.lib().hcp_debug_set_gemm_loaders(0)
             heur = round(timeit(lambda: K.gemm_lora(a, b, l, e)), 1)
             t_two = round(timeit(two), 1)
             res = {}
@@ -157,6 +161,7 @@ def main():
                 K.lib().hcp_debug_set_gemm_config(cid + 16)
                 res[cid] = round(timeit(lambda: K.gemm_lora(a, b, l, e)), 1)
             K.lib().hcp_debug_set_gemm_config(-1)
+            K.lib().hcp_debug_set_gemm_loaders(-1)
             us, cid = min((v, k) for k, v in res.items())
             if t_two < us:
                 us, cid = t_two, -1
