@@ -109,10 +109,9 @@ class ResnetBlock2D(nn.Module):
         slice of the batched time-embedding projection (fp32 [B,Cout]) when the UNet precomputed it."""
         if skip is not None:
             x = ops.concat_channels(x, skip)          # GroupNorm needs the joint tensor once; convs read it back
-        if hasattr(self, "conv_shortcut"):
-            h = self.norm1(x, silu=True)
-        else:
-            h, x = self.norm1(x, silu=True, fork=True)       # x continues as the identity residual
+        # x continues as the residual (identity, or the input of the 1x1 shortcut conv): the fork hands the gradient arriving on
+        # that path to norm1's backward kernel as its addend instead of leaving an aten::add to autograd
+        h, x = self.norm1(x, silu=True, fork=True)
         if temb_bias is not None:
             tb = temb_bias
         elif (isinstance(self.time_emb_proj, HipLinear) and not temb_act.requires_grad
