@@ -71,7 +71,8 @@ HCP_KERNEL(256) attn_dkv_convert_kernel(AttnParams p, int B, int C) {
     }
 }
 
-HCP_TUNABLE(int, g_attn_cfg, -1);   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32, bit3 fwd 8-wave workgroups; -1 = heuristic
+constexpr int kMinQTilesPerSplit = 8, kSplitTargetWgs = 512;   // cross-attention dK/dV: query-loop split (launch_dkv)
+HCP_TUNABLE(int, g_attn_cfg, -1);   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32, bit3 fwd 8-wave workgroups, bit4 = keep the heuristic for bits 0-3, bits 8-11 / 12-15 = min query tiles per dK/dV split / target workgroups / 256; -1 = heuristic
 
 template <int D, int QT, int NW>
 int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
@@ -104,8 +105,11 @@ int launch_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t str
     const long base = (long)nkv * p.H * B;
     const size_t need = (size_t)2 * B * p.Nk * p.H * D * sizeof(float);
     if (base < 256 && nqt >= 8 && ws && ws_bytes >= need) {
-        qsplit = (int)((512 + base - 1) / base);
-        if (qsplit > nqt / 8) qsplit = nqt / 8;       // >= 8 query tiles per workgroup, else memset + convert dominate
+        const bool ovr = g_attn_cfg >= 0 && (g_attn_cfg >> 8);                    // tools: bits 8-11 min tiles, bits 12-15 target / 256
+        const int min_tiles = ovr ? ((g_attn_cfg >> 8) & 15) : kMinQTilesPerSplit;
+        const int target = ovr ? 256 * ((g_attn_cfg >> 12) & 15) : kSplitTargetWgs;
+        qsplit = (int)((target + base - 1) / base);
+        if (qsplit > nqt / min_tiles) qsplit = nqt / min_tiles;       // >= min_tiles query tiles per workgroup, else memset + convert dominate
         if (qsplit < 2) qsplit = 1;
     }
     p.qsplit = qsplit;
@@ -135,7 +139,7 @@ int run_fwd(AttnParams& p, int B, hipStream_t stream) {
     const long bh = (long)B * p.H;
     bool wide = kWide<D> && bh * hcp_cdiv(p.Nq, 128) >= 512;
     bool w8 = (D == 40 || D == 80) && bh * hcp_cdiv(p.Nq, D == 40 ? 256 : 128) >= 256;
-    if (g_attn_cfg >= 0) { wide = kWide<D> && (g_attn_cfg & 1); w8 = (D == 40 || D == 80) && (g_attn_cfg & 8); }
+    if (g_attn_cfg >= 0 && !(g_attn_cfg & 16)) { wide = kWide<D> && (g_attn_cfg & 1); w8 = (D == 40 || D == 80) && (g_attn_cfg & 8); }
     if constexpr (D == 40) {
         if (w8) return wide ? launch_fwd<D, 2, 8>(p, B, stream) : launch_fwd<D, 1, 8>(p, B, stream);
         return wide ? launch_fwd<D, 2, 4>(p, B, stream) : launch_fwd<D, 1, 4>(p, B, stream);
@@ -152,7 +156,7 @@ int run_bwd(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t stream
     if (int e = launch_delta<D>(p, B, stream)) return e;
     // measured on MI355X: 32 rows per wave pay off once the grid has >= 512 such workgroups
     bool wq = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512, wk = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nk, 128) >= 512;
-    if (g_attn_cfg >= 0) { wq = kWide<D> && (g_attn_cfg & 2); wk = kWide<D> && (g_attn_cfg & 4); }
+    if (g_attn_cfg >= 0 && !(g_attn_cfg & 16)) { wq = kWide<D> && (g_attn_cfg & 2); wk = kWide<D> && (g_attn_cfg & 4); }
     int e;
     if constexpr (kWide<D>) { e = wq ? launch_dq<D, 2>(p, B, stream) : launch_dq<D, 1>(p, B, stream); }
     else e = launch_dq<D, 1>(p, B, stream);
