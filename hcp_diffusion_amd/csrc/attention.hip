@@ -71,8 +71,8 @@ HCP_KERNEL(256) attn_dkv_convert_kernel(AttnParams p, int B, int C) {
     }
 }
 
-constexpr int kMinQTilesPerSplit = 8, kSplitTargetWgs = 512;   // cross-attention dK/dV: query-loop split (launch_dkv)
-HCP_TUNABLE(int, g_attn_cfg, -1);   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32, bit3 fwd 8-wave workgroups, bit4 = keep the heuristic for bits 0-3, bits 8-11 / 12-15 = min query tiles per dK/dV split / target workgroups / 256; -1 = heuristic
+constexpr int kMinQTilesPerSplit = 16, kSplitTargetWgs = 256;   // cross-attention dK/dV query-loop split (tools/tune_attn_split.py: 8 / 512 gave 78.5 us for the 64x64 backward, 16 / 256 gives 64.0; finer splits lose to the fp32 atomics)
+HCP_TUNABLE(int, g_attn_cfg, -1);   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32, bit3 fwd 8-wave workgroups, bit4 = keep the heuristic for bits 0-3, bits 8-15 / 16-19 = min query tiles per dK/dV split / target workgroups / 256; -1 = heuristic
 
 template <int D, int QT, int NW>
 int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
@@ -105,9 +105,9 @@ int launch_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t str
     const long base = (long)nkv * p.H * B;
     const size_t need = (size_t)2 * B * p.Nk * p.H * D * sizeof(float);
     if (base < 256 && nqt >= 8 && ws && ws_bytes >= need) {
-        const bool ovr = g_attn_cfg >= 0 && (g_attn_cfg >> 8);                    // tools: bits 8-11 min tiles, bits 12-15 target / 256
-        const int min_tiles = ovr ? ((g_attn_cfg >> 8) & 15) : kMinQTilesPerSplit;
-        const int target = ovr ? 256 * ((g_attn_cfg >> 12) & 15) : kSplitTargetWgs;
+        const bool ovr = g_attn_cfg >= 0 && (g_attn_cfg >> 8);                    // tools: bits 8-15 min tiles, bits 16-19 target / 256
+        const int min_tiles = ovr ? ((g_attn_cfg >> 8) & 255) : kMinQTilesPerSplit;
+        const int target = ovr ? 256 * ((g_attn_cfg >> 16) & 15) : kSplitTargetWgs;
         qsplit = (int)((target + base - 1) / base);
         if (qsplit > nqt / min_tiles) qsplit = nqt / min_tiles;       // >= min_tiles query tiles per workgroup, else memset + convert dominate
         if (qsplit < 2) qsplit = 1;

@@ -16,8 +16,8 @@ for (B, H, Nq, Nk, D) in [(4, 8, 4096, 77, 40), (4, 8, 1024, 77, 80), (4, 8, 256
     k, v = rnd(B, Nk, C), rnd(B, Nk, C)
     o, lse = K.attention_fwd(q, k, v, H)
     row = []
-    for mt, tg in ((8, 2), (4, 4), (2, 8), (4, 8), (1, 8), (2, 15)):
-        K.lib().hcp_debug_set_attention_config(16 + (mt << 8) + (tg << 12))
+    for mt, tg in ((8, 2), (16, 1), (32, 1), (64, 1), (128, 1)):
+        K.lib().hcp_debug_set_attention_config(16 + (mt << 8) + (tg << 16))
         row.append(f"min {mt} target {256 * tg}: {timeit(lambda: K.attention_bwd(q, k, v, o, do, lse, H), iters=20):6.1f} us")
     K.lib().hcp_debug_set_attention_config(-1)
     print(f"B{B} H{H} Nq{Nq} Nk{Nk} d{D} backward (delta + dQ + memset + dK/dV + convert): " + " | ".join(row), flush=True)
