@@ -746,6 +746,9 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)res_v[i][j][q]);
             }
+#if defined(HCP_TOOLS)
+            if ((p.dbg & 64) && v[0] != 12345.678f) continue;      // ablation: no output stores (the compare keeps the math alive)
+#endif
             if (p.out_f32) {
                 *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
             } else {
@@ -957,7 +960,7 @@ HCP_API int hcp_debug_set_gemm_config(int cfg) { g_force_cfg = cfg; return 0; }
 // TOOLS ONLY: 1 = default (v2 main loop where its requirements hold), 0 / 2 = the first LDS-DMA loop (gemm_glds_kernel) everywhere.
 HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = 1; g_use_v2 = on == 1; return 0; }
 // TOOLS ONLY: ablation (results are wrong when != 0).  First LDS-DMA loop: 1 no DMA after tile 0, 2 no MFMA, 4 no LDS reads;
-// v2 loop (tools build only): 8 no DMA after the ring prologue, 16 no MFMA, 32 no LDS fragment reads.
+// v2 loop (tools build only): 8 no DMA after the ring prologue, 16 no MFMA, 32 no LDS fragment reads, 64 no output stores.
 HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; return 0; }
 // TOOLS ONLY: -1 = as the dispatch table says, 0 = never, 1 = the loader-wave variant wherever one is instantiated (tile ids 12-15).
 HCP_API int hcp_debug_set_gemm_loaders(int mode) { g_force_loaders = mode; return 0; }
