@@ -185,6 +185,8 @@ def main():
                     "modules (train_ac.py:467-504 restated: eager module calls, torch autograd, clip_grad_norm_, optimizer.step(), "
                     "zero_grad, loss.item() every step) instead of NativeTrainer's captured step; sd15 workload, 1 GPU")
     ap.add_argument("--seam-optimizer", choices=["fused", "torch"], default="fused")
+    ap.add_argument("--seam-graph", action="store_true", help="with --seam: unet.enable_hip_graph() — the module replays captured forward / "
+                    "backward hipGraphs under the same eager trainer loop")
     ap.add_argument("--comm", choices=["torch", "abi"], default=os.environ.get("HCP_COMM", "torch"),
                     help="gradient exchange: torch.distributed (backend nccl = RCCL) or RCCL through the C ABI (hcp_allreduce_flat / "
                          "hcp_reduce_scatter_flat / hcp_allgather_flat, csrc/comm.hip)")
@@ -321,6 +323,8 @@ def main():
         params = [p for blk in tr.bucket.blocks for p in (blk.layer.W_down, blk.layer.W_up)]
         opt = (FusedAdamW if args.seam_optimizer == "fused" else torch.optim.AdamW)([dict(params=params, lr=1e-4 * B)], weight_decay=1e-3)
         crit = torch.nn.MSELoss(reduction="none")
+        if args.seam_graph:
+            unet.enable_hip_graph()
 
         def seam_step():
             noise = torch.randn_like(latents)
@@ -342,7 +346,8 @@ def main():
         dt = time.perf_counter() - t0
         print(json.dumps({"metric": "training images/sec, SD1.5 LoRA 512px bs=4, native modules driven the reference trainer's way (eager seam)",
                           "value": round(B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 3), "optimizer": args.seam_optimizer, "final_loss": round(lv, 5),
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "optimizer": args.seam_optimizer, "unet_hip_graph": bool(args.seam_graph),
+                          "final_loss": round(lv, 5),
                           "config": {"workload": "SD1.5 UNet LoRA rank=%d bf16 bs=%d, eager, clip_grad_norm_ + %s AdamW + loss.item() per step" %
                                      (args.rank_lora, B, args.seam_optimizer)}}), flush=True)
         return

@@ -415,9 +415,10 @@ class NativeUNet2DConditionModel(nn.Module):
         return cls(**dict(config or {}, **kw))
 
     @classmethod
-    def from_pretrained(cls, path=None, subfolder=None, pretrained_model_name_or_path=None, **kw):
+    def from_pretrained(cls, path=None, subfolder=None, pretrained_model_name_or_path=None, hip_graph=False, **kw):
         """Load diffusers-format weights (config.json + *.safetensors) — names are identical by construction.
-        (``pretrained_model_name_or_path``: diffusers' own keyword, as the YAML overlays of cfgs/train/mi355x pass it.)"""
+        (``pretrained_model_name_or_path``: diffusers' own keyword, as the YAML overlays of cfgs/train/mi355x pass it;
+        ``hip_graph: True`` = enable_hip_graph(): the module replays captured graphs under the reference's eager trainer loop.)"""
         path = path if path is not None else pretrained_model_name_or_path
         import json
         import os
@@ -435,6 +436,8 @@ class NativeUNet2DConditionModel(nn.Module):
                     projection_class_embeddings_input_dim=cfg.get("projection_class_embeddings_input_dim"))
         from safetensors.torch import load_file
         model.load_state_dict(load_file(os.path.join(root, "diffusion_pytorch_model.safetensors")))
+        if hip_graph:
+            model.enable_hip_graph()
         return model
 
     @property
@@ -481,8 +484,32 @@ class NativeUNet2DConditionModel(nn.Module):
         allp = K.gemm(temb_act.reshape(-1, temb_act.shape[-1]), w, bias=b, out_f32=True)        # [B, sum Cout] fp32
         temb_act._hcp_tb = {id(r): allp[:, o:o + r.time_emb_proj.weight.shape[0]] for r, o in zip(res, offs)}
 
+    def enable_hip_graph(self, on=True):
+        """Replay the forward and the backward of `unet(...)` as captured hipGraphs when an ordinary trainer calls the module in grad
+        mode (LoRA-only training; see graphed.py).  Call again (or `reset_hip_graph()`) after adding / removing LoRA layers."""
+        self._hip_graph, self._hip_graphs = bool(on), {}
+
+    def reset_hip_graph(self):
+        self._hip_graphs = {}
+
     def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, added_cond_kwargs=None,
                 cross_attention_kwargs=None, **kwargs):
+        if (getattr(self, "_hip_graph", False) and torch.is_grad_enabled() and sample.is_cuda and torch.is_tensor(timestep)
+                and not torch.cuda.is_current_stream_capturing()):
+            from . import graphed
+            if graphed.capturable(self):
+                added = added_cond_kwargs or {}
+                ins = [sample, timestep, encoder_hidden_states, encoder_attention_mask, added.get("text_embeds"), added.get("time_ids")]
+                key = tuple(None if t is None else (tuple(t.shape), t.dtype, bool(t.requires_grad)) for t in ins) + \
+                    (any(getattr(m, "gradient_checkpointing", False) for m in self.modules()),)
+
+                def fwd(s_, t_, e_, m_, te_, ti_):
+                    ak = dict(text_embeds=te_, time_ids=ti_) if te_ is not None else None
+                    return self._forward_impl(s_, t_, e_, m_, ak).sample
+                return UNet2DConditionOutput(graphed.call(self, ins, fwd, self._hip_graphs, key))
+        return self._forward_impl(sample, timestep, encoder_hidden_states, encoder_attention_mask, added_cond_kwargs)
+
+    def _forward_impl(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, added_cond_kwargs=None):
         text_time = self.config["addition_embed_type"] == "text_time"
         if bool(added_cond_kwargs) != text_time:
             raise ValueError("hcp_diffusion_amd: added_cond_kwargs={text_embeds,time_ids} is required by (and only by) a UNet with "

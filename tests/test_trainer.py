@@ -195,3 +195,48 @@ def test_graph_cache_per_latent_shape():
         if use_graph:
             assert len(tr._graph_cache) == 3
     assert ((outs[0] - outs[1]).abs().max() / outs[0].abs().max()).item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_unet_hip_graph_under_a_plain_trainer_loop_matches_eager():
+    """unet.enable_hip_graph(): an ordinary eager loop (module call, loss.backward(), clip, torch AdamW, zero_grad) — what the
+    reference's Trainer.train_one_step does — replays captured forward / backward graphs and follows the eager trajectory; the
+    capture leaves gradients untouched; zero_grad(set_to_none=True) is survived; a second input shape gets its own graphs."""
+    from hcp_diffusion_amd.lora import make_lora
+    dev = torch.device("cuda:0")
+
+    def run(graph, steps=5):
+        unet = _native(dev).requires_grad_(False)                   # the host is frozen, as the reference trainer leaves it (train_ac.py:232-240)
+        groups, grp, bucket = make_lora(unet, [dict(layers=PATS_A + PATS_F, rank=4, lr=1e-2)])
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for blk in bucket.blocks:
+                blk.layer.W_up.copy_((torch.randn(blk.layer.W_up.shape, generator=g) * 0.05).to(dev))
+        bucket.pack()
+        params = [p for blk in bucket.blocks for p in (blk.layer.W_down, blk.layer.W_up)]
+        opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=1e-3)
+        if graph:
+            unet.enable_hip_graph()
+        losses = []
+        for i in range(steps):
+            hw = (8, 8) if i != 3 else (8, 16)                       # step 3: another aspect-ratio bucket
+            b = _batch(dev, 100 + i, hw=hw, B=2)
+            t = torch.tensor([10 + 100 * i, 900 - 50 * i], device=dev)
+            target = torch.randn(2, 4, *hw, generator=torch.Generator().manual_seed(i)).to(dev)
+            pred = unet(b["latents"], t, b["encoder_hidden_states"].to(torch.bfloat16)).sample
+            loss = torch.nn.functional.mse_loss(pred.float(), target)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=(i % 2 == 1))
+            losses.append(loss.item())
+        if graph:
+            assert len(unet._hip_graphs) == 2
+        return losses, torch.cat([p.detach().flatten() for p in params]).cpu()
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (le, lg)
+    assert ((pe - pg).abs().max() / pe.abs().max()).item() < 5e-3
+    assert le[0] != le[-1]
