@@ -42,6 +42,9 @@ def capturable(unet):
             return False
     if unet._forward_pre_hooks or unet._forward_hooks:
         return False
+    d = torch.distributed
+    if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
+        return False                                # under torch DDP the reducer's per-parameter hooks must run with every backward: eager module
     any_lora = False
     for p in unet.parameters():
         if p.requires_grad:

@@ -134,3 +134,79 @@ def test_two_rank_gloo_matches_single_process(tmp_path, mode):
         assert dp < 2.5e-2, dp                                      # lr 1e-2: one AdamW step moves a parameter by <= lr; sign flips of tiny gradients aside
     finally:
         K._set_backend_for_tests(None)
+
+
+def _ddp_model(tiny_cfg):
+    """Frozen native UNet + LoRA the way the reference's trainer holds it: no NativeTrainer, gradients in `.grad`."""
+    from hcp_diffusion_amd.lora import make_lora
+    from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
+    from oracle.unet_sd15 import OracleUNet2DConditionModel, seeded_init_
+    torch.manual_seed(0)
+    nat = NativeUNet2DConditionModel(**tiny_cfg)
+    nat.load_state_dict(seeded_init_(OracleUNet2DConditionModel(**tiny_cfg), 1).state_dict())
+    nat.requires_grad_(False)
+    _, _, bucket = make_lora(nat, [dict(layers=PATS, rank=4)])
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for blk in bucket.blocks:
+            blk.layer.W_up.copy_(torch.randn(blk.layer.W_up.shape, generator=g) * 0.05)
+    bucket.pack()
+    return nat, bucket
+
+
+def _plain_steps(model, unet_params, x, ehs, t, target, steps=2):
+    opt = torch.optim.AdamW(unet_params, lr=1e-2, weight_decay=1e-3)
+    for _ in range(steps):
+        pred = model(x, t, ehs).sample
+        loss = torch.nn.functional.mse_loss(pred.float(), target)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+
+
+def _ddp_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import emu_cdll
+    from hcp_diffusion_amd import kernels as K
+    from oracle.unet_sd15 import MICRO_CONFIG
+    K._set_backend_for_tests(emu_cdll())
+    nat, bucket = _ddp_model(MICRO_CONFIG)
+    ddp = torch.nn.parallel.DistributedDataParallel(nat, broadcast_buffers=False)       # train_ac.py:117: DistributedDataParallelKwargs(broadcast_buffers=False)
+    x0, ehs, noise, t = _data()
+    sl = slice(rank, rank + 1)
+    params = [p for blk in bucket.blocks for p in (blk.layer.W_down, blk.layer.W_up)]
+    _plain_steps(ddp, params, x0[sl].contiguous(), ehs[sl].to(torch.bfloat16).contiguous(), t[sl], noise[sl].contiguous())
+    torch.save({"params": bucket.params.clone()}, os.path.join(out, f"ddp{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_stock_torch_ddp_around_the_native_unet(tmp_path):
+    """The reference's multi-GPU loop wraps the model in torch DDP (accelerate, train_ac.py:117-123,175).  The native layers write
+    parameter gradients in place and return None to autograd; the engine still runs each parameter's AccumulateGrad node (with an
+    undefined gradient), so the reducer's hooks fire AFTER the kernel that wrote `.grad` was enqueued and stock DDP averages the
+    bucket views like any other gradient: two steps, both ranks end with identical parameters, equal to one process on both samples."""
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "ddp0.pt"); r1 = torch.load(tmp_path / "ddp1.pt")
+    assert torch.equal(r0["params"], r1["params"])
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import emu_cdll
+    from hcp_diffusion_amd import kernels as K
+    from oracle.unet_sd15 import MICRO_CONFIG
+    K._set_backend_for_tests(emu_cdll())
+    try:
+        nat, bucket = _ddp_model(MICRO_CONFIG)
+        x0, ehs, noise, t = _data()
+        params = [p for blk in bucket.blocks for p in (blk.layer.W_down, blk.layer.W_up)]
+        _plain_steps(nat, params, x0, ehs.to(torch.bfloat16), t, noise)          # mse over the 2-sample batch = mean of the per-rank losses
+        p_init = _ddp_model(MICRO_CONFIG)[1].params
+        upd_single, upd_ddp = bucket.params - p_init, r0["params"] - p_init
+        cos = torch.nn.functional.cosine_similarity(upd_single, upd_ddp, dim=0).item()
+        assert cos > 0.98, cos                                                  # same two AdamW updates (sign flips of near-zero gradients aside)
+        assert (upd_ddp.abs().max().item() > 5e-3)                              # ... and they are real updates
+    finally:
+        K._set_backend_for_tests(None)
