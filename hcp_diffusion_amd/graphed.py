@@ -28,7 +28,7 @@ def _lora_buckets(unet):
     return blocks, buckets
 
 
-def capturable(unet):
+def capturable(unet):  # (any native module that holds LoRA layers: the UNet or the text encoder)
     """LoRA-only training (frozen host), no active dropout, no hooks feeding per-step data."""
     from .lora import LoraBucket, LoraHipLayer
     lora_params = set()

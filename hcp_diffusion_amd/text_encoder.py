@@ -107,7 +107,23 @@ class NativeCLIPTextModel(nn.Module):
     def device(self):
         return self.text_model.final_layer_norm.weight.device
 
+    def enable_hip_graph(self, on=True):
+        """As NativeUNet2DConditionModel.enable_hip_graph: under an ordinary eager trainer loop the encoder's forward and backward
+        (text-encoder LoRA training, lora_conventional.yaml:14-19) replay captured hipGraphs, one pair per input signature."""
+        self._hip_graph, self._hip_graphs = bool(on), {}
+
     def forward(self, input_ids, position_ids=None, attention_mask=None, output_hidden_states=None):
+        if (getattr(self, "_hip_graph", False) and torch.is_grad_enabled() and input_ids.is_cuda
+                and not torch.cuda.is_current_stream_capturing()):
+            from . import graphed
+            if graphed.capturable(self):
+                ins = [input_ids, position_ids, attention_mask]
+                key = tuple(None if t is None else (tuple(t.shape), t.dtype) for t in ins)
+                x = graphed.call(self, ins, lambda i_, p_, m_: self._forward_impl(i_, p_, m_), self._hip_graphs, key)
+                return (x, None) if output_hidden_states is not None else x
+        return self._forward_impl(input_ids, position_ids, attention_mask, output_hidden_states)
+
+    def _forward_impl(self, input_ids, position_ids=None, attention_mask=None, output_hidden_states=None):
         """int64 [B, L] token ids -> bf16 [B, L, C] conditioning states (TEEXHook's selection).  attention_mask [B, L] (1 = attend) is
         combined with the causal mask like transformers' CLIPTextTransformer does; token 0 must stay visible.
         Called the way the reference's wrapper calls its hooked text encoder — ``TE(ids, position_ids=..., attention_mask=...,
@@ -142,8 +158,8 @@ class NativeCLIPTextModel(nn.Module):
         return (x, None) if output_hidden_states is not None else x
 
     @classmethod
-    def from_pretrained(cls, path=None, subfolder="text_encoder", device="cuda", pretrained_model_name_or_path=None, **kw):
-        """A diffusers / transformers directory (config.json + model.safetensors) by parameter name."""
+    def from_pretrained(cls, path=None, subfolder="text_encoder", device="cuda", pretrained_model_name_or_path=None, hip_graph=False, **kw):
+        """A diffusers / transformers directory (config.json + model.safetensors) by parameter name (hip_graph: enable_hip_graph())."""
         from safetensors.torch import load_file
         path = path if path is not None else pretrained_model_name_or_path
         root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
@@ -156,4 +172,7 @@ class NativeCLIPTextModel(nn.Module):
         if missing:
             raise ValueError(f"text-encoder checkpoint lacks {len(missing)} tensors, e.g. {missing[:3]}")
         model.load_state_dict(sd)
-        return model.to(device)
+        model = model.to(device)
+        if hip_graph:
+            model.enable_hip_graph()
+        return model

@@ -240,3 +240,59 @@ def test_unet_hip_graph_under_a_plain_trainer_loop_matches_eager():
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (le, lg)
     assert ((pe - pg).abs().max() / pe.abs().max()).item() < 5e-3
     assert le[0] != le[-1]
+
+
+@pytest.mark.gpu
+def test_text_encoder_and_unet_hip_graphs_under_a_plain_trainer_loop():
+    """lora_conventional.yaml trains LoRA on the UNet AND the text encoder: with enable_hip_graph() on both modules the encoder's graph
+    feeds the UNet's, the UNet's backward graph returns d(encoder_hidden_states) to the encoder's backward graph; same trajectory as eager."""
+    from hcp_diffusion_amd.lora import make_lora
+    from hcp_diffusion_amd.text_encoder import NativeCLIPTextModel
+    from oracle.clip_ref import OracleCLIPTextModel
+    dev = torch.device("cuda:0")
+    tcfg = dict(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1, max_position_embeddings=77)
+    ucfg = dict(MICRO_CONFIG, cross_attention_dim=64)
+
+    def run(graph, steps=4):
+        torch.manual_seed(0)
+        unet = NativeUNet2DConditionModel(**ucfg)
+        unet.load_state_dict(seeded_init_(OracleUNet2DConditionModel(**ucfg), 1).state_dict())
+        unet = unet.to(dev).requires_grad_(False)
+        te = NativeCLIPTextModel(**tcfg)
+        te.load_state_dict(seeded_init_(OracleCLIPTextModel(**tcfg), 2).state_dict())
+        te = te.to(dev).requires_grad_(False)
+        _, _, bu = make_lora(unet, [dict(layers=PATS_A + PATS_F, rank=4)])
+        _, _, bt = make_lora(te, [dict(layers=[r"re:.*self_attn$", r"re:.*mlp$"], rank=4)])
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for bk in (bu, bt):
+                for blk in bk.blocks:
+                    blk.layer.W_up.copy_((torch.randn(blk.layer.W_up.shape, generator=g) * 0.05).to(dev))
+                bk.pack()
+        params = [p for bk in (bu, bt) for blk in bk.blocks for p in (blk.layer.W_down, blk.layer.W_up)]
+        opt = torch.optim.AdamW(params, lr=5e-3, weight_decay=1e-3)
+        if graph:
+            unet.enable_hip_graph(); te.enable_hip_graph()
+        losses = []
+        for i in range(steps):
+            gi = torch.Generator().manual_seed(50 + i)
+            ids = torch.randint(0, 100, (2, 24), generator=gi).to(dev)
+            x = torch.randn(2, 4, 8, 8, generator=gi).to(dev); target = torch.randn(2, 4, 8, 8, generator=gi).to(dev)
+            t = torch.tensor([30 + 200 * i, 950 - 100 * i], device=dev)
+            ehs = te(ids, output_hidden_states=True)[0]
+            loss = torch.nn.functional.mse_loss(unet(x, t, ehs).sample.float(), target)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step(); opt.zero_grad(set_to_none=False)
+            losses.append(loss.item())
+        if graph:
+            assert len(unet._hip_graphs) == 1 and len(te._hip_graphs) == 1
+        return losses, torch.cat([p.detach().flatten() for p in params]).cpu(), bt.params.detach().cpu().clone()
+
+    le, pe, te_e = run(False)
+    lg, pg, te_g = run(True)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (le, lg)
+    assert ((pe - pg).abs().max() / pe.abs().max()).item() < 5e-3
+    init = run(False, steps=0)[2]
+    assert (te_g - init).abs().max().item() > 1e-3          # the text-encoder factors really trained through both graphs
