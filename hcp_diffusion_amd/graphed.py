@@ -14,7 +14,7 @@ from . import kernels as K  # noqa: F401  (the library must be loaded before any
 
 
 class _Entry:
-    __slots__ = ("g_fwd", "g_bwd", "static_in", "out", "dout", "grad_in", "buckets", "blocks", "keep")
+    __slots__ = ("g_fwd", "g_bwd", "static_in", "out", "dout", "grad_in", "buckets", "blocks", "keep", "pending")
 
 
 def _lora_buckets(unet):
@@ -64,6 +64,7 @@ class _GraphedFn(torch.autograd.Function):
             if bk._stale(bk.blocks):
                 bk.pack()
         entry.g_fwd.replay()
+        entry.pending = True                        # the graph's saved activations now belong to THIS call until its backward ran
         ctx.entry = entry
         return entry.out.detach().clone()          # the caller may keep the prediction across the next replay
 
@@ -72,6 +73,7 @@ class _GraphedFn(torch.autograd.Function):
         e = ctx.entry
         e.dout.copy_(dy)
         e.g_bwd.replay()
+        e.pending = False
         for bk in e.buckets:                       # zero_grad(set_to_none=True) drops the .grad views; the kernels wrote into the bucket
             for b in bk.blocks:
                 bk.grad_views_for(b)
@@ -135,5 +137,8 @@ def call(unet, inputs, fwd, cache, key):
     e = cache.get(key)
     if e is None:
         e = cache[key] = capture(unet, inputs, fwd)
+        e.pending = False
+    if e.pending:                                   # a second forward before the first one's backward (two losses summed, then one
+        return fwd(*inputs)                         # backward): the graph holds ONE set of activations, so this call runs eagerly
     anchor = next(p for b in e.blocks for p in b.parameters() if p.requires_grad)
     return _GraphedFn.apply(e, anchor, *[t for t in inputs])

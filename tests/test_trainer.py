@@ -240,6 +240,25 @@ def test_unet_hip_graph_under_a_plain_trainer_loop_matches_eager():
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (le, lg)
     assert ((pe - pg).abs().max() / pe.abs().max()).item() < 5e-3
     assert le[0] != le[-1]
+    # two forwards before one backward (losses summed): the second call must not overwrite the first one's saved activations
+    unet = _native(dev).requires_grad_(False)
+    _, _, bucket = make_lora(unet, [dict(layers=PATS_A, rank=4)])
+    with torch.no_grad():
+        for blk in bucket.blocks:
+            blk.layer.W_up.normal_(0, 0.05)
+    bucket.pack()
+
+    def two(graph):
+        unet.enable_hip_graph(graph)
+        bucket.grads.zero_()
+        b1, b2 = _batch(dev, 1, B=2), _batch(dev, 2, B=2)
+        t = torch.tensor([100, 800], device=dev)
+        p1 = unet(b1["latents"], t, b1["encoder_hidden_states"].to(torch.bfloat16)).sample
+        p2 = unet(b2["latents"], t, b2["encoder_hidden_states"].to(torch.bfloat16)).sample
+        (p1.float().square().mean() + p2.float().square().mean()).backward()
+        return bucket.grads.clone()
+    ge, gg = two(False), two(True)
+    assert torch.nn.functional.cosine_similarity(ge, gg, dim=0).item() > 0.9999
 
 
 @pytest.mark.gpu
