@@ -6,54 +6,13 @@
 // Tensors stay in the token-major [B, N, heads*d] layout the QKV GEMMs write — no head permutes.
 //
 // The kernels live in attn_dma.h (forward, dQ, dK/dV: LDS-DMA tile fills, XCD-aware work order, one exp per score);
-// here: the delta = rowsum(dO * O) pre-pass, the fp32 -> bf16 conversion of the query-split dK/dV pass, the choice of
-// rows per wave, argument checks.  Backward = delta pre-pass + dQ kernel + dK/dV kernel: no atomics on the
+// here: the fp32 -> bf16 conversion of the query-split dK/dV pass, the choice of
+// rows per wave, argument checks.  Backward = dQ kernel (which also produces delta) + dK/dV kernel: no atomics on the
 // self-attention path, deterministic.
 #include "attn_dma.h"     // forward kernel (second generation: LDS-DMA tiles, one VALU op per score) + shared parameter block
 
 namespace {
 using namespace hcp_attn;
-
-// ------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
-// One thread per 16-byte chunk of a (row, head) slice (D/8 chunks: 5 / 8 / 10 / 20), partial dot products meet in LDS; the block size
-// is a multiple of the chunk count so no slice straddles two workgroups.  (The first version — one thread per (row, head) walking
-// its whole slice — launched 32 workgroups for the 16x16 level and took 12.9 us for 5 MB.)
-template <int D>
-HCP_KERNEL(320) attn_delta_kernel(AttnParams p, int B) {
-    constexpr int NCH = D / 8;
-    constexpr int NT = (NCH == 8) ? 256 : 320;               // 320 = 64 x 5 = 32 x 10 = 16 x 20
-    constexpr int SL = NT / NCH;                             // slices per workgroup
-    HCP_DYN_SMEM(smem);
-    float* s_part = (float*)smem;                              // [NT]
-    const int tid = threadIdx.x;
-    const long total = (long)B * p.Nq * p.H;
-    const long nblk = (total + SL - 1) / SL;
-    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const long sl = blk * SL + tid / NCH;                // (b, q, h) slice of this thread
-        const int c = tid % NCH;
-        float acc = 0.f;
-        if (sl < total) {
-            const int h = (int)(sl % p.H); long r = sl / p.H; const int q = (int)(r % p.Nq); const int b = (int)(r / p.Nq);
-            const size_t off = (size_t)b * p.o_bs + (size_t)q * p.o_rs + h * D + c * 8;
-            const hcp_bf16x8 a = *(const hcp_bf16x8*)(p.O + off), g = *(const hcp_bf16x8*)(p.dO + off);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += hcp_bf2f((unsigned short)a[e]) * hcp_bf2f((unsigned short)g[e]);
-        }
-        s_part[tid] = acc;
-        HCP_SYNC();
-        if (tid < SL) {
-            const long s2 = blk * SL + tid;
-            if (s2 < total) {
-                float t = 0.f;
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) t += s_part[tid * NCH + k];
-                const int h = (int)(s2 % p.H); long r = s2 / p.H; const int q = (int)(r % p.Nq); const int b = (int)(r / p.Nq);
-                p.delta[((size_t)b * p.H + h) * p.Nq + q] = t;
-            }
-        }
-        HCP_SYNC();
-    }
-}
 
 // fp32 accumulators of the query-split dK/dV pass -> bf16 outputs (token-major, strided)
 HCP_KERNEL(256) attn_dkv_convert_kernel(AttnParams p, int B, int C) {
@@ -80,14 +39,6 @@ int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
     if (p.kbias || p.causal) HCP_LAUNCH((attn2_fwd_kernel<D, QT, true, VAR_PRODUCT, NW>), dim3(n), dim3(64 * NW), fwd_smem<D>(), stream, p);
     else HCP_LAUNCH((attn2_fwd_kernel<D, QT, false, VAR_PRODUCT, NW>), dim3(n), dim3(64 * NW), fwd_smem<D>(), stream, p);
     HCP_LAUNCH_CHECK("attn_fwd");
-}
-template <int D>
-int launch_delta(AttnParams& p, int B, hipStream_t stream) {
-    constexpr int NCH = D / 8, NT = (NCH == 8) ? 256 : 320, SL = NT / NCH;
-    long tot = (long)B * p.Nq * p.H;
-    long g = (tot + SL - 1) / SL; if (g > 8192) g = 8192;
-    HCP_LAUNCH((attn_delta_kernel<D>), dim3((int)g), dim3(NT), NT * sizeof(float), stream, p, B);
-    HCP_LAUNCH_CHECK("attn_delta");
 }
 template <int D, int QT>
 int launch_dq(AttnParams& p, int B, hipStream_t stream) {
@@ -153,7 +104,7 @@ int run_fwd(AttnParams& p, int B, hipStream_t stream) {
 }
 template <int D>
 int run_bwd(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t stream) {
-    if (int e = launch_delta<D>(p, B, stream)) return e;
+    // (delta = rowsum(dO * O) is produced by the dQ kernel's prologue and read by the dK/dV kernel behind it)
     // measured on MI355X: 32 rows per wave pay off once the grid has >= 512 such workgroups
     bool wq = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512, wk = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nk, 128) >= 512;
     if (g_attn_cfg >= 0 && !(g_attn_cfg & 16)) { wq = kWide<D> && (g_attn_cfg & 2); wk = kWide<D> && (g_attn_cfg & 4); }

@@ -410,19 +410,29 @@ HCP_WAVES_PER_SIMD((dq_waves<D, QT>())) HCP_KERNEL(256) attn2_bwd_dq_kernel(Attn
 
     hcp_bf16x8 qf[QT][G::NQK], gf[QT][G::NQK];
     hcp_f32x4 nl4[QT], nd4[QT], dq[QT][G::NDV];
+    const hcp_bf16* Ob = p.O + (size_t)b * p.o_bs + h * D;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int row = q_base + t * 16 + fr;
+        // delta = rowsum(dO * O) is computed HERE (it was a launch of its own in front of this kernel): the lane already holds its
+        // 8-column pieces of the row's dO; the four lanes fr, fr+16, fr+32, fr+48 own the row between them.  Written out for the
+        // dK/dV kernel that follows on the stream.
+        float dpart = 0.f;
 #pragma unroll
         for (int s = 0; s < G::NQK; ++s) {
             const int dc = s * 32 + fg * 8;
             const bool ok = row < p.Nq && dc < D;
             qf[t][s] = ok ? *(const hcp_bf16x8*)(Qb + (size_t)row * p.q_rs + dc) : hcp_zero8();
             gf[t][s] = ok ? *(const hcp_bf16x8*)(dOb + (size_t)row * p.o_rs + dc) : hcp_zero8();
+            const hcp_bf16x8 of = ok ? *(const hcp_bf16x8*)(Ob + (size_t)row * p.o_rs + dc) : hcp_zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dpart += hcp_bf2f((unsigned short)of[e]) * hcp_bf2f((unsigned short)gf[t][s][e]);
         }
+        dpart += hcp_shfl_xor(dpart, 16); dpart += hcp_shfl_xor(dpart, 32);
+        if (fg == 0 && row < p.Nq) p.delta[((size_t)b * p.H + h) * p.Nq + row] = dpart;
         // rows past the end: P = exp2(0 - 0) = 1 (finite) against dP - delta = 0: dS = 0, and nothing of theirs is stored
         const float l2 = row < p.Nq ? p.lse[((size_t)b * p.H + h) * p.Nq + row] * LOG2E / cs : 0.f;
-        const float dl = row < p.Nq ? p.delta[((size_t)b * p.H + h) * p.Nq + row] : 0.f;
+        const float dl = row < p.Nq ? dpart : 0.f;
         const hcp_f32x4 a = {-l2, -l2, -l2, -l2}, c = {-dl, -dl, -dl, -dl}, z = {0.f, 0.f, 0.f, 0.f};
         nl4[t] = a; nd4[t] = c;
 #pragma unroll
