@@ -108,8 +108,12 @@ class LoraHipLayer(PatchPluginBlock):
     container_cls = LoraHipContainer
     wrapable_classes = (nn.Linear, nn.Conv2d)
 
-    def __init__(self, lora_id, host, rank=1, dropout=0.0, alpha=1.0, bias=False, alpha_auto_scale=True, parent_block=None,
+    def __init__(self, lora_id, host, rank=1, dropout=0.1, alpha=1.0, bias=False, alpha_auto_scale=True, parent_block=None,
                  host_name=None, **kwargs):
+        """Signature and defaults of the reference's ``LoraLayer`` (lora_layers_patch.py:21-23; ``dropout=0.1`` when the class is
+        constructed directly).  The path every trainer config takes — make_hcpdiff -> ``wrap_model`` -> ``wrap_layer`` — passes
+        ``wrap_layer``'s OWN default ``dropout=0.0`` (lora_base_patch.py:148-149) unless the cfg item names one, and so does this
+        class: a cfg item without a ``dropout`` key trains without dropout in both code bases."""
         super().__init__(f"lora_block_{lora_id}", host, parent_block=parent_block, host_name=host_name)
         host = self.host()
         if not isinstance(host, (HipLinear, HipConv2d)):
@@ -501,6 +505,6 @@ def make_lora(model, cfg_lora):
                 v.requires_grad_(True)
                 v.train()
                 params.extend(v.parameters())
-        groups.append({"params": params, "lr": lr})
+        groups.append({"params": params, "lr": lr} if lr is not None else {"params": params})   # no key: a torch optimizer's own default applies
     bucket = LoraBucket(blocks.values()) if blocks else None
     return groups, PluginGroup(blocks), bucket

@@ -151,7 +151,7 @@ class NativeTrainer:
         self.acp = ddpm_alphas_cumprod(num_train_timesteps, device=self.device)
         self.num_train_timesteps = num_train_timesteps
         self.pg = process_group
-        self._ctor_lr = lr
+        self._ctor_lr, self._scale_lr_factor = lr, scale_lr_factor
         self.use_graph = use_graph
         # measured on MI355X / ROCm 7.2: the side-stream (parallel graph branch) form is SLOWER (32.6 vs 30.0 ms/step:
         # every fork/join edge of the hipGraph costs more than the overlap buys); one grouped launch at the end wins.
@@ -168,7 +168,7 @@ class NativeTrainer:
         for g in groups:
             n = sum(p.numel() for p in g["params"])
             if n:
-                segs.append((off, n, (g["lr"] if g["lr"] is not None else default_lr) * scale))
+                segs.append((off, n, g.get("lr", default_lr) * scale))
             off += n
         assert off == bucket.params.numel(), "LoRA cfg items must own disjoint layers (a layer matched by two items)"
         return segs
@@ -313,7 +313,14 @@ class NativeTrainer:
                 lr_t.fill_(base * factor)
 
     def set_lr(self, lr):
-        """Set the lr of the groups that were built with the constructor's `lr`; groups with their own lr keep their ratio to it."""
+        """Set the lr of the groups that were built with the constructor's `lr`; groups with their own lr keep their ratio to it
+        (the constructor's ``scale_lr_factor`` stays applied, as the reference's scale_lr multiplies every group's lr once:
+        train_ac.py:192-197)."""
+        if self._ctor_lr == 0:                 # built with lr 0 (e.g. a warm-up that starts from zero): no ratio to keep
+            for st in self._states():
+                for lr_t in st.lrs:
+                    lr_t.fill_(lr * self._scale_lr_factor)
+            return
         self.set_lr_factor(lr / self._ctor_lr)
 
     # ---- one optimisation step

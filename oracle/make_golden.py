@@ -299,6 +299,207 @@ def sdxl_full_vectors():
                 fingerprint=grad_fingerprint([(n, p.grad) for n, p in lora_named]))
 
 
+def tensor_sketch(name, g, n=4096, seed=91):
+    """Per-tensor record of a gradient that is too large to ship whole (full fine-tune: 859.5 M elements): L2 norm, and a seeded
+    sample of min(numel, n) elements at LOGICAL (row-major over the parameter's shape) positions, int16 with one absmax scale."""
+    import zlib
+    g = g.detach().float().cpu().contiguous().flatten()
+    gen = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
+    idx = torch.arange(g.numel()) if g.numel() <= n else torch.randint(0, g.numel(), (n,), generator=gen)
+    v = g[idx]
+    s_ = float(v.abs().max()) / 32767.0 or 1.0
+    return dict(norm=float(g.norm()), scale=s_, q=torch.clamp((v / s_).round(), -32767, 32767).to(torch.int16))
+
+
+def sketch_values(name, g, n=4096, seed=91):
+    """The same sample of a live tensor, fp32 (test side)."""
+    import zlib
+    g = g.detach().float().cpu().contiguous().flatten()
+    gen = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
+    idx = torch.arange(g.numel()) if g.numel() <= n else torch.randint(0, g.numel(), (n,), generator=gen)
+    return g[idx]
+
+
+def _full_oracle(cfg=None, seed=1):
+    from oracle import unet_sd15 as U
+    U.ATTN_RECOMPUTE = True                         # identical arithmetic; the N x N score tensors are not kept for backward
+    with torch.device("meta"):
+        m = U.OracleUNet2DConditionModel(**(cfg or {}))
+    return U.seeded_init_(m.to_empty(device="cpu"), seed)
+
+
+def dreambooth_inputs():
+    """BASELINE.json configs[2] as cfgs/train/examples/DreamBooth.yaml lays the step out: TWO datasets per optimisation step —
+    the instance batch (bs 2, the configuration's batch size) and the class / regularisation batch (DreamBooth.yaml:47-48:
+    batch_size 1, loss_weight 1.0) — 512 px (64x64 latents), 77x768 context."""
+    g2 = torch.Generator().manual_seed(4343)
+    out = []
+    for B, ts in ((2, [37, 803]), (1, [512])):
+        out.append(dict(x0=torch.randn(B, 4, 64, 64, generator=g2), ehs=torch.randn(B, 77, 768, generator=g2),
+                        noise=torch.randn(B, 4, 64, 64, generator=g2), t=torch.tensor(ts), loss_weight=1.0))
+    return out
+
+
+def dreambooth_b2_vectors():
+    """SD1.5 full fine-tune (every one of the 686 parameter tensors / 859.5 M elements trainable, DreamBooth.yaml:6-10), one
+    optimisation step's gradient = instance batch + class batch (train_ac.py:467-483): fp32 oracle predictions and losses per
+    dataset, and a sketch (norm + 4096-element seeded sample) of EVERY parameter's accumulated gradient."""
+    import torch.nn.functional as F
+    from oracle.unet_sd15 import add_noise, ddpm_alphas_cumprod
+    m = _full_oracle()
+    preds, losses = [], []
+    for d in dreambooth_inputs():
+        pred = m(add_noise(d["x0"], d["noise"], d["t"], ddpm_alphas_cumprod()), d["t"], d["ehs"]).sample
+        loss = F.mse_loss(pred, d["noise"]) * d["loss_weight"]
+        loss.backward()
+        preds.append(pred.detach()); losses.append(float(loss))
+    named = list(m.named_parameters())
+    return dict(preds=preds, losses=losses, names=[n for n, _ in named], sketch={n: tensor_sketch(n, p.grad) for n, p in named},
+                grad_norm=float(torch.sqrt(sum(p.grad.double().pow(2).sum() for _, p in named))))
+
+
+def sdxl_b2_inputs():
+    """BASELINE.json configs[3] at its REAL shape: SDXL-base, bs 2, 1024 px = 128x128 latents, 77x2048 context, pooled 1280,
+    crop_info = [1024, 1024, 0, 0, 1024, 1024]."""
+    g2 = torch.Generator().manual_seed(4444)
+    x0 = torch.randn(2, 4, 128, 128, generator=g2); ehs = torch.randn(2, 77, 2048, generator=g2)
+    noise = torch.randn(2, 4, 128, 128, generator=g2); t = torch.tensor([91, 707])
+    added = dict(text_embeds=torch.randn(2, 1280, generator=g2), time_ids=torch.tensor([[1024.0, 1024.0, 0.0, 0.0, 1024.0, 1024.0]] * 2))
+    return x0, ehs, noise, t, added
+
+
+def sdxl_b2_vectors():
+    """Full SDXL-base (2.567 B parameters), LoRA rank 16 on attn / ff (700 layers, 41,861,120 LoRA parameters): prediction, loss and
+    the ENTIRE flat LoRA gradient (int8, one absmax scale per tensor) of the fp32 oracle with the reference-form merged-weight LoRA."""
+    import torch.nn.functional as F
+    from oracle.lora_ref import wrap_lora
+    from oracle.unet_sd15 import SDXL_CONFIG, add_noise, ddpm_alphas_cumprod
+    m = _full_oracle(SDXL_CONFIG)
+    m.requires_grad_(False)
+    wrap_lora(m, [r"re:.*\.attn.?$", r"re:.*\.ff$"], rank=16)
+    lora_named = [(n, p) for n, p in m.named_parameters() if "lora_block_" in n]
+    sd15_lora_init_(lora_named)
+    x0, ehs, noise, t, added = sdxl_b2_inputs()
+    pred = m(add_noise(x0, noise, t, ddpm_alphas_cumprod()), t, ehs, added_cond_kwargs=added).sample
+    loss = F.mse_loss(pred, noise)
+    loss.backward()
+    q, scales = quantize_grads([(n, p.grad) for n, p in lora_named])
+    return dict(pred=pred.detach().half(), loss=float(loss), grad_q=q, grad_scales=scales, grad_names=[n for n, _ in lora_named],
+                grad_norm=float(torch.cat([p.grad.flatten() for _, p in lora_named]).norm()))
+
+
+def controlnet_b4_inputs():
+    """BASELINE.json configs[4]: frozen SD1.5 + ControlNet branch, bs 4, 512 px; control image [4,3,512,512] ~ U[0,1]."""
+    g2 = torch.Generator().manual_seed(4545)
+    x0 = torch.randn(4, 4, 64, 64, generator=g2); ehs = torch.randn(4, 77, 768, generator=g2)
+    noise = torch.randn(4, 4, 64, 64, generator=g2); t = torch.tensor([10, 250, 500, 999])
+    cond = torch.rand(4, 3, 512, 512, generator=g2)
+    return x0, ehs, noise, t, cond
+
+
+def controlnet_init_(ocn, seed=8):
+    """Seeded non-zero values for the branch's zero convs and cond_head (a branch 'after some training': with the reference's zero
+    init every gradient upstream of the zero convs is exactly zero), by parameter name."""
+    import zlib
+    with torch.no_grad():
+        for n_, p_ in ocn.named_parameters():
+            if n_.startswith(("cond_head", "controlnet_")):
+                gen = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(n_.encode())) % (2 ** 31))
+                p_.copy_(torch.randn(p_.shape, generator=gen) * (0.3 / max(1.0, p_[0].numel() ** 0.5) if p_.dim() > 1 else 0.05))
+
+
+def controlnet_b4_vectors():
+    """Full SD1.5 host (frozen) + full ControlNet branch (361 M trainable parameters: deep copy of the encoder, cond_head, 13 zero
+    convs — reference controlnet.py:11-62), one step at bs 4: prediction, loss, a sample of the 13 residuals' norms, and a sketch of
+    EVERY branch parameter's gradient (fp32 oracle restatement, itself pinned to the reference's plugin code at small size)."""
+    import torch.nn.functional as F
+    from oracle.unet_sd15 import OracleControlNet, add_noise, ddpm_alphas_cumprod
+    m = _full_oracle()
+    m.requires_grad_(False)
+    torch.manual_seed(3)
+    ocn = OracleControlNet(m)
+    for p_ in ocn.parameters():
+        p_.requires_grad_(True)
+    controlnet_init_(ocn)
+    x0, ehs, noise, t, cond = controlnet_b4_inputs()
+    xt = add_noise(x0, noise, t, ddpm_alphas_cumprod())
+    res = ocn(xt, t, ehs, cond)
+    pred = m(xt, t, ehs, control_residuals=res).sample
+    loss = F.mse_loss(pred, noise)
+    loss.backward()
+    named = list(ocn.named_parameters())
+    return dict(pred=pred.detach(), loss=float(loss), residual_norms=[float(r.detach().norm()) for r in res], names=[n for n, _ in named],
+                sketch={n: tensor_sketch(n, p.grad) for n, p in named},
+                grad_norm=float(torch.sqrt(sum(p.grad.double().pow(2).sum() for _, p in named))))
+
+
+def reference_trainer_trajectory():
+    """Ten optimisation steps of the reference's OWN inner loop — hcpdiff/train_ac.py Trainer.train_one_step / forward / make_noise /
+    get_loss (train_ac.py:437-515) on a TrainerSingleCard with a real accelerate.Accelerator, its TEUnetWrapper (models/wrapper.py),
+    its make_hcpdiff + LoraLayer (the reference's own LoRA, type 'lora', dropout 0) and torch.optim.AdamW — over the fp32 ORACLE UNet
+    and text encoder (the un-vendored diffusers / transformers arithmetic), BASELINE.json configs[0] in miniature (rank 4 on attn + ff,
+    CPU, fp32).  No native code runs: this is the reference side of the parity test that NativeTrainer must reproduce on the GPU.
+    Recorded: the data, the noise / timesteps the reference drew (its torch CPU RNG stream cannot be reproduced on a device), the ten
+    losses, the initial and final LoRA factors."""
+    import types
+    from oracle.ref_shims import load_reference_trainer
+    train_ac, single = load_reference_trainer()
+    import hcpdiff.utils.cfg_net_tools as tools
+    from hcpdiff.models import CFGContext, TEUnetWrapper
+    from oracle.clip_ref import OracleCLIPTextModel
+    from oracle.unet_sd15 import MICRO_CONFIG, OracleUNet2DConditionModel, add_noise, ddpm_alphas_cumprod, seeded_init_
+    UCFG = dict(MICRO_CONFIG, cross_attention_dim=64)
+    TCFG = dict(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1, max_position_embeddings=77)
+    STEPS, B = 10, 2
+    u = seeded_init_(OracleUNet2DConditionModel(**UCFG), 1); u.requires_grad_(False); u.eval()
+    te = seeded_init_(OracleCLIPTextModel(**TCFG), 2); te.requires_grad_(False); te.eval()
+    g = torch.Generator().manual_seed(9)
+    data = [dict(img=torch.randn(B, 4, 8, 8, generator=g), prompt=torch.randint(0, 100, (B, 77), generator=g)) for _ in range(STEPS)]
+    ns = types.SimpleNamespace
+    t = single.TrainerSingleCard.__new__(single.TrainerSingleCard)
+    t.cfgs = ns(seed=114514, mixed_precision="no", train=ns(gradient_accumulation_steps=1, max_grad_norm=1.0, set_grads_to_none=False, loss=ns(type="eps")))
+    t.init_context(None)
+    t.weight_dtype = torch.float32
+    pats = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
+    groups, lora_unet = tools.make_hcpdiff(u, None, [_Item(layers=pats, rank=4, dropout=0.0, lr=1e-3)])
+    gi = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for path in sorted(lora_unet.plugin_dict):
+            blk = lora_unet.plugin_dict[path]
+            blk.layer.W_up.copy_(torch.randn(blk.layer.W_up.shape, generator=gi) * 0.05)
+            blk.layer.W_down.copy_(torch.randn(blk.layer.W_down.shape, generator=gi) * blk.layer.W_down.shape[1] ** -0.5)
+    init = {k: (b.layer.W_down.detach().clone(), b.layer.W_up.detach().clone()) for k, b in lora_unet.plugin_dict.items()}
+    drawn = []
+
+    class Sched:                                       # the seam-4 object: DDPMScheduler.add_noise [ext], recording what make_noise drew
+        config = ns(num_train_timesteps=1000)
+
+        def add_noise(self, latents, noise, timesteps):
+            drawn.append((noise.clone(), timesteps.clone()))
+            return add_noise(latents, noise, timesteps, ddpm_alphas_cumprod())
+
+    class TE(torch.nn.Module):                         # transformers' CLIPTextModel call surface (wrapper.py:20): output[0] = last_hidden_state
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, input_ids, position_ids=None, attention_mask=None, output_hidden_states=False):
+            return (self.m.encode(input_ids, position_ids, attention_mask=attention_mask),)
+    t.TE_unet = TEUnetWrapper(u, TE(te))
+    t.noise_scheduler = Sched()
+    t.cfg_context = CFGContext()
+    t.criterion = torch.nn.MSELoss(reduction="none")
+    t.embedding_hook = ns(emb_train=[])
+    t.train_loader_group = ns(get_dataset=lambda idx: ns(latents=True), get_loss_weights=lambda idx: 1.0)
+    t.optimizer = torch.optim.AdamW(groups, weight_decay=1e-3)
+    t.lr_scheduler = None
+    torch.manual_seed(1234)
+    losses = [t.train_one_step([dict(d)]) for d in data]
+    final = {k: (b.layer.W_down.detach().clone(), b.layer.W_up.detach().clone()) for k, b in lora_unet.plugin_dict.items()}
+    return dict(unet_cfg=UCFG, te_cfg=TCFG, data=data, drawn=drawn, losses=losses, lora_init=init, lora_final=final, lr=1e-3, weight_decay=1e-3,
+                source="hcpdiff/train_ac.py Trainer.train_one_step (unmodified) over oracle UNet / CLIP, reference LoraLayer, torch AdamW")
+
+
 class _Item(dict):
     """The reference reads cfg items both as mappings and as attribute bags (OmegaConf DictConfig)."""
 
@@ -469,6 +670,14 @@ if __name__ == "__main__":
         torch.save(minsnr_reference_vectors(), os.path.join(GOLD, "minsnr_reference.pt"))
         print("minsnr_reference.pt", os.path.getsize(os.path.join(GOLD, "minsnr_reference.pt")))
         sys.exit(0)
+    for key, fn, fname in (("dreambooth", dreambooth_b2_vectors, "sd15_dreambooth_b2_oracle.pt"), ("sdxl_b2", sdxl_b2_vectors, "sdxl_full_b2_oracle.pt"),
+                           ("controlnet_b4", controlnet_b4_vectors, "sd15_controlnet_b4_oracle.pt"), ("trainer", reference_trainer_trajectory, "ref_trainer_trajectory.pt")):
+        if len(sys.argv) > 1 and sys.argv[1] == key:
+            import time
+            t0 = time.time()
+            torch.save(fn(), os.path.join(GOLD, fname))
+            print(fname, os.path.getsize(os.path.join(GOLD, fname)), f"{time.time() - t0:.0f} s")
+            sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sdxl":
         torch.save(sdxl_full_vectors(), os.path.join(GOLD, "sdxl_full_oracle.pt"))
         print("sdxl_full_oracle.pt", os.path.getsize(os.path.join(GOLD, "sdxl_full_oracle.pt")))

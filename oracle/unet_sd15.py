@@ -113,6 +113,19 @@ class ResnetBlock2D(nn.Module):  # unet_struct.txt:92-100, :199-208 (conv_shortc
         return x + h                                                            # output_scale_factor = 1
 
 
+# Golden generators for the full-size configurations (oracle/make_golden.py) set this: the [B, heads, N, N] score / probability
+# tensors of every attention layer are then recomputed in backward instead of kept (same arithmetic, same order: the result is
+# bit-identical; SDXL at 128x128 latents would otherwise keep ~70 GB of them).
+ATTN_RECOMPUTE = False
+
+
+def _attention_core(q, k, v, key_bias, scale):
+    s = q @ k.transpose(-1, -2) * scale                                         # scale = dim_head^-0.5 [ext]
+    if key_bias is not None:                                                    # [B, L] additive, every head / query [ext]
+        s = s + key_bias[:, None, None, :]
+    return torch.softmax(s, dim=-1) @ v
+
+
 class CrossAttention(nn.Module):  # unet_struct.txt:17-25, :34-42
     def __init__(self, dim, ctx_dim, heads):
         super().__init__()
@@ -129,11 +142,12 @@ class CrossAttention(nn.Module):  # unet_struct.txt:17-25, :34-42
         q = self.to_q(x).view(B, N, self.heads, d).transpose(1, 2)
         k = self.to_k(ctx).view(B, -1, self.heads, d).transpose(1, 2)
         v = self.to_v(ctx).view(B, -1, self.heads, d).transpose(1, 2)
-        s = q @ k.transpose(-1, -2) * d ** -0.5                                 # scale = dim_head^-0.5 [ext]
-        if key_bias is not None:                                                # [B, L] additive, every head / query [ext]
-            s = s + key_bias[:, None, None, :]
-        p = torch.softmax(s, dim=-1)
-        o = (p @ v).transpose(1, 2).reshape(B, N, C)
+        if ATTN_RECOMPUTE and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+            o = checkpoint(_attention_core, q, k, v, key_bias, d ** -0.5, use_reentrant=False)
+        else:
+            o = _attention_core(q, k, v, key_bias, d ** -0.5)
+        o = o.transpose(1, 2).reshape(B, N, C)
         return self.to_out[1](self.to_out[0](o))
 
 
