@@ -131,6 +131,8 @@ constexpr int VAR_RAW = 64;       // scores stay in raw q.k units: exp2(acc * sc
 constexpr int VAR_PRIO = 256;     // s_setprio(1) around the MFMA clusters (guide T5)
 constexpr int VAR_DEEP = 128;     // forward: three LDS buffers, DMA two tiles ahead (counted vmcnt)
 constexpr int VAR_PADZERO = 32;   // lab fallback: pad lanes stay in the DMA and write zeros (needs !VAR_ONES)
+constexpr int VAR_PRE = 512;      // forward: Q arrives pre-multiplied by scale*log2(e) (its projection carries the factor): the accumulator IS the exp2 argument
+constexpr int VAR_LSUM = 2048;    // forward: lazy rescale from the ROW SUMS instead of a per-score maximum (exact fallback on exp2 overflow)
 constexpr int VAR_PRODUCT = VAR_XCD | VAR_ONES | VAR_RAW;
 
 #if defined(HCP_EMU)
@@ -141,6 +143,7 @@ constexpr int VAR_PRODUCT = VAR_XCD | VAR_ONES | VAR_RAW;
 
 template <int D, int QT> constexpr int fwd_waves() { return D > 80 ? 2 : (QT == 2 ? (D == 40 ? 4 : 3) : 4); }   // per SIMD
 template <bool V> struct BoolC { static constexpr bool value = V; };
+template <int V> struct IntC { static constexpr int value = V; };
 
 // Maximum of a lane's 16 scores.  ONE asm statement: fmaxf() on MFMA results makes hipcc canonicalise every operand first
 // (v_max x, x: +16 VALU per 16 scores), and a bare asm v_max3 reading an MFMA result is a hazard hipcc does not pad (guide §5.7
@@ -178,8 +181,17 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
     constexpr int AHEAD = (VAR & VAR_DEEP) ? 2 : 1;   // tiles in flight ahead of the one being consumed
     constexpr int NBUF = AHEAD + 1;
     constexpr bool ONES = G::SPARE && (VAR & VAR_ONES) && MASKPAD;   // row sums from the PV MFMA
+    constexpr bool PRE = (VAR & VAR_PRE) != 0;        // (implies the exp2-domain accumulator: no multiply in front of v_exp_f32)
+    constexpr bool LSUM = (VAR & VAR_LSUM) != 0;
+    // LSUM: the reference maximum is the exact row maximum of the FIRST tile; afterwards no per-score maximum is taken (16 v_max3 +
+    // hazard nops per 32 x 64 wave-tile).  A tile only looks at the running sum of probabilities — the PV MFMA keeps it in O's spare
+    // row at d = 40, a VALU partial sum otherwise — and when a row's sum passes 2^20, O and l are divided by it and the reference moves
+    // by its log2.  Magnitude costs no precision (P is bf16 with its own exponent, O / l are fp32); only exp2 overflow (a score more
+    // than 2^127 above the reference) would be fatal: the epilogue checks the row sums and the workgroup then repeats its rows with
+    // per-score maxima (the EXACT tile code below).
+    constexpr float L_LAZY = 1048576.0f;
     HCP_DYN_SMEM(smem);
-    hcp_bf16* lds = (hcp_bf16*)smem;                  // NBUF x { K [64][RS] | V [64][RS] }
+    hcp_bf16* lds = (hcp_bf16*)smem;                  // NBUF x { K [64][RS] | V [64][RS] } (+ one flag word, LSUM)
     constexpr int BUF = 2 * G::IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = hcp_uniform(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
@@ -193,11 +205,11 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
     const hcp_bf16* Kb = p.K + (size_t)b * p.k_bs + h * D;
     const hcp_bf16* Vb = p.V + (size_t)b * p.v_bs + h * D;
     const float c2 = p.scale * LOG2E;
-    const float cs = RAW ? c2 : 1.0f;                 // what one unit of the accumulator is worth in the exp2 domain
+    const float cs = PRE ? 1.0f : RAW ? c2 : 1.0f;    // what one unit of the accumulator is worth in the exp2 domain
     const float rescale_thr = 6.0f / cs;              // lazy rescale: a score may exceed the reference max by 2^6 before O is rescaled
 
     // LDS init: zeros (the K pad granules stay zero for the kernel's life), then 1.0 in the V pad granules
-    for (int i = tid * 8; i < NBUF * BUF; i += 64 * NW * 8) *(hcp_bf16x8*)(lds + i) = hcp_zero8();
+    for (int i = tid * 8; i < NBUF * BUF + (LSUM ? 8 : 0); i += 64 * NW * 8) *(hcp_bf16x8*)(lds + i) = hcp_zero8();
     TileDma<D, NW> dma;
     dma.init(wave, lane, p.k_rs, p.v_rs);
     const int nt = (p.Nk + KVT - 1) / KVT;
@@ -227,7 +239,7 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
 #pragma unroll
     for (int t = 0; t < QT; ++t)
 #pragma unroll
-        for (int s = 0; s < G::NQK; ++s) if (!RAW) qf[t][s] = scale8(qf[t][s], c2);     // scores come out in the exp2 domain
+        for (int s = 0; s < G::NQK; ++s) if (!RAW && !PRE) qf[t][s] = scale8(qf[t][s], c2);     // scores come out in the exp2 domain
 
     float m_i[QT], l_i[QT];
     hcp_f32x4 o[QT][G::NDV], nm4[QT];
@@ -249,8 +261,8 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
     int cur = 0;                                      // LDS buffer of the tile being consumed
     // One 64-key tile.  FIRST: the tile that sets the reference maximum (always rescales); RAGGED: fewer than 64 live keys
     // (the dead ones enter the score MFMA chain as -inf through the accumulator).
-    auto tile = [&](auto first_c, auto ragged_c, int it) {
-        constexpr bool FIRST = decltype(first_c)::value, RAGGED = decltype(ragged_c)::value;
+    auto tile = [&](auto first_c, auto ragged_c, auto exact_c, int it) {
+        constexpr bool FIRST = decltype(first_c)::value, RAGGED = decltype(ragged_c)::value, EXACT = decltype(exact_c)::value || !LSUM;
         const int kv0 = it * KVT;
         const int nvalid = p.Nk - kv0 < KVT ? p.Nk - kv0 : KVT;
         const hcp_bf16* sK = lds + cur * BUF;
@@ -293,10 +305,29 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
         hcp_bf16x8 pf[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const float mx = max16(sc[t]);
+            if (!EXACT && !FIRST) {                                      // LSUM: one compare per 16 rows on the running row sum
+                const float lane_sum = ONES ? o[t][D / 16][D % 16 % 4] : l_i[t];
+                const bool ok = (ONES && fg != (D % 16) / 4) || lane_sum <= L_LAZY;
+                if (!hcp_all(ok)) {
+                    float rm;
+                    if (ONES) rm = hcp_shfl(lane_sum, ((D % 16) / 4) * 16 + fr);
+                    else { rm = lane_sum; rm += hcp_shfl_xor(rm, 16); rm += hcp_shfl_xor(rm, 32); }
+                    const bool up = rm > 1.0f;
+                    const float delta = up ? log2f(rm) / cs : 0.f, alpha = up ? 1.0f / rm : 1.0f;
+                    m_i[t] += delta;
+                    const hcp_f32x4 n4 = {-m_i[t], -m_i[t], -m_i[t], -m_i[t]};
+                    nm4[t] = n4;
+                    l_i[t] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < G::NDV; ++d) o[t][d] *= alpha;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) sc[t][kt] -= delta;
+                }
+            }
+            const float mx = (EXACT || FIRST) ? max16(sc[t]) : 0.f;
             // Lazy rescale: the scores are already relative to the reference max m_i; while no lane of the wave sees one above
             // 2^6 nothing is rescaled.
-            if (FIRST || !hcp_all(mx <= rescale_thr)) {
+            if (FIRST || (EXACT && !hcp_all(mx <= rescale_thr))) {
                 float rm = fmaxf(mx, hcp_shfl_xor(mx, 16));
                 rm = fmaxf(rm, hcp_shfl_xor(rm, 32));                   // row maximum of this tile, relative to m_i
                 float delta = FIRST ? rm : fmaxf(rm, 0.f);
@@ -318,7 +349,7 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = (VAR & VAR_NOEXP) ? sc[t][kt][r] : hcp_exp2(sc[t][kt][r] * cs);
+                    const float e = (VAR & VAR_NOEXP) ? sc[t][kt][r] : hcp_exp2(PRE ? sc[t][kt][r] : sc[t][kt][r] * cs);
                     sc[t][kt][r] = e;
                     if (!ONES) rs += e;
                 }
@@ -343,20 +374,51 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
         cur = cur + 1 == NBUF ? 0 : cur + 1;
     };
     const bool ragged = (p.Nk & (KVT - 1)) != 0;
-    if (nt == 1) {
-        if (ragged) tile(BoolC<true>{}, BoolC<true>{}, 0); else tile(BoolC<true>{}, BoolC<false>{}, 0);
-    } else {
-        tile(BoolC<true>{}, BoolC<false>{}, 0);
-        for (int it = 1; it < nt - 1; ++it) tile(BoolC<false>{}, BoolC<false>{}, it);
-        if (ragged) tile(BoolC<false>{}, BoolC<true>{}, nt - 1); else tile(BoolC<false>{}, BoolC<false>{}, nt - 1);
+    auto all_tiles = [&](auto exact_c) {
+        if (nt == 1) {
+            if (ragged) tile(BoolC<true>{}, BoolC<true>{}, exact_c, 0); else tile(BoolC<true>{}, BoolC<false>{}, exact_c, 0);
+        } else {
+            tile(BoolC<true>{}, BoolC<false>{}, exact_c, 0);
+            for (int it = 1; it < nt - 1; ++it) tile(BoolC<false>{}, BoolC<false>{}, exact_c, it);
+            if (ragged) tile(BoolC<false>{}, BoolC<true>{}, exact_c, nt - 1); else tile(BoolC<false>{}, BoolC<false>{}, exact_c, nt - 1);
+        }
+    };
+    auto row_sum = [&](int t) {
+        float lsum;
+        if (ONES) lsum = hcp_shfl(o[t][D / 16][D % 16 % 4], ((D % 16) / 4) * 16 + fr);   // O^T row D lives in lane group (D%16)/4
+        else { lsum = l_i[t]; lsum += hcp_shfl_xor(lsum, 16); lsum += hcp_shfl_xor(lsum, 32); }
+        return lsum;
+    };
+    all_tiles(BoolC<false>{});
+    if (LSUM) {                                        // exp2 overflow check: any bad row sum sends the WORKGROUP through the exact pass
+        int* redo_flag = (int*)(lds + NBUF * BUF);
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) { const float ls = row_sum(t); bad = bad || !(ls > 0.f && ls < 3.0e38f); }
+        if (!hcp_all(!bad) && lane == 0) *redo_flag = 1;
+        HCP_SYNC();
+        if (hcp_uniform(*redo_flag) != 0) {                       // workgroup-uniform (SGPR: the DMA descriptors below need a scalar branch)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                m_i[t] = 0.f; l_i[t] = 0.f;
+                hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                nm4[t] = z;
+#pragma unroll
+                for (int d = 0; d < G::NDV; ++d) o[t][d] = z;
+            }
+            cur = 0;
+            fetch(0, 0);
+            if (AHEAD == 2 && nt > 1) fetch(1, 1);
+            hcp_dma_wait_all();
+            HCP_SYNC();
+            all_tiles(BoolC<true>{});
+        }
     }
     // epilogue: lane holds O[q = q_base + t*16 + fr][d*16 + 4*fg + r]
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int row = q_base + t * 16 + fr;
-        float lsum;
-        if (ONES) lsum = hcp_shfl(o[t][D / 16][D % 16 % 4], ((D % 16) / 4) * 16 + fr);   // O^T row D lives in lane group (D%16)/4
-        else { lsum = l_i[t]; lsum += hcp_shfl_xor(lsum, 16); lsum += hcp_shfl_xor(lsum, 32); }
+        const float lsum = row_sum(t);
         if (row >= p.Nq) continue;
         const float inv = 1.0f / lsum;
         hcp_bf16* orow = p.Out + (size_t)b * p.o_bs + (size_t)row * p.o_rs + h * D;
@@ -374,7 +436,7 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
     }
 }
 
-template <int D> constexpr size_t fwd_smem(int nbuf = 2) { return (size_t)nbuf * 2 * Geom<D>::IMG * sizeof(hcp_bf16); }
+template <int D> constexpr size_t fwd_smem(int nbuf = 2) { return (size_t)nbuf * 2 * Geom<D>::IMG * sizeof(hcp_bf16) + 16; }
 
 // ------------------------------------------------------------------------------------------ dQ
 // Same walk as the forward: a workgroup owns 64*QT query rows and streams the K|V tiles.  Per score: P = exp2(acc) with the

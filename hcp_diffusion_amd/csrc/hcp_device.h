@@ -116,6 +116,9 @@ HCP_DEVICE void hcp_dma16(hcp_desc4 desc, unsigned voffset, void* lds_wave_base)
                  : "=&s"(keep) : "v"(voffset), "s"(desc), "s"(la) : "memory");
 }
 template <int P> HCP_DEVICE void hcp_setprio() { __builtin_amdgcn_s_setprio(P); }
+// Compile-time scheduling fence: no instruction is moved across it (the phase structure of the ping-pong attention kernels is
+// a property of the instruction ORDER around the workgroup barriers).
+HCP_DEVICE void hcp_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 HCP_DEVICE void hcp_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 HCP_DEVICE int hcp_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }   // value known to be wave-uniform -> SGPR
 // "This register is consumed here": makes the compiler retire the global load that produces `v` BEFORE a loop instead of at the
@@ -153,6 +156,12 @@ template <int N> HCP_DEVICE void hcp_wait_vmcnt_c() {         // compile-time co
 // retired (lgkmcnt(0)), DMA completion is the caller's counted hcp_wait_vmcnt.
 HCP_DEVICE void hcp_barrier_keep_dma() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// Bare workgroup barrier: no counter is drained (callers whose in-flight LDS reads and DMA are safe across it).
+HCP_DEVICE void hcp_barrier_only() {
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }

@@ -123,6 +123,7 @@ HCP_DEVICE void hcp_dma16(hcp_desc4 d, unsigned voffset, void* lds_wave_base) {
     if (voffset >= d.nbytes || voffset + 16 > d.nbytes) memset(dst, 0, 16); else memcpy(dst, d.base + voffset, 16);
 }
 template <int P> HCP_DEVICE void hcp_setprio() {}
+HCP_DEVICE void hcp_sched_fence() {}
 HCP_DEVICE void hcp_dma_wait_all() {}
 HCP_DEVICE int hcp_uniform(int v) { return v; }
 HCP_DEVICE void hcp_force_ready(hcp_bf16x8&) {}
@@ -130,6 +131,7 @@ HCP_DEVICE void hcp_force_ready(float&) {}
 #define HCP_DEVICE_GLOBAL static
 HCP_DEVICE void hcp_wait_vmcnt(int) {}                       // DMA is synchronous in the interpreter
 HCP_DEVICE void hcp_barrier_keep_dma() { hcp_emu::yield_barrier(); }
+HCP_DEVICE void hcp_barrier_only() { hcp_emu::yield_barrier(); }
 template <int N> HCP_DEVICE void hcp_wait_vmcnt_c() {}
 HCP_DEVICE bool hcp_all(bool pred) {
     int v = pred ? 1 : 0;

@@ -9,6 +9,8 @@
 //    the same random data, interleaved in one process (guide §5.4 rules 24/25), and checks every variant's O / lse
 //    against it.
 #include "attn_dma.h"
+#include "attn_sw.h"
+#include "attn_pp.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -122,7 +124,23 @@ static void launch_v2(AttnParams p, hipStream_t st) {
     hipLaunchKernelGGL((attn2_fwd_kernel<D, QT, false, VAR, NW>), dim3(n), dim3(64 * NW), fwd_smem<D>((VAR & VAR_DEEP) ? 3 : 2), st, p);
 }
 
+template <int D, int VAR, int NW, int WPS = 2>
+static void launch_v4(AttnParams p, hipStream_t st) {
+    const int n = ((p.Nq + 32 * NW - 1) / (32 * NW)) * p.H * p.B;
+    hipLaunchKernelGGL((attn4_fwd_kernel<D, VAR, NW, WPS>), dim3(n), dim3(64 * NW), sw_fwd_smem<D>(), st, p);
+}
+#define V4(D, VAR, NW, EXACT) Variant{"sw<" #D "," #VAR ",w" #NW ">", &launch_v4<D, VAR, NW>, EXACT}
+#define V4P(D, VAR, NW, WPS, EXACT) Variant{"sw<" #D "," #VAR ",w" #NW ",wps" #WPS ">", &launch_v4<D, VAR, NW, WPS>, EXACT}
+struct Variant;
+template <int D, int VAR, int WPS, int NW = 8>
+static void launch_v3(AttnParams p, hipStream_t st) {
+    const int n = ((p.Nq + 32 * NW - 1) / (32 * NW)) * p.H * p.B;
+    hipLaunchKernelGGL((attn3_fwd_kernel<D, VAR, WPS, NW>), dim3(n), dim3(64 * NW), pp_fwd_smem<D>(), st, p);
+}
+#define V3W(D, VAR, WPS, NW, EXACT) Variant{"pp<" #D "," #VAR ",wps" #WPS ",w" #NW ">", &launch_v3<D, VAR, WPS, NW>, EXACT}
+
 struct Variant { std::string name; void (*fn)(AttnParams, hipStream_t); bool exact; };
+#define V3(D, VAR, WPS, EXACT) Variant{"pp<" #D "," #VAR ",wps" #WPS ">", &launch_v3<D, VAR, WPS>, EXACT}
 
 template <int D>
 static void run_problem(const Problem& pr, const std::vector<Variant>& vars, int iters) {
@@ -275,17 +293,19 @@ int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 20;
     {
         std::vector<Variant> vars = {
-            V2(40, 2, 67, true), V2W(40, 2, 67, 8, true), V2(40, 2, 323, true), V2W(40, 2, 323, 8, true),
+            V2W(40, 2, 67, 8, true), V2W(40, 2, 2115, 8, true), V2W(40, 2, 579, 8, false), V2W(40, 2, 2627, 8, false),   // + LSUM (2048), + PRE (512)
+            V2(40, 2, 2115, true), V2(40, 2, 2627, false),
+            V4P(40, 1091, 4, 3, true), V4P(40, 1603, 4, 3, false),
         };
         if (!masked_ok) printf("NOTE: masked-DMA probe failed\n");
         run_problem<40>({4, 8, 4096, 4096, 40}, vars, iters);
-        run_problem<40>({2, 8, 4096 - 24, 4096 - 24, 40}, {V2(40, 2, 3, true), V2W(40, 2, 3, 8, true)}, iters);     // ragged tiles
+        run_problem<40>({2, 8, 4096 - 24, 4096 - 24, 40}, {V2(40, 2, 3, true), V2W(40, 2, 3, 8, true), V2W(40, 2, 2115, 8, true), V4(40, 67, 8, true)}, iters);     // ragged tiles
         run_problem<40>({4, 8, 4096, 77, 40}, {V2(40, 2, 3, true), V2W(40, 2, 3, 8, true), V2(40, 1, 3, true)}, iters);                  // cross-attention
     }
     run_bwd<40>({4, 8, 4096, 4096, 40}, {VDQ(40, 2, 3), VDQ(40, 1, 3), VDQ(40, 2, 67), VDKV(40, 2, 3), VDKV(40, 1, 3), VDKV(40, 2, 67)}, iters);
     run_bwd<80>({4, 8, 1024, 1024, 80}, {VDQ(80, 1, 3), VDKV(80, 1, 3)}, iters);
-    run_problem<80>({4, 8, 1024, 1024, 80}, {V2(80, 1, 3, true), V2W(80, 1, 3, 8, true), V2(80, 2, 3, true)}, iters);
+    run_problem<80>({4, 8, 1024, 1024, 80}, {V2(80, 1, 3, true), V2W(80, 1, 3, 8, true), V2W(80, 1, 2051, 8, true), V2(80, 2, 3, true), V4(80, 67, 4, true), V4(80, 67, 8, true)}, iters);
     run_problem<160>({4, 8, 256, 256, 160}, {V2(160, 1, 3, true)}, iters);
-    run_problem<64>({2, 10, 4096, 4096, 64}, {V2(64, 2, 3, true), V2W(64, 2, 3, 8, true), V2W(64, 1, 3, 8, true)}, iters);
+    run_problem<64>({2, 10, 4096, 4096, 64}, {V2(64, 2, 3, true), V2(64, 2, 2051, true), V2W(64, 2, 3, 8, true), V2W(64, 1, 3, 8, true), V4(64, 67, 4, true), V4(64, 67, 8, true)}, iters);
     return 0;
 }
