@@ -35,12 +35,15 @@ constexpr int kMinQTilesPerSplit = 16, kSplitTargetWgs = 256;   // cross-attenti
 HCP_TUNABLE(int, g_attn_cfg, -1);   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32, bit3 fwd 8-wave workgroups, bit4 = keep the heuristic for bits 0-3, bit5 / bit6 = force / forbid the generation-3 (software-pipelined) kernels, bits 8-15 / 16-19 = min query tiles per dK/dV split / target workgroups / 256; -1 = heuristic
 
 constexpr int VAR_FWD = VAR_PRODUCT | VAR_LSUM;      // forward: lazy rescale from the row sums (exact fallback inside the kernel)
+constexpr int VAR_PRE_BASE = VAR_XCD | VAR_ONES | VAR_PRE;   // Q pre-scaled by its projection: no multiply in front of v_exp_f32
+constexpr int VAR_FWD_PRE = VAR_PRE_BASE | VAR_LSUM;
 template <int D, int QT, int NW>
 int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
     const int n = hcp_cdiv(p.Nq, 16 * QT * NW) * p.H * B;   // one-dimensional: the kernel maps workgroup id -> (query tile, head, batch) XCD-aware
     // (the masked / causal instantiations keep the per-score maximum: short problems, and their scalar-register budget leaves no
     //  room for the fallback pass's DMA descriptors)
     if (p.kbias || p.causal) HCP_LAUNCH((attn2_fwd_kernel<D, QT, true, VAR_PRODUCT, NW>), dim3(n), dim3(64 * NW), fwd_smem<D>(), stream, p);
+    else if (p.pre) HCP_LAUNCH((attn2_fwd_kernel<D, QT, false, VAR_FWD_PRE, NW>), dim3(n), dim3(64 * NW), fwd_smem<D>(), stream, p);
     else HCP_LAUNCH((attn2_fwd_kernel<D, QT, false, VAR_FWD, NW>), dim3(n), dim3(64 * NW), fwd_smem<D>(), stream, p);
     HCP_LAUNCH_CHECK("attn_fwd");
 }
@@ -55,12 +58,13 @@ int launch_fwd3(AttnParams& p, int B, hipStream_t stream) {
 inline bool use_sw(const AttnParams& p, int B, int rows_per_wg) {
     if (p.kbias || p.causal) return false;
     (void)B; (void)rows_per_wg;
-    return g_attn_cfg >= 0 && (g_attn_cfg & 32) && !(g_attn_cfg & 64);   // measured no faster than generation 2 + LSUM: tools / tests only
+    return !p.pre && g_attn_cfg >= 0 && (g_attn_cfg & 32) && !(g_attn_cfg & 64);   // measured no faster than generation 2 + LSUM: tools / tests only
 }
 template <int D, int QT>
 int launch_dq(AttnParams& p, int B, hipStream_t stream) {
     const int n = hcp_cdiv(p.Nq, 64 * QT) * p.H * B;
     if (p.kbias || p.causal) HCP_LAUNCH((attn2_bwd_dq_kernel<D, QT, true, VAR_PRODUCT>), dim3(n), dim3(256), fwd_smem<D>(), stream, p);
+    else if (p.pre) HCP_LAUNCH((attn2_bwd_dq_kernel<D, QT, false, VAR_PRE_BASE>), dim3(n), dim3(256), fwd_smem<D>(), stream, p);
     else HCP_LAUNCH((attn2_bwd_dq_kernel<D, QT, false, VAR_PRODUCT>), dim3(n), dim3(256), fwd_smem<D>(), stream, p);
     HCP_LAUNCH_CHECK("attn_bwd_dq");
 }
@@ -87,6 +91,7 @@ int launch_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t str
     }
     const int n = nkv * qsplit * p.H * B;
     if (p.kbias || p.causal) HCP_LAUNCH((attn2_bwd_dkv_kernel<D, KT, true, VAR_PRODUCT>), dim3(n), dim3(256), dkv_smem<D>(), stream, p);
+    else if (p.pre) HCP_LAUNCH((attn2_bwd_dkv_kernel<D, KT, false, VAR_PRE_BASE>), dim3(n), dim3(256), dkv_smem<D>(), stream, p);
     else HCP_LAUNCH((attn2_bwd_dkv_kernel<D, KT, false, VAR_PRODUCT>), dim3(n), dim3(256), dkv_smem<D>(), stream, p);
     if (qsplit > 1) {
         long tot = (long)B * p.Nk * (p.H * D / 4);
@@ -157,12 +162,14 @@ HCP_API int hcp_attention_fwd(const void* Q, const void* K, const void* V, void*
                               int D, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
                               float scale, const float* key_bias, long key_bias_bs, int causal, hipStream_t stream) {
     AttnParams p = {};
-    p.kbias = key_bias; p.kb_bs = key_bias_bs; p.causal = causal ? 1 : 0; p.B = B;
+    p.kbias = key_bias; p.kb_bs = key_bias_bs; p.causal = causal & 1; p.pre = (causal >> 1) & 1; p.B = B;
     p.Q = (const hcp_bf16*)Q; p.K = (const hcp_bf16*)K; p.V = (const hcp_bf16*)V; p.Out = (hcp_bf16*)O; p.lse = lse;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = 1;
     HCP_REQUIRE(Q && K && V && O && lse, "hcp_attention_fwd: null pointer");
-    HCP_REQUIRE(!causal || Nq == Nk, "hcp_attention_fwd: causal masking is defined for self-attention (Nq == Nk)");
+    HCP_REQUIRE(!(causal & 1) || Nq == Nk, "hcp_attention_fwd: causal masking is defined for self-attention (Nq == Nk)");
+    HCP_REQUIRE(!(causal & ~3), "hcp_attention_fwd: unknown flag bits (1 = causal, 2 = Q pre-scaled)");
+    HCP_REQUIRE(!p.pre || !(key_bias || p.causal), "hcp_attention_fwd: pre-scaled Q is provided for the unmasked kernels only");
     if (int e = attn_check(p, B, D)) return e;
     switch (D) {
         case 40: return run_fwd<40>(p, B, stream);
@@ -180,14 +187,16 @@ HCP_API int hcp_attention_bwd(const void* Q, const void* K, const void* V, const
                               const float* key_bias, long key_bias_bs, int causal, void* workspace, size_t workspace_bytes,
                               hipStream_t stream) {
     AttnParams p = {};
-    p.kbias = key_bias; p.kb_bs = key_bias_bs; p.causal = causal ? 1 : 0; p.B = B;
+    p.kbias = key_bias; p.kb_bs = key_bias_bs; p.causal = causal & 1; p.pre = (causal >> 1) & 1; p.B = B;
     p.Q = (const hcp_bf16*)Q; p.K = (const hcp_bf16*)K; p.V = (const hcp_bf16*)V; p.O = (const hcp_bf16*)O;
     p.dO = (const hcp_bf16*)dO; p.lse = (float*)lse; p.delta = delta;
     p.dQ = (hcp_bf16*)dQ; p.dK = (hcp_bf16*)dK; p.dV = (hcp_bf16*)dV;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
     p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale; p.qsplit = 1;
     HCP_REQUIRE(Q && K && V && O && dO && lse && delta && dQ && dK && dV, "hcp_attention_bwd: null pointer");
-    HCP_REQUIRE(!causal || Nq == Nk, "hcp_attention_bwd: causal masking is defined for self-attention (Nq == Nk)");
+    HCP_REQUIRE(!(causal & 1) || Nq == Nk, "hcp_attention_bwd: causal masking is defined for self-attention (Nq == Nk)");
+    HCP_REQUIRE(!(causal & ~3), "hcp_attention_bwd: unknown flag bits (1 = causal, 2 = Q pre-scaled)");
+    HCP_REQUIRE(!p.pre || !(key_bias || p.causal), "hcp_attention_bwd: pre-scaled Q is provided for the unmasked kernels only");
     if (int e = attn_check(p, B, D)) return e;
     float* ws = (float*)workspace; const size_t wb = workspace ? workspace_bytes : 0;
     switch (D) {

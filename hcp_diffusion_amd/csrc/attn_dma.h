@@ -39,6 +39,7 @@ struct AttnParams {
     // scores of every head and query; reference models/wrapper.py:22-23,29)
     const float* kbias; long kb_bs;
     int causal;                     // 1: key k is visible to query q only if k <= q (CLIP text encoder); KB instantiations only
+    int pre;                        // 1: Q holds Q * scale*log2(e) (its projection's weights carry the factor); `scale` then only names the factor
     int B;
     // dK/dV kernel: the query loop may be split over workgroups that accumulate into fp32 buffers
     int qsplit;
@@ -261,7 +262,7 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
     int cur = 0;                                      // LDS buffer of the tile being consumed
     // One 64-key tile.  FIRST: the tile that sets the reference maximum (always rescales); RAGGED: fewer than 64 live keys
     // (the dead ones enter the score MFMA chain as -inf through the accumulator).
-    auto tile = [&](auto first_c, auto ragged_c, auto exact_c, int it) {
+    auto tile = [&](auto first_c, auto ragged_c, auto exact_c, int it) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_c)::value, RAGGED = decltype(ragged_c)::value, EXACT = decltype(exact_c)::value || !LSUM;
         const int kv0 = it * KVT;
         const int nvalid = p.Nk - kv0 < KVT ? p.Nk - kv0 : KVT;
@@ -374,7 +375,7 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
         cur = cur + 1 == NBUF ? 0 : cur + 1;
     };
     const bool ragged = (p.Nk & (KVT - 1)) != 0;
-    auto all_tiles = [&](auto exact_c) {
+    auto all_tiles = [&](auto exact_c) __attribute__((always_inline)) {   // (a call boundary would put the DMA descriptors into VGPRs)
         if (nt == 1) {
             if (ragged) tile(BoolC<true>{}, BoolC<true>{}, exact_c, 0); else tile(BoolC<true>{}, BoolC<false>{}, exact_c, 0);
         } else {
@@ -447,7 +448,8 @@ template <int D, int QT> constexpr int dq_waves() { return D > 80 ? 2 : 3; }
 template <int D, int QT, bool KB, int VAR>
 HCP_WAVES_PER_SIMD((dq_waves<D, QT>())) HCP_KERNEL(256) attn2_bwd_dq_kernel(AttnParams p) {
     using G = Geom<D>;
-    constexpr bool RAW = (VAR & VAR_RAW) != 0;
+    constexpr bool PRE = (VAR & VAR_PRE) != 0;        // Q arrives pre-multiplied by scale*log2(e): dQ is the gradient w.r.t. THAT tensor
+    constexpr bool RAW = (VAR & VAR_RAW) != 0 && !PRE;
     HCP_DYN_SMEM(smem);
     hcp_bf16* lds = (hcp_bf16*)smem;                  // 2 x { K [64][RS] | V [64][RS] }, pad granules zero
     constexpr int BUF = 2 * G::IMG;
@@ -505,7 +507,7 @@ HCP_WAVES_PER_SIMD((dq_waves<D, QT>())) HCP_KERNEL(256) attn2_bwd_dq_kernel(Attn
 #pragma unroll
     for (int t = 0; t < QT; ++t)
 #pragma unroll
-        for (int s = 0; s < G::NQK; ++s) if (!RAW) qf[t][s] = scale8(qf[t][s], c2);     // the forward's rounding of Q * scale*log2e
+        for (int s = 0; s < G::NQK; ++s) if (!RAW && !PRE) qf[t][s] = scale8(qf[t][s], c2);     // the forward's rounding of Q * scale*log2e
     const int kfull = fr * G::RS + fg * 8;
     const int ktail = fr * G::RS + ((G::NFULL * 32 + fg * 8) < D ? G::NFULL * 32 + fg * 8 : D);
     const int vfrag = (4 * fg + (fr >> 2)) * G::RS + 4 * (fr & 3);
@@ -592,7 +594,7 @@ HCP_WAVES_PER_SIMD((dq_waves<D, QT>())) HCP_KERNEL(256) attn2_bwd_dq_kernel(Attn
             if (col < D) {
                 hcp_bf16x4 w;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = (short)hcp_f2bf(dq[t][d][r] * p.scale);
+                for (int r = 0; r < 4; ++r) w[r] = (short)hcp_f2bf(dq[t][d][r] * (PRE ? LN2 : p.scale));   // PRE: d/dQ' = (scale / (scale log2e)) dS K
                 *(hcp_bf16x4*)(orow + col) = w;
             }
         }
@@ -609,7 +611,8 @@ template <int D, int KT> constexpr int dkv_waves() { return (D > 80 || KT == 2) 
 template <int D, int KT, bool KB, int VAR>
 HCP_WAVES_PER_SIMD((dkv_waves<D, KT>())) HCP_KERNEL(256) attn2_bwd_dkv_kernel(AttnParams p) {
     using G = Geom<D>;
-    constexpr bool RAW = (VAR & VAR_RAW) != 0;
+    constexpr bool PRE = (VAR & VAR_PRE) != 0;        // the streamed Q tiles are Q' = Q * scale*log2(e): dK = ln2 * dS^T Q'
+    constexpr bool RAW = (VAR & VAR_RAW) != 0 && !PRE;
     HCP_DYN_SMEM(smem);
     hcp_bf16* lds = (hcp_bf16*)smem;                  // 2 x { Q [64][RS] | dO [64][RS] | -lse2[64], -delta[64] (fp32) }
     constexpr int BUF = 2 * G::IMG + 4 * KVT;         // 2*64 floats = 4*64 bf16 slots
@@ -677,7 +680,7 @@ HCP_WAVES_PER_SIMD((dkv_waves<D, KT>())) HCP_KERNEL(256) attn2_bwd_dkv_kernel(At
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
-        for (int s = 0; s < G::NQK; ++s) if (!RAW) kf[t][s] = scale8(kf[t][s], c2);
+        for (int s = 0; s < G::NQK; ++s) if (!RAW && !PRE) kf[t][s] = scale8(kf[t][s], c2);
     const int qfull = fr * G::RS + fg * 8;
     const int qtail = fr * G::RS + ((G::NFULL * 32 + fg * 8) < D ? G::NFULL * 32 + fg * 8 : D);
     const int tfrag = (4 * fg + (fr >> 2)) * G::RS + 4 * (fr & 3);
@@ -752,6 +755,7 @@ HCP_WAVES_PER_SIMD((dkv_waves<D, KT>())) HCP_KERNEL(256) attn2_bwd_dkv_kernel(At
         hcp_dma_wait_all();
         HCP_SYNC();
     }
+    const float kscale = PRE ? LN2 : p.scale;
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
         const int row = k_base + t * 16 + fr;
@@ -764,7 +768,7 @@ HCP_WAVES_PER_SIMD((dkv_waves<D, KT>())) HCP_KERNEL(256) attn2_bwd_dkv_kernel(At
                 const int col = d * 16 + 4 * fg;
                 if (col < D) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { hcp_atomic_add(k32 + col + r, dk[t][d][r] * p.scale); hcp_atomic_add(v32 + col + r, dv[t][d][r]); }
+                    for (int r = 0; r < 4; ++r) { hcp_atomic_add(k32 + col + r, dk[t][d][r] * kscale); hcp_atomic_add(v32 + col + r, dv[t][d][r]); }
                 }
             }
             continue;
@@ -777,7 +781,7 @@ HCP_WAVES_PER_SIMD((dkv_waves<D, KT>())) HCP_KERNEL(256) attn2_bwd_dkv_kernel(At
             if (col < D) {
                 hcp_bf16x4 wk, wv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { wk[r] = (short)hcp_f2bf(dk[t][d][r] * p.scale); wv[r] = (short)hcp_f2bf(dv[t][d][r]); }
+                for (int r = 0; r < 4; ++r) { wk[r] = (short)hcp_f2bf(dk[t][d][r] * kscale); wv[r] = (short)hcp_f2bf(dv[t][d][r]); }
                 *(hcp_bf16x4*)(krow + col) = wk;
                 *(hcp_bf16x4*)(vrow + col) = wv;
             }

@@ -209,9 +209,10 @@ def _key_bias(key_bias, B, Nk):
     return key_bias, key_bias.stride(0)
 
 
-def attention_fwd(q, k, v, heads, scale=None, key_bias=None, causal=False):
+def attention_fwd(q, k, v, heads, scale=None, key_bias=None, causal=False, q_prescaled=False):
     """q [B,Nq,H*d], k/v [B,Nk,H*d] (views with arbitrary batch/row strides allowed) -> (o [B,Nq,H*d], lse [B,H,Nq]).
-    key_bias: optional fp32 [B,Nk] added to the scaled scores (additive key mask); causal: key k visible to query q iff k <= q."""
+    key_bias: optional fp32 [B,Nk] added to the scaled scores (additive key mask); causal: key k visible to query q iff k <= q;
+    q_prescaled: q already holds q * scale * log2(e) (folded into the projection that produced it; unmasked problems only)."""
     B, Nq, C = q.shape
     Nk = k.shape[1]
     D = C // heads
@@ -221,11 +222,11 @@ def attention_fwd(q, k, v, heads, scale=None, key_bias=None, causal=False):
     qb, qr = _attn_strides(q); kb, kr = _attn_strides(k); vb, vr = _attn_strides(v); ob, orr = _attn_strides(o)
     kbt, kbs = _key_bias(key_bias, B, Nk)
     _chk(lib().hcp_attention_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, heads, Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr,
-                                 float(scale), _p(kbt), kbs, 1 if causal else 0, _stream(q)), "hcp_attention_fwd")
+                                 float(scale), _p(kbt), kbs, (1 if causal else 0) | (2 if q_prescaled else 0), _stream(q)), "hcp_attention_fwd")
     return o, lse
 
 
-def attention_bwd(q, k, v, o, do, lse, heads, scale=None, out=None, key_bias=None, causal=False):
+def attention_bwd(q, k, v, o, do, lse, heads, scale=None, out=None, key_bias=None, causal=False, q_prescaled=False):
     """Gradients (dq, dk, dv).  q/k/v may be column-slice views of a fused projection buffer; `out` = preallocated
     (dq, dk, dv) with the SAME strides as (q, k, v) (e.g. slices of one [B,N,3C] gradient buffer)."""
     B, Nq, C = q.shape
@@ -244,7 +245,8 @@ def attention_bwd(q, k, v, o, do, lse, heads, scale=None, out=None, key_bias=Non
     ws = _workspace(q)
     kbt, kbs = _key_bias(key_bias, B, Nk)
     _chk(lib().hcp_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, heads,
-                                 Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr, float(scale), _p(kbt), kbs, 1 if causal else 0, _p(ws),
+                                 Nq, Nk, D, qb, qr, kb, kr, vb, vr, ob, orr, float(scale), _p(kbt), kbs,
+                                 (1 if causal else 0) | (2 if q_prescaled else 0), _p(ws),
                                  ws.numel(), _stream(q)), "hcp_attention_bwd")
     return dq, dk, dv
 

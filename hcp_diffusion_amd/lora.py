@@ -246,8 +246,12 @@ class FusedLoraGroup:
     (q/k/v of self-attention; k/v of cross-attention): outputs concatenated along N, the layers' rank slots packed
     side by side in one 32-wide slot group.  `blocks[i]` may be None for a host without LoRA."""
 
-    def __init__(self, hosts, blocks):
+    def __init__(self, hosts, blocks, out_scale=None):
+        """out_scale[i]: a constant folded into member i's output, y_i = c_i (x W_i^T + alpha_i T_i W_up_i^T) — in the packed host
+        weight (one rounding of c W, as W itself) and in the member's LoRA alpha, forward and backward alike.  The attention modules use
+        it to hand the kernels Q * d^-0.5 * log2(e) (no per-score multiply in front of the exponential)."""
         self.hosts, self.blocks = list(hosts), list(blocks)
+        self.out_scale = [1.0] * len(self.hosts) if out_scale is None else [float(c) for c in out_scale]
         self.n_off, n = [], 0
         for h in self.hosts:
             self.n_off.append(n); n += h.weight.shape[0]
@@ -265,7 +269,7 @@ class FusedLoraGroup:
         """bf16 [Ntot, K] (forward B operand) and [K, Ntot] (dX B operand) of the concatenated frozen host weights."""
         key = tuple((h.weight._version, h.weight.data_ptr()) for h in self.hosts)
         if self._pk is None or self._pk[0] != key:
-            w = torch.cat([h.weight.detach().reshape(h.weight.shape[0], -1) for h in self.hosts], 0).to(BF16).contiguous()
+            w = torch.cat([h.weight.detach().reshape(h.weight.shape[0], -1) * c for h, c in zip(self.hosts, self.out_scale)], 0).to(BF16).contiguous()
             self._pk = (key, w, w.t().contiguous())
         return self._pk[1], self._pk[2]
 
@@ -384,11 +388,11 @@ class LoraBucket:
         self._conv_tiles += ((n_out + 63) // 64) * tc
         return o
 
-    def _add_desc(self, b, o, slot0, n0, n_total):
+    def _add_desc(self, b, o, slot0, n0, n_total, alpha_mul=1.0):
         r, k = b.layer.W_down.shape[:2]
         n_out = b.layer.W_up.shape[0]
         self._desc_bytes += struct.pack("<6Q3if4i", b.layer.W_down.data_ptr(), b.layer.W_up.data_ptr(), o.ad.data_ptr(), o.adt.data_ptr(),
-                                        o.bu.data_ptr(), o.but.data_ptr(), k, n_out, r, b.alpha_f, slot0, n0, n_total, 0)
+                                        o.bu.data_ptr(), o.but.data_ptr(), k, n_out, r, b.alpha_f * alpha_mul, slot0, n0, n_total, 0)
         self._desc_count += 1
 
     def _upload_descs(self):
@@ -399,10 +403,10 @@ class LoraBucket:
         if group.slots > RANK_SLOT:
             raise ValueError("fused LoRA group needs more than 32 rank slots")
         group.ops = self._new_images(group.k, group.n_total)
-        for b, n0, s0 in zip(group.blocks, group.n_off, group.slot_off):
+        for b, n0, s0, c in zip(group.blocks, group.n_off, group.slot_off, group.out_scale):
             if b is not None:
                 assert b._bucket is self
-                self._add_desc(b, group.ops, s0, n0, group.n_total)
+                self._add_desc(b, group.ops, s0, n0, group.n_total, alpha_mul=c)
         self._upload_descs()
         self.groups.append(group)
         self.pack()

@@ -204,10 +204,10 @@ class _LinearGroupFn(torch.autograd.Function):
                 dx, U = K.gemm_lora(dy2, wt, o.but, o.adt)
             else:
                 U = K.gemm(dy2, o.but)
-            for blk, n0, s0, host in zip(g.blocks, g.n_off, g.slot_off, g.hosts):
+            for blk, n0, s0, host, sc_ in zip(g.blocks, g.n_off, g.slot_off, g.hosts, g.out_scale):
                 if blk is not None:
                     gd, gu = blk.grad_views()
-                    _wgrad(U, x2, gd, T, dy2[:, n0:n0 + host.weight.shape[0]], gu, blk.rank, blk.alpha_f, s0)
+                    _wgrad(U, x2, gd, T, dy2[:, n0:n0 + host.weight.shape[0]], gu, blk.rank, blk.alpha_f * sc_, s0)
         elif ctx.needs_input_grad[0]:
             dx = K.gemm(dy2, wt)
         if dx is not None:
@@ -461,16 +461,16 @@ class _AttentionPackedFn(torch.autograd.Function):
     into ONE buffer per input — no slice/concat nodes in the autograd graph."""
 
     @staticmethod
-    def forward(ctx, a, kv, heads, key_bias=None):
+    def forward(ctx, a, kv, heads, key_bias=None, q_prescaled=False):
         if kv is None:
             C = a.shape[-1] // 3
             q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
         else:
             C = a.shape[-1]
             q, k, v = a, kv[..., :C], kv[..., C:]
-        o, lse = K.attention_fwd(q, k, v, heads, key_bias=key_bias)
+        o, lse = K.attention_fwd(q, k, v, heads, key_bias=key_bias, q_prescaled=q_prescaled)
         ctx.save_for_backward(a, kv, o, lse, key_bias)
-        ctx.heads, ctx.C = heads, C
+        ctx.heads, ctx.C, ctx.pre = heads, C, q_prescaled
         return o
 
     @staticmethod
@@ -481,16 +481,18 @@ class _AttentionPackedFn(torch.autograd.Function):
             da = torch.empty_like(a)
             q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
             K.attention_bwd(q, k, v, o, do.contiguous(), lse, ctx.heads, out=(da[..., :C], da[..., C:2 * C], da[..., 2 * C:]),
-                            key_bias=key_bias)
-            return da, None, None, None
+                            key_bias=key_bias, q_prescaled=ctx.pre)
+            return da, None, None, None, None
         da = torch.empty_like(a); dkv = torch.empty_like(kv)
         K.attention_bwd(a, kv[..., :C], kv[..., C:], o, do.contiguous(), lse, ctx.heads, out=(da, dkv[..., :C], dkv[..., C:]),
-                        key_bias=key_bias)
-        return da, dkv, None, None
+                        key_bias=key_bias, q_prescaled=ctx.pre)
+        return da, dkv, None, None, None
 
 
-def attention_packed(a, kv, heads, key_bias=None):
-    return _AttentionPackedFn.apply(a, kv, heads, key_bias)
+def attention_packed(a, kv, heads, key_bias=None, q_prescaled=False):
+    """q_prescaled: the q columns of `a` were produced by a projection group with out_scale = d^-0.5 * log2(e) (lora.FusedLoraGroup):
+    the kernels skip the per-score multiply and return the gradient w.r.t. the scaled tensor, which is what that group's backward expects."""
+    return _AttentionPackedFn.apply(a, kv, heads, key_bias, q_prescaled)
 
 
 class _AddFn(torch.autograd.Function):

@@ -125,6 +125,9 @@ class ResnetBlock2D(nn.Module):
         return self.conv2(h, residual=sc)
 
 
+LOG2E = 1.4426950408889634
+
+
 def _fusable_linear(m):
     """(host, lora block or None) if `m` is a native bias-free Linear — bare or in a single-block native LoRA
     container — with no hooks attached (a hooked module must be called through __call__); else None."""
@@ -150,15 +153,16 @@ def _fusable_linear(m):
 class CrossAttention(nn.Module):
     def __init__(self, dim, ctx_dim, heads):
         super().__init__()
-        self.heads = heads
+        self.heads, self.head_dim = heads, dim // heads
         self.to_q = HipLinear(dim, dim, bias=False)
         self.to_k = HipLinear(ctx_dim, dim, bias=False)
         self.to_v = HipLinear(ctx_dim, dim, bias=False)
         self.to_out = nn.ModuleList([HipLinear(dim, dim), nn.Dropout(0.0)])
         self._groups = {}
 
-    def _group(self, mods):
-        """FusedLoraGroup for projections that share an input, or None when any of them must stay a separate call."""
+    def _group(self, mods, scales=None):
+        """FusedLoraGroup for projections that share an input, or None when any of them must stay a separate call.
+        scales: per-member output constants (the q projection carries d^-0.5 * log2(e) for the attention kernels)."""
         from .lora import FusedLoraGroup
         key = tuple(id(m) for m in mods)
         hit = self._groups.get(key)
@@ -171,28 +175,35 @@ class CrossAttention(nn.Module):
             buckets = {id(b._bucket) for b in blocks if b is not None}
             ok = len(buckets) <= 1 and all(b is None or b._bucket is not None for b in blocks)
             if ok and sum(8 * ((b.rank + 7) // 8) for b in blocks if b is not None) <= 32:
-                group = FusedLoraGroup([p[0] for p in pairs], blocks)
+                group = FusedLoraGroup([p[0] for p in pairs], blocks, scales)
                 lb = next((b for b in blocks if b is not None), None)
                 group.bucket = lb._bucket if lb is not None else None
                 if lb is not None:
                     group.bucket.add_group(group)
-        self._groups = {key: (group, mods)}          # keeps the modules alive so the ids stay unique
+        if len(self._groups) >= 4:                   # stale keys (layers wrapped / unwrapped since): drop the oldest
+            self._groups.pop(next(iter(self._groups)))
+        self._groups[key] = (group, mods)            # keeps the modules alive so the ids stay unique
         return group
 
     def forward(self, x, context=None, residual=None, key_bias=None):
+        qc = self.head_dim ** -0.5 * LOG2E
         if context is None:
-            g = self._group((self.to_q, self.to_k, self.to_v))
-            if g is not None:                          # q|k|v in one fused-LoRA GEMM, attention reads the slices in place
-                o = ops.attention_packed(ops.linear_group(x, g), None, self.heads)
+            # q|k|v in one fused-LoRA GEMM, attention reads the slices in place; the q third comes out as q * d^-0.5 * log2(e)
+            # (folded into the packed q weights and that block's LoRA alpha): the kernels exponentiate the accumulator as it is
+            g = self._group((self.to_q, self.to_k, self.to_v), (qc, 1.0, 1.0))
+            if g is not None:
+                o = ops.attention_packed(ops.linear_group(x, g), None, self.heads, q_prescaled=True)
             else:
                 o = ops.attention(self.to_q(x), self.to_k(x), self.to_v(x), self.heads)
         else:
-            q = self.to_q(x)
             g = self._group((self.to_k, self.to_v))
-            if g is not None:
-                o = ops.attention_packed(q, ops.linear_group(context, g), self.heads, key_bias)
+            gq = self._group((self.to_q,), (qc,)) if (g is not None and key_bias is None) else None
+            if g is not None and gq is not None:       # unmasked cross-attention: pre-scaled q from a one-member group
+                o = ops.attention_packed(ops.linear_group(x, gq), ops.linear_group(context, g), self.heads, None, q_prescaled=True)
+            elif g is not None:
+                o = ops.attention_packed(self.to_q(x), ops.linear_group(context, g), self.heads, key_bias)
             else:
-                o = ops.attention(q, self.to_k(context), self.to_v(context), self.heads, key_bias)
+                o = ops.attention(self.to_q(x), self.to_k(context), self.to_v(context), self.heads, key_bias)
         return _call_res(self.to_out[0], o, residual) if residual is not None else self.to_out[0](o)
 
 

@@ -61,8 +61,11 @@ int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int B, int 
  * Replaces diffusers CrossAttention/AttnProcessor2_0 (SDPA) or xformers (reference train_ac.py:258-260). D in {40,64,80,160}. */
 /* key_bias (optional, fp32 [B,Nk], batch stride key_bias_bs): additive bias on the SCALED scores of every head/query —
  * diffusers' encoder_attention_mask -> (1 - mask) * -10000 (the attn_mask the reference passes at models/wrapper.py:22-29).
- * causal != 0 (self-attention only, Nq == Nk): key k contributes to query q only if k <= q — the CLIP text encoder's
- * causal_attention_mask (cfgs/te_struct.txt CLIPAttention; text-encoder LoRA, cfgs/train/examples/lora_conventional.yaml:14-19). */
+ * `causal` is a flag word.  bit 0 (self-attention only, Nq == Nk): key k contributes to query q only if k <= q — the CLIP text encoder's
+ * causal_attention_mask (cfgs/te_struct.txt CLIPAttention; text-encoder LoRA, cfgs/train/examples/lora_conventional.yaml:14-19). 
+ * bit 1 (unmasked problems only): Q already holds Q * scale * log2(e) — the caller folded the factor into the weights of the Q
+ * projection (and into the LoRA alpha of that layer), so the score accumulator is the exp2 argument and no multiply precedes the
+ * exponential; `scale` still names the softmax scale.  hcp_attention_bwd then returns dQ as the gradient w.r.t. THAT tensor. */
 int hcp_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int Nq, int Nk, int D,
                       long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
                       const float* key_bias, long key_bias_bs, int causal, hcpStream_t stream);

@@ -233,6 +233,27 @@ def test_attention_rows_per_wave_variants(tbackend, cfg):
     assert relerr(dq, dq_ref) < 2e-2 and relerr(dk, dk_ref) < 2e-2 and relerr(dv, dv_ref) < 2e-2
 
 
+@pytest.mark.parametrize("shape", [(1, 2, 150, 200, 40), (2, 1, 64, 77, 80), (1, 1, 100, 130, 64)])
+def test_attention_prescaled_q(backend, shape):
+    """Flag bit 1 of hcp_attention_fwd / _bwd: Q arrives as q * d^-0.5 * log2(e) (the attention modules fold the factor into the q
+    projection).  Output and lse equal the plain call's; dQ comes back as the gradient w.r.t. the SCALED tensor (= dq / c)."""
+    B, H, Nq, Nk, D = shape
+    torch.manual_seed(Nq)
+    q, k, v, do = rnd(B, Nq, H * D), rnd(B, Nk, H * D), rnd(B, Nk, H * D), rnd(B, Nq, H * D)
+    k[0, Nk - 1, :D] = q[0, Nq // 2, :D] * 4.0
+    c = D ** -0.5 * 1.4426950408889634
+    qs = (q.float() * c).to(BF)
+    # reference on the bf16-rounded scaled tensor (what the kernel is given): scores = qs . k / log2(e)
+    o_ref, lse_ref, dq_ref, dk_ref, dv_ref = attn_ref((qs.float() / c), k, v, H, do)
+    to = backend.to
+    o, lse = K.attention_fwd(to(qs), to(k), to(v), H, q_prescaled=True)
+    assert relerr(o, o_ref) < 1e-2 and (lse.cpu() - lse_ref).abs().max().item() < 2e-2
+    dq, dk, dv = K.attention_bwd(to(qs), to(k), to(v), o, to(do), lse, H, q_prescaled=True)
+    assert relerr(dq.float() * c, dq_ref) < 2e-2 and relerr(dk, dk_ref) < 2e-2 and relerr(dv, dv_ref) < 2e-2
+    with pytest.raises(RuntimeError):
+        K.attention_fwd(to(qs), to(k), to(v), H, key_bias=to(torch.zeros(B, Nk)), q_prescaled=True)
+
+
 def test_attention_strided_qkv(backend):
     """q/k/v as column slices of one fused [B,N,3C] projection (non-contiguous rows)."""
     torch.manual_seed(3)
