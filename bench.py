@@ -141,19 +141,20 @@ def attention_roofline(dev):
     from hcp_diffusion_amd import kernels as K
     B, H, N, D = 4, 8, 4096, 40
     q, k, v = [torch.randn(B, N, H * D, device=dev).to(torch.bfloat16) for _ in range(3)]
-    for _ in range(3):
-        K.attention_fwd(q, k, v, H)
+    q = (q.float() * (D ** -0.5 * 1.4426950408889634)).to(torch.bfloat16)      # the form the UNet's attention modules call the kernel in:
+    for _ in range(3):                                                         # q * d^-0.5 * log2(e) out of the q|k|v projection group
+        K.attention_fwd(q, k, v, H, q_prescaled=True)
     torch.cuda.synchronize()
     n = 30
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        K.attention_fwd(q, k, v, H)
+        K.attention_fwd(q, k, v, H, q_prescaled=True)
     e1.record()
     torch.cuda.synchronize()
     dt = e0.elapsed_time(e1) * 1e-3 / n
     flops = 4.0 * B * H * N * N * D
-    out = {"kernel": "attn2_fwd_kernel<40,2,8 waves> B4 H8 N4096 d40", "achieved": round(flops / dt / 1e12, 1), "unit": "TFLOP/s",
+    out = {"kernel": "attn2_fwd_kernel<40,2,8 waves, pre-scaled Q, row-sum lazy rescale> B4 H8 N4096 d40", "achieved": round(flops / dt / 1e12, 1), "unit": "TFLOP/s",
            "frac": round(flops / dt / MFMA_BF16_PEAK, 4), "avg_launch_us": round(dt * 1e6, 1)}
     rec = _pmc_record("attn_fwd_b4_h8_n4096_d40")
     if rec:

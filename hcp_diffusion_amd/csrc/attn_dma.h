@@ -183,7 +183,11 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
     constexpr int NBUF = AHEAD + 1;
     constexpr bool ONES = G::SPARE && (VAR & VAR_ONES) && MASKPAD;   // row sums from the PV MFMA
     constexpr bool PRE = (VAR & VAR_PRE) != 0;        // (implies the exp2-domain accumulator: no multiply in front of v_exp_f32)
-    constexpr bool LSUM = (VAR & VAR_LSUM) != 0;
+    // Only with ONES (d = 40): there l is the sum of the bf16-ROUNDED probabilities the PV MFMA used, so a row dominated by one key
+    // normalises exactly whatever its reference is.  With a VALU row sum of the unrounded exponentials a dominant P that is not
+    // exactly 1 (any reference but the true maximum) leaves a 2^-9 relative error in O, which the backward's delta = rowsum(dO * O)
+    // turns into a spurious gradient on exactly the saturated rows (measured: dQ error 0.98 % -> 2.4 % at d = 160).
+    constexpr bool LSUM = (VAR & VAR_LSUM) != 0 && ONES;
     // LSUM: the reference maximum is the exact row maximum of the FIRST tile; afterwards no per-score maximum is taken (16 v_max3 +
     // hazard nops per 32 x 64 wave-tile).  A tile only looks at the running sum of probabilities — the PV MFMA keeps it in O's spare
     // row at d = 40, a VALU partial sum otherwise — and when a row's sum passes 2^20, O and l are divided by it and the reference moves

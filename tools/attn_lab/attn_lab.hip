@@ -302,7 +302,7 @@ int main(int argc, char** argv) {
         run_problem<40>({2, 8, 4096 - 24, 4096 - 24, 40}, {V2(40, 2, 3, true), V2W(40, 2, 3, 8, true), V2W(40, 2, 2115, 8, true), V4(40, 67, 8, true)}, iters);     // ragged tiles
         run_problem<40>({4, 8, 4096, 77, 40}, {V2(40, 2, 3, true), V2W(40, 2, 3, 8, true), V2(40, 1, 3, true)}, iters);                  // cross-attention
     }
-    run_bwd<40>({4, 8, 4096, 4096, 40}, {VDQ(40, 2, 3), VDQ(40, 1, 3), VDQ(40, 2, 67), VDKV(40, 2, 3), VDKV(40, 1, 3), VDKV(40, 2, 67)}, iters);
+    run_bwd<40>({4, 8, 4096, 4096, 40}, {VDQ(40, 2, 67), VDQ(40, 2, 515), VDKV(40, 2, 67), VDKV(40, 2, 515)}, iters);   // 515 = pre-scaled Q
     run_bwd<80>({4, 8, 1024, 1024, 80}, {VDQ(80, 1, 3), VDKV(80, 1, 3)}, iters);
     run_problem<80>({4, 8, 1024, 1024, 80}, {V2(80, 1, 3, true), V2W(80, 1, 3, 8, true), V2W(80, 1, 2051, 8, true), V2(80, 2, 3, true), V4(80, 67, 4, true), V4(80, 67, 8, true)}, iters);
     run_problem<160>({4, 8, 256, 256, 160}, {V2(160, 1, 3, true)}, iters);
