@@ -40,6 +40,7 @@ class HostBucket:
         self.params = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
         self.named = list(params)
+        self._gv = []                                   # (parameter, its .grad view): re-attached after zero_grad(set_to_none=True)
         with torch.no_grad():
             for (name, p), o in zip(params, offs):
                 seg, gseg = self.params[o:o + p.numel()], self.grads[o:o + p.numel()]
@@ -53,9 +54,35 @@ class HostBucket:
                 p.data = v
                 p.grad = g
                 p.requires_grad_(True)
+                p._hcp_bucket = self
+                self._gv.append((p, g))
         owned = {id(p) for _, p in params}
         self.layers = [m for m in model.modules() if isinstance(m, (HipLinear, HipConv2d)) and id(m.weight) in owned]
         self._pieces = None
+        self._packed_ver = None
+
+    # ---- a trainer that is not NativeTrainer steps / zeroes through the Parameters (graphed.py)
+    def _version(self):
+        return sum(p._version for p, _ in self._gv)
+
+    def stale(self):
+        """Has an optimizer written the fp32 masters since the bf16 operands were derived?  (every in-place step bumps p._version)"""
+        return self._packed_ver != self._version()
+
+    def attach_grads(self):
+        for p, g in self._gv:
+            if p.grad is None:
+                p.grad = g
+
+    def zero_dropped(self):
+        """zero_grad(set_to_none=True) dropped `.grad` views = the trainer's zero: clear those slices, hand the views back."""
+        dropped = [(p, g) for p, g in self._gv if p.grad is None]
+        if dropped and len(dropped) == len(self._gv):
+            self.grads.zero_()
+        for p, g in dropped:
+            if len(dropped) != len(self._gv):
+                g.zero_()
+            p.grad = g
 
     # ---- bf16 operand refresh
     def _build_pieces(self):
@@ -97,3 +124,4 @@ class HostBucket:
                     break
         if self._n_pieces:
             K.pack_weights(self._pieces, self._n_pieces, self._tiles)
+        self._packed_ver = self._version()

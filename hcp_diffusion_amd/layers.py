@@ -22,6 +22,12 @@ def _key(*ts):
     return tuple((t._version, t.data_ptr(), t.device) if t is not None else None for t in ts)
 
 
+def _same_storage(k_old, k_new):
+    """Only the version counters moved (an optimizer stepped the parameter in place): the bf16 operand buffers are refreshed IN
+    PLACE then, so that captured hipGraphs (graphed.py) and grouped pack descriptors (fullft.py) that hold their addresses stay valid."""
+    return len(k_old) == len(k_new) and all((a is None) == (b is None) and (a is None or a[1:] == b[1:]) for a, b in zip(k_old, k_new))
+
+
 def _pad_last(t, mult):
     c = t.shape[-1]
     cp = (c + mult - 1) // mult * mult
@@ -39,8 +45,15 @@ class HipLinear(nn.Linear):
     def packed(self):
         k = _key(self.weight, self.bias)
         if self._pk is None or self._pk.key != k:
-            pk = _Packed(); pk.key = k
             w = self.weight.detach()
+            if self._pk is not None and _same_storage(self._pk.key, k):
+                pk = self._pk
+                pk.w.copy_(w); pk.wt.copy_(w.t())
+                if pk.bias is not None and pk.bias.data_ptr() != self.bias.data_ptr():
+                    pk.bias.copy_(self.bias.detach())
+                pk.key = k
+                return pk
+            pk = _Packed(); pk.key = k
             pk.w = w.to(BF16).contiguous()                 # [N, K]   forward B operand
             pk.wt = w.t().to(BF16).contiguous()            # [K, N]   dX B operand
             pk.bias = self.bias.detach().float().contiguous() if self.bias is not None else None
@@ -56,11 +69,30 @@ class HipConv2d(nn.Conv2d):
     supports_fused_residual = True
     _pk = None
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.kernel_size == (3, 3):
+            # diffusers shape [Cout,Cin,3,3], channels_last STORAGE = the kernels' [Cout][ky][kx][Cin], from construction on: the flat
+            # fine-tuning bucket (fullft.HostBucket) keeps this layout, so a parameter's strides never change under a wrapper that
+            # recorded them when it was built (torch DDP's bucket views: a later switch scrambled the 3x3 gradients it copied back)
+            self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+
     def packed(self):
         k = _key(self.weight, self.bias)
         if self._pk is None or self._pk.key != k:
-            pk = _Packed(); pk.key = k
             w = self.weight.detach()
+            if self._pk is not None and _same_storage(self._pk.key, k):
+                pk = self._pk
+                if self.kernel_size == (1, 1):
+                    w2 = w.reshape(pk.cout, pk.cin)
+                    pk.w.copy_(w2); pk.wt.copy_(w2.t())
+                else:
+                    pk.w[..., :pk.cin].copy_(w.permute(0, 2, 3, 1)); pk.wd[..., :pk.cout].copy_(w.permute(1, 2, 3, 0))
+                if pk.bias is not None and pk.bias.data_ptr() != self.bias.data_ptr():
+                    pk.bias.copy_(self.bias.detach())
+                pk.key = k
+                return pk
+            pk = _Packed(); pk.key = k
             cout, cin = w.shape[0], w.shape[1]
             pk.cout, pk.cin = cout, cin
             pk.bias = self.bias.detach().float().contiguous() if self.bias is not None else None
@@ -106,7 +138,13 @@ class _F32Affine:
     def f32_params(self):
         k = _key(self.weight, self.bias)
         if self._af is None or self._af[0] != k:
-            self._af = (k, self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
+            if self._af is not None and _same_storage(self._af[0], k):       # (fp32 contiguous parameters: these ARE the parameters)
+                for dst, src in ((self._af[1], self.weight), (self._af[2], self.bias)):
+                    if dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src.detach())
+                self._af = (k, self._af[1], self._af[2])
+            else:
+                self._af = (k, self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
         return self._af[1], self._af[2]
 
 

@@ -456,9 +456,24 @@ class LoraBucket:
 
     def grad_views_for(self, blk):
         gd, gu = self._gviews[id(blk)]
-        if blk.layer.W_down.grad is None:      # zero_grad(set_to_none=True) dropped the views: re-attach
-            blk.layer.W_down.grad, blk.layer.W_up.grad = self._pgrads[id(blk)]
+        if blk.layer.W_down.grad is None:      # zero_grad(set_to_none=True) (torch's default) dropped the views: that WAS the trainer's
+            pg = self._pgrads[id(blk)]         # zero — clear the slices the kernels are about to accumulate into, then re-attach
+            for g in pg:
+                g.zero_()
+            blk.layer.W_down.grad, blk.layer.W_up.grad = pg
         return gd, gu
+
+    def zero_dropped(self):
+        """Before a captured backward replays (graphed.py): clear and re-attach whatever `.grad` views the trainer dropped."""
+        dropped = [b for b in self.blocks if b.layer.W_down.grad is None]
+        if dropped and len(dropped) == len(self.blocks):
+            self.grads.zero_()
+        for b in dropped:
+            pg = self._pgrads[id(b)]
+            if len(dropped) != len(self.blocks):
+                for g in pg:
+                    g.zero_()
+            b.layer.W_down.grad, b.layer.W_up.grad = pg
 
     @property
     def numel(self):

@@ -12,60 +12,76 @@ from . import kernels as K
 
 BF16 = torch.bfloat16
 
-# ---- side stream for the LoRA weight-gradient kernels -------------------------------------------------------------
-# dW_down / dW_up are leaves of the backward graph (only the optimizer reads them), while the dX chain is a long
-# sequence of small, latency-bound kernels.  When enabled (NativeTrainer does), each layer's wgrad launch goes to a
-# second HIP stream, ordered after the dX kernel that produced U by an event, and joins the main stream once, after
-# the backward pass.  Under hipGraph capture this becomes a parallel branch of the graph.
-_side = {"enabled": False, "stream": None, "keep": []}
+# ---- how the LoRA weight gradients of a backward pass are launched ------------------------------------------------
+# dW_down / dW_up are leaves of the backward graph (only the optimizer reads them), while the dX chain is a long sequence of
+# small, latency-bound kernels.  A WgradContext says what a layer's backward does with its (U, x, T, dY):
+#   immediate   one launch per layer (the default: any trainer, any thread, nothing to flush)
+#   grouped     collect every layer's operands; flush() computes all pairs in ONE launch at the end of the backward pass
+#   side        each layer's launch goes to a second HIP stream ordered behind the dX kernel by an event; join() at the end
+#               (under hipGraph capture: a parallel branch; measured slower on ROCm 7.2, kept as an option)
+# The context is an OBJECT owned by whoever drives the step (NativeTrainer, a graphed-module entry), made current around the
+# FORWARD (`with wgrad_context(c): pred = unet(...)`); every autograd node records the context it was built under and its backward —
+# on the autograd engine's thread — talks to that object only.  No process-global flag is read or flipped during backward: two
+# trainers (a UNet and a second model) in one process cannot see each other's settings.
+import threading
+from contextlib import contextmanager
 
 
-def enable_wgrad_side_stream(flag=True):
-    _side["enabled"] = bool(flag)
+class WgradContext:
+    def __init__(self, grouped=False, side_stream=False):
+        self.grouped, self.side = bool(grouped), bool(side_stream)
+        self.items, self.keep = [], []            # grouped: pending operands / what the last grouped launch keeps alive (hipGraph replays)
+        self.stream, self.side_keep = None, []
+
+    def add(self, U, x2, gd, T, dy2, gu, rank, alpha, slot0=0):
+        if self.grouped:
+            self.items.append((U, x2, gd, T, dy2, gu, rank, alpha, slot0))
+            return
+        if slot0 != 0 or not dy2.is_contiguous():     # member of a fused group: the grouped entry point handles slots / strides
+            self.keep = [K.lora_wgrad_grouped([(U, x2, gd, T, dy2, gu, rank, alpha, slot0)])]
+            return
+        if not (self.side and x2.is_cuda):
+            K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
+            return
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=x2.device)
+        ev = torch.cuda.Event()
+        ev.record()                                   # after the dX kernel (U is complete)
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
+        self.side_keep.append((U, x2, T, dy2))        # the allocator must not recycle these before the side kernel ran
+
+    def flush(self):
+        """grouped: all collected layers' weight gradients as one launch."""
+        if self.items:
+            keep = K.lora_wgrad_grouped(self.items)
+            self.keep = [keep, self.items]            # descriptor table + operand tensors stay alive (hipGraph replays)
+            self.items = []
+
+    def join(self):
+        """side: make the current stream wait for every launch on the side stream; release the tensors kept alive for it."""
+        if self.stream is not None and self.side_keep:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.side_keep.clear()
 
 
-def join_side_stream():
-    """Make the current stream wait for every wgrad launched on the side stream; release the tensors kept alive for it."""
-    if _side["stream"] is not None and _side["keep"]:
-        torch.cuda.current_stream().wait_stream(_side["stream"])
-    _side["keep"].clear()
+_IMMEDIATE = WgradContext()
+_tls = threading.local()
 
 
-# ---- grouped LoRA weight gradients -------------------------------------------------------------------------------
-# dW_down / dW_up are leaves of the backward graph: instead of one small launch per layer inside the latency-bound
-# dX chain, the trainer collects (U, x, T, dY) of every layer and computes all 160 pairs in ONE launch at the end.
-_group = {"enabled": False, "items": [], "keep": []}
+def current_wgrad():
+    return getattr(_tls, "ctx", None) or _IMMEDIATE
 
 
-def enable_grouped_wgrad(flag=True):
-    _group["enabled"] = bool(flag)
-
-
-def flush_grouped_wgrad():
-    if _group["items"]:
-        keep = K.lora_wgrad_grouped(_group["items"])
-        _group["keep"] = [keep, _group["items"]]      # descriptor table + operand tensors stay alive (hipGraph replays)
-        _group["items"] = []
-
-
-def _wgrad(U, x2, gd, T, dy2, gu, rank, alpha, slot0=0):
-    if _group["enabled"]:
-        _group["items"].append((U, x2, gd, T, dy2, gu, rank, alpha, slot0))
-        return
-    if slot0 != 0 or not dy2.is_contiguous():     # member of a fused group: the grouped entry point handles slots / strides
-        _group["keep"] = [K.lora_wgrad_grouped([(U, x2, gd, T, dy2, gu, rank, alpha, slot0)])]
-        return
-    if not (_side["enabled"] and x2.is_cuda):
-        K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
-        return
-    if _side["stream"] is None:
-        _side["stream"] = torch.cuda.Stream(device=x2.device)
-    ev = torch.cuda.Event()
-    ev.record()                                   # after the dX kernel (U is complete)
-    _side["stream"].wait_event(ev)
-    with torch.cuda.stream(_side["stream"]):
-        K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
-    _side["keep"].append((U, x2, T, dy2))         # the allocator must not recycle these before the side kernel ran
+@contextmanager
+def wgrad_context(ctx):
+    prev = getattr(_tls, "ctx", None)
+    _tls.ctx = ctx
+    try:
+        yield ctx
+    finally:
+        _tls.ctx = prev
 
 
 def _tr(p):
@@ -114,6 +130,7 @@ class _LinearFn(torch.autograd.Function):
         else:
             y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2, out_f32=out_f32)
         ctx.host, ctx.lora = host, lora
+        ctx.wg = current_wgrad()
         ctx.train_w, ctx.train_b = hw is not None, hb is not None
         ctx.save_for_backward(x2 if (lora is not None or hw is not None) else None, T)
         ctx.xshape = shp
@@ -147,7 +164,7 @@ class _LinearFn(torch.autograd.Function):
                 U = K.gemm(dy2, lp.but)
             for blk, s0 in lora.members():             # one block, or several sharing the 32 rank slots (lora.MultiLora)
                 gd, gu = blk.grad_views()
-                _wgrad(U, x2, gd, T, dy2, gu, blk.rank, blk.alpha_f, s0)
+                ctx.wg.add(U, x2, gd, T, dy2, gu, blk.rank, blk.alpha_f, s0)
         elif ctx.needs_input_grad[0]:
             dx = K.gemm(dy2, pk.wt)
         if ctx.train_w:                                # dW[N,K] += dY^T X (nn.Linear [N,K]; 1x1 conv [N,K,1,1] = same memory)
@@ -185,6 +202,7 @@ class _LinearGroupFn(torch.autograd.Function):
         else:
             y = K.gemm(x2, w)
         ctx.group = group
+        ctx.wg = current_wgrad()
         ctx.save_for_backward(x2 if group.has_lora else None, T)
         ctx.xshape = shp
         return y.view(*shp[:-1], group.n_total)
@@ -207,7 +225,7 @@ class _LinearGroupFn(torch.autograd.Function):
             for blk, n0, s0, host, sc_ in zip(g.blocks, g.n_off, g.slot_off, g.hosts, g.out_scale):
                 if blk is not None:
                     gd, gu = blk.grad_views()
-                    _wgrad(U, x2, gd, T, dy2[:, n0:n0 + host.weight.shape[0]], gu, blk.rank, blk.alpha_f * sc_, s0)
+                    ctx.wg.add(U, x2, gd, T, dy2[:, n0:n0 + host.weight.shape[0]], gu, blk.rank, blk.alpha_f * sc_, s0)
         elif ctx.needs_input_grad[0]:
             dx = K.gemm(dy2, wt)
         if dx is not None:

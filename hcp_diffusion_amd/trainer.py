@@ -157,6 +157,7 @@ class NativeTrainer:
         # every fork/join edge of the hipGraph costs more than the overlap buys); one grouped launch at the end wins.
         self.overlap_wgrad = overlap_wgrad and self.device.type == "cuda"
         self.grouped_wgrad = grouped_wgrad
+        self._wgrad_ctx = ops.WgradContext(grouped=grouped_wgrad, side_stream=self.overlap_wgrad)   # this trainer's own (no process-global switch)
         self._graph_cache = {}           # batch signature -> (forward/backward graph, static inputs, loss tensor)
         self._opt_graph = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -184,19 +185,21 @@ class NativeTrainer:
         """attn_mask: the batch's ``attn_mask`` [B, L] (train_ac.py:473; wrapper.py:20,29 hands it to the text encoder as
         attention_mask and to the UNet as encoder_attention_mask)."""
         noisy, noise, t = self.make_noise(latents)
-        if encoder_hidden_states is None:                                 # wrapper.py:20: the prompt is encoded inside the step
-            if self.text_encoder is None or prompt_ids is None:
-                raise ValueError("a batch needs encoder_hidden_states, or prompt_ids together with a text_encoder")
-            with torch.set_grad_enabled(self.te_bucket is not None):
-                encoder_hidden_states = self.text_encoder(prompt_ids, attention_mask=attn_mask)
-        if plugin_input:                                                  # wrapper.py:15,25-28: feeders see the batch dict
-            for feeder in getattr(self.unet, "input_feeder", []):
-                feeder(dict(noisy_latents=noisy, timesteps=t, encoder_hidden_states=encoder_hidden_states, **plugin_input))
         kw = {"encoder_attention_mask": attn_mask} if attn_mask is not None else {}
-        if added_cond_kwargs:                                             # SDXL: wrapper.py:66-73
-            pred = self.unet(noisy, t, encoder_hidden_states, added_cond_kwargs=added_cond_kwargs, **kw).sample
-        else:
-            pred = self.unet(noisy, t, encoder_hidden_states, **kw).sample      # wrapper.py:29
+        wg = self._wgrad_ctx
+        with ops.wgrad_context(wg):                                       # this step's autograd nodes report their LoRA weight gradients to `wg`
+            if encoder_hidden_states is None:                             # wrapper.py:20: the prompt is encoded inside the step
+                if self.text_encoder is None or prompt_ids is None:
+                    raise ValueError("a batch needs encoder_hidden_states, or prompt_ids together with a text_encoder")
+                with torch.set_grad_enabled(self.te_bucket is not None):
+                    encoder_hidden_states = self.text_encoder(prompt_ids, attention_mask=attn_mask)
+            if plugin_input:                                              # wrapper.py:15,25-28: feeders see the batch dict
+                for feeder in getattr(self.unet, "input_feeder", []):
+                    feeder(dict(noisy_latents=noisy, timesteps=t, encoder_hidden_states=encoder_hidden_states, **plugin_input))
+            if added_cond_kwargs:                                         # SDXL: wrapper.py:66-73
+                pred = self.unet(noisy, t, encoder_hidden_states, added_cond_kwargs=added_cond_kwargs, **kw).sample
+            else:
+                pred = self.unet(noisy, t, encoder_hidden_states, **kw).sample      # wrapper.py:29
         sw = K.snr_loss_weight(t, self.acp, self.loss_kind, self.loss_gamma) if self.loss_kind else None
         lw = self.loss_weight / self.accum                                # accelerator.accumulate: micro-step losses average
         if self.loss_type == "eps":                                       # train_ac.py:458-459: target = noise
@@ -206,15 +209,12 @@ class NativeTrainer:
             w_s = ((1.0 - a) / a).view(-1)
             sw = w_s if sw is None else sw * w_s
             loss, grad = K.mse_masked_mean(pred.detach(), noise, mask, weight=lw, sample_weight=sw)
-        ops.enable_wgrad_side_stream(self.overlap_wgrad)
-        ops.enable_grouped_wgrad(self.grouped_wgrad)
         try:
             torch.autograd.backward(pred, grad)
-            ops.flush_grouped_wgrad()            # all layers' LoRA weight gradients: one grouped launch
+            wg.flush()                           # all layers' LoRA weight gradients: one grouped launch
         finally:
-            ops.join_side_stream()
-            ops.enable_wgrad_side_stream(False)
-            ops.enable_grouped_wgrad(False)
+            wg.items.clear()                     # (an exception mid-backward must not leak operands into the next step)
+            wg.join()
         return loss
 
     def _states(self):

@@ -55,7 +55,12 @@ def _ckpt(module, fn, *args, **kwargs):
     enable_gradient_checkpointing() is called."""
     if getattr(module, "gradient_checkpointing", False) and torch.is_grad_enabled():
         from torch.utils.checkpoint import checkpoint
-        return checkpoint(fn, *args, use_reentrant=False, preserve_rng_state=False, **kwargs)
+        wg = ops.current_wgrad()                       # the recompute runs on the autograd thread: its nodes belong to the same step
+
+        def run(*a, **k):
+            with ops.wgrad_context(wg):
+                return fn(*a, **k)
+        return checkpoint(run, *args, use_reentrant=False, preserve_rng_state=False, **kwargs)
     return fn(*args, **kwargs)
 
 
@@ -495,18 +500,20 @@ class NativeUNet2DConditionModel(nn.Module):
         allp = K.gemm(temb_act.reshape(-1, temb_act.shape[-1]), w, bias=b, out_f32=True)        # [B, sum Cout] fp32
         temb_act._hcp_tb = {id(r): allp[:, o:o + r.time_emb_proj.weight.shape[0]] for r, o in zip(res, offs)}
 
-    def enable_hip_graph(self, on=True):
+    def enable_hip_graph(self, on=True, _recorded_on_cpu=False):
         """Replay the forward and the backward of `unet(...)` as captured hipGraphs when an ordinary trainer calls the module in grad
-        mode (LoRA-only training; see graphed.py).  Call again (or `reset_hip_graph()`) after adding / removing LoRA layers."""
-        self._hip_graph, self._hip_graphs = bool(on), {}
+        mode (LoRA and / or host parameters training, alone or under torch DDP; see graphed.py).  Call again (or `reset_hip_graph()`)
+        after adding / removing LoRA layers or changing what trains.  `_recorded_on_cpu`: tests only — the same wiring with recorded
+        callables in place of graphs on the interpreter backend."""
+        self._hip_graph, self._hip_graphs, self._hip_graph_cpu = bool(on), {}, bool(_recorded_on_cpu)
 
     def reset_hip_graph(self):
         self._hip_graphs = {}
 
     def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, added_cond_kwargs=None,
                 cross_attention_kwargs=None, **kwargs):
-        if (getattr(self, "_hip_graph", False) and torch.is_grad_enabled() and sample.is_cuda and torch.is_tensor(timestep)
-                and not torch.cuda.is_current_stream_capturing()):
+        if (getattr(self, "_hip_graph", False) and torch.is_grad_enabled() and torch.is_tensor(timestep)
+                and ((sample.is_cuda and not torch.cuda.is_current_stream_capturing()) or getattr(self, "_hip_graph_cpu", False))):
             from . import graphed
             if graphed.capturable(self):
                 added = added_cond_kwargs or {}

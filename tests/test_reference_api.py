@@ -55,8 +55,10 @@ mgr = CkptManagerSafe(); mgr.set_save_dir(d)
 mgr.save_model_with_lora(u, group, name="unet", step=1)
 u2 = seeded_init_(NativeUNet2DConditionModel(**MICRO_CONFIG), 1); u2.requires_grad_(False)
 g2, _ = NativeModelLoader(u2).load_lora([dict(path=os.path.join(d, "unet-1.safetensors"), alpha=1.0)])
+def same(a, b):        # (u runs the fused q|k|v group — q pre-scaled for the attention kernel —, the freshly loaded blocks the per-layer
+    return ((a - b).norm() / b.norm()).item() < 2e-2      # path until they are bucketed: same model, two bf16 evaluation orders (1.3e-2 measured))
 with torch.no_grad():
-    assert torch.equal(u2(x, t, ehs).sample, y.detach())
+    assert same(u2(x, t, ehs).sample, y.detach())
 # ... and the reference's OWN HCPModelLoader.load_lora does too once its registry's default entry points at the native class
 # (get_lora_rank_and_cls hard-codes lora_layer_map['lora'], cfg_net_tools.py:77-88)
 llp.lora_layer_map["lora"] = LoraHipLayer
@@ -64,7 +66,7 @@ u3 = seeded_init_(NativeUNet2DConditionModel(**MICRO_CONFIG), 1); u3.requires_gr
 g3 = tools.HCPModelLoader(u3).load_lora([_Item(path=os.path.join(d, "unet-1.safetensors"), alpha=1.0)])
 assert len(g3.plugin_dict) == 40 and all(isinstance(b, LoraHipLayer) for b in g3.plugin_dict.values())
 with torch.no_grad():
-    assert torch.equal(u3(x, t, ehs).sample, y.detach())
+    assert same(u3(x, t, ehs).sample, y.detach())
 group.remove()                                            # PluginGroup.remove -> PatchPluginBlock.remove restores the plain hosts
 assert type(u.down_blocks[0].attentions[0].transformer_blocks[0].attn1.to_q).__name__ == "HipLinear"
 # --- seam 3: the reference's make_plugin builds the native ControlNet (cfg_net_tools.py:130-162, plugin_controlnet.yaml)
