@@ -209,14 +209,30 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product path has no CPU fallback)"
-    assert torch.cuda.device_count() >= (args.gpus if world > 1 else 1), \
-        f"--gpus {args.gpus} but only {torch.cuda.device_count()} visible"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TEST SWITCH (tests/test_bench.py only; never set by the driver): the same launcher, rank plumbing, trainer and JSON line on
+    # the CPU interpreter build of the kernels with gloo and a two-level miniature UNet — so that the first multi-rank run of this file
+    # is not the one on the driver's 8-GPU node.  Timings of such a run mean nothing and the line says so.
+    emu = os.environ.get("HCP_BENCH_BACKEND") == "emu"
+    if emu:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        from conftest import emu_cdll
+        from hcp_diffusion_amd import kernels as _K
+        _K._set_backend_for_tests(emu_cdll())
+        dev = torch.device("cpu")
+        args.no_graph, args.no_cpu_baseline, args.no_ckpt_line = True, True, True
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.distributed.init_process_group("gloo")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product path has no CPU fallback)"
+        assert torch.cuda.device_count() >= (args.gpus if world > 1 else 1), \
+            f"--gpus {args.gpus} but only {torch.cuda.device_count()} visible"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.distributed.init_process_group("nccl", device_id=dev)       # nccl == RCCL on ROCm
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)       # nccl == RCCL on ROCm
         assert torch.distributed.get_world_size() == args.gpus
 
     from hcp_diffusion_amd.comm import make_comm
@@ -231,9 +247,16 @@ def main():
     args.batch = args.batch or (2 if (sdxl or fullft) else 4)
     args.rank_lora = args.rank_lora or (16 if sdxl else 8)
     torch.manual_seed(114514)                      # same weights on every rank (train_base.yaml:5)
-    with torch.device("meta"):
-        unet = NativeUNet2DConditionModel(**SDXL_CONFIG) if sdxl else NativeUNet2DConditionModel()
-    unet = unet.to_empty(device=dev)
+    lat_hw, ctx_dim = (128 if sdxl else 64), (2048 if sdxl else 768)
+    if emu:                                        # two-level miniature with the SD1.5 block types (head dims 40 / 80), 8x8 latents
+        lat_hw, ctx_dim = 8, 32
+        cfg = dict(block_out_channels=(40, 80), layers_per_block=1, num_attention_heads=1, cross_attention_dim=32, norm_num_groups=8,
+                   down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+        unet = NativeUNet2DConditionModel(**cfg)
+    else:
+        with torch.device("meta"):
+            unet = NativeUNet2DConditionModel(**SDXL_CONFIG) if sdxl else NativeUNet2DConditionModel()
+        unet = unet.to_empty(device=dev)
     with torch.no_grad():                          # random-init weights of the SD1.5 architecture, generated on the GPU
         for name, p in unet.named_parameters():
             if p.dim() > 1:
@@ -293,13 +316,13 @@ def main():
     B = args.batch
     added = None
     if sdxl:                                       # [2,4,128,128], ctx [2,77,2048], pooled [2,1280], crop_info [2,6]
-        latents = torch.randn(B, 4, 128, 128, device=dev)
-        ehs = torch.randn(B, 77, 2048, device=dev).to(torch.bfloat16)
+        latents = torch.randn(B, 4, lat_hw, lat_hw, device=dev)
+        ehs = torch.randn(B, 77, ctx_dim, device=dev).to(torch.bfloat16)
         added = dict(text_embeds=torch.randn(B, 1280, device=dev),
                      time_ids=torch.tensor([[1024.0, 1024.0, 0.0, 0.0, 1024.0, 1024.0]] * B, device=dev))
     else:
-        latents = torch.randn(B, 4, 64, 64, device=dev)
-        ehs = torch.randn(B, 77, 768, device=dev).to(torch.bfloat16)
+        latents = torch.randn(B, 4, lat_hw, lat_hw, device=dev)
+        ehs = torch.randn(B, 77, ctx_dim, device=dev).to(torch.bfloat16)
 
     prompt_ids = None
     if te:                                         # random token ids in [0, 49407], BOS / EOS at the ends; no precomputed states
@@ -310,19 +333,23 @@ def main():
     def sync():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if not emu:
+            torch.cuda.synchronize()
 
     if args.seam:
         # What the reference's Trainer does with the native modules behind its seams (tests/test_reference_trainer.py runs its
         # real code on the CPU interpreter; /root/reference does not exist on the GPU box, so the loop is restated here):
         # TEUnetWrapper-style module call, MSE(reduction none).mean(), loss.backward(), accelerator.clip_grad_norm_,
         # optimizer.step(), zero_grad(set_to_none=False), loss.item().
-        assert args.workload == "sd15" and world == 1
+        assert args.workload in ("sd15", "dreambooth") and world == 1
         from hcp_diffusion_amd.optim import FusedAdamW
         from hcp_diffusion_amd.scheduler import NativeDDPMScheduler
         sched = NativeDDPMScheduler()
-        params = [p for blk in tr.bucket.blocks for p in (blk.layer.W_down, blk.layer.W_up)]
-        opt = (FusedAdamW if args.seam_optimizer == "fused" else torch.optim.AdamW)([dict(params=params, lr=1e-4 * B)], weight_decay=1e-3)
+        if fullft:                                 # DreamBooth.yaml:6-10: every UNet parameter (the flat HostBucket NativeTrainer built is reused by the module graph)
+            params = [p for p in unet.parameters() if p.requires_grad]
+        else:
+            params = [p for blk in tr.bucket.blocks for p in (blk.layer.W_down, blk.layer.W_up)]
+        opt = (FusedAdamW if args.seam_optimizer == "fused" else torch.optim.AdamW)([dict(params=params, lr=(1e-6 if fullft else 1e-4) * B)], weight_decay=1e-3)
         crit = torch.nn.MSELoss(reduction="none")
         if args.seam_graph:
             unet.enable_hip_graph()
@@ -333,7 +360,7 @@ def main():
             pred = unet(sched.add_noise(latents, noise, t), t, ehs).sample
             loss = crit(pred.float(), noise.float()).mean()
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(unet.parameters(), 1.0)
+            torch.nn.utils.clip_grad_norm_(params, 1.0)              # accelerator.clip_grad_norm_(TE_unet.trainable_parameters(), ...), train_ac.py:485-490
             opt.step()
             opt.zero_grad(set_to_none=False)
             return loss.item()
@@ -345,12 +372,13 @@ def main():
             lv = seam_step()
         sync()
         dt = time.perf_counter() - t0
-        print(json.dumps({"metric": "training images/sec, SD1.5 LoRA 512px bs=4, native modules driven the reference trainer's way (eager seam)",
+        print(json.dumps({"metric": ("training images/sec, SD1.5 full fine-tune (DreamBooth) 512px bs=%d" % B if fullft else "training images/sec, SD1.5 LoRA 512px bs=4") +
+                                    ", native modules driven the reference trainer's way (eager seam)",
                           "value": round(B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "optimizer": args.seam_optimizer, "unet_hip_graph": bool(args.seam_graph),
                           "final_loss": round(lv, 5),
-                          "config": {"workload": "SD1.5 UNet LoRA rank=%d bf16 bs=%d, eager, clip_grad_norm_ + %s AdamW + loss.item() per step" %
-                                     (args.rank_lora, B, args.seam_optimizer)}}), flush=True)
+                          "config": {"workload": ("SD1.5 UNet full fine-tune bf16 bs=%d" % B if fullft else "SD1.5 UNet LoRA rank=%d bf16 bs=%d" % (args.rank_lora, B)) +
+                                     ", eager loop, clip_grad_norm_ + %s AdamW + loss.item() per step" % args.seam_optimizer}}), flush=True)
         return
     for _ in range(args.warmup):
         tr.train_one_step(latents, ehs, None, added, plugin_input, prompt_ids)
@@ -413,6 +441,14 @@ def main():
                                    "steps": k2, "note": "same workload with enable_gradient_checkpointing() (+1 forward per step)"}
             unet.disable_gradient_checkpointing()
             tr._graph_cache.clear()
+        if emu:
+            out["data"] = "synthetic (HCP_BENCH_BACKEND=emu: launcher / rank plumbing check on the CPU interpreter, timings meaningless)"
+            out["config"]["comm"] = "gloo via torch.distributed" if world > 1 else "none"
+            print(json.dumps(out), flush=True)
+            if world > 1:
+                torch.distributed.barrier()
+                torch.distributed.destroy_process_group()
+            return
         out["roofline"] = dominant_kernel_roofline(dev)
         out["roofline_attention"] = attention_roofline(dev)
         if world == 1 and not args.no_cpu_baseline and args.workload == "sd15":

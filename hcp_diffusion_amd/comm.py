@@ -103,9 +103,31 @@ class AbiComm:
         """Bootstrap over an initialised torch.distributed group: rank 0 publishes the token via broadcast_object_list."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.new_unique_id() if rank == 0 else None]
+        err = None
+        try:
+            box = [cls.new_unique_id() if rank == 0 else None]
+        except RuntimeError as e_:                    # librccl.so missing / without a symbol on rank 0: tell everybody instead of leaving them waiting
+            box, err = [None], e_
         dist.broadcast_object_list(box, src=0, group=group)
-        return cls(rank, world, box[0], device)
+        comm = None
+        if box[0] is not None:
+            try:
+                comm = cls(rank, world, box[0], device)
+            except RuntimeError as e_:
+                err = e_
+        # every rank learns whether EVERY rank has a communicator (one small all-reduce on the bootstrap group, which has its own
+        # timeout): a partial failure must not leave the healthy ranks inside their first collective forever
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32,
+                          device=device if dist.get_backend(group) != "gloo" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            return comm
+        if comm is not None:
+            comm.close()
+        import warnings
+        warnings.warn(f"hcp_diffusion_amd: RCCL through the C ABI could not be initialised on every rank ({err or 'another rank failed'}); "
+                      "falling back to torch.distributed collectives for the gradient exchange", RuntimeWarning)
+        return TorchComm(group)
 
     def _s(self, t):
         assert t.is_cuda and t.is_contiguous() and t.dtype in _DT, "AbiComm: contiguous fp32/bf16 device tensors"

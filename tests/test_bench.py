@@ -19,6 +19,47 @@ def test_bench_refuses_a_world_that_is_not_one_rank_per_gpu():
     assert "--gpus 2 but WORLD_SIZE=1" in (r.stderr + r.stdout)
 
 
+@pytest.mark.slow
+def test_bench_launcher_runs_two_ranks_end_to_end():
+    """`python bench.py --gpus 2` is its own launcher (re-executes under torch.distributed.run, one rank per device).  With the test switch
+    HCP_BENCH_BACKEND=emu the very same code path — exec, rendezvous on 127.0.0.1, process group, NativeTrainer with the exchange, timed
+    loop, MAX over ranks, ONE JSON line from rank 0 — runs on the CPU interpreter with gloo: the first 2-rank execution of this file
+    must not be the driver's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HCP_BENCH_BACKEND="emu", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", "--rank-lora", "4"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0 and "emu" in d["data"]
+
+
+def test_abi_comm_bootstrap_falls_back_loudly_when_rccl_cannot_start(monkeypatch):
+    """AbiComm.from_torch_store on a machine where the C-ABI communicator cannot be created (here: the interpreter build refuses
+    world > 1... emulated with a world of 1 and a failing init) warns and hands back torch.distributed collectives instead of raising
+    on one rank while the others wait."""
+    import torch
+    import torch.distributed as dist
+    from hcp_diffusion_amd import comm as C
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29000 + os.getpid() % 2000))
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(C.AbiComm, "new_unique_id", staticmethod(lambda: b"\0" * 128))
+
+        def boom(self, *a, **k):
+            raise RuntimeError("hcp_comm_init: librccl.so not found")
+        monkeypatch.setattr(C.AbiComm, "__init__", boom)
+        with pytest.warns(RuntimeWarning, match="falling back to torch.distributed"):
+            c = C.AbiComm.from_torch_store(torch.device("cpu"))
+        assert isinstance(c, C.TorchComm) and c.world == 1
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.gpu
 def test_bench_json_line_contract():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-ckpt-line"],
