@@ -147,3 +147,83 @@ def load_reference_trainer():
     train_ac = importlib.import_module("hcpdiff.train_ac")
     single = importlib.import_module("hcpdiff.train_ac_single")
     return train_ac, single
+
+
+class ShimDDIMScheduler:
+    """Stand-in for the diffusers scheduler object the reference's pipeline drives (pipe_hook.py:85-87,121-122,139-140): Stable
+    Diffusion's DDIM configuration (prediction_type 'epsilon', eta 0, clip_sample False, set_alpha_to_one False, timestep_spacing
+    'leading', steps_offset 1) [ext] — the arithmetic of oracle/sampler_ref.cfg_ddim_step behind diffusers' method names."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000):
+        import torch
+        from oracle.unet_sd15 import ddpm_alphas_cumprod
+        self.alphas_cumprod = ddpm_alphas_cumprod(num_train_timesteps)
+        self.T = num_train_timesteps
+        self.timesteps = torch.zeros(0, dtype=torch.long)
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        import torch
+        self.ratio = self.T // num_inference_steps
+        self.timesteps = ((torch.arange(num_inference_steps) * self.ratio).flip(0) + 1).clamp(max=self.T - 1).to(device)
+
+    def scale_model_input(self, sample, t):
+        return sample
+
+    def step(self, noise_pred, t, latents, **kwargs):
+        import types
+        t = int(t)
+        prev = t - self.ratio
+        a_t = float(self.alphas_cumprod[t]); a_prev = float(self.alphas_cumprod[prev] if prev >= 0 else self.alphas_cumprod[0])
+        x0 = (latents - (1 - a_t) ** 0.5 * noise_pred) / a_t ** 0.5
+        return types.SimpleNamespace(prev_sample=a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * noise_pred)
+
+
+def load_reference_pipe():
+    """hcpdiff/utils/pipe_hook.py executed where it lies: HookPipe_T2I.__call__ (the denoising loop :116-140 with the CFG-doubled batch,
+    ``encoder_attention_mask``, SDXL ``added_cond_kwargs``) is the reference's own code.  Its diffusers base class is replaced by a
+    stand-in that provides exactly the helpers the loop calls (prepare_latents, prepare_extra_step_kwargs, progress_bar, the image
+    processor's postprocess); the inpainting pipeline it imports next to it is stubbed (out of scope)."""
+    import contextlib
+    import torch
+    load_reference_lora()
+    d = sys.modules["diffusers"]
+
+    class _Pipe:                                           # StableDiffusionPipeline's surface as HookPipe_T2I.__call__ uses it
+        vae_scale_factor = 8
+
+        def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet=None, scheduler=None, **kw):
+            self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
+            self.image_processor = types.SimpleNamespace(postprocess=lambda image, output_type=None, do_denormalize=None: image)
+
+        def prepare_extra_step_kwargs(self, generator, eta):
+            return {}
+
+        def prepare_latents(self, batch_size, channels, height, width, dtype, device, generator, latents=None):
+            if latents is None:
+                latents = torch.randn(batch_size, channels, height // 8, width // 8, generator=generator, dtype=dtype)
+            return latents.to(device) * self.scheduler.init_noise_sigma
+
+        @contextlib.contextmanager
+        def progress_bar(self, total=None):
+            yield types.SimpleNamespace(update=lambda *a: None)
+
+    d.StableDiffusionPipeline = _Pipe
+    d.StableDiffusionImg2ImgPipeline = type("StableDiffusionImg2ImgPipeline", (_Pipe,), {})
+    for modname, attrs in (("diffusers.image_processor", dict(VaeImageProcessor=type("VaeImageProcessor", (), {}))),
+                           ("diffusers.pipelines", {}),
+                           ("diffusers.pipelines.stable_diffusion", dict(StableDiffusionPipelineOutput=lambda images=None, nsfw_content_detected=None:
+                                                                      types.SimpleNamespace(images=images)))):
+        if modname not in sys.modules:
+            m = types.ModuleType(modname); m.__path__ = []
+            sys.modules[modname] = m
+        for k, v in attrs.items():
+            setattr(sys.modules[modname], k, v)
+    if "PIL" not in sys.modules:
+        import PIL  # noqa: F401
+    ip = types.ModuleType("hcpdiff.utils.inpaint_pipe")     # inpainting: out of scope (SURVEY §8); names only
+    ip.preprocess_mask = ip.preprocess_image = lambda *a, **k: None
+    ip.StableDiffusionInpaintPipelineLegacy = type("StableDiffusionInpaintPipelineLegacy", (_Pipe,), {})
+    sys.modules["hcpdiff.utils.inpaint_pipe"] = ip
+    return importlib.import_module("hcpdiff.utils.pipe_hook")

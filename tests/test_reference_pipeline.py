@@ -1,0 +1,74 @@
+"""f4 through the reference's OWN code: hcpdiff/utils/pipe_hook.py HookPipe_T2I.__call__ — the pipeline the in-training previewer
+(loggers/preview/image_previewer.py:97-149 -> ``self.pipe(prompt_embeds=..., negative_prompt_embeds=..., pooled_output=...,
+encoder_attention_mask=...)``) and the inference workflow (workflow/diffusion.py:143-149) drive — runs its denoising loop (:116-140:
+CFG-doubled batch, ONE UNet call, guidance combine, scheduler.step) UNMODIFIED over the native UNet on the interpreter, for an SD1.5-style
+call with ``encoder_attention_mask`` and an SDXL-style call with ``added_cond_kwargs``; ``NativeDDIMSampler`` (the fused on-device loop)
+must land on the same latents.  Only where /root/reference exists."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, torch
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+from oracle.ref_shims import load_reference_pipe, ShimDDIMScheduler
+pipe_hook = load_reference_pipe()
+from conftest import emu_cdll
+from hcp_diffusion_amd import kernels as K
+K._set_backend_for_tests(emu_cdll())
+from hcp_diffusion_amd.sampler import NativeDDIMSampler
+from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
+from oracle.unet_sd15 import MICRO_CONFIG, TINY_SDXL_CONFIG, OracleUNet2DConditionModel, seeded_init_
+
+class CpuPipe(pipe_hook.HookPipe_T2I):                    # the reference hard-codes torch.device('cuda') in these two properties
+    _execution_device = property(lambda self: torch.device("cpu"))
+    device = property(lambda self: torch.device("cpu"))
+
+import types
+def run(cfg, sdxl):
+    torch.manual_seed(0)
+    nat = NativeUNet2DConditionModel(**cfg)
+    nat.load_state_dict(seeded_init_(OracleUNet2DConditionModel(**cfg), 1).state_dict())
+    nat.config = dict(nat.config); nat.config.update(sample_size=8)
+    cfg_ns = types.SimpleNamespace(**nat.config)
+    unet = nat
+    class U(torch.nn.Module):                             # diffusers' `unet.config.<attr>` access on top of the native module
+        def __init__(s): super().__init__(); s.m = nat; s.config = cfg_ns
+        def forward(s, *a, cross_attention_kwargs=None, **k): return s.m(*a, **k)
+    g = torch.Generator().manual_seed(3)
+    B, L, Dc = 2, 16, cfg["cross_attention_dim"]
+    lat = torch.randn(B, 4, 8, 8, generator=g); cond = torch.randn(B, L, Dc, generator=g); unc = torch.randn(B, L, Dc, generator=g)
+    mask = torch.ones(2 * B, L); mask[:, 12:] = 0         # (the reference passes ONE mask for the doubled batch)
+    te = types.SimpleNamespace(dtype=torch.float32); vae = types.SimpleNamespace(dtype=torch.float32, config=types.SimpleNamespace(scaling_factor=0.18215))
+    pipe = CpuPipe(vae=vae, text_encoder=te, tokenizer=None, unet=U(), scheduler=ShimDDIMScheduler())
+    kw = dict(prompt_embeds=cond, negative_prompt_embeds=unc, latents=lat.clone(), num_inference_steps=4, guidance_scale=5.0, output_type="latent",
+              height=64, width=64)
+    added = uadded = None
+    if sdxl:
+        pooled = torch.randn(2 * B, 64, generator=g)      # [uncond; cond] pooled text states, as the previewer hands them over
+        ref = pipe(pooled_output=pooled, **kw).images
+        crop = torch.tensor([[64.0, 64.0, 0.0, 0.0, 64.0, 64.0]] * B)
+        added = dict(text_embeds=pooled[B:], time_ids=crop); uadded = dict(text_embeds=pooled[:B], time_ids=crop)
+        out = NativeDDIMSampler().sample(nat, lat, cond, unc, guidance_scale=5.0, num_inference_steps=4, added_cond_kwargs=added,
+                                         uncond_added_cond_kwargs=uadded)
+    else:
+        ref = pipe(encoder_attention_mask=mask, **kw).images
+        out = NativeDDIMSampler().sample(nat, lat, cond, unc, guidance_scale=5.0, num_inference_steps=4, encoder_attention_mask=mask[:B])
+    err = ((out - ref).norm() / ref.norm()).item()
+    assert ref.shape == lat.shape and torch.isfinite(ref).all() and err < 2e-3, err       # same bf16 UNet: the loops differ in fp32 rounding only
+    return err
+
+e1 = run(dict(MICRO_CONFIG), False)
+e2 = run(dict(TINY_SDXL_CONFIG), True)
+print("REFERENCE_PIPE_OK", e1, e2)
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/hcpdiff"), reason="reference tree only exists in the build container")
+def test_reference_pipeline_hook_drives_the_native_unet():
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + SCRIPT], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0 and "REFERENCE_PIPE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-5000:]
