@@ -61,6 +61,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                        "the flat AdamW moments cannot follow")
                 cached = (sig, self._build_runs(group))
                 self._runs[gi] = cached
+                self._apply_resume(group, cached[1])
             b1, b2 = group["betas"]
             for r in cached[1]:
                 r["lr"].fill_(group["lr"])
@@ -73,8 +74,66 @@ class FusedAdamW(torch.optim.Optimizer):
         """The kernel wrote through raw pointers: advance the parameters' autograd version counters, as the in-place torch ops of
         torch.optim.AdamW would have (the native layers key their bf16 operand caches on them).  No kernel, no data touched."""
         ps = [p for group in self.param_groups for p in group["params"] if p.grad is not None]
-        if hasattr(torch._C._autograd, "_unsafe_set_version_counter"):
-            torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
-        else:                                              # older torch: an in-place op on an empty slice bumps the counter
-            for p in ps:
-                p[:0].add_(0)
+        fn = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+        if fn is not None:
+            try:
+                fn(ps, [p._version + 1 for p in ps])
+                return
+            except TypeError:                              # earlier 2.x: (Tensor, int) per call
+                try:
+                    for p in ps:
+                        fn(p, p._version + 1)
+                    return
+                except TypeError:
+                    pass
+        for p in ps:                                       # any torch: an in-place op on an empty slice bumps the counter
+            p[:0].add_(0)
+
+    # ---- checkpoint / resume: the flat moments live outside `self.state` (one tensor per contiguous run, not per parameter)
+    def state_dict(self):
+        """torch's layout ({'state': {index: {...}}, 'param_groups': [...]}) with PER-PARAMETER exp_avg / exp_avg_sq / step cut out of the
+        flat runs, so that the file resumes a torch.optim.AdamW as well as a FusedAdamW (train_ac.py:370 builds either from the same cfg)."""
+        base = super().state_dict()
+        state, index = {}, 0
+        ids = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                ids[id(p)] = index; index += 1
+        for gi, group in enumerate(self.param_groups):
+            cached = self._runs.get(gi)
+            if cached is None:
+                continue
+            for r in cached[1]:
+                base_ptr, step = r["p"].data_ptr(), r["step"].item()
+                for p in group["params"]:
+                    off = (p.data_ptr() - base_ptr) // 4
+                    if p.grad is None or off < 0 or off + p.numel() > r["p"].numel() or p.untyped_storage().data_ptr() != r["p"].untyped_storage().data_ptr():
+                        continue
+                    view = lambda flat: flat[off:off + p.numel()].as_strided(p.shape, p.stride()).clone()
+                    state[ids[id(p)]] = {"step": torch.tensor(float(step)), "exp_avg": view(r["m"]), "exp_avg_sq": view(r["v"])}
+        base["state"] = state
+        return base
+
+    def load_state_dict(self, state_dict):
+        """Moments and step counts of a file written by state_dict() above or by torch.optim.AdamW over the same parameters; the flat
+        runs are (re)built on the first step, so the values wait in `_resume` until then."""
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        order = [p for group in self.param_groups for p in group["params"]]
+        self._resume = {id(order[int(i)]): st for i, st in state_dict.get("state", {}).items()}
+        self._runs = {}
+
+    def _apply_resume(self, group, runs):
+        res = getattr(self, "_resume", None)
+        if not res:
+            return
+        for r in runs:
+            base_ptr = r["p"].data_ptr()
+            for p in group["params"]:
+                st = res.get(id(p))
+                off = (p.data_ptr() - base_ptr) // 4
+                if st is None or p.grad is None or off < 0 or off + p.numel() > r["p"].numel() or \
+                        p.untyped_storage().data_ptr() != r["p"].untyped_storage().data_ptr():
+                    continue
+                for name, flat in (("exp_avg", r["m"]), ("exp_avg_sq", r["v"])):
+                    flat[off:off + p.numel()].as_strided(p.shape, p.stride()).copy_(st[name].to(flat.device))
+                r["step"].fill_(int(float(st["step"])))

@@ -63,6 +63,21 @@ class _OptState:
         return [self.exp_avg, self.exp_avg_sq, self.sumsq] + self.lrs + self.steps + ([self.ema] if hasattr(self, "ema") else [])
 
 
+class _WarmupComm(NullComm):
+    """Local stand-in for the communicator during a graph warm-up: same world / rank (slices keep their shapes), no traffic."""
+
+    def __init__(self, real):
+        self.world, self.rank = real.world, real.rank
+
+    def reduce_scatter(self, send, recv):
+        recv.copy_(send[self.rank * recv.numel():(self.rank + 1) * recv.numel()])
+        return recv
+
+    def all_gather(self, send, recv):
+        recv[self.rank * send.numel():(self.rank + 1) * send.numel()].copy_(send)
+        return recv
+
+
 class NativeTrainer:
     def __init__(self, unet, lora_cfg=None, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000,
@@ -432,11 +447,17 @@ class NativeTrainer:
         saved = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self._run_all(static)
-                self.all_reduce()
-                self.optimizer_step()
+        # The warm-up exchanges NOTHING: a rank that meets a new batch signature alone (a data pipeline that does not hand every rank
+        # the same shape on the same step) must not issue collectives its peers do not — NullComm stands in while it runs.
+        comm, self.comm = self.comm, _WarmupComm(self.comm)
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._run_all(static)
+                    self.all_reduce()
+                    self.optimizer_step()
+        finally:
+            self.comm = comm
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._restore(saved)
