@@ -115,3 +115,11 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
     assert rc < 0 and b"causal" in lib.hcp_last_error()
     rc = lib.hcp_attention_fwd(one, one, one, one, one, 1, 1, 8, 8, 48, 0, 48, 0, 48, 0, 48, 0, 48, 0.1, None, 0, 0, None)
     assert rc < 0 and b"head_dim" in lib.hcp_last_error()
+
+
+def test_integration_doc_quotes_the_shipped_overlay():
+    """INTEGRATION.md shows the seam-1 YAML a maintainer copies: it must BE the shipped file, not a paraphrase of it."""
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    yaml = (root / "cfgs" / "train" / "mi355x" / "lora_sd15_hip.yaml").read_text()
+    assert yaml in (root / "INTEGRATION.md").read_text()
