@@ -5,7 +5,7 @@ set -u
 out=$1; shift; shift
 mkdir -p "$out"
 export TMPDIR=/tmp
-groups=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS")
+groups=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES")
 i=0
 for g in "${groups[@]}"; do
   rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$out/p$i" -o pmc -- "$@" > "$out/p$i.log" 2>&1 || echo "pass $i ($g) failed, see $out/p$i.log"

@@ -12,8 +12,9 @@ dev = torch.device("cuda:0")
 x = torch.randn(4, 64, 64, 320, device=dev).to(torch.bfloat16)
 w = (torch.randn(320, 3, 3, 320, device=dev) * 0.02).to(torch.bfloat16)
 q, k, v, do = [torch.randn(4, 4096, 320, device=dev).to(torch.bfloat16) for _ in range(4)]
+q = (q.float() * (40 ** -0.5 * 1.4426950408889634)).to(torch.bfloat16)      # the form the UNet calls the kernels in: pre-scaled Q
 for _ in range(4):
     K.conv3x3(x, w, 320)
-    o, lse = K.attention_fwd(q, k, v, 8)
-    K.attention_bwd(q, k, v, o, do, lse, 8)
+    o, lse = K.attention_fwd(q, k, v, 8, q_prescaled=True)
+    K.attention_bwd(q, k, v, o, do, lse, 8, q_prescaled=True)
 torch.cuda.synchronize()
