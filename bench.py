@@ -191,6 +191,9 @@ def main():
     ap.add_argument("--comm", choices=["torch", "abi"], default=os.environ.get("HCP_COMM", "torch"),
                     help="gradient exchange: torch.distributed (backend nccl = RCCL) or RCCL through the C ABI (hcp_allreduce_flat / "
                          "hcp_reduce_scatter_flat / hcp_allgather_flat, csrc/comm.hip)")
+    ap.add_argument("--exchange", choices=["plain", "overlap", "overlap-bf16"], default="plain",
+                    help="sharded host buckets (dreambooth / controlnet, N > 1): 'overlap' = chunks reduce-scattered from backward on a side "
+                         "stream; 'overlap-bf16' = also bf16 gradients and parameters on the wire (DDP bf16_compress_hook numerics)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -268,6 +271,7 @@ def main():
     if args.grad_ckpt:
         unet.enable_gradient_checkpointing()
     plugin_input = None
+    xkw = dict(overlap_exchange=args.exchange != "plain", **(dict(grad_wire="bf16", param_wire="bf16") if args.exchange == "overlap-bf16" else {}))
     if cnet:                                       # cfgs/plugins/plugin_controlnet.yaml: frozen host + trainable branch, lr 1e-4
         from hcp_diffusion_amd.controlnet import make_controlnet
         plug = make_controlnet(unet)
@@ -275,12 +279,12 @@ def main():
             for m in list(plug.controlnet_down_blocks) + [plug.controlnet_mid_block, plug.cond_head[-1]]:
                 m.weight.normal_(0, 0.02)          # time the steady state ("after some training") instead
         tr = NativeTrainer(unet, None, lr=1e-4, weight_decay=1e-3, scale_lr_factor=args.batch * world, use_graph=not args.no_graph,
-                           plugins=[(plug, 1e-4)], comm=comm)
+                           plugins=[(plug, 1e-4)], comm=comm, **xkw)
         torch.manual_seed(114514 + rank)
         plugin_input = dict(cond=torch.rand(args.batch, 3, 512, 512, device=dev))
     elif fullft:                                   # cfgs/train/examples/DreamBooth.yaml:6-10: unet: [{lr: 1e-6, layers: ['']}]
         tr = NativeTrainer(unet, None, lr=1e-6, weight_decay=1e-3, scale_lr_factor=args.batch * world, use_graph=not args.no_graph,
-                           train_cfg=[dict(layers=[""], lr=1e-6)], comm=comm)
+                           train_cfg=[dict(layers=[""], lr=1e-6)], comm=comm, **xkw)
         torch.manual_seed(114514 + rank)
     else:
         text_encoder = None
@@ -414,7 +418,7 @@ def main():
                                     "grad-ckpt off" % (args.rank_lora, B) if te else
                                     "SD1.5 UNet LoRA rank=%d bf16, bs=%d/GPU, 512x512 (64x64 latents), 77-token context, "
                                     "random-init weights, cached latents, grad-ckpt off" % (args.rank_lora, B)),
-                       "global_batch": B * world, "parallelism": f"dp{world}", "rccl_ranks": world,
+                       "global_batch": B * world, "parallelism": f"dp{world}", "rccl_ranks": world, **({"exchange": args.exchange} if (fullft or cnet) else {}),
                        "comm": ("RCCL via " + ("C ABI (hcp_allreduce_flat)" if args.comm == "abi" else "torch.distributed")) if world > 1 else "none",
                        "hip_graph": not args.no_graph,
                        "gradient_checkpointing": bool(args.grad_ckpt)},

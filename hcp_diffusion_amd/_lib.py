@@ -57,6 +57,9 @@ _PROTOTYPES = {
     "hcp_colsum_bf16": (I, [P, I, P, I, I, I, I, P]),
     # ema, p, n, step, inv_gamma, power, decay_max, stream
     "hcp_ema_update": (I, [P, P, L, P, F, F, F, P]),
+    # src, dst_bf16, n, scale, zero_src, stream / src_bf16, dst, n, stream
+    "hcp_cast_f32_bf16": (I, [P, P, L, F, I, P]),
+    "hcp_cast_bf16_f32": (I, [P, P, L, P]),
     "hcp_pack_piece_bytes": (I, []),
     # pieces, count, total_tiles, stream
     "hcp_pack_weights": (I, [P, I, I, P]),

@@ -66,6 +66,37 @@ HCP_KERNEL(256) ema_kernel(float* ema, const float* p, long n, const int* step_p
     }
 }
 
+// Wire formats of the sharded exchange: dst_bf16[i] = bf16(src[i] * scale) (optionally clearing src: the zero_grad of a bucket whose
+// gradients leave as bf16), and back.  8 elements per thread-iteration where the pointers allow it.
+HCP_KERNEL(256) cast_f32_bf16_kernel(float* src, unsigned short* dst, long n, float scale, int zero_src) {
+    const bool vec = (((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 7) == 0;
+    const long n4 = vec ? n / 4 : 0;
+    hcp_f32x4* s4 = (hcp_f32x4*)src;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const hcp_f32x4 v = s4[i];
+        unsigned short o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = hcp_f2bf(v[j] * scale);
+        *(uint64_t*)(dst + 4 * i) = *(const uint64_t*)o;
+        if (zero_src) s4[i] = hcp_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        dst[i] = hcp_f2bf(src[i] * scale);
+        if (zero_src) src[i] = 0.f;
+    }
+}
+
+HCP_KERNEL(256) cast_bf16_f32_kernel(const unsigned short* src, float* dst, long n) {
+    const bool vec = (((uintptr_t)dst) & 15) == 0 && (((uintptr_t)src) & 7) == 0;
+    const long n4 = vec ? n / 4 : 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        unsigned short in[4];
+        *(uint64_t*)in = *(const uint64_t*)(src + 4 * i);
+        ((hcp_f32x4*)dst)[i] = hcp_f32x4{hcp_bf2f(in[0]), hcp_bf2f(in[1]), hcp_bf2f(in[2]), hcp_bf2f(in[3])};
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = hcp_bf2f(src[i]);
+}
+
 inline int opt_grid(long n) { long g = (n + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1; return (int)g; }
 
 }  // namespace
@@ -101,4 +132,17 @@ HCP_API int hcp_ema_update(float* ema, const float* p, long n, const int* step, 
     HCP_REQUIRE(ema && p && step && n > 0 && inv_gamma > 0.f, "hcp_ema_update: bad arguments");
     HCP_LAUNCH(ema_kernel, dim3(opt_grid(n)), dim3(256), 0, stream, ema, p, n, step, inv_gamma, power, decay_max);
     HCP_LAUNCH_CHECK("ema_update");
+}
+
+// Sharded exchange, bf16 on the wire (trainer.py `grad_wire` / `param_wire`): dst = bf16(src * scale), src cleared when zero_src.
+HCP_API int hcp_cast_f32_bf16(float* src, void* dst, long n, float scale, int zero_src, hipStream_t stream) {
+    HCP_REQUIRE(src && dst && n > 0, "hcp_cast_f32_bf16: bad arguments");
+    HCP_LAUNCH(cast_f32_bf16_kernel, dim3(opt_grid((n + 3) / 4)), dim3(256), 0, stream, src, (unsigned short*)dst, n, scale, zero_src);
+    HCP_LAUNCH_CHECK("cast_f32_bf16");
+}
+
+HCP_API int hcp_cast_bf16_f32(const void* src, float* dst, long n, hipStream_t stream) {
+    HCP_REQUIRE(src && dst && n > 0, "hcp_cast_bf16_f32: bad arguments");
+    HCP_LAUNCH(cast_bf16_f32_kernel, dim3(opt_grid((n + 3) / 4)), dim3(256), 0, stream, (const unsigned short*)src, dst, n);
+    HCP_LAUNCH_CHECK("cast_bf16_f32");
 }

@@ -24,18 +24,29 @@ def _is_conv3(p):
 
 
 class HostBucket:
-    def __init__(self, model, params, pad_multiple=1):
-        """params: list of (name, parameter) to train (all on one device, fp32); pad_multiple: the flat buffers' length is
-        rounded up to a multiple of it (sharded optimizer: equal slices per rank; the tail stays zero)."""
+    def __init__(self, model, params, pad_multiple=1, chunk_of=None):
+        """params: list of (name, parameter) to train (all on one device, fp32); pad_multiple: the length of the flat buffers (of
+        every chunk of them) is rounded up to a multiple of it (sharded optimizer: equal slices per rank; the tails stay zero);
+        chunk_of: (name, parameter) -> chunk id.  Parameters are laid out chunk by chunk (`self.chunks` = [(lo, hi)]): the trainer orders
+        the chunks by WHEN backward finishes their gradients, so that a chunk's reduce-scatter can leave while the rest of
+        backward still runs (trainer.py, `overlap_exchange`)."""
         assert params, "no trainable host parameter selected"
         dev = params[0][1].device
-        offs, n = [], 0
-        for _, p in params:
+        if chunk_of is not None:
+            params = sorted(params, key=lambda np_: chunk_of(*np_))          # stable: registration order inside a chunk
+        offs, n, self.chunks, cur, lo = [], 0, [], None, 0       # chunks: [(chunk id, lo, hi)]
+        for name, p in params:
             if p.dtype != torch.float32:
                 raise TypeError("hcp_diffusion_amd: full fine-tuning keeps fp32 master parameters (reference: fp32 params + autocast)")
+            c = chunk_of(name, p) if chunk_of is not None else 2          # (2 = 'complete when backward ends')
+            if cur is not None and c != cur:
+                n = (n + pad_multiple - 1) // pad_multiple * pad_multiple
+                self.chunks.append((cur, lo, n)); lo = n
+            cur = c
             offs.append(n)
             n += (p.numel() + 3) // 4 * 4                      # 16-byte aligned segments
         n = (n + pad_multiple - 1) // pad_multiple * pad_multiple
+        self.chunks.append((cur, lo, n))
         self.numel = n
         self.params = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)

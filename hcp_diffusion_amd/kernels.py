@@ -622,6 +622,19 @@ def adamw_clip_fused(p, g, m, v, lr, step, *, beta1=0.9, beta2=0.999, eps=1e-8, 
                                     _p(sumsq_t), float(grad_scale), float(max_norm), _p(step), _stream(p)), "hcp_adamw_clip_fused")
 
 
+def cast_f32_bf16(src, dst, scale=1.0, zero_src=False):
+    """dst (bf16) <- src (fp32) * scale; zero_src clears src in the same pass (wire format of the sharded exchange)."""
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    _chk(lib().hcp_cast_f32_bf16(_p(src), _p(dst), src.numel(), float(scale), int(bool(zero_src)), _stream(src)), "hcp_cast_f32_bf16")
+    return dst
+
+
+def cast_bf16_f32(src, dst):
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    _chk(lib().hcp_cast_bf16_f32(_p(src), _p(dst), src.numel(), _stream(src)), "hcp_cast_bf16_f32")
+    return dst
+
+
 def ema_update(ema, p, step, inv_gamma=1.0, power=2.0 / 3.0, decay_max=0.9997):
     assert ema.dtype == torch.float32 and p.dtype == torch.float32 and ema.is_contiguous() and p.is_contiguous() and ema.numel() == p.numel()
     assert step.dtype == torch.int32

@@ -14,6 +14,8 @@ Everything between two host interactions is stream-ordered device work with stat
 captured once into a hipGraph (two graphs around the all-reduce when world_size > 1) and replayed; the reference's
 per-step ``loss.item()`` sync (train_ac.py:504) is deferred to whenever the caller reads the loss tensor.
 """
+import contextlib
+
 import torch
 
 from . import kernels as K
@@ -36,31 +38,66 @@ class _OptState:
     segments: [(offset, numel, lr)] — one per cfg item whose parameters lie contiguously in the bucket (the reference builds one
     optimizer param group per ``lora_unet`` / ``lora_text_encoder`` item, each with its own lr: cfg_net_tools.py:108-123); each
     segment has its own device-resident lr and step counter, all segments share the bucket's squared-norm scalar.
-    shard=True (full fine-tune / plugin buckets under data parallelism): this rank owns elements [lo, lo + own) — moments and
-    the reduce-scattered gradient exist for that slice only (optimizer memory and HBM traffic / world)."""
+    shard=True (full fine-tune / plugin buckets under data parallelism): this rank owns slice `rank` of every chunk of the bucket
+    (`parts`: [(chunk id, lo, hi, own, offset into the rank-local state)]) — moments and the reduce-scattered gradient exist for those
+    slices only (optimizer memory and HBM traffic / world).  grad_wire / param_wire 'bf16': the gradients leave, and the updated
+    parameters return, as bf16 (half the bytes on xGMI; the fp32 masters of a slice then live on its owner only)."""
 
-    def __init__(self, bucket, lr, device, segments=None, comm=None, shard=False):
+    def __init__(self, bucket, lr, device, segments=None, comm=None, shard=False, grad_wire="fp32", param_wire="fp32"):
         self.bucket = bucket
         n = bucket.params.numel()
-        self.shard = bool(shard and comm is not None and comm.world > 1)
+        self.shard = bool(shard and comm is not None and (comm.world > 1 or shard == "force"))
+        self.parts = []
         if self.shard:
-            assert n % comm.world == 0 and not segments, "sharded bucket: padded to a multiple of world, one lr"
-            self.own, self.lo = n // comm.world, comm.rank * (n // comm.world)
+            assert not segments, "sharded bucket: one lr"
+            off = 0
+            for cid, lo, hi in getattr(bucket, "chunks", [(2, 0, n)]):
+                assert (hi - lo) % comm.world == 0, "sharded bucket: every chunk padded to a multiple of world"
+                own = (hi - lo) // comm.world
+                self.parts.append((cid, lo, hi, own, off)); off += own
+            self.own = off
             self.gshard = torch.zeros(self.own, dtype=torch.float32, device=device)
+            self.gwire = torch.zeros(n, dtype=torch.bfloat16, device=device) if grad_wire == "bf16" else None
+            self.gshard_w = torch.zeros(self.own, dtype=torch.bfloat16, device=device) if grad_wire == "bf16" else None
+            self.pwire = torch.zeros(n, dtype=torch.bfloat16, device=device) if param_wire == "bf16" else None
         else:
-            self.own, self.lo = n, 0
+            self.own = n
         self.segments = [(o, m) for o, m, _ in segments] if segments else [(0, self.own)]
         self.base_lrs = [l for _, _, l in segments] if segments else [lr]
         self.exp_avg = torch.zeros(self.own, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(self.own, dtype=torch.float32, device=device)
         self.lrs = [torch.full((1,), l, dtype=torch.float32, device=device) for l in self.base_lrs]
-        self.steps = [torch.zeros(1, dtype=torch.int32, device=device) for _ in self.base_lrs]
+        # (the kernel advances its step counter per launch: one counter per segment / per chunk of a sharded bucket, in lockstep)
+        self.steps = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(max(len(self.base_lrs), len(self.parts)))]
         self.lr, self.step_count = self.lrs[0], self.steps[0]
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
 
     def tensors(self):
         """Everything a step mutates besides the bucket itself (snapshot / restore around the graph warm-up)."""
         return [self.exp_avg, self.exp_avg_sq, self.sumsq] + self.lrs + self.steps + ([self.ema] if hasattr(self, "ema") else [])
+
+
+FP32_WIRE = 10      # chunk ids >= 10: parameters the kernels read as fp32 (biases, norm affine) — never rounded on the wire
+
+
+def _chunker(overlap, param_wire, unet_names=True):
+    """(name, parameter) -> chunk id of a sharded host bucket.  With overlap: the order backward finishes the gradients of a UNet —
+    0 = up blocks + output head (first), 1 = mid block, 2 = everything else (down blocks, conv_in, time / class / addition embeddings:
+    complete only when backward ends).  With param_wire='bf16': vectors (biases, GroupNorm / LayerNorm affine — 0.1 % of the elements,
+    consumed by the kernels in fp32) form a chunk of their own that always returns as fp32, so that every rank computes with the same
+    values; matrices are consumed as bf16 operands anyway."""
+    if not overlap and param_wire != "bf16":
+        return None
+
+    def chunk_of(name, p):
+        if param_wire == "bf16" and p.dim() <= 1:
+            return FP32_WIRE + 2
+        if not (overlap and unet_names):
+            return 2
+        if name.startswith(("up_blocks.", "conv_norm_out.", "conv_out.")):
+            return 0
+        return 1 if name.startswith("mid_block.") else 2
+    return chunk_of
 
 
 class _WarmupComm(NullComm):
@@ -82,7 +119,8 @@ class NativeTrainer:
     def __init__(self, unet, lora_cfg=None, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000,
                  overlap_wgrad=False, grouped_wgrad=True, train_cfg=None, plugins=None, ema=None, loss_cfg=None, text_encoder=None,
-                 lora_te_cfg=None, comm=None, shard_optimizer=None, gradient_accumulation_steps=1, loss_type="eps"):
+                 lora_te_cfg=None, comm=None, shard_optimizer=None, gradient_accumulation_steps=1, loss_type="eps",
+                 overlap_exchange=False, grad_wire="fp32", param_wire="fp32"):
         """lora_cfg: the reference's ``lora_unet`` list ({layers, rank, alpha, lr, ...}); train_cfg: its ``unet`` list
         ({layers, lr}) of host modules to fine-tune in full (DreamBooth.yaml:6-10 uses ``layers: ['']`` = everything);
         plugins: [(plugin module, lr)] — trainable hook plugins such as controlnet.ControlNetHipPlugin (make_plugin,
@@ -100,12 +138,26 @@ class NativeTrainer:
         all-gather — and keep the small LoRA buckets on one all-reduce; gradient_accumulation_steps: ``accelerator.accumulate``
         (train_ac.py:119,468): the exchange, clip and optimizer step run on every N-th call only, the loss gradients of the
         N micro-steps add up scaled by 1/N; loss_type: 'eps' | 'sample' (train_ac.py:458-465: target = noise, or the clean latents
-        against x0 recovered from the prediction)."""
+        against x0 recovered from the prediction).
+        Sharded buckets only — overlap_exchange: a full fine-tune's bucket is laid out as three chunks in the order backward completes
+        them (up blocks + head | mid block | down blocks + embeddings) and the reduce-scatter of a chunk leaves on a side stream the moment
+        backward has passed it, under the rest of backward (torch DDP overlaps its buckets the same way: reducer hooks, train_ac.py:117);
+        grad_wire='bf16': gradients are rounded to bf16 for the reduce-scatter (DDP's bf16_compress_hook numerics); param_wire='bf16':
+        the all-gather returns the updated parameters as bf16 — bit-identical bf16 operands on every rank, but the fp32 masters of a
+        slice are then current on its owner only (`sync_masters()` re-gathers them; save_model calls it)."""
         self.unet = unet
         self.device = next(unet.parameters()).device
         self.comm = comm if comm is not None else make_comm(self.device, process_group)
         self.world = self.comm.world
         shard = (self.world > 1) if shard_optimizer is None else bool(shard_optimizer and self.world > 1)
+        if shard_optimizer == "force":        # tests: the sharded code path (chunks, side stream, wire casts) on ONE rank
+            shard = "force"
+        if grad_wire not in ("fp32", "bf16") or param_wire not in ("fp32", "bf16"):
+            raise ValueError("grad_wire / param_wire: 'fp32' or 'bf16'")
+        if param_wire == "bf16" and ema is not None:
+            raise ValueError("param_wire='bf16' leaves the fp32 masters of a slice on its owner: keep 'fp32' with an EMA model")
+        self._overlap = bool(overlap_exchange and shard)
+        wires = dict(grad_wire=grad_wire, param_wire=param_wire) if shard else {}
         pad = self.world * 64 if shard else 1
         if loss_type not in ("eps", "sample"):
             raise ValueError(f"Unknown loss type {loss_type}")
@@ -122,13 +174,14 @@ class NativeTrainer:
                     full = f"{layer_name}.{n_}" if layer_name else n_
                     if id(p_) not in seen and "lora_block_" not in full:
                         seen.add(id(p_)); params.append((full, p_))
-            hb = HostBucket(unet, params, pad_multiple=pad)
-            self.host_buckets.append(_OptState(hb, item.get("lr", lr) * scale_lr_factor, self.device, comm=self.comm, shard=shard))
+            hb = HostBucket(unet, params, pad_multiple=pad, chunk_of=_chunker(self._overlap, param_wire) if shard else None)
+            self.host_buckets.append(_OptState(hb, item.get("lr", lr) * scale_lr_factor, self.device, comm=self.comm, shard=shard, **wires))
         self.plugins = []
         for plugin, plr in (plugins or []):
             plugin.train()
-            hb = HostBucket(plugin, list(plugin.named_parameters()), pad_multiple=pad)
-            self.host_buckets.append(_OptState(hb, plr * scale_lr_factor, self.device, comm=self.comm, shard=shard))
+            hb = HostBucket(plugin, list(plugin.named_parameters()), pad_multiple=pad,
+                            chunk_of=_chunker(False, param_wire, unet_names=False) if shard else None)
+            self.host_buckets.append(_OptState(hb, plr * scale_lr_factor, self.device, comm=self.comm, shard=shard, **wires))
             self.plugins.append(plugin)
         self.param_groups, self.lora_group, self.bucket = make_lora(unet, lora_cfg) if lora_cfg else ([], None, None)
         assert self.bucket is not None or self.host_buckets or lora_te_cfg, "nothing to train: no LoRA layer matched and no host group given"
@@ -173,6 +226,7 @@ class NativeTrainer:
         self.overlap_wgrad = overlap_wgrad and self.device.type == "cuda"
         self.grouped_wgrad = grouped_wgrad
         self._wgrad_ctx = ops.WgradContext(grouped=grouped_wgrad, side_stream=self.overlap_wgrad)   # this trainer's own (no process-global switch)
+        self._xstream = torch.cuda.Stream(self.device) if (self._overlap and self.device.type == "cuda") else None
         self._graph_cache = {}           # batch signature -> (forward/backward graph, static inputs, loss tensor)
         self._opt_graph = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -196,10 +250,14 @@ class NativeTrainer:
         return K.add_noise(latents, noise, t, self.acp), noise, t
 
     def forward_backward(self, latents, encoder_hidden_states, mask=None, added_cond_kwargs=None, plugin_input=None, prompt_ids=None,
-                         attn_mask=None):
+                         attn_mask=None, exchange=False):
         """attn_mask: the batch's ``attn_mask`` [B, L] (train_ac.py:473; wrapper.py:20,29 hands it to the text encoder as
-        attention_mask and to the UNet as encoder_attention_mask)."""
+        attention_mask and to the UNet as encoder_attention_mask).  exchange: this is the last backward before the optimizer step —
+        with overlap_exchange the chunks of the sharded UNet buckets are reduce-scattered as backward completes them."""
         noisy, noise, t = self.make_noise(latents)
+        self.unet._bwd_marks = ({"after_up": lambda g: self._exchange_early(0), "after_mid": lambda g: self._exchange_early(1)}
+                                if (exchange and self._overlap) else None)
+        self._sent = set()                   # chunk ids this backward reduce-scattered itself
         kw = {"encoder_attention_mask": attn_mask} if attn_mask is not None else {}
         wg = self._wgrad_ctx
         with ops.wgrad_context(wg):                                       # this step's autograd nodes report their LoRA weight gradients to `wg`
@@ -230,7 +288,44 @@ class NativeTrainer:
         finally:
             wg.items.clear()                     # (an exception mid-backward must not leak operands into the next step)
             wg.join()
+            self.unet._bwd_marks = None
+            if self._xstream is not None and exchange:
+                torch.cuda.current_stream(self.device).wait_stream(self._xstream)      # join (inside the capture, when there is one)
         return loss
+
+    # ---- the sharded exchange
+    def _exchange_part(self, st, k):
+        """Reduce-scatter chunk k of a sharded bucket: this rank receives the summed gradient of its slice of the chunk."""
+        _, lo, hi, own, off = st.parts[k]
+        g = st.bucket.grads[lo:hi]
+        if st.gwire is not None:               # bf16 on the wire; the same pass clears the fp32 gradients (= zero_grad)
+            K.cast_f32_bf16(g, st.gwire[lo:hi], scale=1.0, zero_src=True)
+            self.comm.reduce_scatter(st.gwire[lo:hi], st.gshard_w[off:off + own])
+        else:
+            self.comm.reduce_scatter(g, st.gshard[off:off + own])
+
+    def _exchange_early(self, cid):
+        """Backward hook (unet._bwd_marks): every gradient of chunk `cid` is enqueued — send it from the side stream."""
+        xs = self._xstream
+        self._sent.add(cid)
+        if xs is not None:
+            xs.wait_stream(torch.cuda.current_stream(self.device))
+        with (torch.cuda.stream(xs) if xs is not None else contextlib.nullcontext()):
+            for st in self.host_buckets:
+                for k, part in enumerate(st.parts):
+                    if part[0] == cid:
+                        self._exchange_part(st, k)
+        return None
+
+    def sync_masters(self):
+        """param_wire='bf16': all-gather the fp32 masters of every sharded bucket (each rank holds fp32 truth for its own slices only);
+        every rank must call it.  save_model does."""
+        for st in self.host_buckets:
+            if st.shard and st.pwire is not None:
+                for cid, lo, hi, own, _ in st.parts:
+                    r = self.comm.rank
+                    if cid < FP32_WIRE:
+                        self.comm.all_gather(st.bucket.params[lo + r * own:lo + (r + 1) * own], st.bucket.params[lo:hi])
 
     def _states(self):
         return (([self._lora_state] if self._lora_state is not None else []) + self.host_buckets +
@@ -243,12 +338,17 @@ class NativeTrainer:
                 if not st.shard:
                     self.comm.all_reduce_(st.bucket.grads)
 
-    def optimizer_step(self):
+    def optimizer_step(self, early_sent=()):
+        """early_sent: ids of the chunks the last backward already reduce-scattered (overlap_exchange)."""
         states = self._states()
         sharded = [st for st in states if st.shard]
         for st in states:
-            if st.shard:                       # reduce-scatter: this rank receives the summed gradient of its slice only
-                self.comm.reduce_scatter(st.bucket.grads, st.gshard)
+            if st.shard:                       # reduce-scatter: this rank receives the summed gradient of its slices only
+                for k, part in enumerate(st.parts):
+                    if part[0] not in early_sent:
+                        self._exchange_part(st, k)
+                if st.gshard_w is not None:
+                    K.cast_bf16_f32(st.gshard_w, st.gshard)
                 K.sumsq(st.gshard, st.sumsq)
             else:
                 K.sumsq(st.bucket.grads, st.sumsq)
@@ -265,12 +365,24 @@ class NativeTrainer:
         for st in states:
             b = st.bucket
             if st.shard:
-                mine = b.params[st.lo:st.lo + st.own]
-                K.adamw_clip_fused(mine, st.gshard, st.exp_avg, st.exp_avg_sq, st.lrs[0], st.steps[0], beta1=self.betas[0],
-                                   beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, sumsq_t=total,
-                                   grad_scale=1.0 / self.world, max_norm=self.max_grad_norm)
-                self.comm.all_gather(mine, b.params)          # every rank holds the updated masters again
-                b.grads.zero_()                               # zero_grad of the full bucket (the kernel cleared the slice copy only)
+                r = self.comm.rank
+                for k, (_, lo, hi, own, off) in enumerate(st.parts):
+                    mlo, mhi = lo + r * own, lo + (r + 1) * own
+                    mine = b.params[mlo:mhi]
+                    K.adamw_clip_fused(mine, st.gshard[off:off + own], st.exp_avg[off:off + own], st.exp_avg_sq[off:off + own], st.lrs[0],
+                                       st.steps[k], beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,
+                                       sumsq_t=total, grad_scale=1.0 / self.world, max_norm=self.max_grad_norm)
+                    if st.pwire is None or st.parts[k][0] >= FP32_WIRE:
+                        self.comm.all_gather(mine, b.params[lo:hi])      # every rank holds the updated masters again
+                        continue
+                    K.cast_f32_bf16(mine, st.pwire[mlo:mhi])             # bf16 on the wire: what the layers' operands are made of anyway
+                    self.comm.all_gather(st.pwire[mlo:mhi], st.pwire[lo:hi])
+                    if mlo > lo:                                          # the other ranks' slices: bf16 -> fp32 -> (repack) bf16 is exact
+                        K.cast_bf16_f32(st.pwire[lo:mlo], b.params[lo:mlo])
+                    if mhi < hi:
+                        K.cast_bf16_f32(st.pwire[mhi:hi], b.params[mhi:hi])
+                if st.gwire is None:
+                    b.grads.zero_()                           # zero_grad of the full bucket (the kernel cleared the slice copy only)
                 continue
             for (off, n), lr_t, step_t in zip(st.segments, st.lrs, st.steps):
                 K.adamw_clip_fused(b.params[off:off + n], b.grads[off:off + n], st.exp_avg[off:off + n], st.exp_avg_sq[off:off + n],
@@ -309,6 +421,7 @@ class NativeTrainer:
         ``{name}-{plugin}-{step}`` file per plugin, through a ckpt.CkptManagerNative (or the reference's own manager)."""
         from .ckpt import _EMAView
         from .patch_api import PluginGroup
+        self.sync_masters()
         ema = _EMAView(self.ema_state_dict(), self.unet) if self.ema_cfg else None
         paths = [ckpt_manager.save_model_with_lora(self.unet, self.lora_group, name=name, step=step, model_ema=ema)]
         if self.lora_te_group is not None:     # train_ac.py:529-533: the text encoder's own file
@@ -360,15 +473,16 @@ class NativeTrainer:
                     if torch.is_tensor(v2):
                         yield (k, k2), v2
 
-    def _run_all(self, data_list):
+    def _run_all(self, data_list, exchange=False):
         K.wgrad_staging_begin_step()
         total = None
-        for b in data_list:
+        for i, b in enumerate(data_list):
             lw = b.get("loss_weight", 1.0)
             keep, self.loss_weight = self.loss_weight, self.loss_weight * lw
             try:
                 l = self.forward_backward(b["latents"], b.get("encoder_hidden_states"), b.get("mask"), b.get("added_cond_kwargs"),
-                                          b.get("plugin_input"), b.get("prompt_ids"), b.get("attn_mask"))
+                                          b.get("plugin_input"), b.get("prompt_ids"), b.get("attn_mask"),
+                                          exchange=exchange and i == len(data_list) - 1)
             finally:
                 self.loss_weight = keep
             total = l if total is None else total + l
@@ -382,14 +496,17 @@ class NativeTrainer:
         data_list = [{**b, "latents": b["latents"].float().contiguous()} for b in data_list]     # the caller's dicts stay untouched
         self._micro += 1
         sync = self._micro % self.accum == 0
+        early = sync and self._overlap             # this backward sends the early chunks itself
+        sent = ()
         if not self.use_graph:
-            self.loss = self._run_all(data_list)
+            self.loss = self._run_all(data_list, exchange=early)
+            sent = tuple(self._sent)
         else:
-            sig = self._signature(data_list)
+            sig = self._signature(data_list) + (early,)
             entry = self._graph_cache.get(sig)
             if entry is None:                      # a new aspect-ratio bucket / context length: capture once, replay afterwards
-                entry = self._capture(data_list, sig)
-            graph, static, loss = entry
+                entry = self._capture(data_list, sig, early)
+            graph, static, loss, sent = entry
             for sb, b in zip(static, data_list):
                 live = dict(self._tensors(b))
                 for path, t in self._tensors(sb):
@@ -400,6 +517,8 @@ class NativeTrainer:
             self.all_reduce()
             if self._opt_graph is not None:
                 self._opt_graph.replay()
+            elif sent:
+                self.optimizer_step(early_sent=sent)
             else:
                 self.optimizer_step()
         return self.loss
@@ -435,7 +554,7 @@ class NativeTrainer:
         for st in self.host_buckets:
             st.bucket.repack()
 
-    def _capture(self, data_list, sig):
+    def _capture(self, data_list, sig, early=False):
         def clone(b):
             return {k: (v.clone() if torch.is_tensor(v) else {k2: v2.clone() for k2, v2 in v.items()} if isinstance(v, dict) else v)
                     for k, v in b.items() if v is not None}
@@ -453,9 +572,9 @@ class NativeTrainer:
         try:
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._run_all(static)
+                    self._run_all(static, exchange=early)
                     self.all_reduce()
-                    self.optimizer_step()
+                    self.optimizer_step(early_sent=tuple(self._sent))
         finally:
             self.comm = comm
         torch.cuda.current_stream().wait_stream(side)
@@ -465,8 +584,8 @@ class NativeTrainer:
         pool = next(iter(self._graph_cache.values()))[0].pool() if self._graph_cache else None
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, pool=pool):
-            loss = self._run_all(static)
-        entry = (g1, static, loss)
+            loss = self._run_all(static, exchange=early)      # (the early chunks' reduce-scatters become a side branch of this graph)
+        entry = (g1, static, loss, tuple(self._sent))
         self._graph_cache[sig] = entry
         if self._opt_graph is None and not any(st.shard for st in self._states()):
             # the optimizer step is shape independent: captured once.  (Sharded buckets interleave RCCL collectives with the

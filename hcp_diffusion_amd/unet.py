@@ -553,12 +553,19 @@ class NativeUNet2DConditionModel(nn.Module):
             if m.shape != ctx.shape[:2]:
                 raise ValueError(f"encoder_attention_mask {tuple(m.shape)} does not match encoder_hidden_states {tuple(ctx.shape[:2])}")
             ctx = (ctx, ((1.0 - m.to(torch.float32)) * -10000.0).contiguous())
+        # NativeTrainer(overlap_exchange=True): callbacks that fire when backward has finished every gradient of up_blocks + the
+        # output head ('after_up': the gradient of the mid block's output is complete) and of the mid block ('after_mid')
+        marks = getattr(self, "_bwd_marks", None)
         h = self.conv_in(sample)
         skips = (h,)
         for blk in self.down_blocks:
             h, s = blk(h, temb_act, ctx)
             skips += s
+        if marks and h.requires_grad:
+            h.register_hook(marks["after_mid"])
         h = self.mid_block(h, temb_act, ctx)
+        if marks and h.requires_grad:
+            h.register_hook(marks["after_up"])
         for blk in self.up_blocks:
             k = len(blk.resnets)
             h = blk(h, skips[-k:], temb_act, ctx)

@@ -186,6 +186,11 @@ int hcp_adamw_clip_fused(float* p, float* g, float* m, float* v, long n, const f
 /* ModelEMA.update (reference hcpdiff/utils/ema.py:17-27) over a flat bucket: ema <- lerp(ema, p, 1 - decay(step)) */
 int hcp_ema_update(float* ema, const float* p, long n, const int* step, float inv_gamma, float power, float decay_max,
                    hcpStream_t stream);
+/* bf16 wire formats of the sharded gradient / parameter exchange (what torch DDP's bf16_compress_hook does around its all-reduce,
+ * torch/distributed/algorithms/ddp_comm_hooks/default_hooks.py; the reference reaches DDP through accelerate, train_ac.py:117-123):
+ * dst_bf16[i] = bf16(src[i] * scale), src cleared when zero_src != 0 (the bucket's zero_grad);  dst_f32[i] = float(src_bf16[i]). */
+int hcp_cast_f32_bf16(float* src, void* dst_bf16, long n, float scale, int zero_src, hcpStream_t stream);
+int hcp_cast_bf16_f32(const void* src_bf16, float* dst, long n, hcpStream_t stream);
 
 /* One DDIM (eta = 0) sampler step with classifier-free guidance fused in (reference utils/pipe_hook.py:120-140 + scheduler.step):
  * eps = eps2[:n] + g (eps2[n:] - eps2[:n]) when guided (eps2 = UNet output on [uncond ; cond]), else eps2[:n];

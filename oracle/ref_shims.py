@@ -34,11 +34,13 @@ def load_reference_lora():
         return sys.modules["hcpdiff.models.lora_layers_patch"], sys.modules["hcpdiff.models.plugin"]
     if "diffusers" not in sys.modules:
         d = types.ModuleType("diffusers"); d.__path__ = []
+        sys.modules["diffusers"] = d
+    if "diffusers.optimization" not in sys.modules:       # (whichever loader ran first may have made the bare package stub)
         opt = types.ModuleType("diffusers.optimization")
         opt.SchedulerType = type("SchedulerType", (), {})
         opt.TYPE_TO_SCHEDULER_FUNCTION = {}
         opt.Optimizer = object
-        sys.modules["diffusers"] = d; sys.modules["diffusers.optimization"] = opt
+        sys.modules["diffusers.optimization"] = opt
     if "omegaconf" not in sys.modules:
         oc = types.ModuleType("omegaconf")
         oc.OmegaConf = type("OmegaConf", (), {}); oc.ListConfig = list

@@ -90,6 +90,8 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
         "hcp_sumsq_f32": (N, 0, N, N),
         "hcp_adamw_clip_fused": (N, N, N, N, 0, N, 0.9, 0.999, 1e-8, 0.0, N, 1.0, 1.0, N, N),
         "hcp_ema_update": (N, N, 0, N, 1.0, 0.6, 0.99, N),
+        "hcp_cast_f32_bf16": (N, N, 0, 1.0, 0, N),
+        "hcp_cast_bf16_f32": (N, N, 0, N),
         "hcp_timestep_embedding": (N, N, 0, 3, 1e4, N),
         "hcp_add_noise": (N, N, N, N, N, 0, 0, N),
         "hcp_cfg_ddim_step": (N, N, N, 0, 1, 7.5, 0.5, 0.6, N),

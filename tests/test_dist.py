@@ -210,3 +210,86 @@ def test_stock_torch_ddp_around_the_native_unet(tmp_path):
         assert (upd_ddp.abs().max().item() > 5e-3)                              # ... and they are real updates
     finally:
         K._set_backend_for_tests(None)
+
+
+# ---- sharded exchange variants: chunks reduce-scattered from backward, bf16 on the wire (trainer.py overlap_exchange / *_wire)
+VARIANTS = {"overlap": dict(overlap_exchange=True),
+            "overlap_bf16_grads": dict(overlap_exchange=True, grad_wire="bf16"),
+            "bf16_both": dict(overlap_exchange=True, grad_wire="bf16", param_wire="bf16"),
+            "bf16_params_no_overlap": dict(param_wire="bf16")}
+
+
+def _fullft(tiny_cfg, **kw):
+    from hcp_diffusion_amd.trainer import NativeTrainer
+    from hcp_diffusion_amd.unet import NativeUNet2DConditionModel
+    from oracle.unet_sd15 import OracleUNet2DConditionModel, seeded_init_
+    nat = NativeUNet2DConditionModel(**tiny_cfg)
+    nat.load_state_dict(seeded_init_(OracleUNet2DConditionModel(**tiny_cfg), 1).state_dict())
+    return NativeTrainer(nat, None, lr=1e-3, train_cfg=[dict(layers=[""])], shard_optimizer=True, **kw)
+
+
+def _variant_worker(rank, world, port, out, variant):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import emu_cdll
+    from hcp_diffusion_amd import kernels as K
+    from oracle.unet_sd15 import MICRO_CONFIG
+    K._set_backend_for_tests(emu_cdll())
+    x0, ehs, noise, t = _data()
+    sl = slice(rank, rank + 1)
+    res = {}
+    for name, kw in (("base", {}), ("var", VARIANTS[variant])):
+        tr = _fullft(MICRO_CONFIG, **kw)
+        st = tr.host_buckets[0]
+        assert st.shard and len(st.parts) == (3 if kw.get("overlap_exchange") else 1) + (kw.get("param_wire") == "bf16")
+        tr.make_noise = lambda lat: (K.add_noise(lat, noise[sl], t[sl], tr.acp), noise[sl], t[sl])
+        sent = []
+        for _ in range(2):                          # two steps: the second one sees gradients cleared by the first (fused into the wire cast)
+            tr.train_one_step(x0[sl].contiguous(), ehs[sl].contiguous())
+            sent.append(sorted(tr._sent))
+        res[name] = {n: p.detach().clone() for n, p in tr.unet.named_parameters()}
+        if name == "var":
+            assert sent == [[0, 1], [0, 1]] if kw.get("overlap_exchange") else sent == [[], []]
+            assert st.bucket.grads.abs().max().item() == 0
+            res["var_before_sync"] = res["var"]
+            tr.sync_masters()
+            res["var"] = {n: p.detach().clone() for n, p in tr.unet.named_parameters()}
+            res["own"] = [(lo + rank * own, lo + (rank + 1) * own) for _, lo, hi, own, _ in st.parts]
+    torch.save(res, os.path.join(out, f"v{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_sharded_exchange_variants(tmp_path, variant):
+    """Full fine-tune on 2 ranks (gloo, interpreter), two optimisation steps, against the plain sharded path (one reduce-scatter after
+    backward, fp32 both ways):
+    * overlap: the three chunks leave from backward hooks in completion order — same sums, same parameters (the clip norm adds the slices
+      in another order: 1e-6);
+    * bf16 gradients on the wire: torch DDP's bf16_compress_hook numerics — AdamW updates agree to the rounding of the gradients;
+    * bf16 parameters on the wire: every rank derives BIT-IDENTICAL bf16 operands; the fp32 masters are exact on the owner and, after
+      sync_masters(), everywhere."""
+    port = 30100 + os.getpid() % 2000 + list(VARIANTS).index(variant) * 3
+    mp.spawn(_variant_worker, args=(2, port, str(tmp_path), variant), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "v0.pt"), torch.load(tmp_path / "v1.pt")
+    kw = VARIANTS[variant]
+    flat = lambda d: torch.cat([d[n].flatten() for n in sorted(d)])
+    base, var0, var1 = flat(r0["base"]), flat(r0["var"]), flat(r1["var"])
+    assert torch.equal(flat(r0["base"]), flat(r1["base"]))
+    assert torch.equal(var0, var1)                                  # masters agree on both ranks (after the sync where it is needed)
+    b0, b1 = flat(r0["var_before_sync"]), flat(r1["var_before_sync"])
+    assert torch.equal(b0.to(torch.bfloat16), b1.to(torch.bfloat16))       # what the layers compute with is the same everywhere, always
+    vec = lambda d: torch.cat([d[n].flatten() for n in sorted(d) if d[n].dim() <= 1])
+    assert torch.equal(vec(r0["var_before_sync"]), vec(r1["var_before_sync"]))   # biases / norm affine (fp32 in the kernels): never rounded
+    if kw.get("param_wire") == "bf16":
+        assert not torch.equal(b0, b1)                                       # (the fp32 tails of a slice live on its owner only)
+    else:
+        assert torch.equal(b0, b1)
+    from oracle.unet_sd15 import MICRO_CONFIG, OracleUNet2DConditionModel, seeded_init_
+    init = flat({n: p.detach() for n, p in seeded_init_(OracleUNet2DConditionModel(**MICRO_CONFIG), 1).named_parameters()})
+    moved = (base - init).norm().item()
+    assert moved > 0
+    err = (var0 - base).norm().item() / moved
+    assert err < (1e-4 if kw.get("grad_wire") != "bf16" else 5e-2), err

@@ -596,6 +596,24 @@ def test_adamw_clip(backend):
     assert relerr(p, pr.detach()) < 1e-5 and step.item() == 3
 
 
+@pytest.mark.parametrize("n,off", [(5000, 0), (4099, 1), (3, 2)])
+def test_wire_casts(backend, n, off):
+    """bf16 wire format of the sharded exchange: bit-equal to torch's round-to-nearest-even cast, aligned or not, with and without the
+    fused clear of the source."""
+    torch.manual_seed(n)
+    to = backend.to
+    src = to(torch.randn(n + off) * 10)[off:]
+    want = (src.cpu() * 0.25).to(torch.bfloat16)
+    dst = to(torch.zeros(n + off, dtype=torch.bfloat16))[off:]
+    K.cast_f32_bf16(src, dst, scale=0.25)
+    assert torch.equal(dst.cpu(), want) and src.abs().max().item() > 0
+    back = to(torch.zeros(n + off))[off:]
+    K.cast_bf16_f32(dst, back)
+    assert torch.equal(back.cpu(), want.float())
+    K.cast_f32_bf16(src, dst, scale=1.0, zero_src=True)
+    assert src.abs().max().item() == 0
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 2 + 16 * 2, 3 + 16 * 4, 1 + 16 * 3, 8 + 16 * 2, 11 + 16 * 2])
 def test_gemm_every_tile_config_and_splitk(tbackend, cfg):
     """Each tile shape / split-K decomposition the dispatcher can pick gives the same answer (forced via the tuning hook)."""

@@ -358,3 +358,34 @@ def test_fused_adamw_state_dict_round_trip(backend):
     c.step(); d.step()
     for p_c, p_d in zip(ps, d.param_groups[0]["params"]):
         assert torch.allclose(p_c.detach(), p_d.detach(), atol=1e-6), (p_c - p_d).abs().max()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_sharded_exchange_from_backward_on_one_rank(backend, use_graph):
+    """The sharded-optimizer machinery with everything on — chunks reduce-scattered from backward hooks on the side stream, bf16 wire
+    casts, per-chunk AdamW launches — forced onto ONE rank (the collectives degenerate to copies), DreamBooth's two datasets per step:
+    the same training as the plain full fine-tune, up to the bf16 rounding of the gradients on the wire.  On the GPU also inside the
+    captured step: the side-stream branch must fork from and join the capture."""
+    if use_graph and not backend.is_gpu:
+        pytest.skip("hipGraph capture needs the GPU")
+    dev = backend.device
+    data = [dict(**_batch(dev, 1)), dict(**_batch(dev, 2), loss_weight=0.5)]
+    res = {}
+    for name, kw in (("plain", {}), ("fp32", dict(shard_optimizer="force", overlap_exchange=True)),
+                     ("bf16", dict(shard_optimizer="force", overlap_exchange=True, grad_wire="bf16", param_wire="bf16"))):
+        tr = NativeTrainer(_native(dev), None, lr=1e-3, train_cfg=[dict(layers=[""])], use_graph=use_graph, **kw)
+        _fix_noise(tr, dev)
+        for _ in range(3):
+            tr.train_data_list([dict(d) for d in data])
+        if kw:
+            st = tr.host_buckets[0]
+            assert st.shard and [p[0] for p in st.parts] == ([0, 1, 2, 12] if name == "bf16" else [0, 1, 2])
+            assert tuple(sorted(tr._sent if not use_graph else next(iter(tr._graph_cache.values()))[3])) == (0, 1)
+            assert all(s_.item() == 3 for s_ in st.steps)
+            assert st.bucket.grads.abs().max().item() == 0
+        res[name] = torch.cat([p.detach().float().flatten().cpu() for _, p in sorted(tr.unet.named_parameters())])
+    init = torch.cat([p.detach().float().flatten() for _, p in sorted(_native("cpu").named_parameters())])
+    moved = (res["plain"] - init).norm().item()
+    assert moved > 0
+    assert (res["fp32"] - res["plain"]).norm().item() / moved < 1e-4
+    assert (res["bf16"] - res["plain"]).norm().item() / moved < 5e-2
