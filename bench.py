@@ -272,6 +272,8 @@ def main():
         unet.enable_gradient_checkpointing()
     plugin_input = None
     xkw = dict(overlap_exchange=args.exchange != "plain", **(dict(grad_wire="bf16", param_wire="bf16") if args.exchange == "overlap-bf16" else {}))
+    if os.environ.get("HCP_BENCH_FORCE_SHARD") == "1" and world == 1:      # lab: the sharded machinery's own cost (casts, chunked launches,
+        xkw["shard_optimizer"] = "force"                                   # side-stream branch) on one GPU, collectives = copies
     if cnet:                                       # cfgs/plugins/plugin_controlnet.yaml: frozen host + trainable branch, lr 1e-4
         from hcp_diffusion_amd.controlnet import make_controlnet
         plug = make_controlnet(unet)

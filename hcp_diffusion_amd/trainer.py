@@ -500,7 +500,7 @@ class NativeTrainer:
         sent = ()
         if not self.use_graph:
             self.loss = self._run_all(data_list, exchange=early)
-            sent = tuple(self._sent)
+            sent = tuple(sorted(self._sent))
         else:
             sig = self._signature(data_list) + (early,)
             entry = self._graph_cache.get(sig)
@@ -515,7 +515,7 @@ class NativeTrainer:
             self.loss = loss
         if sync:
             self.all_reduce()
-            if self._opt_graph is not None:
+            if self._opt_graph is not None and getattr(self, "_opt_graph_sent", ()) == tuple(sent):
                 self._opt_graph.replay()
             elif sent:
                 self.optimizer_step(early_sent=sent)
@@ -574,7 +574,7 @@ class NativeTrainer:
                 for _ in range(2):
                     self._run_all(static, exchange=early)
                     self.all_reduce()
-                    self.optimizer_step(early_sent=tuple(self._sent))
+                    self.optimizer_step(**({"early_sent": tuple(sorted(self._sent))} if self._sent else {}))
         finally:
             self.comm = comm
         torch.cuda.current_stream().wait_stream(side)
@@ -585,15 +585,19 @@ class NativeTrainer:
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, pool=pool):
             loss = self._run_all(static, exchange=early)      # (the early chunks' reduce-scatters become a side branch of this graph)
-        entry = (g1, static, loss, tuple(self._sent))
+        entry = (g1, static, loss, tuple(sorted(self._sent)))
         self._graph_cache[sig] = entry
-        if self._opt_graph is None and not any(st.shard for st in self._states()):
-            # the optimizer step is shape independent: captured once.  (Sharded buckets interleave RCCL collectives with the
-            # kernels: they stay eager — a dozen launches.)
+        from .comm import AbiComm
+        sharded = any(st.shard for st in self._states())
+        if self._opt_graph is None and (not sharded or isinstance(self.comm, (NullComm, AbiComm))):
+            # the optimizer step is shape independent: captured once.  Sharded buckets interleave collectives with the kernels:
+            # captured when they go through the C ABI (hcp_reduce_scatter_flat / hcp_allgather_flat are stream-ordered launches like any
+            # kernel: tests/test_comm.py); torch.distributed collectives stay eager — some twenty launches.
             saved = self._snapshot()
+            sent = tuple(sorted(self._sent))
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, pool=g1.pool()):
-                self.optimizer_step()
-            self._opt_graph = g2
+                self.optimizer_step(**({"early_sent": sent} if sent else {}))
+            self._opt_graph, self._opt_graph_sent = g2, sent
             self._restore(saved)              # capture does not execute, but keep the contract explicit
         return entry
