@@ -136,7 +136,8 @@ struct LoraPackDesc {
     hcp_bf16* but;         // [32, Ntot]    rows slot0.., cols n0.. : W_up^T              (B operand of U = dY Bu)
     int K, N, r;
     float alpha;
-    int slot0, n0, Ntot, pad;   // placement inside a (possibly shared) operand image; images are zero-initialised once
+    int slot0, n0, Ntot, bu_ld;   // placement inside a (possibly shared) operand image; images are zero-initialised once.
+                                  // bu_ld: row stride of `bu` in elements (0 = 32); adt / but may be null (image not wanted)
 };
 
 HCP_KERNEL(256) lora_pack_kernel(const LoraPackDesc* descs) {
@@ -148,17 +149,18 @@ HCP_KERNEL(256) lora_pack_kernel(const LoraPackDesc* descs) {
         int kk = i / d.r, pp = i - kk * d.r;
         int k = k0 + kk;
         float w = d.w_down[(size_t)pp * d.K + k];
-        d.adt[(size_t)k * 32 + d.slot0 + pp] = hcp_f2bf(w * d.alpha);
+        if (d.adt) d.adt[(size_t)k * 32 + d.slot0 + pp] = hcp_f2bf(w * d.alpha);
         d.ad[(size_t)(d.slot0 + pp) * d.K + k] = hcp_f2bf(w);
     }
+    const int bu_ld = d.bu_ld ? d.bu_ld : 32;
     const int nper = (d.N + nchunk - 1) / nchunk, n0 = chunk * nper;
     int n1 = n0 + nper; if (n1 > d.N) n1 = d.N;
     for (int i = threadIdx.x; i < d.r * (n1 - n0); i += blockDim.x) {
         int nn = i / d.r, pp = i - nn * d.r;
         int n = n0 + nn;
         float w = d.w_up[(size_t)n * d.r + pp];
-        d.bu[(size_t)(d.n0 + n) * 32 + d.slot0 + pp] = hcp_f2bf(w * d.alpha);
-        d.but[(size_t)(d.slot0 + pp) * d.Ntot + d.n0 + n] = hcp_f2bf(w);
+        d.bu[(size_t)(d.n0 + n) * bu_ld + d.slot0 + pp] = hcp_f2bf(w * d.alpha);
+        if (d.but) d.but[(size_t)(d.slot0 + pp) * d.Ntot + d.n0 + n] = hcp_f2bf(w);
     }
 }
 
@@ -229,7 +231,8 @@ HCP_API int hcp_lora_wgrad_grouped(const void* descs, int count, int total_block
 // One launch converts the fp32 master LoRA factors of `count` layers into the four bf16 operand
 // layouts the GEMMs consume. `descs` is a DEVICE array of 64-byte descriptors:
 //   { const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r; float alpha;
-//     int slot0; int n0; int Ntot; int pad; }   (80 bytes; the operand images must be zero-initialised once by the caller)
+//     int slot0; int n0; int Ntot; int bu_ld; }   (80 bytes; the operand images must be zero-initialised once by the caller;
+//   bu_ld = row stride of bu in elements, 0 = 32; adt / but may be null)
 HCP_API int hcp_lora_pack(const void* descs, int count, hipStream_t stream) {
     HCP_REQUIRE(descs && count > 0, "hcp_lora_pack: bad arguments");
     HCP_LAUNCH(lora_pack_kernel, dim3(count, 16), dim3(256), 0, stream, (const LoraPackDesc*)descs);

@@ -541,7 +541,7 @@ def lora_wgrad_pair(U, x, grad_down, T, dy, grad_up, r, scale):
 
 def lora_wgrad_grouped(items):
     """items: list of (U, x, grad_down, T, dy, grad_up, r, scale[, slot0]) — every layer's LoRA weight gradients, ONE launch.
-    dy may be a column-slice view (row stride = its stride(0)); slot0 = first rank column of the layer in U / T."""
+    dy, U and T may be column-slice views (row stride = their stride(0)); slot0 = first rank column of the layer in U / T."""
     import struct
     L = lib()
     assert L.hcp_lora_wgrad_group_desc_bytes() == 144
@@ -554,8 +554,9 @@ def lora_wgrad_grouped(items):
         M, Kd = x.shape
         N = dy.shape[1]
         nb = L.hcp_lora_wgrad_group_geometry(M, Kd, N, ctypes.byref(qt), ctypes.byref(sp), ctypes.byref(rows))
-        buf += struct.pack("<Qi4xQi4xQiiii", U.data_ptr(), 32, x.data_ptr(), x.stride(0), gd.data_ptr(), Kd, Kd, 0, slot0)
-        buf += struct.pack("<Qi4xQi4xQiiii", T.data_ptr(), 32, dy.data_ptr(), dy.stride(0), gu.data_ptr(), r, N, 1, slot0)
+        assert U.stride(1) == 1 and T.stride(1) == 1 and U.stride(0) % 8 == 0 and T.stride(0) % 8 == 0
+        buf += struct.pack("<Qi4xQi4xQiiii", U.data_ptr(), U.stride(0), x.data_ptr(), x.stride(0), gd.data_ptr(), Kd, Kd, 0, slot0)
+        buf += struct.pack("<Qi4xQi4xQiiii", T.data_ptr(), T.stride(0), dy.data_ptr(), dy.stride(0), gu.data_ptr(), r, N, 1, slot0)
         buf += struct.pack("<iifiiiii", M, r, float(scale), rows.value, qt.value, sp.value, begin, 0)
         begin += nb
     dev = items[0][1].device

@@ -274,6 +274,47 @@ class FusedLoraGroup:
         return self._pk[1], self._pk[2]
 
 
+class CtxBatch:
+    """The K/V projection groups of ALL cross-attention layers of a model as ONE GEMM: they read the same tensor (the prompt states,
+    wrapper.py:29 hands every layer the same encoder_hidden_states), so  [K_0|V_0|K_1|V_1|...] = [ctx | T_all] [W_all | BU]^T  with
+    T_all = ctx AD_all^T (every layer's rank slots side by side, 32 columns per group) and BU block-diagonal (alpha W_up of group g in
+    rows of group g, columns of group g; zeros elsewhere, written once).  32 small launches per forward -> 3.  Built by
+    unet.NativeUNet2DConditionModel when every group is fusable and the prompt states need no gradient."""
+
+    def __init__(self, groups):
+        self.groups = list(groups)
+        self.k = self.groups[0].k
+        assert all(g.k == self.k for g in self.groups)
+        self.n_off, n = [], 0
+        for g in self.groups:
+            self.n_off.append(n); n += g.n_total
+        self.n_total = n
+        buckets = [g.bucket for g in self.groups if g.has_lora]
+        self.bucket = buckets[0] if buckets else None
+        assert all(b is self.bucket for b in buckets), "one LoRA bucket per model"
+        self.k2 = RANK_SLOT * len(self.groups) if self.bucket is not None else 0
+        dev = self.groups[0].hosts[0].weight.device
+        self.ad_all = torch.zeros(max(self.k2, 1), self.k, dtype=BF16, device=dev) if self.k2 else None
+        self.b_cat = torch.zeros(self.n_total, self.k + self.k2, dtype=BF16, device=dev)       # [W_all | BU]: padding stays zero forever
+        self._host_key = None
+        self.refresh_hosts()
+        if self.bucket is not None:
+            self.bucket.add_ctx_batch(self)
+
+    def refresh_hosts(self):
+        """(Re)write the frozen host weights' columns of the joint operand when a host weight was replaced (load_state_dict)."""
+        key = tuple((h.weight._version, h.weight.data_ptr()) for g in self.groups for h in g.hosts)
+        if key != self._host_key:
+            for g, off in zip(self.groups, self.n_off):
+                self.b_cat[off:off + g.n_total, :self.k].copy_(g.packed_host()[0])
+            self._host_key = key
+
+    def operands(self):
+        if self.bucket is not None and self.bucket._stale([b for g in self.groups for b in g.blocks]):
+            self.bucket.pack()
+        return self.ad_all, self.b_cat
+
+
 class LoraBucket:
     """All LoRA factors of a model in ONE flat fp32 parameter buffer + ONE flat gradient buffer.
 
@@ -411,6 +452,24 @@ class LoraBucket:
         self.groups.append(group)
         self.pack()
         return group
+
+    def add_ctx_batch(self, batch):
+        """Pack descriptors that ALSO write every member block of the batch's groups into the batch's joint operands (CtxBatch)."""
+        for gi, (g, goff) in enumerate(zip(batch.groups, batch.n_off)):
+            for b, n0, s0, c in zip(g.blocks, g.n_off, g.slot_off, g.out_scale):
+                if b is None:
+                    continue
+                assert b._bucket is self
+                r, k = b.layer.W_down.shape[:2]
+                n_out = b.layer.W_up.shape[0]
+                self._desc_bytes += struct.pack("<6Q3if4i", b.layer.W_down.data_ptr(), b.layer.W_up.data_ptr(),
+                                                batch.ad_all.data_ptr() + 2 * RANK_SLOT * gi * k, 0,
+                                                batch.b_cat.data_ptr() + 2 * (batch.k + RANK_SLOT * gi), 0, k, n_out, r, b.alpha_f * c,
+                                                s0, goff + n0, batch.n_total, batch.k + batch.k2)
+                self._desc_count += 1
+        self._images.append(batch.b_cat)
+        self._upload_descs()
+        self.pack()
 
     def add_multi(self, multi):
         """Shared operand images for several blocks on one host (MultiLora): same output columns, adjacent rank slots."""

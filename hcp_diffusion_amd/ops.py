@@ -233,6 +233,62 @@ class _LinearGroupFn(torch.autograd.Function):
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
+class _CtxKVFn(torch.autograd.Function):
+    """K/V projections of every cross-attention layer from the shared prompt states in three launches (lora.CtxBatch).  Outputs: one
+    [.., N_g] column-slice VIEW of the joint result per group; their gradients arrive in the matching slices of one joint buffer
+    (the attention backward writes them there: `_hcp_grad_buf`), the input needs no gradient by construction."""
+
+    @staticmethod
+    def forward(ctx, x, batch, *lora_params):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        ad_all, b_cat = batch.operands()
+        T_all = None
+        if ad_all is not None:
+            T_all = K.gemm(x2, ad_all)                               # [M, 32 G]: every layer's x W_down^T
+            y = K.gemm(K.concat_channels(x2, T_all), b_cat)          # [M, sum N_g]
+        else:
+            y = K.gemm(x2, b_cat)
+        ctx.batch, ctx.wg = batch, current_wgrad()
+        ctx.dkv_all = torch.empty_like(y)
+        ctx.save_for_backward(x2, T_all)
+        y3 = y.view(*shp[:-1], batch.n_total)
+        return tuple(y3[..., o:o + g.n_total] for g, o in zip(batch.groups, batch.n_off))
+
+    @staticmethod
+    def backward(ctx, *dkvs):
+        x2, T_all = ctx.saved_tensors
+        batch, dall = ctx.batch, ctx.dkv_all
+        for gi, (g, off, d) in enumerate(zip(batch.groups, batch.n_off, dkvs)):
+            if d is None or not g.has_lora:
+                continue
+            sl = dall[:, off:off + g.n_total]
+            d2 = d.reshape(-1, g.n_total) if d.dim() != 2 else d
+            if d2.data_ptr() != sl.data_ptr() or d2.stride() != sl.stride():
+                sl.copy_(d2)                                          # (a consumer that did not write in place)
+            o = g.bucket.packed_group(g)
+            U = K.gemm(sl, o.but)
+            T = T_all[:, 32 * gi:32 * gi + 32]
+            for blk, n0, s0, host, sc_ in zip(g.blocks, g.n_off, g.slot_off, g.hosts, g.out_scale):
+                if blk is not None:
+                    gd, gu = blk.grad_views()
+                    ctx.wg.add(U, x2, gd, T, sl[:, n0:n0 + host.weight.shape[0]], gu, blk.rank, blk.alpha_f * sc_, s0)
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def ctx_kv(x, batch):
+    """[(k|v) of group g as a view [.., N_g]] for every group of a lora.CtxBatch; x = the prompt states (no gradient wanted)."""
+    assert not x.requires_grad
+    params = [p for g in batch.groups for b in g.blocks if b is not None for p in (b.layer.W_down, b.layer.W_up)]
+    outs = _CtxKVFn.apply(x, batch, *params)
+    node = outs[0].grad_fn
+    if node is not None:                                             # hand every consumer its slice of the joint gradient buffer
+        d3 = node.dkv_all.view(*x.shape[:-1], batch.n_total)
+        for kv, g, o in zip(outs, batch.groups, batch.n_off):
+            kv._hcp_grad_buf = d3[..., o:o + g.n_total]
+    return outs
+
+
 def linear_group(x, group):
     for h in group.hosts:                              # unet._fusable_linear never groups trainable hosts
         assert _tr(h.weight) is None and _tr(h.bias) is None, "fused projection groups require frozen host weights"
@@ -489,6 +545,7 @@ class _AttentionPackedFn(torch.autograd.Function):
         o, lse = K.attention_fwd(q, k, v, heads, key_bias=key_bias, q_prescaled=q_prescaled)
         ctx.save_for_backward(a, kv, o, lse, key_bias)
         ctx.heads, ctx.C, ctx.pre = heads, C, q_prescaled
+        ctx.dkv_buf = getattr(kv, "_hcp_grad_buf", None)      # a slice of ops._CtxKVFn's joint gradient buffer (same strides as kv)
         return o
 
     @staticmethod
@@ -501,7 +558,10 @@ class _AttentionPackedFn(torch.autograd.Function):
             K.attention_bwd(q, k, v, o, do.contiguous(), lse, ctx.heads, out=(da[..., :C], da[..., C:2 * C], da[..., 2 * C:]),
                             key_bias=key_bias, q_prescaled=ctx.pre)
             return da, None, None, None, None
-        da = torch.empty_like(a); dkv = torch.empty_like(kv)
+        da = torch.empty_like(a)
+        dkv = ctx.dkv_buf if ctx.dkv_buf is not None else torch.empty_like(kv)
+        if dkv.stride() != kv.stride():                       # (a strided kv whose producer offered no buffer)
+            dkv = torch.empty_strided(kv.shape, kv.stride(), dtype=kv.dtype, device=kv.device)
         K.attention_bwd(a, kv[..., :C], kv[..., C:], o, do.contiguous(), lse, ctx.heads, out=(da, dkv[..., :C], dkv[..., C:]),
                         key_bias=key_bias, q_prescaled=ctx.pre)
         return da, dkv, None, None, None

@@ -203,10 +203,14 @@ class CrossAttention(nn.Module):
         else:
             g = self._group((self.to_k, self.to_v))
             gq = self._group((self.to_q,), (qc,)) if (g is not None and key_bias is None) else None
+            pre = getattr(context, "_hcp_kv", None)    # every layer's k|v from ONE GEMM over the shared prompt states (unet._batched_ctx_kv)
+            kv = pre.get(id(self)) if (pre is not None and g is not None) else None
+            if g is not None and kv is None:
+                kv = ops.linear_group(context, g)
             if g is not None and gq is not None:       # unmasked cross-attention: pre-scaled q from a one-member group
-                o = ops.attention_packed(ops.linear_group(x, gq), ops.linear_group(context, g), self.heads, None, q_prescaled=True)
+                o = ops.attention_packed(ops.linear_group(x, gq), kv, self.heads, None, q_prescaled=True)
             elif g is not None:
-                o = ops.attention_packed(self.to_q(x), ops.linear_group(context, g), self.heads, key_bias)
+                o = ops.attention_packed(self.to_q(x), kv, self.heads, key_bias)
             else:
                 o = ops.attention(self.to_q(x), self.to_k(context), self.to_v(context), self.heads, key_bias)
         return _call_res(self.to_out[0], o, residual) if residual is not None else self.to_out[0](o)
@@ -500,6 +504,33 @@ class NativeUNet2DConditionModel(nn.Module):
         allp = K.gemm(temb_act.reshape(-1, temb_act.shape[-1]), w, bias=b, out_f32=True)        # [B, sum Cout] fp32
         temb_act._hcp_tb = {id(r): allp[:, o:o + r.time_emb_proj.weight.shape[0]] for r, o in zip(res, offs)}
 
+    def _batched_ctx_kv(self, ctx):
+        """Every cross-attention layer projects the SAME prompt states to its keys and values: when all of those projection pairs are
+        fusable (frozen bias-free hosts, bare or with one native LoRA block of rank <= 16 each, no dropout, no hooks) and the states need
+        no gradient, evaluate them as one GEMM up front (lora.CtxBatch: 32 launches -> 3 for SD1.5) and hand each layer its column slice."""
+        if not torch.is_tensor(ctx) or ctx.requires_grad:
+            return
+        pairs = [(m.attn2, m.attn2._group((m.attn2.to_k, m.attn2.to_v))) for m in self.modules() if isinstance(m, BasicTransformerBlock)]
+        pairs = [(a, g) for a, g in pairs if g is not None and g.k == ctx.shape[-1]]      # (trainable / hooked layers keep their own call)
+        if len(pairs) < 2:
+            return
+        xs, groups = [a for a, _ in pairs], [g for _, g in pairs]
+        if len({id(g.bucket) for g in groups if g.has_lora}) > 1:
+            return
+        key = tuple(id(g) for g in groups)
+        hit = getattr(self, "_ctx_batch", None)
+        if hit is None or hit[0] != key:
+            if ctx.is_cuda and torch.cuda.is_current_stream_capturing():
+                return                                  # (built by the warm-up; never allocate / pack under capture)
+            from .lora import CtxBatch
+            hit = (key, CtxBatch(groups), groups)       # keeps the groups alive so the ids stay unique
+            self._ctx_batch = hit
+        batch = hit[1]
+        if not (ctx.is_cuda and torch.cuda.is_current_stream_capturing()):
+            batch.refresh_hosts()
+        kvs = ops.ctx_kv(ctx, batch)
+        ctx._hcp_kv = {id(a): kv for a, kv in zip(xs, kvs)}
+
     def enable_hip_graph(self, on=True, _recorded_on_cpu=False):
         """Replay the forward and the backward of `unet(...)` as captured hipGraphs when an ordinary trainer calls the module in grad
         mode (LoRA and / or host parameters training, alone or under torch DDP; see graphed.py).  Call again (or `reset_hip_graph()`)
@@ -548,6 +579,9 @@ class NativeUNet2DConditionModel(nn.Module):
         if ctx.dtype != BF16:
             ctx = ctx.to(BF16)
         ctx = ctx.contiguous()
+        if ctx is encoder_hidden_states and not ctx.requires_grad:
+            ctx = ctx.detach()                         # (a private alias: _batched_ctx_kv hangs this call's k|v tensors on it)
+        self._batched_ctx_kv(ctx)
         if encoder_attention_mask is not None:         # [B,L] 1 = attend: diffusers turns it into (1 - mask) * -10000, added
             m = encoder_attention_mask                 # to the cross-attention scores of every head / query [ext]
             if m.shape != ctx.shape[:2]:

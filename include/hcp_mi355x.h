@@ -173,8 +173,10 @@ int hcp_lora_wgrad_pair(const void* U, const void* x, int ldx, int K, float* gra
 int hcp_lora_wgrad_group_geometry(int M, int K, int N, int* qt, int* splits, int* rows_per_split);
 int hcp_lora_wgrad_group_desc_bytes(void);
 int hcp_lora_wgrad_grouped(const void* descs, int count, int total_blocks, hcpStream_t stream);
-/* fp32 LoRA factors -> the four bf16 operand layouts, all layers in one launch (descs: device array, 64 B each:
- * {const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r; float alpha;}) */
+/* fp32 LoRA factors -> the four bf16 operand layouts, all layers in one launch (descs: device array, 80 B each, see
+ * hcp_lora_pack_desc_bytes(): {const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r;
+ * float alpha; int slot0; int n0; int Ntot; int bu_ld;} — slot0 / n0 / Ntot place a layer inside operand images shared by a fused
+ * group; bu_ld = row stride of bu in elements (0 = 32); adt / but may be NULL when that image is not wanted) */
 int hcp_lora_pack(const void* descs, int count, hcpStream_t stream);
 int hcp_lora_pack_desc_bytes(void);
 

@@ -765,3 +765,46 @@ def test_controlnet_branch_from_a_lora_wrapped_host(backend):
     assert not any("lora_block" in n for n, _ in plug.named_parameters())
     n_host = sum(p.numel() for n, p in nat.down_blocks.named_parameters() if "lora_block" not in n)
     assert sum(p.numel() for p in plug.down_blocks.parameters()) == n_host
+
+
+@pytest.mark.parametrize("variant", ["lora", "lora_masked", "frozen_hosts"])
+def test_batched_cross_attention_kv_matches_the_per_layer_projections(backend, variant):
+    """Every cross-attention layer reads the same prompt states: unet._batched_ctx_kv projects all their keys / values in three launches
+    (lora.CtxBatch: T_all = ctx AD_all^T, [ctx | T_all] [W_all | BU]^T) and the attention backward writes the K/V gradients into slices of
+    ONE buffer.  Same prediction and the same LoRA gradients as one fused launch pair per layer — with LoRA on the projections, with an
+    encoder_attention_mask (key-bias attention path), and with bare frozen hosts (LoRA elsewhere only)."""
+    from hcp_diffusion_amd import kernels as Kn
+    dev = backend.device
+    pats = PATS if variant != "frozen_hosts" else [r"re:.*\.ff$"]
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(2, 4, 8, 8, generator=g); ehs = torch.randn(2, 24, 64, generator=g)
+    noise = torch.randn(2, 4, 8, 8, generator=g); t = torch.tensor([20, 700])
+    mask = None
+    if variant == "lora_masked":
+        mask = torch.ones(2, 24); mask[0, 10:] = 0
+    res = {}
+    for batched in (True, False):
+        _, nat = _pair(TINY_CONFIG, dev)
+        tr = NativeTrainer(nat, [dict(layers=pats, rank=4)], lr=1e-3)
+        gen = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for blk in tr.bucket.blocks:
+                blk.layer.W_up.copy_((torch.randn(blk.layer.W_up.shape, generator=gen) * 0.05).to(dev))
+        tr.bucket.pack()
+        if not batched:
+            nat._batched_ctx_kv = lambda ctx: None
+        tr.make_noise = lambda lat: (Kn.add_noise(lat, backend.to(noise), backend.to(t), tr.acp), backend.to(noise), backend.to(t))
+        Kn.TRACE = []
+        try:
+            loss = tr.forward_backward(backend.to(x0), backend.to(ehs), attn_mask=backend.to(mask) if mask is not None else None)
+            trace = list(Kn.TRACE)
+        finally:
+            Kn.TRACE = None
+        res[batched] = (loss.item(), tr.bucket.grads.detach().float().cpu().clone(), len(trace))
+        if batched:
+            n_layers = sum(1 for n, _ in nat.named_modules() if n.endswith(".attn2"))
+            assert nat._ctx_batch[1].n_total > 0 and len(nat._ctx_batch[1].groups) == n_layers
+    (lb, gb, nb), (lp, gp, np_) = res[True], res[False]
+    assert abs(lb - lp) <= 2e-3 * abs(lp)
+    assert torch.nn.functional.cosine_similarity(gb, gp, dim=0).item() > 0.9995 and abs(gb.norm() - gp.norm()) / gp.norm() < 1e-2
+    assert nb < np_                                                   # fewer GEMM launches
