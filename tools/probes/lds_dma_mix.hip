@@ -10,10 +10,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // mode bits: 1 = loaders run, 2 = consumers read LDS, 4 = consumers issue MFMAs (on the values read when bit 1, else on registers)
-__global__ void mix(const unsigned char* src, int nl, int mode, int dma_pieces, int reads, int mfmas_per_read, unsigned* sink) {
+__global__ void mix(const unsigned char* src, int nl, int mode, int dma_pieces, int reads, int mfmas_per_read, unsigned* sink, unsigned* role_ticks) {
     extern __shared__ unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned acc0 = 0;
+    const unsigned long long t_begin = wall_clock64();
     if (wave < nl) {
         if (mode & 1) {
             __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, (short)0, 0x7fffffff, 0x00020000);
@@ -55,10 +56,12 @@ __global__ void mix(const unsigned char* src, int nl, int mode, int dma_pieces, 
         }
         acc0 += (unsigned)acc[0];
     }
+    const unsigned long long t_end = wall_clock64();
     __syncthreads();
-    if (lane == 0) sink[blockIdx.x * 16 + wave] = acc0;
+    if (lane == 0) { sink[blockIdx.x * 16 + wave] = acc0; role_ticks[blockIdx.x * 16 + wave] = (unsigned)(t_end - t_begin); }
 }
 
+static unsigned* g_ticks; static float g_loader_us, g_consumer_us;
 static float run(const unsigned char* src, int nl, int nc, int mode, int dma_pieces, int reads, int mpr, unsigned* sink) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const size_t lds = 65536 + (size_t)nl * 9 * 1024;
@@ -66,16 +69,25 @@ static float run(const unsigned char* src, int nl, int nc, int mode, int dma_pie
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(mix, dim3(256), dim3(64 * (nl + nc)), lds, 0, src, nl, mode, dma_pieces, reads, mpr, sink);
+        hipLaunchKernelGGL(mix, dim3(256), dim3(64 * (nl + nc)), lds, 0, src, nl, mode, dma_pieces, reads, mpr, sink, g_ticks);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);
     }
+    static unsigned h[256 * 16];
+    (void)hipMemcpy(h, g_ticks, sizeof(h), hipMemcpyDeviceToHost);
+    double lo = 0, co = 0;                                   // mean over workgroups of the slowest wave of each role (100 MHz wall clock)
+    for (int b = 0; b < 256; ++b) {
+        unsigned ml = 0, mc = 0;
+        for (int w = 0; w < nl + nc; ++w) { unsigned v = h[b * 16 + w]; if (w < nl) ml = v > ml ? v : ml; else mc = v > mc ? v : mc; }
+        lo += ml; co += mc;
+    }
+    g_loader_us = (float)(lo / 256 / 100.0); g_consumer_us = (float)(co / 256 / 100.0);
     return ms * 1e3f;
 }
 
 int main() {
     unsigned char* src; unsigned* sink;
-    (void)hipMalloc(&src, 1 << 20); (void)hipMemset(src, 1, 1 << 20); (void)hipMalloc(&sink, 256 * 16 * 4);
+    (void)hipMalloc(&src, 1 << 20); (void)hipMemset(src, 1, 1 << 20); (void)hipMalloc(&sink, 256 * 16 * 4); (void)hipMalloc(&g_ticks, 256 * 16 * 4);
     const int nl = 4, nc = 8;
     const int pieces = 9 * 400;                    // per loader wave: 3.6 MB per wave, 14.4 MB per CU
     const int reads = 4 * 1400;                    // per consumer wave: 5600 ds_read_b128 = 5.6 MB per wave, 45 MB per CU
@@ -85,13 +97,13 @@ int main() {
     float t_both = run(src, nl, nc, 3, pieces, reads, 1, sink);
     printf("DMA only            %8.1f  (%.0f GB/s per CU)\n", t_dma, nl * pieces * 1024.0 / t_dma / 1e3);
     printf("LDS reads only      %8.1f  (%.0f B/clk per CU at 2.4 GHz)\n", t_rd, nc * reads * 1024.0 / (t_rd * 2400.0));
-    printf("DMA + reads         %8.1f  (sum %.1f, max %.1f)\n", t_both, t_dma + t_rd, t_dma > t_rd ? t_dma : t_rd);
+    printf("DMA + reads         %8.1f  (sum %.1f, max %.1f)   loaders done after %.1f us, readers after %.1f us\n", t_both, t_dma + t_rd, t_dma > t_rd ? t_dma : t_rd, g_loader_us, g_consumer_us);
     for (int mpr : {1, 2}) {
         float t_m = run(src, nl, nc, 4, pieces, reads, mpr, sink);
         float t_rm = run(src, nl, nc, 6, pieces, reads, mpr, sink);
         float t_dm = run(src, nl, nc, 5, pieces, reads, mpr, sink);
         float t_all = run(src, nl, nc, 7, pieces, reads, mpr, sink);
-        printf("MFMA only (%d per read slot) %8.1f | reads+MFMA %8.1f | DMA+MFMA %8.1f | DMA+reads+MFMA %8.1f\n", mpr, t_m, t_rm, t_dm, t_all);
+        printf("MFMA only (%d per read slot) %8.1f | reads+MFMA %8.1f | DMA+MFMA %8.1f | DMA+reads+MFMA %8.1f (loaders done after %.1f us)\n", mpr, t_m, t_rm, t_dm, t_all, g_loader_us);
     }
     return 0;
 }
