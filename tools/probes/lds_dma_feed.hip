@@ -47,19 +47,21 @@ static void run(const unsigned char* src, size_t region, int regions, int nw, in
            bytes / grid / (ms * 1e-3) / 1e9 * (grid > 256 ? grid / 256.0 : 1.0), bytes / (ms * 1e-3) / 1e12, ms);
 }
 
-int main() {
+int main(int argc, char**) {
+    const bool quick = argc > 1;
     const size_t total = 512ull << 20;
     unsigned char* src; unsigned* sink;
     hipMalloc(&src, total); hipMemset(src, 1, total); hipMalloc(&sink, 4096 * 4);
     struct { size_t region; int regions; const char* what; } cases[] = {
-        {256 << 10, 1, "shared 256 KB (L2)"}, {256 << 10, 256, "own 256 KB (L2)"}, {2 << 20, 256, "own 2 MB (MALL/HBM)"}};
+        {256 << 10, 1, "shared 256 KB (L2)"}, {16 << 10, 256, "own 16 KB (L2)"}, {64 << 10, 256, "own 64 KB (L2)"}, {112 << 10, 256, "own 112 KB (L2)"},
+        {256 << 10, 256, "own 256 KB (MALL)"}, {2 << 20, 256, "own 2 MB (MALL/HBM)"}};
     for (auto& c : cases)
         for (int nw : {1, 2, 4, 8}) {
-            run<2>(src, c.region, c.regions, nw, 256, sink, c.what);
-            run<4>(src, c.region, c.regions, nw, 256, sink, c.what);
+            if (quick && nw != 4) continue;
+            if (!quick) { run<2>(src, c.region, c.regions, nw, 256, sink, c.what); run<4>(src, c.region, c.regions, nw, 256, sink, c.what); }
             run<9>(src, c.region, c.regions, nw, 256, sink, c.what);
             run<18>(src, c.region, c.regions, nw, 256, sink, c.what);
-            if (nw <= 4) run<36>(src, c.region, c.regions, nw, 256, sink, c.what);
+            if (nw <= 4 && !quick) run<36>(src, c.region, c.regions, nw, 256, sink, c.what);
         }
     return 0;
 }
