@@ -296,6 +296,8 @@ class CtxBatch:
         dev = self.groups[0].hosts[0].weight.device
         self.ad_all = torch.zeros(max(self.k2, 1), self.k, dtype=BF16, device=dev) if self.k2 else None
         self.b_cat = torch.zeros(self.n_total, self.k + self.k2, dtype=BF16, device=dev)       # [W_all | BU]: padding stays zero forever
+        # backward: U_all = dY_all BUT^T, every layer's dY W_up in ONE deep-K GEMM (block-diagonal again)
+        self.but_all = torch.zeros(max(self.k2, 1), self.n_total, dtype=BF16, device=dev) if self.k2 else None
         self._host_key = None
         self.refresh_hosts()
         if self.bucket is not None:
@@ -313,6 +315,9 @@ class CtxBatch:
         if self.bucket is not None and self.bucket._stale([b for g in self.groups for b in g.blocks]):
             self.bucket.pack()
         return self.ad_all, self.b_cat
+
+    def all_have_lora(self):
+        return all(b is not None for g in self.groups for b in g.blocks)
 
 
 class LoraBucket:
@@ -464,10 +469,11 @@ class LoraBucket:
                 n_out = b.layer.W_up.shape[0]
                 self._desc_bytes += struct.pack("<6Q3if4i", b.layer.W_down.data_ptr(), b.layer.W_up.data_ptr(),
                                                 batch.ad_all.data_ptr() + 2 * RANK_SLOT * gi * k, 0,
-                                                batch.b_cat.data_ptr() + 2 * (batch.k + RANK_SLOT * gi), 0, k, n_out, r, b.alpha_f * c,
+                                                batch.b_cat.data_ptr() + 2 * (batch.k + RANK_SLOT * gi),
+                                                batch.but_all.data_ptr() + 2 * RANK_SLOT * gi * batch.n_total, k, n_out, r, b.alpha_f * c,
                                                 s0, goff + n0, batch.n_total, batch.k + batch.k2)
                 self._desc_count += 1
-        self._images.append(batch.b_cat)
+        self._images += [batch.b_cat, batch.but_all]
         self._upload_descs()
         self.pack()
 

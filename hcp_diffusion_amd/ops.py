@@ -6,6 +6,10 @@ Host parameters with ``requires_grad`` (full fine-tuning, reference DreamBooth.y
 column-sum / norm-affine kernels, accumulated in place into ``param.grad`` (fp32; 3x3 conv weights in channels_last
 storage = the kernels' [Cout][ky][kx][Cin]) — autograd sees ``None`` for them.
 """
+import os
+import threading
+from contextlib import contextmanager
+
 import torch
 
 from . import kernels as K
@@ -23,8 +27,6 @@ BF16 = torch.bfloat16
 # FORWARD (`with wgrad_context(c): pred = unet(...)`); every autograd node records the context it was built under and its backward —
 # on the autograd engine's thread — talks to that object only.  No process-global flag is read or flipped during backward: two
 # trainers (a UNet and a second model) in one process cannot see each other's settings.
-import threading
-from contextlib import contextmanager
 
 
 class WgradContext:
@@ -259,15 +261,24 @@ class _CtxKVFn(torch.autograd.Function):
     def backward(ctx, *dkvs):
         x2, T_all = ctx.saved_tensors
         batch, dall = ctx.batch, ctx.dkv_all
-        for gi, (g, off, d) in enumerate(zip(batch.groups, batch.n_off, dkvs)):
+        joint = (T_all is not None and batch.all_have_lora() and all(d is not None for d in dkvs)
+                 and os.environ.get("HCP_LAB_NO_U_BATCH") != "1")                                   # (lab switch: A/B runs)
+        for g, off, d in zip(batch.groups, batch.n_off, dkvs):
             if d is None or not g.has_lora:
                 continue
             sl = dall[:, off:off + g.n_total]
             d2 = d.reshape(-1, g.n_total) if d.dim() != 2 else d
             if d2.data_ptr() != sl.data_ptr() or d2.stride() != sl.stride():
                 sl.copy_(d2)                                          # (a consumer that did not write in place)
-            o = g.bucket.packed_group(g)
-            U = K.gemm(sl, o.but)
+        U_all = None
+        if joint:                                                     # every layer's U = dY W_up in ONE deep-K GEMM (block-diagonal operand)
+            batch.operands()
+            U_all = K.gemm(dall, batch.but_all)                       # [M, 32 G]
+        for gi, (g, off, d) in enumerate(zip(batch.groups, batch.n_off, dkvs)):
+            if d is None or not g.has_lora:
+                continue
+            sl = dall[:, off:off + g.n_total]
+            U = U_all[:, 32 * gi:32 * gi + 32] if joint else K.gemm(sl, g.bucket.packed_group(g).but)
             T = T_all[:, 32 * gi:32 * gi + 32]
             for blk, n0, s0, host, sc_ in zip(g.blocks, g.n_off, g.slot_off, g.hosts, g.out_scale):
                 if blk is not None:

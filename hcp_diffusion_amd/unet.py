@@ -9,6 +9,8 @@ op is a hand-written gfx950 kernel (ops.py -> C ABI).  Internally activations ar
 conv_in / conv_out.  GroupNorm+SiLU, bias, time-embedding add, residual adds, the skip concat and the nearest-2x
 upsample are fused into the producing / consuming kernels where the module boundaries allow it.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -508,7 +510,7 @@ class NativeUNet2DConditionModel(nn.Module):
         """Every cross-attention layer projects the SAME prompt states to its keys and values: when all of those projection pairs are
         fusable (frozen bias-free hosts, bare or with one native LoRA block of rank <= 16 each, no dropout, no hooks) and the states need
         no gradient, evaluate them as one GEMM up front (lora.CtxBatch: 32 launches -> 3 for SD1.5) and hand each layer its column slice."""
-        if not torch.is_tensor(ctx) or ctx.requires_grad:
+        if not torch.is_tensor(ctx) or ctx.requires_grad or os.environ.get("HCP_LAB_NO_CTX_BATCH") == "1":    # (lab switch: A/B runs)
             return
         pairs = [(m.attn2, m.attn2._group((m.attn2.to_k, m.attn2.to_v))) for m in self.modules() if isinstance(m, BasicTransformerBlock)]
         pairs = [(a, g) for a, g in pairs if g is not None and g.k == ctx.shape[-1]]      # (trainable / hooked layers keep their own call)
