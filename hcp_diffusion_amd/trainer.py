@@ -144,7 +144,7 @@ class NativeTrainer:
         backward has passed it, under the rest of backward (torch DDP overlaps its buckets the same way: reducer hooks, train_ac.py:117);
         grad_wire='bf16': gradients are rounded to bf16 for the reduce-scatter (DDP's bf16_compress_hook numerics); param_wire='bf16':
         the all-gather returns the updated parameters as bf16 — bit-identical bf16 operands on every rank, but the fp32 masters of a
-        slice are then current on its owner only (`sync_masters()` re-gathers them; save_model calls it)."""
+        slice are then current on its owner only (`sync_masters()`, a collective, re-gathers them; save_model insists on it)."""
         self.unet = unet
         self.device = next(unet.parameters()).device
         self.comm = comm if comm is not None else make_comm(self.device, process_group)
@@ -318,8 +318,10 @@ class NativeTrainer:
         return None
 
     def sync_masters(self):
-        """param_wire='bf16': all-gather the fp32 masters of every sharded bucket (each rank holds fp32 truth for its own slices only);
-        every rank must call it.  save_model does."""
+        """param_wire='bf16': all-gather the fp32 masters of every sharded bucket (each rank holds fp32 truth for its own slices only).
+        A COLLECTIVE: every rank must call it — save_model (which the reference's trainer runs on the main process only,
+        train_ac.py:523) refuses to write rounded masters and asks for this call instead of issuing it behind one rank's back."""
+        self._masters_stale = False
         for st in self.host_buckets:
             if st.shard and st.pwire is not None:
                 for cid, lo, hi, own, _ in st.parts:
@@ -375,6 +377,7 @@ class NativeTrainer:
                     if st.pwire is None or st.parts[k][0] >= FP32_WIRE:
                         self.comm.all_gather(mine, b.params[lo:hi])      # every rank holds the updated masters again
                         continue
+                    self._masters_stale = True
                     K.cast_f32_bf16(mine, st.pwire[mlo:mhi])             # bf16 on the wire: what the layers' operands are made of anyway
                     self.comm.all_gather(st.pwire[mlo:mhi], st.pwire[lo:hi])
                     if mlo > lo:                                          # the other ranks' slices: bf16 -> fp32 -> (repack) bf16 is exact
@@ -421,7 +424,9 @@ class NativeTrainer:
         ``{name}-{plugin}-{step}`` file per plugin, through a ckpt.CkptManagerNative (or the reference's own manager)."""
         from .ckpt import _EMAView
         from .patch_api import PluginGroup
-        self.sync_masters()
+        if getattr(self, "_masters_stale", False) and self.world > 1:
+            raise RuntimeError("param_wire='bf16': the fp32 masters of other ranks' slices are bf16-rounded here; call sync_masters() on "
+                               "EVERY rank before save_model()")
         ema = _EMAView(self.ema_state_dict(), self.unet) if self.ema_cfg else None
         paths = [ckpt_manager.save_model_with_lora(self.unet, self.lora_group, name=name, step=step, model_ema=ema)]
         if self.lora_te_group is not None:     # train_ac.py:529-533: the text encoder's own file

@@ -519,7 +519,7 @@ class NativeUNet2DConditionModel(nn.Module):
         xs, groups = [a for a, _ in pairs], [g for _, g in pairs]
         if len({id(g.bucket) for g in groups if g.has_lora}) > 1:
             return
-        key = tuple(id(g) for g in groups)
+        key = tuple(id(g) for g in groups) + (str(ctx.device),)
         hit = getattr(self, "_ctx_batch", None)
         if hit is None or hit[0] != key:
             if ctx.is_cuda and torch.cuda.is_current_stream_capturing():
