@@ -89,6 +89,19 @@ def capturable(unet):  # (any native module that holds LoRA layers and / or trai
     return any(p.requires_grad for p in unet.parameters())
 
 
+def capturable_cached(mod):
+    """(capturable(mod), any submodule checkpointing) without walking the module tree on every call (3 walks over ~1000 modules cost
+    4.4 ms per forward under the reference-style loop: tools/lab/graph_launch_cost.py).  Re-evaluated when the cheap tell-tales move —
+    train()/eval() (LoRA dropout), hooks attached to / removed from the module (ControlNet feeders) — and by `enable_hip_graph()` /
+    `reset_hip_graph()` / `enable_gradient_checkpointing()`, which the caller runs after changing what trains (unet.py docstrings)."""
+    key = (mod.training, len(mod._forward_pre_hooks), len(mod._forward_hooks))
+    hit = getattr(mod, "_hcp_capturable", None)
+    if hit is None or hit[0] != key:
+        hit = (key, capturable(mod), any(getattr(m, "gradient_checkpointing", False) for m in mod.modules()))
+        mod._hcp_capturable = hit
+    return hit[1], hit[2]
+
+
 class _GraphedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, entry, n_params, *args):      # args = the trainable parameters (autograd schedules backward; DDP's hooks fire), then the inputs

@@ -111,12 +111,13 @@ class NativeCLIPTextModel(nn.Module):
         """As NativeUNet2DConditionModel.enable_hip_graph: under an ordinary eager trainer loop the encoder's forward and backward
         (text-encoder LoRA training, lora_conventional.yaml:14-19) replay captured hipGraphs, one pair per input signature."""
         self._hip_graph, self._hip_graphs = bool(on), {}
+        self._hcp_capturable = None
 
     def forward(self, input_ids, position_ids=None, attention_mask=None, output_hidden_states=None):
         if (getattr(self, "_hip_graph", False) and torch.is_grad_enabled() and input_ids.is_cuda
                 and not torch.cuda.is_current_stream_capturing()):
             from . import graphed
-            if graphed.capturable(self):
+            if graphed.capturable_cached(self)[0]:
                 ins = [input_ids, position_ids, attention_mask]
                 key = tuple(None if t is None else (tuple(t.shape), t.dtype) for t in ins)
                 x = graphed.call(self, ins, lambda i_, p_, m_: self._forward_impl(i_, p_, m_), self._hip_graphs, key)

@@ -479,11 +479,13 @@ class NativeUNet2DConditionModel(nn.Module):
         for m in self.modules():
             if hasattr(m, "gradient_checkpointing"):
                 m.gradient_checkpointing = True
+        self._hcp_capturable = None
 
     def disable_gradient_checkpointing(self):
         for m in self.modules():
             if hasattr(m, "gradient_checkpointing"):
                 m.gradient_checkpointing = False
+        self._hcp_capturable = None
 
     def _batched_time_proj(self, temb_act):
         """All ResnetBlock2D.time_emb_proj layers read the same SiLU(temb): evaluate them as ONE GEMM against the
@@ -539,20 +541,22 @@ class NativeUNet2DConditionModel(nn.Module):
         after adding / removing LoRA layers or changing what trains.  `_recorded_on_cpu`: tests only — the same wiring with recorded
         callables in place of graphs on the interpreter backend."""
         self._hip_graph, self._hip_graphs, self._hip_graph_cpu = bool(on), {}, bool(_recorded_on_cpu)
+        self._hcp_capturable = None
 
     def reset_hip_graph(self):
         self._hip_graphs = {}
+        self._hcp_capturable = None
 
     def forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None, added_cond_kwargs=None,
                 cross_attention_kwargs=None, **kwargs):
         if (getattr(self, "_hip_graph", False) and torch.is_grad_enabled() and torch.is_tensor(timestep)
                 and ((sample.is_cuda and not torch.cuda.is_current_stream_capturing()) or getattr(self, "_hip_graph_cpu", False))):
             from . import graphed
-            if graphed.capturable(self):
+            ok, ckpt = graphed.capturable_cached(self)
+            if ok:
                 added = added_cond_kwargs or {}
                 ins = [sample, timestep, encoder_hidden_states, encoder_attention_mask, added.get("text_embeds"), added.get("time_ids")]
-                key = tuple(None if t is None else (tuple(t.shape), t.dtype, bool(t.requires_grad)) for t in ins) + \
-                    (any(getattr(m, "gradient_checkpointing", False) for m in self.modules()),)
+                key = tuple(None if t is None else (tuple(t.shape), t.dtype, bool(t.requires_grad)) for t in ins) + (ckpt,)
 
                 def fwd(s_, t_, e_, m_, te_, ti_):
                     ak = dict(text_embeds=te_, time_ids=ti_) if te_ is not None else None

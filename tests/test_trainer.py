@@ -389,3 +389,26 @@ def test_sharded_exchange_from_backward_on_one_rank(backend, use_graph):
     assert moved > 0
     assert (res["fp32"] - res["plain"]).norm().item() / moved < 1e-3       # (GPU: split-K / atomic orders differ from run to run: 2e-4)
     assert (res["bf16"] - res["plain"]).norm().item() / moved < 5e-2
+
+
+def test_fused_adamw_zero_grad_clears_flat_runs_and_stragglers(backend):
+    """zero_grad(set_to_none=False) of the seam optimizer: one fill per flat run (the bucket views) plus torch's way for a parameter that
+    lives elsewhere; set_to_none=True stays torch's (views dropped)."""
+    from hcp_diffusion_amd.optim import FusedAdamW
+    dev = backend.device
+    flat_p, flat_g = torch.randn(96, device=dev), torch.zeros(96, device=dev)
+    ps = []
+    for i in range(3):
+        p = torch.nn.Parameter(torch.empty(0, device=dev))
+        p.data = flat_p[32 * i:32 * i + 32].view(4, 8); p.grad = flat_g[32 * i:32 * i + 32].view(4, 8)
+        ps.append(p)
+    lone = torch.nn.Parameter(torch.randn(5, device=dev)); lone.grad = torch.zeros(5, device=dev)
+    opt = FusedAdamW([dict(params=ps + [lone], lr=1e-2)])
+    flat_g.fill_(1.0); lone.grad.fill_(1.0)
+    opt.step()
+    assert len(opt._runs[0][1]) == 2                       # the three views are ONE run, the lone parameter another
+    flat_g.fill_(2.0); lone.grad.fill_(2.0)                 # a backward that ran after the step
+    opt.zero_grad(set_to_none=False)
+    assert flat_g.abs().max().item() == 0 and lone.grad.abs().max().item() == 0 and all(p.grad is not None for p in ps)
+    opt.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in ps + [lone])
