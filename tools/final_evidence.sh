@@ -1,0 +1,30 @@
+#!/bin/bash
+# GPU box: the round's evidence in one call -> gpurun_out/<tag>/ (copied into profiles/ afterwards).
+# usage: tools/final_evidence.sh <tag>
+tag=${1:-final}
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd $root
+(timeout 1500 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1; echo "rc=$?" >> $out/gpu_tests.log)
+tail -2 $out/gpu_tests.log
+python bench.py > $out/bench_sd15.json 2> $out/bench_sd15.err
+for w in sdxl dreambooth controlnet sd15te; do
+  python bench.py --workload $w --no-cpu-baseline > $out/bench_$w.json 2> $out/bench_$w.err
+done
+python bench.py --seam > $out/bench_seam_sd15.json 2>/dev/null
+python bench.py --seam --seam-graph > $out/bench_seam_graph_sd15.json 2>/dev/null
+python bench.py --seam --workload dreambooth > $out/bench_seam_dreambooth.json 2>/dev/null
+python bench.py --seam --seam-graph --workload dreambooth > $out/bench_seam_graph_dreambooth.json 2>/dev/null
+bash tools/step_profile.sh $tag/step_sd15 > /dev/null 2>&1
+bash tools/step_profile.sh $tag/step_sdxl --workload sdxl > /dev/null 2>&1
+rm -rf $out/step_sd15 $out/step_sdxl          # the raw traces (tens of MB); the summaries stay
+for f in $out/bench_*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[1].split('/')[-1], d.get("ms_per_step"), d.get("value"), (d.get("roofline") or {}).get("avg_launch_us"), (d.get("roofline_attention") or {}).get("avg_launch_us"))
+except Exception as e:
+    print(sys.argv[1], "unreadable", e)
+PY
+done

@@ -19,7 +19,9 @@ def main():
         n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         n = re.sub(r"^void ", "", n)
         n = re.sub(r"\(.*", "", n)[:100]
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n))
+        wg = max(1, int(r.get("Workgroup_Size_X", 1) or 1))
+        shape = (int(r.get("Grid_Size_X", 0) or 0) // wg, int(r.get("Grid_Size_Y", 1) or 1), wg)
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, shape))
     rows.sort()
     ends = [i for i, r in enumerate(rows) if anchor.search(r[2])]
     # several optimizer launches may end one step (one per bucket): a step boundary = the last anchor of a run
@@ -29,8 +31,11 @@ def main():
     sel = rows[lo:hi]
     wall = (sel[-1][1] - sel[0][0]) / steps / 1e6
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for s, e, n in sel:
+    by_shape = collections.defaultdict(lambda: [0, 0.0])      # GEMM family per (kernel template, workgroups x split-K slabs, threads)
+    for s, e, n, shape in sel:
         agg[n][0] += 1; agg[n][1] += (e - s) / 1e3
+        if "gemm_" in n:
+            by_shape[(n, shape)][0] += 1; by_shape[(n, shape)][1] += (e - s) / 1e3
     tot = sum(v[1] for v in agg.values())
     fam = collections.defaultdict(lambda: [0, 0.0])
     for n, (c, t) in agg.items():
@@ -46,6 +51,10 @@ def main():
     L += ["", "| kernel | launches / step | ms / step | avg us | % |", "|---|---|---|---|---|"]
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         L.append(f"| {n} | {c / steps:.1f} | {t / steps / 1e3:.3f} | {t / c:.1f} | {100 * t / tot:.1f} |")
+    L += ["", "GEMM family by launch geometry (one row = one problem shape class: tiles along M x N in `workgroups`, split-K slabs in `y`):", "",
+          "| kernel | workgroups | y | threads | launches / step | avg us | ms / step |", "|---|---|---|---|---|---|---|"]
+    for (n, (wgs, gy, thr)), (c, t) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:60]:
+        L.append(f"| {n} | {wgs} | {gy} | {thr} | {c / steps:.1f} | {t / c:.1f} | {t / steps / 1e3:.3f} |")
     open(out, "w").write("\n".join(L) + "\n")
     print("\n".join(L[:16]))
 
