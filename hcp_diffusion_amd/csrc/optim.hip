@@ -45,9 +45,26 @@ HCP_KERNEL(256) adamw_kernel(float* p, float* g, float* m, float* v, long n, con
     const float bc1 = 1.f - powf(beta1, (float)t), bc2 = 1.f - powf(beta2, (float)t);
     const float step_size = lr / bc1;
     const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    // 16 bytes per lane where the four arrays allow it (the flat buckets do: 27.5 GB of traffic per step for a full fine-tune)
+    const long n4 = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) ? n / 4 : 0;
+    hcp_f32x4* p4 = (hcp_f32x4*)p; hcp_f32x4* g4 = (hcp_f32x4*)g; hcp_f32x4* m4 = (hcp_f32x4*)m; hcp_f32x4* v4 = (hcp_f32x4*)v;
+    const float decay = 1.f - lr * wd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        hcp_f32x4 gq = g4[i], pq = p4[i], mq = m4[i], vq = v4[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float gi = gq[q] * clip;
+            float pi = pq[q] * decay;
+            float mi = beta1 * mq[q] + (1.f - beta1) * gi;
+            float vi = beta2 * vq[q] + (1.f - beta2) * gi * gi;
+            pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+            pq[q] = pi; mq[q] = mi; vq[q] = vi;
+        }
+        p4[i] = pq; m4[i] = mq; v4[i] = vq; g4[i] = hcp_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float gi = g[i] * clip;
-        float pi = p[i] * (1.f - lr * wd);
+        float pi = p[i] * decay;
         float mi = beta1 * m[i] + (1.f - beta1) * gi;
         float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);

@@ -777,14 +777,14 @@ def test_batched_cross_attention_kv_matches_the_per_layer_projections(backend, v
     dev = backend.device
     pats = PATS if variant != "frozen_hosts" else [r"re:.*\.ff$"]
     g = torch.Generator().manual_seed(3)
-    x0 = torch.randn(2, 4, 8, 8, generator=g); ehs = torch.randn(2, 24, 64, generator=g)
+    x0 = torch.randn(2, 4, 8, 8, generator=g); ehs = torch.randn(2, 24, 32, generator=g)
     noise = torch.randn(2, 4, 8, 8, generator=g); t = torch.tensor([20, 700])
     mask = None
     if variant == "lora_masked":
         mask = torch.ones(2, 24); mask[0, 10:] = 0
     res = {}
     for batched in (True, False):
-        _, nat = _pair(TINY_CONFIG, dev)
+        _, nat = _pair(MICRO_CONFIG, dev)                        # 4 cross-attention layers
         tr = NativeTrainer(nat, [dict(layers=pats, rank=4)], lr=1e-3)
         gen = torch.Generator().manual_seed(5)
         with torch.no_grad():

@@ -45,7 +45,7 @@ def run(cfg, sdxl):
     mask = torch.ones(2 * B, L); mask[:, 12:] = 0         # (the reference passes ONE mask for the doubled batch)
     te = types.SimpleNamespace(dtype=torch.float32); vae = types.SimpleNamespace(dtype=torch.float32, config=types.SimpleNamespace(scaling_factor=0.18215))
     pipe = CpuPipe(vae=vae, text_encoder=te, tokenizer=None, unet=U(), scheduler=ShimDDIMScheduler())
-    kw = dict(prompt_embeds=cond, negative_prompt_embeds=unc, latents=lat.clone(), num_inference_steps=4, guidance_scale=5.0, output_type="latent",
+    kw = dict(prompt_embeds=cond, negative_prompt_embeds=unc, latents=lat.clone(), num_inference_steps=3, guidance_scale=5.0, output_type="latent",
               height=64, width=64)
     added = uadded = None
     if sdxl:
@@ -53,11 +53,11 @@ def run(cfg, sdxl):
         ref = pipe(pooled_output=pooled, **kw).images
         crop = torch.tensor([[64.0, 64.0, 0.0, 0.0, 64.0, 64.0]] * B)
         added = dict(text_embeds=pooled[B:], time_ids=crop); uadded = dict(text_embeds=pooled[:B], time_ids=crop)
-        out = NativeDDIMSampler().sample(nat, lat, cond, unc, guidance_scale=5.0, num_inference_steps=4, added_cond_kwargs=added,
+        out = NativeDDIMSampler().sample(nat, lat, cond, unc, guidance_scale=5.0, num_inference_steps=3, added_cond_kwargs=added,
                                          uncond_added_cond_kwargs=uadded)
     else:
         ref = pipe(encoder_attention_mask=mask, **kw).images
-        out = NativeDDIMSampler().sample(nat, lat, cond, unc, guidance_scale=5.0, num_inference_steps=4, encoder_attention_mask=mask[:B])
+        out = NativeDDIMSampler().sample(nat, lat, cond, unc, guidance_scale=5.0, num_inference_steps=3, encoder_attention_mask=mask[:B])
     err = ((out - ref).norm() / ref.norm()).item()
     assert ref.shape == lat.shape and torch.isfinite(ref).all() and err < 2e-3, err       # same bf16 UNet: the loops differ in fp32 rounding only
     return err

@@ -38,7 +38,7 @@ from oracle.unet_sd15 import MICRO_CONFIG, seeded_init_
 PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
 UCFG = dict(MICRO_CONFIG, cross_attention_dim=64)
 TCFG = dict(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1, max_position_embeddings=77)
-STEPS, B = 10, 2
+STEPS, B = 6, 2          # (the 10-step trajectory of configs[0] is the committed fixture: tests/test_full_configs.py)
 
 def models():
     u = seeded_init_(NativeUNet2DConditionModel(**UCFG), 1); u.requires_grad_(False); u.eval()
@@ -99,7 +99,7 @@ for opt_cls in (torch.optim.AdamW, FusedAdamW):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (opt_cls.__name__, lr_, ln)
     assert set(pr) == set(pn)
     worst = max(((pr[k] - pn[k]).abs().max() / pn[k].abs().max()).item() for k in pn)
-    assert worst < 5e-3, (opt_cls.__name__, worst)        # 10 AdamW steps at lr 1e-3 on bf16-rounded gradients
+    assert worst < 5e-3, (opt_cls.__name__, worst)        # AdamW steps at lr 1e-3 on bf16-rounded gradients
 assert ln[0] != ln[-1]
 print("REFERENCE_TRAINER_OK", ln[0], ln[-1])
 '''
