@@ -387,7 +387,11 @@ def test_sharded_exchange_from_backward_on_one_rank(backend, use_graph):
     init = torch.cat([p.detach().float().flatten() for _, p in sorted(_native("cpu").named_parameters())])
     moved = (res["plain"] - init).norm().item()
     assert moved > 0
-    assert (res["fp32"] - res["plain"]).norm().item() / moved < 1e-3       # (GPU: split-K / atomic orders differ from run to run: 2e-4)
+    # Interpreter: deterministic, the fp32 variant is the same arithmetic (the clip norm adds the slices in another order: 1e-6).
+    # GPU: the weight-gradient kernels accumulate with atomics, so two runs of the SAME trainer differ by ~1e-7 in the gradients, and
+    # AdamW's normalised update turns that into O(lr) on elements whose gradient is ~0 — tools/diag/shard_race_diag.py: two plain runs
+    # land in one of two outcomes 7e-3 of the distance moved apart (62 tensors, <= 5e-4 per element), whichever variant runs.
+    assert (res["fp32"] - res["plain"]).norm().item() / moved < (2e-2 if backend.is_gpu else 1e-4)
     assert (res["bf16"] - res["plain"]).norm().item() / moved < 5e-2
 
 
