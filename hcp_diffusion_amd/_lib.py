@@ -6,6 +6,7 @@ The product path opens exactly one file — ``hcp_diffusion_amd/libhcp_mi355x.so
 ``tests/emu`` — through :func:`bind`; the package itself never does.)
 """
 import ctypes
+import os
 from ctypes import c_int, c_long, c_float, c_void_p, c_size_t, c_char_p
 from pathlib import Path
 
@@ -159,6 +160,10 @@ def load():
     global _lib
     if _lib is None:
         import torch  # noqa: F401  torch must map ITS libamdhip64 first: our .so then binds to the same HIP runtime
+        lab = os.environ.get("HCP_LAB_LIB")                  # lab A/B runs: another BUILD of the same library (never a fallback)
+        if lab:
+            _lib = bind(ctypes.CDLL(lab))
+            return _lib
         if not LIB_PATH.exists():
             raise HcpError(
                 f"{LIB_PATH} not found: build it with `python -m hcp_diffusion_amd.build` "

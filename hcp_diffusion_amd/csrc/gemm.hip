@@ -918,13 +918,20 @@ bool lookup_tuned(const GemmParams& p, int mode, int* cfg, int* split, int* load
     return hit;
 }
 
+// The loader table was swept on warm loops, where LDS rings of 3 and 4 K tiles tie; in the step the operands are not in L2 (weights come
+// from HBM, activations from the Infinity Cache) and the deeper ring is 2.5-7 % faster on every shape probed (tools/lab/cold_sweep_probe.py:
+// conv C320@64^2 43.5 -> 42.5 us, fused-LoRA M1024 N1280 K1280 18.5 -> 17.2, M4096 N640 K2560 31.4 -> 29.9).  In the step itself the
+// effect is within noise (same-box A/B of the headline: 19.60 -> 19.56 ms, SDXL unchanged) — kept because it never loses.  launch_cfg
+// falls back to ring 3 where four stages do not fit the 160 KB of LDS.
+inline int deepest_ring(int ld) { return ld == 3 ? 4 : ld; }
+
 template <int MODE, bool FAST>
 int dispatch_gemm(GemmParams& p, float* ws, size_t ws_bytes, hipStream_t stream) {
     int nsplit = 1;
     int id = 0, ld = 0;
     if (!lookup_tuned(p, MODE, &id, &nsplit, &ld)) id = choose_cfg(p, &nsplit);
     if (g_force_cfg >= 0) { id = g_force_cfg % 16; nsplit = g_force_cfg / 16 > 0 ? g_force_cfg / 16 : 1; }
-    p.loaders = g_force_loaders >= 0 ? g_force_loaders : ld;
+    p.loaders = g_force_loaders >= 0 ? g_force_loaders : deepest_ring(ld);
     if (nsplit > 1 && (size_t)nsplit * p.M * p.N * sizeof(float) > ws_bytes) nsplit = 1;
     const int nk1 = hcp_cdiv(p.K, BK);
     p.nsplit = nsplit;
@@ -1050,7 +1057,7 @@ HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, c
         else id = 2;
     }
     if (g_force_cfg >= 0) id = g_force_cfg % 16;
-    p.loaders = g_force_loaders >= 0 ? g_force_loaders : ld;
+    p.loaders = g_force_loaders >= 0 ? g_force_loaders : deepest_ring(ld);
     if (id == 7 || id == 10 || id == 11) id = 6;
     if (id < 0) {
         // two-launch form: T = A L^T, then D = A B^T + T E^T with the measured tile / split-K choice
