@@ -187,7 +187,7 @@ class CrossAttention(nn.Module):
                 group.bucket = lb._bucket if lb is not None else None
                 if lb is not None:
                     group.bucket.add_group(group)
-        if len(self._groups) >= 4:                   # stale keys (layers wrapped / unwrapped since): drop the oldest
+        if len(self._groups) >= 6:                   # stale keys (layers wrapped / unwrapped since): drop the oldest
             self._groups.pop(next(iter(self._groups)))
         self._groups[key] = (group, mods)            # keeps the modules alive so the ids stay unique
         return group
@@ -198,8 +198,14 @@ class CrossAttention(nn.Module):
             # q|k|v in one fused-LoRA GEMM, attention reads the slices in place; the q third comes out as q * d^-0.5 * log2(e)
             # (folded into the packed q weights and that block's LoRA alpha): the kernels exponentiate the accumulator as it is
             g = self._group((self.to_q, self.to_k, self.to_v), (qc, 1.0, 1.0))
+            gq = gkv = None
+            if g is None and os.environ.get("HCP_LAB_NO_QKV_SPLIT") != "1":   # the three blocks' rank slots exceed one 32-wide slot group (rank 16: SDXL's configs[3]):
+                gkv = self._group((self.to_k, self.to_v))                  # q alone + k|v together, the cross-attention form with context = x
+                gq = self._group((self.to_q,), (qc,)) if gkv is not None else None
             if g is not None:
                 o = ops.attention_packed(ops.linear_group(x, g), None, self.heads, q_prescaled=True)
+            elif gq is not None:                       # 2 GEMMs + 1 gradient add instead of 3 + 2, and the pre-scaled-Q attention kernels
+                o = ops.attention_packed(ops.linear_group(x, gq), ops.linear_group(x, gkv), self.heads, None, q_prescaled=True)
             else:
                 o = ops.attention(self.to_q(x), self.to_k(x), self.to_v(x), self.heads)
         else:

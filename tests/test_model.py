@@ -169,6 +169,10 @@ def test_tiny_sdxl_lora_train_step_vs_oracle(backend):
     lo, ln, go, tr, wr = _train_step_pair(TINY_SDXL_CONFIG, backend, 16, (2, 4, 8, 8), 77, 64, pooled_dim=64)
     assert abs(lo - ln) / abs(lo) < 2e-2
     assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.999
+    # three rank-16 blocks do not fit one 32-wide slot group: self-attention runs as q alone + k|v together (the pre-scaled-Q kernels)
+    a1 = next(m for n, m in tr.unet.named_modules() if n.endswith("attn1"))
+    built = sorted(len(k) for k, (g, _) in a1._groups.items() if g is not None)
+    assert built == [1, 2] and any(g is None and len(k) == 3 for k, (g, _) in a1._groups.items())
 
 
 def _full_ft_pair(cfg, backend, shape, ctx_len, ctx_dim, pooled_dim=None, seed=11):
