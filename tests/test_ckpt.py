@@ -258,3 +258,27 @@ def test_reference_auto_manager_reads_native_files(backend, tmp_path, fmt):
     ref_mgr.auto_manager(back)._save_ckpt({k: v for k, v in theirs.items() if v}, save_path=back)
     again = mgr.load_ckpt(back)
     assert all(torch.equal(again["lora"][k], ours["lora"][k]) for k in ours["lora"])
+
+
+def test_webui_round_trip_loads_into_the_native_model(backend, tmp_path):
+    """A natively trained LoRA file -> webui layout (lora_convert CLI) -> back -> NativeModelLoader.load_lora on a fresh UNet: the same
+    prediction as the model that was trained (the whole f2 chain a user of the reference's tools/lora_convert.py walks)."""
+    from hcp_diffusion_amd import lora_convert as LC
+    nat, tr = _trained_native(backend, LORA_CFG)
+    mgr = CkptManagerNative(fmt="safetensors")
+    mgr.set_save_dir(str(tmp_path))
+    (path,) = tr.save_model(mgr, step=5)
+    LC.main(["--lora_path", path, "--dump_path", str(tmp_path / "webui.safetensors"), "--to_webui"])
+    web = mgr.load_ckpt(str(tmp_path / "webui.safetensors"))
+    assert web and all(k.startswith("lora_unet_") and k.rsplit(".", 2)[-2:] in (["lora_down", "weight"], ["lora_up", "weight"]) or k.endswith(".alpha")
+                       for k in web)
+    LC.main(["--lora_path", str(tmp_path / "webui.safetensors"), "--dump_path", str(tmp_path / "back"), "--from_webui"])
+    fresh = _native(backend.device)
+    fresh.requires_grad_(False)
+    group, _ = NativeModelLoader(fresh).load_lora([dict(path=str(tmp_path / "back" / "unet-webui.safetensors"), alpha=2.0)])
+    assert len(group.plugin_dict) == len(tr.lora_group.plugin_dict)
+    to = backend.to
+    g = torch.Generator().manual_seed(8)
+    x, ehs, t = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 77, 32, generator=g), torch.tensor([123])
+    with torch.no_grad():
+        assert torch.equal(nat(to(x), to(t), to(ehs)).sample, fresh(to(x), to(t), to(ehs)).sample)
