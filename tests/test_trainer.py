@@ -319,7 +319,8 @@ def test_text_encoder_and_unet_hip_graphs_under_a_plain_trainer_loop():
 
 def test_fused_adamw_state_dict_round_trip(backend):
     """FusedAdamW keeps flat moments per contiguous run; state_dict() cuts them into torch's per-parameter layout and load_state_dict()
-    puts them back (resume must not silently reset the Adam moments) — and a torch.optim.AdamW resumes from the same file."""
+    puts them back (resume must not silently reset the Adam moments): a resumed FusedAdamW continues exactly like the one that was
+    saved, and a torch.optim.AdamW resumes from the same dict (train_ac.py:370 builds either from the same cfg)."""
     from hcp_diffusion_amd.optim import FusedAdamW
     dev = backend.device
     torch.manual_seed(0)
@@ -329,35 +330,33 @@ def test_fused_adamw_state_dict_round_trip(backend):
     for p, g in zip(ps, (gflat[:64].view(8, 8), gflat[64:].view(6, 8))):
         p.grad = g
 
-    def steps(opt, n):
-        for i in range(n):
-            gflat.copy_(torch.sin(torch.arange(gflat.numel(), device=dev) * (0.1 + i)))
-            opt.step()
+    def grad(i):
+        return torch.sin(torch.arange(gflat.numel(), device=dev) * (0.1 + i))
+
     a = FusedAdamW(ps, lr=1e-2)
-    steps(a, 3)
+    for i in range(3):
+        gflat.copy_(grad(i)); a.step()
     sd = a.state_dict()
     assert set(sd["state"]) == {0, 1} and sd["state"][0]["exp_avg"].shape == (8, 8) and float(sd["state"][1]["step"]) == 3.0
     snapshot = flat.detach().clone()
-    steps(a, 2)
+    gflat.copy_(grad(3)); a.step()                     # the step the saved optimizer takes next
     expect = flat.detach().clone()
+    # a fresh FusedAdamW resumed from the dict takes the same step from the same parameters
     with torch.no_grad():
         flat.copy_(snapshot)
     b = FusedAdamW(ps, lr=1e-2)
     b.load_state_dict(sd)
-    steps(b, 2)                                        # same gradients as steps 4-5 above? (i restarts at 0: feed the same two)
-    with torch.no_grad():
-        flat.copy_(snapshot)
-    c = FusedAdamW(ps, lr=1e-2); c.load_state_dict(sd)
-    d = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-2)
+    gflat.copy_(grad(3)); b.step()
+    assert torch.allclose(flat, expect, atol=1e-7), (flat - expect).abs().max()
+    # ... and so does torch's own AdamW over copies of the parameters
+    d_params = [torch.nn.Parameter(snapshot[:64].view(8, 8).clone()), torch.nn.Parameter(snapshot[64:].view(6, 8).clone())]
+    d = torch.optim.AdamW(d_params, lr=1e-2)
     d.load_state_dict(sd)
-    for p_c, p_d in zip(ps, d.param_groups[0]["params"]):
-        p_d.grad = torch.zeros_like(p_d)
-    gflat.copy_(torch.cos(torch.arange(gflat.numel(), device=dev) * 0.3))
-    for p_c, p_d in zip(ps, d.param_groups[0]["params"]):
-        p_d.grad.copy_(p_c.grad)
-    c.step(); d.step()
-    for p_c, p_d in zip(ps, d.param_groups[0]["params"]):
-        assert torch.allclose(p_c.detach(), p_d.detach(), atol=1e-6), (p_c - p_d).abs().max()
+    g3 = grad(3)
+    d_params[0].grad, d_params[1].grad = g3[:64].view(8, 8).clone(), g3[64:].view(6, 8).clone()
+    d.step()
+    got = torch.cat([p.detach().flatten() for p in d_params])
+    assert torch.allclose(got, expect, atol=1e-6), (got - expect).abs().max()
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
