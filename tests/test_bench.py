@@ -37,6 +37,19 @@ def test_bench_launcher_runs_two_ranks_end_to_end():
     assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0 and "emu" in d["data"]
 
 
+@pytest.mark.slow
+def test_bench_launcher_two_ranks_sharded_overlapped_bf16_exchange():
+    """The host-bucket path of the same launcher: `--workload dreambooth --exchange overlap-bf16` on 2 gloo ranks of the interpreter —
+    sharded optimizer, chunks reduce-scattered from backward hooks, bf16 gradient and parameter wires — end to end through bench.py."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HCP_BENCH_BACKEND="emu", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", "--workload", "dreambooth",
+                        "--exchange", "overlap-bf16"], env=env, capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["exchange"] == "overlap-bf16" and d["final_loss"] > 0
+
+
 def test_abi_comm_bootstrap_falls_back_loudly_when_rccl_cannot_start(monkeypatch):
     """AbiComm.from_torch_store on a machine where the C-ABI communicator cannot be created (here: the interpreter build refuses
     world > 1... emulated with a world of 1 and a failing init) warns and hands back torch.distributed collectives instead of raising
