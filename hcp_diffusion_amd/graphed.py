@@ -86,7 +86,11 @@ def capturable(unet):  # (any native module that holds LoRA layers and / or trai
             return False
     if unet._forward_pre_hooks or unet._forward_hooks:
         return False
-    return any(p.requires_grad for p in unet.parameters())
+    lora_ids = {id(p) for m in unet.modules() if isinstance(m, LoraHipLayer) for p in m.parameters()}
+    trainable = [p for p in unet.parameters() if p.requires_grad]
+    if any(p.dtype != torch.float32 for p in trainable if id(p) not in lora_ids):
+        return False                                # HostBucket keeps fp32 masters only: a non-fp32 trainable host parameter stays eager
+    return bool(trainable)
 
 
 def capturable_cached(mod):
@@ -94,6 +98,8 @@ def capturable_cached(mod):
     4.4 ms per forward under the reference-style loop: tools/lab/graph_launch_cost.py).  Re-evaluated when the cheap tell-tales move —
     train()/eval() (LoRA dropout), hooks attached to / removed from the module (ControlNet feeders) — and by `enable_hip_graph()` /
     `reset_hip_graph()` / `enable_gradient_checkpointing()`, which the caller runs after changing what trains (unet.py docstrings)."""
+    # (requires_grad_() flips after the first call are NOT seen here — a walk over the parameters is the cost this cache removes:
+    #  call reset_hip_graph() after changing what trains)
     key = (mod.training, len(mod._forward_pre_hooks), len(mod._forward_hooks))
     hit = getattr(mod, "_hcp_capturable", None)
     if hit is None or hit[0] != key:
@@ -238,26 +244,53 @@ def capture(unet, inputs, fwd, pool=None):
 _warned = set()
 
 
+def set_max_signatures(mod, n):
+    """Overlay key `hip_graph_max_signatures` (next to `hip_graph`; `enable_hip_graph(max_signatures=n)`): how many input signatures
+    (aspect-ratio buckets x datasets, data/bucket.py:63-229) of THIS module keep their captured pair; None = `MAX_SIGNATURES`.  Past it
+    the least recently used pair is dropped and re-captured on its next use (2 warm-up steps + 2 captures), which `call` reports once
+    per module."""
+    if n is not None and int(n) < 1:
+        raise ValueError("hip_graph_max_signatures must be >= 1")
+    mod._hip_graph_max = None if n is None else int(n)
+
+
+def _live_pending(e):
+    """True while a forward of this entry still awaits its backward (its autograd node is alive)."""
+    if not e.pending:
+        return False
+    node = e.pending_node() if e.pending_node is not None else None
+    if node is None:
+        e.pending = False                           # the call's graph was dropped without a backward (eval in grad mode, an exception)
+        return False
+    return True
+
+
+def _warn_once(unet, tag, msg):
+    if (id(unet), tag) not in _warned:
+        _warned.add((id(unet), tag))
+        import warnings
+        warnings.warn("hcp_diffusion_amd: " + msg)
+
+
 def call(unet, inputs, fwd, cache, key):
+    # All signatures of a module capture into ONE memory pool: the activations a pending forward saved live in pool blocks that any
+    # other signature's replay (or a new capture) is free to overwrite.  So while ANY entry awaits its backward, nothing is replayed,
+    # captured or evicted: that call runs eagerly (fwd(shape A) -> fwd(shape B) -> backward stays correct).
+    if any(_live_pending(x) for x in cache.values()):
+        _warn_once(unet, "pending", "a second forward before the pending backward runs eagerly (hip_graph holds one set of activations)")
+        return fwd(*inputs)
     e = cache.get(key)
     if e is None:
         pool = next((x.g_fwd.pool() for x in cache.values()), None)       # one pool for every signature of this module
-        while len(cache) >= MAX_SIGNATURES:
+        cap = getattr(unet, "_hip_graph_max", None) or MAX_SIGNATURES
+        while len(cache) >= cap:
             cache.pop(next(iter(cache)))                                    # least recently used first (dict order = use order, below)
+            _warn_once(unet, "evict", f"more than {cap} input signatures: the least recently used hipGraph pair is dropped and "
+                                      "re-captured on its next use (raise `hip_graph_max_signatures`)")
         e = capture(unet, inputs, fwd, pool)
     else:
         cache.pop(key)
     cache[key] = e                                                          # most recently used last
-    if e.pending:
-        node = e.pending_node() if e.pending_node is not None else None
-        if node is None:
-            e.pending = False                       # the previous call's graph was dropped without a backward (eval in grad mode, an exception)
-        else:                                       # a second forward before the first one's backward (two losses summed, then one
-            if id(unet) not in _warned:             # backward): the graph holds ONE set of activations, so this call runs eagerly
-                _warned.add(id(unet))
-                import warnings
-                warnings.warn("hcp_diffusion_amd: a second forward before the pending backward runs eagerly (hip_graph holds one set of activations)")
-            return fwd(*inputs)
     out = _GraphedFn.apply(e, len(e.params), *e.params, *inputs)
     e.pending_node = weakref.ref(out.grad_fn) if out.grad_fn is not None else None
     return out

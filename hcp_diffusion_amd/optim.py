@@ -21,7 +21,8 @@ def _dense_flat(t):
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._runs = {}            # group index -> (signature, [run])
+        self._runs = {}            # group index -> (sampled signature, [run], full signature)
+        self._nsteps = {}          # group index -> steps since the runs were built (full pointer check every FULL_CHECK_EVERY)
 
     def _build_runs(self, group):
         items = []
@@ -49,13 +50,17 @@ class FusedAdamW(torch.optim.Optimizer):
                             lr=torch.zeros(1, dtype=torch.float32, device=pf.device), step=torch.zeros(1, dtype=torch.int32, device=pf.device)))
         return out
 
+    FULL_CHECK_EVERY = 64
+
     @staticmethod
-    def _sig(group):
+    def _sig(group, full=False):
         """What the flat runs were built from: which parameters have gradients and where both live.  Per step only a sample is compared
         (count + first / middle / last pointers: a re-homed bucket or a dropped gradient moves those); 640 data_ptr() calls per step
-        were 0.25 ms of the reference-style loop's host time."""
+        were 0.25 ms of the reference-style loop's host time.  full=True compares every pointer: step() does that every
+        FULL_CHECK_EVERY steps, so an INTERIOR gradient re-allocated outside the flat run (p.grad = None on one layer, a module
+        swapping a tensor) while the count stays the same is still caught instead of stepping from a stale slice for the whole run."""
         ps = [p for p in group["params"] if p.grad is not None]
-        pick = [ps[0], ps[len(ps) // 2], ps[-1]] if ps else []
+        pick = ps if full else ([ps[0], ps[len(ps) // 2], ps[-1]] if ps else [])
         return (len(ps),) + tuple((p.data_ptr(), p.grad.data_ptr()) for p in pick)
 
     @torch.no_grad()
@@ -64,11 +69,16 @@ class FusedAdamW(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             sig = self._sig(group)
             cached = self._runs.get(gi)
-            if cached is None or cached[0] != sig:
+            moved = cached is not None and cached[0] != sig
+            if cached is not None and not moved:
+                self._nsteps[gi] = self._nsteps.get(gi, 0) + 1
+                if self._nsteps[gi] % self.FULL_CHECK_EVERY == 0:
+                    moved = self._sig(group, full=True) != cached[2]
+            if cached is None or moved:
                 if cached is not None:
                     raise RuntimeError("FusedAdamW: the set of parameters with gradients (or their storage) changed between steps; "
                                        "the flat AdamW moments cannot follow")
-                cached = (sig, self._build_runs(group))
+                cached = (sig, self._build_runs(group), self._sig(group, full=True))
                 self._runs[gi] = cached
                 self._apply_resume(group, cached[1])
             b1, b2 = group["betas"]

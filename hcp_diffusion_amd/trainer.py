@@ -80,17 +80,26 @@ class _OptState:
 FP32_WIRE = 10      # chunk ids >= 10: parameters the kernels read as fp32 (biases, norm affine) — never rounded on the wire
 
 
-def _chunker(overlap, param_wire, unet_names=True):
+def _bf16_consumed(model):
+    """ids of the parameters the kernels consume as bf16 operands: the weights of HipLinear / HipConv2d (what HostBucket.layers packs).
+    Everything else — biases, norm affine, embedding / positional tables, any non-Hip layer inside a plugin or text encoder — is read
+    in fp32 by its module and must come back from the wire exact, or data-parallel replicas would compute with different values."""
+    from .layers import HipConv2d, HipLinear
+    return {id(m.weight) for m in model.modules() if isinstance(m, (HipLinear, HipConv2d))}
+
+
+def _chunker(overlap, param_wire, unet_names=True, bf16_ids=None):
     """(name, parameter) -> chunk id of a sharded host bucket.  With overlap: the order backward finishes the gradients of a UNet —
     0 = up blocks + output head (first), 1 = mid block, 2 = everything else (down blocks, conv_in, time / class / addition embeddings:
-    complete only when backward ends).  With param_wire='bf16': vectors (biases, GroupNorm / LayerNorm affine — 0.1 % of the elements,
-    consumed by the kernels in fp32) form a chunk of their own that always returns as fp32, so that every rank computes with the same
-    values; matrices are consumed as bf16 operands anyway."""
+    complete only when backward ends).  With param_wire='bf16': only the parameters in `bf16_ids` (`_bf16_consumed`: HipLinear /
+    HipConv2d weights, consumed as bf16 operands anyway) travel as bf16; the rest (biases, GroupNorm / LayerNorm affine, tables of
+    non-Hip layers — consumed in fp32) form a chunk of their own that always returns as fp32, so that every rank computes with the
+    same values."""
     if not overlap and param_wire != "bf16":
         return None
 
     def chunk_of(name, p):
-        if param_wire == "bf16" and p.dim() <= 1:
+        if param_wire == "bf16" and (p.dim() <= 1 or (bf16_ids is not None and id(p) not in bf16_ids)):
             return FP32_WIRE + 2
         if not (overlap and unet_names):
             return 2
@@ -174,13 +183,13 @@ class NativeTrainer:
                     full = f"{layer_name}.{n_}" if layer_name else n_
                     if id(p_) not in seen and "lora_block_" not in full:
                         seen.add(id(p_)); params.append((full, p_))
-            hb = HostBucket(unet, params, pad_multiple=pad, chunk_of=_chunker(self._overlap, param_wire) if shard else None)
+            hb = HostBucket(unet, params, pad_multiple=pad, chunk_of=_chunker(self._overlap, param_wire, bf16_ids=_bf16_consumed(unet)) if shard else None)
             self.host_buckets.append(_OptState(hb, item.get("lr", lr) * scale_lr_factor, self.device, comm=self.comm, shard=shard, **wires))
         self.plugins = []
         for plugin, plr in (plugins or []):
             plugin.train()
             hb = HostBucket(plugin, list(plugin.named_parameters()), pad_multiple=pad,
-                            chunk_of=_chunker(False, param_wire, unet_names=False) if shard else None)
+                            chunk_of=_chunker(False, param_wire, unet_names=False, bf16_ids=_bf16_consumed(plugin)) if shard else None)
             self.host_buckets.append(_OptState(hb, plr * scale_lr_factor, self.device, comm=self.comm, shard=shard, **wires))
             self.plugins.append(plugin)
         self.param_groups, self.lora_group, self.bucket = make_lora(unet, lora_cfg) if lora_cfg else ([], None, None)
@@ -227,7 +236,8 @@ class NativeTrainer:
         self.grouped_wgrad = grouped_wgrad
         self._wgrad_ctx = ops.WgradContext(grouped=grouped_wgrad, side_stream=self.overlap_wgrad)   # this trainer's own (no process-global switch)
         self._xstream = torch.cuda.Stream(self.device) if (self._overlap and self.device.type == "cuda") else None
-        self._graph_cache = {}           # batch signature -> (forward/backward graph, static inputs, loss tensor)
+        self._graph_cache = {}           # batch signature -> (forward/backward graph, static inputs, loss tensor), least recently used first
+        self.max_graph_signatures = 32   # aspect-ratio buckets x context lengths kept captured (each holds its static inputs; the pool is shared)
         self._opt_graph = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
@@ -508,9 +518,17 @@ class NativeTrainer:
             sent = tuple(sorted(self._sent))
         else:
             sig = self._signature(data_list) + (early,)
-            entry = self._graph_cache.get(sig)
+            entry = self._graph_cache.pop(sig, None)
             if entry is None:                      # a new aspect-ratio bucket / context length: capture once, replay afterwards
+                if len(self._graph_cache) >= self.max_graph_signatures:
+                    self._graph_cache.pop(next(iter(self._graph_cache)))          # least recently used (dict order = use order)
+                    if not getattr(self, "_warned_evict", False):
+                        self._warned_evict = True
+                        import warnings
+                        warnings.warn(f"hcp_diffusion_amd: more than {self.max_graph_signatures} batch signatures: the least recently used step "
+                                      "graph is dropped and re-captured on its next use (raise NativeTrainer.max_graph_signatures)")
                 entry = self._capture(data_list, sig, early)
+            self._graph_cache[sig] = entry         # most recently used last
             graph, static, loss, sent = entry
             for sb, b in zip(static, data_list):
                 live = dict(self._tensors(b))
@@ -519,6 +537,10 @@ class NativeTrainer:
             graph.replay()
             self.loss = loss
         if sync:
+            # param_wire='bf16': after this step the other ranks' slices of the fp32 masters are bf16-rounded here.  Set at the SYNC STEP,
+            # not inside optimizer_step(): a captured optimizer step replays without running that Python.
+            if any(st.shard and st.pwire is not None for st in self._states()):
+                self._masters_stale = True
             self.all_reduce()
             if self._opt_graph is not None and getattr(self, "_opt_graph_sent", ()) == tuple(sent):
                 self._opt_graph.replay()

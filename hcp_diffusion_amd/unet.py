@@ -443,10 +443,11 @@ class NativeUNet2DConditionModel(nn.Module):
         return cls(**dict(config or {}, **kw))
 
     @classmethod
-    def from_pretrained(cls, path=None, subfolder=None, pretrained_model_name_or_path=None, hip_graph=False, **kw):
+    def from_pretrained(cls, path=None, subfolder=None, pretrained_model_name_or_path=None, hip_graph=False, hip_graph_max_signatures=None, **kw):
         """Load diffusers-format weights (config.json + *.safetensors) — names are identical by construction.
         (``pretrained_model_name_or_path``: diffusers' own keyword, as the YAML overlays of cfgs/train/mi355x pass it;
-        ``hip_graph: True`` = enable_hip_graph(): the module replays captured graphs under the reference's eager trainer loop.)"""
+        ``hip_graph: True`` = enable_hip_graph(): the module replays captured graphs under the reference's eager trainer loop;
+        ``hip_graph_max_signatures: N`` = how many aspect-ratio bucket shapes keep their captured pair, default graphed.MAX_SIGNATURES.)"""
         path = path if path is not None else pretrained_model_name_or_path
         import json
         import os
@@ -465,7 +466,7 @@ class NativeUNet2DConditionModel(nn.Module):
         from safetensors.torch import load_file
         model.load_state_dict(load_file(os.path.join(root, "diffusion_pytorch_model.safetensors")))
         if hip_graph:
-            model.enable_hip_graph()
+            model.enable_hip_graph(max_signatures=hip_graph_max_signatures)
         return model
 
     @property
@@ -541,13 +542,15 @@ class NativeUNet2DConditionModel(nn.Module):
         kvs = ops.ctx_kv(ctx, batch)
         ctx._hcp_kv = {id(a): kv for a, kv in zip(xs, kvs)}
 
-    def enable_hip_graph(self, on=True, _recorded_on_cpu=False):
+    def enable_hip_graph(self, on=True, _recorded_on_cpu=False, max_signatures=None):
         """Replay the forward and the backward of `unet(...)` as captured hipGraphs when an ordinary trainer calls the module in grad
         mode (LoRA and / or host parameters training, alone or under torch DDP; see graphed.py).  Call again (or `reset_hip_graph()`)
         after adding / removing LoRA layers or changing what trains.  `_recorded_on_cpu`: tests only — the same wiring with recorded
         callables in place of graphs on the interpreter backend."""
         self._hip_graph, self._hip_graphs, self._hip_graph_cpu = bool(on), {}, bool(_recorded_on_cpu)
         self._hcp_capturable = None
+        from . import graphed
+        graphed.set_max_signatures(self, max_signatures)
 
     def reset_hip_graph(self):
         self._hip_graphs = {}

@@ -153,3 +153,43 @@ def test_module_graph_under_stock_ddp(tmp_path, mode):
         assert (r0 - p_init).abs().max().item() > (5e-3 if mode == "lora" else 1e-4)
     finally:
         K._set_backend_for_tests(None)
+
+
+def test_a_second_signature_while_a_backward_is_pending_runs_eagerly_and_the_cap_evicts_the_oldest(backend):
+    """All signatures of a module capture into ONE memory pool, so while ANY signature's forward awaits its backward no other signature
+    may replay, capture or be evicted: fwd(shape A) -> fwd(shape B) -> backward of the sum must give the eager gradients.
+    `enable_hip_graph(max_signatures=N)` (overlay key hip_graph_max_signatures) bounds the per-module cache; the least recently used
+    pair goes first, with one warning."""
+    import warnings
+    dev = backend.device
+    g = torch.Generator().manual_seed(11)
+    xa, xb = torch.randn(2, 4, 8, 8, generator=g).to(dev), torch.randn(1, 4, 8, 8, generator=g).to(dev)
+    ta, tb = torch.tensor([10, 500]).to(dev), torch.tensor([900]).to(dev)
+    ea, eb = (torch.randn(n, 9, 32, generator=g).to(torch.bfloat16).to(dev) for n in (2, 1))
+    grads = {}
+    for graph in (False, True):
+        nat, params = _model(dev, "lora")
+        if graph:
+            nat.enable_hip_graph(True, _recorded_on_cpu=not backend.is_gpu, max_signatures=2)
+            for x, t, e in ((xa, ta, ea), (xb, tb, eb)):                    # both signatures captured, nothing pending
+                nat(x, t, e).sample.float().sum().backward()
+            for p in params:
+                p.grad.zero_()
+            assert len(nat._hip_graphs) == 2
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            la = nat(xa, ta, ea).sample.float().pow(2).mean()              # A replays: pending
+            lb = nat(xb, tb, eb).sample.float().pow(2).mean()              # B must NOT replay into the shared pool: eager
+            if graph:
+                assert any("runs eagerly" in str(x.message) for x in w)
+        (la + lb).backward()
+        grads[graph] = torch.cat([p.grad.detach().float().flatten().cpu() for p in params])
+        if graph:                                                           # a third signature: the cap drops the least recently used pair
+            xc = torch.randn(1, 4, 16, 8, generator=g).to(dev)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                nat(xc, tb, eb).sample.float().sum().backward()
+                assert any("input signatures" in str(x.message) for x in w)
+            assert len(nat._hip_graphs) == 2
+    cos = torch.nn.functional.cosine_similarity(grads[False], grads[True], dim=0).item()
+    assert cos > 0.9999 and torch.allclose(grads[False], grads[True], rtol=2e-2, atol=1e-4), cos

@@ -415,3 +415,30 @@ def test_fused_adamw_zero_grad_clears_flat_runs_and_stragglers(backend):
     assert flat_g.abs().max().item() == 0 and lone.grad.abs().max().item() == 0 and all(p.grad is not None for p in ps)
     opt.zero_grad(set_to_none=True)
     assert all(p.grad is None for p in ps + [lone])
+
+
+def test_bf16_param_wire_routes_only_hip_layer_weights_and_the_stale_flag_follows_the_sync_step():
+    """(a) with param_wire='bf16' only the weights HipLinear / HipConv2d consume as bf16 operands may travel rounded — a
+    matrix-shaped parameter a module reads in fp32 (an embedding table of a non-Hip layer) must use the fp32 chunk, or data-parallel
+    replicas drift apart; (b) `_masters_stale` is raised by the sync STEP (train_data_list), so a captured optimizer step — which
+    replays without running optimizer_step()'s Python — still makes save_model refuse rounded masters."""
+    import types
+    from hcp_diffusion_amd import trainer as T
+    from hcp_diffusion_amd.layers import HipLinear
+    m = torch.nn.Module()
+    m.lin = HipLinear(8, 8)
+    m.table = torch.nn.Embedding(16, 8)
+    ids = T._bf16_consumed(m)
+    assert ids == {id(m.lin.weight)}
+    chunk_of = T._chunker(False, "bf16", unet_names=False, bf16_ids=ids)
+    assert chunk_of("lin.weight", m.lin.weight) < T.FP32_WIRE
+    assert chunk_of("lin.bias", m.lin.bias) >= T.FP32_WIRE
+    assert chunk_of("table.weight", m.table.weight) >= T.FP32_WIRE              # a matrix, but consumed in fp32
+    # (b) the flag is set where the step syncs, whatever runs the optimizer afterwards
+    calls = []
+    st = types.SimpleNamespace(shard=True, pwire=torch.zeros(1))
+    fake = types.SimpleNamespace(_micro=0, accum=1, _overlap=False, use_graph=False, _sent=set(), _opt_graph=types.SimpleNamespace(replay=lambda: calls.append("replay")),
+                                 _opt_graph_sent=(), _masters_stale=False, _states=lambda: [st], all_reduce=lambda: None,
+                                 _run_all=lambda data_list, exchange=False: torch.zeros(1), optimizer_step=lambda **kw: calls.append("eager"))
+    T.NativeTrainer.train_data_list(fake, [dict(latents=torch.zeros(1, 4, 8, 8))])
+    assert calls == ["replay"] and fake._masters_stale is True
