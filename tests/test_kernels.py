@@ -254,6 +254,41 @@ def test_attention_prescaled_q(backend, shape):
         K.attention_fwd(to(qs), to(k), to(v), H, key_bias=to(torch.zeros(B, Nk)), q_prescaled=True)
 
 
+@pytest.mark.parametrize("prescaled", [False, True])
+@pytest.mark.parametrize("mode", ["late_dominant_key", "anti_aligned_first_tile"])
+def test_attention_lsum_overflow_rerun(backend, mode, prescaled):
+    """The d = 40 forward takes its reference maximum from the FIRST key tile and afterwards only watches the row sums (VAR_LSUM,
+    attn_dma.h); a later score more than 2^127 above that reference overflows exp2 and the workgroup must repeat its rows on the exact
+    per-score-maximum path (`redo_flag`).  Trained checkpoints produce such logits, random-init goldens never do:
+    * late_dominant_key: one late key = 16 q for one query row -> (q.k - m) * scale * log2(e) ~ 140 > 128: that row overflows, the
+      other rows of its workgroup ride through the re-run too;
+    * anti_aligned_first_tile: the first 64 keys = -16 q_row for ONE batch row's queries... every later key then sits ~2^146 above the
+      reference (rescale in the other direction, then overflow).
+    o / lse / dQ / dK / dV at the tolerances of test_attention_fwd_bwd, raw and pre-scaled Q."""
+    D, H = 40, 2
+    B, Nq, Nk = (1, 4096, 4096) if backend.is_gpu else (1, 70, 150)
+    torch.manual_seed(17)
+    q, k, v, do = rnd(B, Nq, H * D), rnd(B, Nk, H * D), rnd(B, Nk, H * D), rnd(B, Nq, H * D)
+    row = Nq // 2
+    if mode == "late_dominant_key":
+        k[0, Nk - 7, :D] = (q[0, row, :D].float() * 16.0).to(BF)
+    else:
+        k[0, :64, :D] = (q[0, row, :D].float() * -16.0).to(BF)          # head 0: the first tile's maximum for `row` is ~ -640 raw
+    c = D ** -0.5 * 1.4426950408889634
+    qs = (q.float() * c).to(BF) if prescaled else q
+    o_ref, lse_ref, dq_ref, dk_ref, dv_ref = attn_ref((qs.float() / c) if prescaled else q, k, v, H, do)
+    # the case is what it claims: some exp2 argument relative to the first tile's maximum exceeds the fp32 exponent range
+    s0 = ((qs.float() / c) if prescaled else q.float())[0, row, :D] @ k[0, :, :D].float().T * D ** -0.5 * 1.4426950408889634
+    assert (s0.max() - s0[:64].max()).item() > 130.0
+    to = backend.to
+    o, lse = K.attention_fwd(to(qs), to(k), to(v), H, q_prescaled=prescaled)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert relerr(o, o_ref) < 1e-2 and (lse.cpu() - lse_ref).abs().max().item() < 2e-2
+    dq, dk, dv = K.attention_bwd(to(qs), to(k), to(v), o, to(do), lse, H, q_prescaled=prescaled)
+    dqs = dq.float() * c if prescaled else dq
+    assert relerr(dqs, dq_ref) < 2e-2 and relerr(dk, dk_ref) < 2e-2 and relerr(dv, dv_ref) < 2e-2
+
+
 def test_attention_strided_qkv(backend):
     """q/k/v as column slices of one fused [B,N,3C] projection (non-contiguous rows)."""
     torch.manual_seed(3)
