@@ -21,42 +21,12 @@
 //   Cout of the SD UNet (320/640/1280/2560/5120/10240); small-M (16x16, 8x8 latent) layers
 //   use split-K into fp32 slabs + a fused reduce/epilogue kernel.
 #include "hcp_common.h"
+#include "gemm_params.h"
 
 namespace {
 
-struct ConvDesc {
-    const hcp_bf16* X1; int C1;   // first source tensor  [B, Hs, Ws, C1]
-    const hcp_bf16* X2; int C2;   // optional second source (channel concat), else null/0
-    int Hs, Ws;                   // source spatial dims (memory)
-    int Ho, Wo;                   // output spatial dims (rows of the implicit A matrix)
-    int stride;                   // 1 or 2
-    int up;                       // 1: source is nearest-upsampled 2x before the conv (fwd only)
-    int pad;                      // 1: taps -1..+1 (padding 1); 0: taps 0..+2 (F.pad(0,1,0,1) + padding 0: the VAE encoder's Downsample2D), fwd only
-};
+using namespace hcp_gemm;
 
-struct GemmParams {
-    const hcp_bf16* A; int lda;
-    const hcp_bf16* A2; int lda2; int K2;
-    const hcp_bf16* B; int ldb;
-    const hcp_bf16* B2; int ldb2;
-    int M, N, K;
-    void* D; int ldd; int out_f32;
-    const float* bias;
-    const float* rowbias; int rowbias_ld; int rows_per_group;
-    const hcp_bf16* residual; int ldr;
-    float alpha;
-    int tiles_m;
-    int nsplit; int kt_per_split;   // split-K over the primary K tiles (grid.y)
-    float* slabs;                   // [nsplit][M][N] fp32 partials when nsplit > 1
-    // fused LoRA (LORA kernels): T = A L^T is accumulated next to the main tile from the same A tiles, rounded to
-    // bf16, then D += T E^T as one extra k-step.  L [32,K] (ldl = K), E [N,32], Tout [M,32] (optional, for wgrad).
-    const hcp_bf16* L; const hcp_bf16* E; hcp_bf16* Tout;
-    int loaders;                    // 1: launch the loader-wave variant of the v2 kernel where one is instantiated (dispatch table / tools)
-    int dbg;                        // tools/ablate_gemm.py: 1 = skip the DMA after the first tile, 2 = skip the MFMAs, 4 = skip LDS reads + MFMAs
-    ConvDesc cv;
-};
-
-constexpr int BK = 64;
 
 HCP_DEVICE void epilogue_store(const GemmParams& p, int m, int n, hcp_f32x4 v) {
     v = v * p.alpha;
@@ -837,8 +807,25 @@ constexpr TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 1
                              {128, 320}, {256, 160}, {128, 160}, {64, 160}, {128, 128}};   // 11: 16 waves (4x4), 12: 16 waves (8x2), 13-15: 8 waves as 4x2
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
+// p.loaders >= 8: the ping-pong main loop (gemm_pp.hip) with an LDS ring of p.loaders - 8 tiles, where it is instantiated for
+// this tile shape and its requirements hold (the v2 ones: K % 64 == 0, FAST conv gathers, 32-bit offsets).  -2 = not taken.
+int try_pp(int id, int mode, bool fast_or_plain, bool lora, GemmParams& p, hipStream_t stream) {
+    if (p.loaders < 8 || !fast_or_plain || !g_use_v2 || (g_dbg_ablate & 7)) return -2;
+    if (p.K % BK != 0 || !(p.K2 == 0 || p.K2 == 32) || (size_t)p.M * p.lda * 2 >= (1ul << 31) || (size_t)p.N * p.ldb * 2 >= (1ul << 31)) return -2;
+    const int bm = kCfgs[id].bm, bn = kCfgs[id].bn;
+    p.tiles_m = hcp_cdiv(p.M, bm);
+    p.dbg = g_dbg_ablate;
+    const int r = gemm_pp_launch(p, bm, bn, mode, lora, p.loaders - 8, stream);
+    if (r != 0 || p.nsplit <= 1) return r;
+    long nv = (long)p.M * (p.N / 4);
+    int g = (int)((nv + 255) / 256); if (g > 2048) g = 2048;
+    HCP_LAUNCH(splitk_reduce_kernel, dim3(g), dim3(256), 0, stream, p);
+    HCP_LAUNCH_CHECK("splitk_reduce_kernel");
+}
+
 template <int MODE, bool FAST>
 int launch_by_id(int id, GemmParams& p, hipStream_t stream) {
+    if (id >= 0 && id < kNumCfgs) { const int r = try_pp(id, MODE, MODE == 0 || FAST, false, p, stream); if (r != -2) return r; }
     switch (id) {
         case 0: return launch_cfg<128, 128, 2, 2, MODE, FAST>(p, stream);
         case 1: return launch_cfg<128, 64, 2, 2, MODE, FAST>(p, stream);
@@ -860,6 +847,7 @@ int launch_by_id(int id, GemmParams& p, hipStream_t stream) {
 }
 
 int launch_lora_by_id(int id, GemmParams& p, hipStream_t stream) {
+    if (id >= 0 && id < kNumCfgs) { const int r = try_pp(id, 0, true, true, p, stream); if (r != -2) return r; }
     switch (id) {
         case 0: return launch_cfg<128, 128, 2, 2, 0, false, true>(p, stream);
         case 1: return launch_cfg<128, 64, 2, 2, 0, false, true>(p, stream);

@@ -90,6 +90,16 @@ HCP_DEVICE hcp_bf16x8 hcp_buf_load16(hcp_rsrc rsrc, unsigned voffset) {
     u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffset, 0, 0);
     return __builtin_bit_cast(hcp_bf16x8, v);
 }
+HCP_DEVICE hcp_bf16x4 hcp_buf_load8(hcp_rsrc rsrc, unsigned voffset) {                 // 8 bytes, zeros outside the resource
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffset, 0, 0);
+    return __builtin_bit_cast(hcp_bf16x4, v);
+}
+HCP_DEVICE hcp_f32x4 hcp_buf_load16f(hcp_rsrc rsrc, unsigned voffset) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffset, 0, 0);
+    return __builtin_bit_cast(hcp_f32x4, v);
+}
 // LDS-DMA the compiler does not see (inline asm): hipcc drains every builtin LDS-DMA with s_waitcnt vmcnt(0) in front of the
 // next ds_read_b64_tr_b16 (it cannot prove the transpose read does not alias the DMA's destination), which serialises the
 // "fill the other buffer while this one is consumed" pipeline of the attention kernels.  Issued through asm the copy is

@@ -116,6 +116,16 @@ HCP_DEVICE hcp_bf16x8 hcp_buf_load16(hcp_rsrc rsrc, unsigned voffset) {
     if (voffset < rsrc.nbytes && voffset + 16 <= rsrc.nbytes) memcpy(&v, rsrc.base + voffset, 16);
     return v;
 }
+HCP_DEVICE hcp_bf16x4 hcp_buf_load8(hcp_rsrc rsrc, unsigned voffset) {
+    hcp_bf16x4 v = {0, 0, 0, 0};
+    if (voffset < rsrc.nbytes && voffset + 8 <= rsrc.nbytes) memcpy(&v, rsrc.base + voffset, 8);
+    return v;
+}
+HCP_DEVICE hcp_f32x4 hcp_buf_load16f(hcp_rsrc rsrc, unsigned voffset) {
+    hcp_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (voffset < rsrc.nbytes && voffset + 16 <= rsrc.nbytes) memcpy(&v, rsrc.base + voffset, 16);
+    return v;
+}
 struct hcp_desc4 { const unsigned char* base; unsigned nbytes; };
 HCP_DEVICE hcp_desc4 hcp_make_desc(const void* base, unsigned nbytes) { hcp_desc4 d; d.base = (const unsigned char*)base; d.nbytes = nbytes; return d; }
 HCP_DEVICE void hcp_dma16(hcp_desc4 d, unsigned voffset, void* lds_wave_base) {

@@ -837,3 +837,44 @@ def test_gemm_loader_wave_variants(tbackend, cfg, stages):
         assert relerr(ol, ref_l) < 1e-2 and relerr(t, a.float() @ l.float().T) < 1e-2
     finally:
         L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1)
+
+
+@pytest.mark.parametrize("ring", [2, 3, 4])
+@pytest.mark.parametrize("cfg", [13, 14, 15])
+def test_gemm_pingpong_variants(tbackend, cfg, ring):
+    """gemm_pp_kernel (csrc/gemm_pp.hip): two compute groups half a phase apart + 4 loader waves; the groups split every K tile
+    by k-step (partial sums exchanged through LDS); LDS ring of 2 / 3 / 4 K tiles.  Plain GEMM with
+    K-extension, bias, residual and ragged M / N; fused-LoRA GEMM with residual; forward convolution (concat input, stride 2) and
+    data gradient; split-K on and off — forced through the tuning hooks (loaders = 8 + ring)."""
+    to = tbackend.to
+    L = K.lib()
+    torch.manual_seed(100 + cfg)
+    M, N, Kd = (200, 320, 192) if not tbackend.is_gpu else (3000, 640, 1280)
+    a, b, a2, b2 = rnd(M, Kd), rnd(N, Kd), rnd(M, 32), rnd(N, 32)
+    bias, res = torch.randn(N), rnd(M, N)
+    ref = a.float() @ b.float().T + a2.float() @ b2.float().T + bias + res.float()
+    l, e = rnd(32, Kd) * 0.2, rnd(N, 32) * 0.2
+    ref_l = a.float() @ b.float().T + (a.float() @ l.float().T).to(BF).float() @ e.float().T + bias + res.float()
+    C1, C2, H, Cout = (64, 64, 6, 64) if not tbackend.is_gpu else (320, 320, 32, 320)
+    x1, x2 = rnd(2, H, H, C1), rnd(2, H, H, C2)
+    w = rnd(Cout, C1 + C2, 3, 3) * 0.1
+    xr = torch.cat([x1, x2], -1).permute(0, 3, 1, 2).float()
+    ref_c = F.conv2d(xr, w.float(), stride=2, padding=1).permute(0, 2, 3, 1)
+    dy = rnd(2, H, H, Cout)
+    wd = rnd(Cout, C1, 3, 3) * 0.1
+    ref_d = F.conv_transpose2d(dy.permute(0, 3, 1, 2).float(), wd.float(), stride=1, padding=1).permute(0, 2, 3, 1)
+    try:
+        L.hcp_debug_set_gemm_loaders(8 + ring)
+        for split in (1, 2):
+            L.hcp_debug_set_gemm_config(cfg + 16 * split)
+            out = K.gemm(to(a), to(b), a2=to(a2), b2=to(b2), bias=to(bias), residual=to(res))
+            assert relerr(out, ref) < 1e-2
+            oc = K.conv3x3(to(x1), to(w.permute(0, 2, 3, 1).contiguous()), Cout, x2=to(x2), stride=2)
+            assert relerr(oc, ref_c) < 1e-2
+            od = K.conv3x3(to(dy), to(wd.permute(1, 2, 3, 0).contiguous()), C1, mode=1, out_hw=(H, H))
+            assert relerr(od, ref_d) < 1e-2
+        L.hcp_debug_set_gemm_config(cfg + 16)
+        ol, t = K.gemm_lora(to(a), to(b), to(l.contiguous()), to(e.contiguous()), bias=to(bias), residual=to(res))
+        assert relerr(ol, ref_l) < 1e-2 and relerr(t, a.float() @ l.float().T) < 1e-2
+    finally:
+        L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1)

@@ -1,7 +1,10 @@
 """GPU-only: where does the loader-wave variant of the v2 GEMM / implicit-conv kernel (csrc/gemm.hip, NLD = 4: four extra waves
 issue the tile's LDS-DMA, the compute waves only read fragments and issue MFMAs) beat the dispatched configuration?
 
-  python tools/tune_loaders.py sd15|sdxl|dreambooth|controlnet [batch]
+  python tools/tune_loaders.py [--pp] sd15|sdxl|dreambooth|controlnet [batch]
+
+--pp (round 4): sweep the ping-pong kernel (csrc/gemm_pp.hip: two compute groups half a phase apart, K-split, LDS ring 3 / 4) on the
+same tile ids against the FULL current dispatch (main + loader tables) -> gpurun_out/tune_pp_<workload>.json.
 
 Traces one training step (kernels.TRACE), then for every distinct shape times the CURRENT dispatch against tile ids 13 / 14 / 15
 (128x160, 64x160, 128x128 with 8 compute waves) x split-K with loaders forced on.  Winners by > 3 % go to
@@ -23,12 +26,17 @@ dev = torch.device("cuda:0")
 LOADER_CFGS = {13: "128x160w8+ld4", 14: "64x160w8+ld4", 15: "128x128w8+ld4"}
 
 
+PP = "--pp" in sys.argv          # sweep the ping-pong kernel (csrc/gemm_pp.hip; loaders = 8 + ring) against the FULL current dispatch
+if PP:
+    sys.argv.remove("--pp")
+
+
 def sweep_loaders(fn, nk1, cfgs=(13, 14, 15), splits=(1, 2, 4, 8)):
-    K.lib().hcp_debug_set_gemm_loaders(0)
+    K.lib().hcp_debug_set_gemm_loaders(-1 if PP else 0)
     K.lib().hcp_debug_set_gemm_config(-1)
     cur = round(A.timeit(fn), 1)
     res = {}
-    for st in (1, 3, 4):                       # LDS ring of 2 / 3 / 4 K tiles
+    for st in ((11, 12) if PP else (1, 3, 4)):  # LDS ring of 2 / 3 / 4 K tiles (ping-pong kernel: 8 + ring)
         K.lib().hcp_debug_set_gemm_loaders(st)
         for cid in cfgs:
             for s in splits:
@@ -81,7 +89,7 @@ def main():
         if not res:
             continue
         us, (cid, s, st) = min((v, k) for k, v in res.items())
-        ent.update(cfg=cid, split=s, stages=st, us=us, cur=cur, count=cnt, us_2stage=min(v for k, v in res.items() if k[2] == 1))
+        ent.update(cfg=cid, split=s, stages=st, us=us, cur=cur, count=cnt, us_2stage=min(v for k, v in res.items() if k[2] == (11 if PP else 1)))
         out.append(ent)
         if us < 0.97 * cur:
             saved += (cur - us) * cnt
@@ -89,7 +97,7 @@ def main():
     print(f"GEMM-family time per step {total / 1e3:.2f} ms; loader variants would save {saved / 1e3:.2f} ms", flush=True)
     root = os.environ.get("GRAFT_REPO_ROOT", ROOT)
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(root, "gpurun_out", f"tune_loaders_{workload}.json"), "w"), indent=0)
+    json.dump(out, open(os.path.join(root, "gpurun_out", f"tune_{'pp' if PP else 'loaders'}_{workload}.json"), "w"), indent=0)
 
 
 if __name__ == "__main__":
