@@ -24,7 +24,9 @@ class NativeDDIMSampler:
     @torch.no_grad()
     def sample(self, unet, latents, cond, uncond=None, guidance_scale=7.5, num_inference_steps=20, encoder_attention_mask=None,
                added_cond_kwargs=None, uncond_added_cond_kwargs=None):
-        """latents [B,4,h,w] fp32 unit-variance noise; cond / uncond [B,L,D] text states.  Returns the denoised latents [B,4,h,w]."""
+        """latents [B,4,h,w] fp32 unit-variance noise; cond / uncond [B,L,D] text states.  encoder_attention_mask: [B,L] (the same key
+        mask for both halves of the guided batch) or [2B,L] in the reference's order [negative prompts; prompts] — what the previewer
+        hands the pipeline when ``encoder_attention_mask`` is on (image_previewer.py:133-135,147).  Returns the denoised latents."""
         dev = latents.device
         x = latents.float().contiguous().clone()
         B = x.shape[0]
@@ -36,7 +38,10 @@ class NativeDDIMSampler:
             added = {k: torch.cat([u[k], v]) if guided else v for k, v in added_cond_kwargs.items()}
         mask = None
         if encoder_attention_mask is not None:
-            mask = torch.cat([encoder_attention_mask] * 2) if guided else encoder_attention_mask
+            if guided and encoder_attention_mask.shape[0] == 2 * B:
+                mask = encoder_attention_mask
+            else:
+                mask = torch.cat([encoder_attention_mask] * 2) if guided else encoder_attention_mask
         ts = self.timesteps(num_inference_steps)
         ratio = self.num_train_timesteps // num_inference_steps
         for t in ts.tolist():

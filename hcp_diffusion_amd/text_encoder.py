@@ -107,6 +107,10 @@ class NativeCLIPTextModel(nn.Module):
     def device(self):
         return self.text_model.final_layer_norm.weight.device
 
+    @property
+    def dtype(self):                                   # utils/pipe_hook.py:25-26 casts the prompt states to text_encoder.dtype
+        return self.text_model.final_layer_norm.weight.dtype
+
     def enable_hip_graph(self, on=True):
         """As NativeUNet2DConditionModel.enable_hip_graph: under an ordinary eager trainer loop the encoder's forward and backward
         (text-encoder LoRA training, lora_conventional.yaml:14-19) replay captured hipGraphs, one pair per input signature."""

@@ -15,6 +15,13 @@ kernel over the fp32 moments.  Parameter names and shapes are diffusers' (``enco
 The reference keeps the VAE in fp32 (``vae_dtype``, train_ac.py:274); here activations are bf16 with fp32 accumulation and
 fp32 statistics, like the UNet — latents agree with the fp32 oracle to bf16 rounding (tests/test_vae.py states the tolerance).
 Image sides up to 1024 px (the convolution kernels index output pixels with 10 bits per axis): SD 512 px and SDXL 1024 px.
+
+Round 4: ``NativeAutoencoderKL`` adds the DECODER half — ``vae.decode(latents / vae.config.scaling_factor, return_dict=False)[0]``
+as the reference's preview / inference pipeline calls it (hcpdiff/utils/pipe_hook.py:154-155, reached from
+loggers/preview/image_previewer.py:97-149 and workflow/diffusion.py's decode action) — from the same kernels: the nearest-2x upsample
+rides in the convolution's gather (``upsample=True``), ``post_quant_conv`` (a per-pixel L x L matrix) is folded into ``conv_in``
+exactly: the latent goes in as [z | 1 | 0..] channels, the composed weight's "1" column carries W_in * b_pq per tap, so the zero
+padding of the border taps drops the bias there just as in the two-op form.
 """
 import json
 import os
@@ -246,3 +253,136 @@ def build_latent_cache(vae, items, cache_path=None, generator=None):
     if cache_path:
         torch.save(latents, cache_path)
     return latents
+
+
+class VaeUpsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = HipConv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return _conv(self.conv, x, upsample=True)             # F.interpolate(x, 2.0, "nearest") folded into the gather
+
+
+class VaeUpBlock(nn.Module):
+    def __init__(self, cin, cout, layers, groups, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([VaeResnet(cin if i == 0 else cout, cout, groups) for i in range(layers)])
+        if up:
+            self.upsamplers = nn.ModuleList([VaeUpsample(cout)])
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if hasattr(self, "upsamplers"):
+            x = self.upsamplers[0](x)
+        return x
+
+
+class VaeDecoderNet(nn.Module):
+    def __init__(self, out_channels, latent_channels, block_out_channels, layers_per_block, norm_num_groups):
+        super().__init__()
+        rev = tuple(reversed(block_out_channels))
+        self.conv_in = HipConv2d(latent_channels, rev[0], 3, padding=1)
+        self.mid_block = VaeMidBlock(rev[0], norm_num_groups)
+        self.up_blocks = nn.ModuleList([VaeUpBlock(rev[max(i - 1, 0)], rev[i], layers_per_block + 1, norm_num_groups, i < len(rev) - 1)
+                                        for i in range(len(rev))])
+        self.conv_norm_out = HipGroupNorm(norm_num_groups, rev[-1], eps=1e-6)
+        self.conv_out = HipConv2d(rev[-1], out_channels, 3, padding=1)
+
+
+class _DecoderOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class NativeAutoencoderKL(NativeVAEEncoder):
+    """Encoder (training path, see above) + decoder (preview / inference).  ``decode(z)`` takes UNSCALED latents [B, L, h, w] (fp32 or
+    bf16; the reference divides by ``vae.config.scaling_factor`` first, pipe_hook.py:155) and returns images [B, 3, 8h, 8w] fp32 in
+    the VAE's [-1, 1] range; ``return_dict=False`` -> a 1-tuple, as diffusers."""
+
+    def __init__(self, in_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2, norm_num_groups=32,
+                 scaling_factor=0.18215, **unused):
+        super().__init__(in_channels, latent_channels, block_out_channels, layers_per_block, norm_num_groups, scaling_factor)
+        self.decoder = VaeDecoderNet(in_channels, latent_channels, block_out_channels, layers_per_block, norm_num_groups)
+        self.post_quant_conv = HipConv2d(latent_channels, latent_channels, 1)
+        self.requires_grad_(False)
+        self._dec_in = None
+        self._slicing = False
+
+    # diffusers' memory switches the previewer flips (image_previewer.py:79-94): slicing = one sample at a time; tiling has nothing
+    # to save next to 288 GB and is accepted as a no-op
+    def enable_slicing(self): self._slicing = True
+    def disable_slicing(self): self._slicing = False
+    def enable_tiling(self): pass
+    def disable_tiling(self): pass
+
+    def _decoder_in(self):
+        """conv_in composed with post_quant_conv: [C0][3][3][8] bf16 over the channels [z_0..z_{L-1} | 1 | 0..] (+ conv_in's own bias)."""
+        ci, pq = self.decoder.conv_in, self.post_quant_conv
+        key = (ci.weight.data_ptr(), ci.weight._version, pq.weight.data_ptr(), pq.weight._version, pq.bias._version, str(ci.weight.device))
+        if self._dec_in is None or self._dec_in[0] != key:
+            L = self.config["latent_channels"]
+            if L + 1 > 8:
+                raise NotImplementedError("hcp_diffusion_amd: VAE decode folds post_quant_conv for latent_channels <= 7")
+            w_in = ci.weight.detach().float()                                    # [C0, L, 3, 3]
+            w_pq = pq.weight.detach().float().reshape(L, L); b_pq = pq.bias.detach().float()
+            w = torch.zeros((w_in.shape[0], 3, 3, 8), dtype=torch.float32, device=w_in.device)
+            w[..., :L] = torch.einsum("omyx,mi->oyxi", w_in, w_pq)               # (pack time, once per weight version)
+            w[..., L] = torch.einsum("omyx,m->oyx", w_in, b_pq)
+            self._dec_in = (key, w.to(BF16).contiguous(), ci.bias.detach().float().contiguous())
+        return self._dec_in[1], self._dec_in[2]
+
+    def _conv_out(self, x):
+        """3 output channels: the kernels store 4-column groups, so the packed weight carries one zero row."""
+        co = self.decoder.conv_out
+        pk = co.packed()
+        if getattr(pk, "w4", None) is None or pk.w4_key != pk.key:
+            n4 = (pk.cout + 3) // 4 * 4
+            w4 = torch.zeros((n4, 3, 3, pk.w.shape[-1]), dtype=BF16, device=pk.w.device); w4[:pk.cout] = pk.w
+            b4 = torch.zeros(n4, dtype=torch.float32, device=pk.w.device)
+            if pk.bias is not None:
+                b4[:pk.cout] = pk.bias
+            pk.w4, pk.b4, pk.w4_key = w4, b4, pk.key
+        y = K.conv3x3(_gn(self.decoder.conv_norm_out, x, True), pk.w4, pk.w4.shape[0], bias=pk.b4, out_f32=True)
+        return K.nhwc_to_nchw_f32(y, pk.cout)
+
+    def _decode(self, z):
+        L = self.config["latent_channels"]
+        w, b = self._decoder_in()
+        x = K.nchw_to_nhwc(z.contiguous(), 8)
+        x[..., L] = 1.0                                                          # the bias channel of the folded post_quant_conv
+        x = K.conv3x3(x, w, w.shape[0], bias=b)
+        x = self.decoder.mid_block(x)
+        for blk in self.decoder.up_blocks:
+            x = blk(x)
+        return self._conv_out(x)
+
+    @torch.no_grad()
+    def decode(self, z, return_dict=True, generator=None):
+        if z.dim() != 4 or z.shape[1] != self.config["latent_channels"]:
+            raise ValueError(f"expected latents [B,{self.config['latent_channels']},h,w], got {tuple(z.shape)}")
+        if max(z.shape[2:]) > 128:
+            raise NotImplementedError("hcp_diffusion_amd: VAE decode takes latent sides up to 128 (1024 px images)")
+        z = z.to(torch.float32) if z.dtype not in (torch.float32, BF16) else z
+        if self._slicing and z.shape[0] > 1:
+            img = torch.cat([self._decode(z[i:i + 1]) for i in range(z.shape[0])])
+        else:
+            img = self._decode(z)
+        return _DecoderOutput(img) if return_dict else (img,)
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder="vae", device="cuda"):
+        """A diffusers model directory: every tensor by name (encoder, decoder, quant_conv, post_quant_conv)."""
+        from safetensors.torch import load_file
+        root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
+        cfg = json.load(open(os.path.join(root, "config.json")))
+        keys = ("in_channels", "latent_channels", "block_out_channels", "layers_per_block", "norm_num_groups", "scaling_factor")
+        model = cls(**{k: cfg[k] for k in keys if k in cfg})
+        sd = load_file(os.path.join(root, "diffusion_pytorch_model.safetensors"))
+        own = model.state_dict()
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise ValueError(f"VAE checkpoint lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        model.load_state_dict({k: sd[k] for k in own})
+        return model.to(device)

@@ -204,7 +204,11 @@ def load_reference_pipe():
 
         def prepare_latents(self, batch_size, channels, height, width, dtype, device, generator, latents=None):
             if latents is None:
-                latents = torch.randn(batch_size, channels, height // 8, width // 8, generator=generator, dtype=dtype)
+                shape = (batch_size, channels, height // 8, width // 8)
+                if isinstance(generator, (list, tuple)):   # diffusers' randn_tensor: one generator per sample (the previewer's seeds)
+                    latents = torch.cat([torch.randn((1,) + shape[1:], generator=g_, dtype=dtype) for g_ in generator])
+                else:
+                    latents = torch.randn(shape, generator=generator, dtype=dtype)
             return latents.to(device) * self.scheduler.init_noise_sigma
 
         @contextlib.contextmanager
@@ -229,3 +233,51 @@ def load_reference_pipe():
     ip.StableDiffusionInpaintPipelineLegacy = type("StableDiffusionInpaintPipelineLegacy", (_Pipe,), {})
     sys.modules["hcpdiff.utils.inpaint_pipe"] = ip
     return importlib.import_module("hcpdiff.utils.pipe_hook")
+
+
+def load_reference_previewer():
+    """(image_previewer module, pipe_hook module, TEEXHook class, TokenizerHook class) of the reference, executed where they lie:
+    ``ImagePreviewer.preview`` / ``vis_images`` (loggers/preview/image_previewer.py:97-149) and everything they call that is the
+    reference's own — HookPipe_T2I.__call__ (utils/pipe_hook.py), TokenizerHook.parse_attn_mult (models/tokenizer_ex.py),
+    TEEXHook.encode_prompt_to_emb / mult_attn (models/textencoder_ex.py).  Replaced by stand-ins: hydra (config instantiation, not
+    installable here), the diffusers pipeline base class (load_reference_pipe), ``Visualizer`` (hcpdiff/visualizer.py drags in the
+    model loaders, compose hooks and the config converter; the two helpers the previewer inherits from it and uses, get_ex_input()
+    and inter_callback, are restated for the no-condition / no-interface case), and ``prepare_seed`` where no CUDA device exists
+    (utils/utils.py:135 builds torch.Generator(device='cuda'))."""
+    import random
+    import torch
+    pipe_hook = load_reference_pipe()
+    d = sys.modules["diffusers"]
+    if not hasattr(d, "PNDMScheduler"):
+        d.PNDMScheduler = type("PNDMScheduler", (), {"__init__": lambda self, **kw: None})
+    if "hydra" not in sys.modules:
+        h = types.ModuleType("hydra"); h.__path__ = []
+        hu = types.ModuleType("hydra.utils"); hu.instantiate = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("hydra is shimmed"))
+        h.utils = hu
+        sys.modules["hydra"] = h; sys.modules["hydra.utils"] = hu
+    models = sys.modules["hcpdiff.models"]
+    tok = importlib.import_module("hcpdiff.models.tokenizer_ex")
+    models.TokenizerHook = tok.TokenizerHook
+    teex = importlib.import_module("hcpdiff.models.textencoder_ex")
+
+    class Visualizer:                                      # hcpdiff/visualizer.py:22,171-183,221-231 for condition None, no ex_input, no interface
+        dtype_dict = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
+
+        def get_pipeline(self):
+            return pipe_hook.HookPipe_T2I
+
+        def get_ex_input(self):
+            assert getattr(self.cfgs, "condition", None) is None and getattr(self.cfgs, "ex_input", None) is None
+            return {}, {}
+
+        def inter_callback(self, i, t, num_t, latents_x0, latents):
+            return latents
+
+    v = types.ModuleType("hcpdiff.visualizer"); v.Visualizer = Visualizer
+    sys.modules["hcpdiff.visualizer"] = v
+    _stub_pkg("hcpdiff.loggers", os.path.join(REFERENCE_ROOT, "hcpdiff", "loggers"))
+    _stub_pkg("hcpdiff.loggers.preview", os.path.join(REFERENCE_ROOT, "hcpdiff", "loggers", "preview"))
+    prev = importlib.import_module("hcpdiff.loggers.preview.image_previewer")
+    if not torch.cuda.is_available():
+        prev.prepare_seed = lambda seeds, device="cpu": [torch.Generator().manual_seed(s or random.randint(0, 1 << 30)) for s in seeds]
+    return prev, pipe_hook, teex.TEEXHook, tok.TokenizerHook

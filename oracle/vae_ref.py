@@ -16,6 +16,14 @@ restates the public diffusers 0.26 architecture — every statement below is [ex
   sample = mean + exp(0.5 logvar) * randn.  scaling_factor 0.18215 (SD1.x/2.x), 0.13025 (SDXL).
 Parameter names are diffusers' (``encoder.down_blocks.0.resnets.0.norm1.weight`` ... ``quant_conv.bias``) so that a diffusers
 ``vae/diffusion_pytorch_model.safetensors`` loads with strict=False (the decoder keys are ignored).
+
+Round 4 — the DECODER half, ``vae.decode(latents / vae.config.scaling_factor)`` as the reference's preview / inference pipeline
+calls it (/root/reference/hcpdiff/utils/pipe_hook.py:154-155 under loggers/preview/image_previewer.py:97-149 and
+workflow/diffusion.py; same [ext] status):
+  post_quant_conv 1x1 (latent -> latent); Decoder: conv_in latent -> 512 (3x3, pad 1); mid_block as above; 4 UpDecoderBlock2D over the
+  REVERSED block_out_channels (512, 512, 256, 128), layers_per_block + 1 = 3 ResnetBlock2D each (the first takes the previous block's
+  width), Upsample2D after blocks 0-2: nearest-neighbour x2 then conv3x3 pad 1; conv_norm_out GN(32, eps 1e-6) -> SiLU -> conv_out
+  128 -> 3 (3x3, pad 1).  Names: ``decoder.up_blocks.0.resnets.0.norm1.weight`` ... ``post_quant_conv.bias``.
 """
 import torch
 import torch.nn.functional as F
@@ -129,3 +137,59 @@ class OracleVAEEncoder(nn.Module):
         logvar = logvar.clamp(-30.0, 20.0)
         z = mean if noise is None else mean + torch.exp(0.5 * logvar) * noise
         return z * self.scaling_factor
+
+
+class VaeUpsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class VaeUpBlock(nn.Module):
+    def __init__(self, cin, cout, layers, groups, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([VaeResnet(cin if i == 0 else cout, cout, groups) for i in range(layers)])
+        if up:
+            self.upsamplers = nn.ModuleList([VaeUpsample(cout)])
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if hasattr(self, "upsamplers"):
+            x = self.upsamplers[0](x)
+        return x
+
+
+class VaeDecoderNet(nn.Module):
+    def __init__(self, out_channels, latent_channels, block_out_channels, layers_per_block, norm_num_groups):
+        super().__init__()
+        rev = tuple(reversed(block_out_channels))
+        self.conv_in = nn.Conv2d(latent_channels, rev[0], 3, padding=1)
+        self.mid_block = VaeMidBlock(rev[0], norm_num_groups)
+        self.up_blocks = nn.ModuleList([VaeUpBlock(rev[max(i - 1, 0)], rev[i], layers_per_block + 1, norm_num_groups, i < len(rev) - 1)
+                                        for i in range(len(rev))])
+        self.conv_norm_out = nn.GroupNorm(norm_num_groups, rev[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(rev[-1], out_channels, 3, padding=1)
+
+    def forward(self, z):
+        x = self.mid_block(self.conv_in(z))
+        for blk in self.up_blocks:
+            x = blk(x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class OracleAutoencoderKL(OracleVAEEncoder):
+    """Encoder + decoder: ``decode(z)`` = decoder(post_quant_conv(z)) on UNSCALED latents (the caller divides by scaling_factor,
+    pipe_hook.py:155)."""
+
+    def __init__(self, in_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2, norm_num_groups=32,
+                 scaling_factor=0.18215):
+        super().__init__(in_channels, latent_channels, block_out_channels, layers_per_block, norm_num_groups, scaling_factor)
+        self.decoder = VaeDecoderNet(in_channels, latent_channels, block_out_channels, layers_per_block, norm_num_groups)
+        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
+
+    def decode(self, z):
+        return self.decoder(self.post_quant_conv(z))

@@ -95,6 +95,10 @@ def test_dreambooth_full_size_two_dataset_step_vs_golden():
     assert torch.isfinite(hb.params).all().item() and hb.grads.abs().max().item() == 0.0
 
 
+# native error / reference-under-autocast error (both against the fp32 oracle), as measured on MI355X + margin; see the test body
+R_SDXL_FLAT, R_SDXL_CLASS, R_SDXL_PRED, R_SDXL_TENSOR = 1.75, 2.75, 1.5, 3.25       # measured 1.45 / 2.18 (median class 1.59) / 1.29 / 2.61
+
+
 @pytest.mark.gpu
 def test_sdxl_full_size_b2_1024px_full_lora_gradient_vs_golden():
     if not torch.cuda.is_available():
@@ -129,12 +133,30 @@ def test_sdxl_full_size_b2_1024px_full_lora_gradient_vs_golden():
         worst = min(worst, (c, n))
     print(f"[sdxl b2 1024px] LoRA gradient cosine {cos:.5f} over {flat.numel()} elements, worst tensor {worst[0]:.4f} ({worst[1]}), "
           f"norm {flat.norm().item():.5f} vs {g['grad_norm']:.5f}")
-    # Measured on MI355X (tools/diag/sdxl_grad_diag.py): 0.99852 flat, UNIFORM over block / layer kind (0.9980-0.9989 per group, median
-    # tensor 0.9987, worst 0.9918), prediction rel-L2 2.65e-2: the bf16 residual stream is rounded at each of the 210 residual adds of
-    # the 70 transformer blocks (sqrt(210) * 2^-9 ~ 2.8e-2), against an fp32 oracle.  SD1.5 (16 blocks) meets SURVEY 8(c)'s 0.999
-    # (tests/test_model.py); for SDXL the gate is the measured class: flat >= 0.998, every tensor >= 0.985 (the worst single tensor
-    # moves between 0.990 and 0.992 from run to run — atomic accumulation order of the weight-gradient kernels — while the flat figure holds).
-    assert cos > 0.998 and worst[0] > 0.985 and abs(flat.norm().item() - g["grad_norm"]) / g["grad_norm"] < 2e-2
+    # Calibrated gate: tests/golden/sdxl_b2_autocast_calibration.pt holds the distance of the REFERENCE's own
+    # execution mode — the same oracle graph under torch.autocast(bfloat16), train_ac.py:449 — from this fp32 fixture (oracle/make_golden.py
+    # sdxl_b2_autocast: flat cosine 0.99899, worst tensor 0.99667, prediction rel-L2 2.03e-2).  The native step must stay within a stated
+    # multiple of THAT error, per (resolution block, layer kind, factor) class, flat, and on the prediction, instead of hand-set
+    # absolute figures.  Both runs round a bf16 residual stream at each of the 210 residual adds of the 70 transformer blocks
+    # (sqrt(210) * 2^-9 ~ 2.8e-2); the native path additionally keeps the rank-r LoRA intermediates (T = x W_down^T, U = dY W_up) and the
+    # attention probabilities in bf16, which the merged-weight reference form does not have: its LoRA-factor gradients are noisier by the
+    # measured factors below, uniformly over classes (tools/diag/sdxl_grad_diag.py).
+    from oracle.make_golden import lora_tensor_class
+    cal = torch.load(os.path.join(GOLD, "sdxl_b2_autocast_calibration.pt"))
+    assert cal["names"] == g["grad_names"]
+    acc, off = {}, 0
+    for n, p in lora_named:
+        a, b = flat[off:off + p.numel()].double(), ref[off:off + p.numel()].double(); off += p.numel()
+        c_ = acc.setdefault(lora_tensor_class(n), [0.0, 0.0, 0.0]); c_[0] += float(a @ b); c_[1] += float(a @ a); c_[2] += float(b @ b)
+    ratios = {k: (1.0 - v[0] / (v[1] * v[2]) ** 0.5) / max(1.0 - cal["class_cos"][k], 1e-9) for k, v in acc.items()}
+    worst_cls = max(ratios.items(), key=lambda kv: kv[1])
+    r_flat = (1.0 - cos) / (1.0 - cal["flat_cos"])
+    r_pred = ((pred - ref_pred).norm() / ref_pred.norm()).item() / cal["pred_rel"]
+    r_worst_tensor = (1.0 - worst[0]) / (1.0 - cal["per_tensor_cos"].min().item())
+    print(f"[sdxl b2 calibration] (1 - cos) native / autocast: flat {r_flat:.2f}, worst class {worst_cls[1]:.2f} ({worst_cls[0]}), median class "
+          f"{sorted(ratios.values())[len(ratios) // 2]:.2f}, worst tensor {r_worst_tensor:.2f}; prediction rel-L2 ratio {r_pred:.2f}")
+    assert r_flat < R_SDXL_FLAT and worst_cls[1] < R_SDXL_CLASS and r_pred < R_SDXL_PRED and r_worst_tensor < R_SDXL_TENSOR
+    assert abs(flat.norm().item() - g["grad_norm"]) / g["grad_norm"] < 2e-2
 
 
 @pytest.mark.gpu

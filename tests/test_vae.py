@@ -7,9 +7,9 @@ import os
 import pytest
 import torch
 
-from hcp_diffusion_amd.vae import NativeVAEEncoder, build_latent_cache
+from hcp_diffusion_amd.vae import NativeAutoencoderKL, NativeVAEEncoder, build_latent_cache
 from oracle.unet_sd15 import seeded_init_
-from oracle.vae_ref import SD_VAE_CONFIG, TINY_VAE_CONFIG, OracleVAEEncoder
+from oracle.vae_ref import SD_VAE_CONFIG, TINY_VAE_CONFIG, OracleAutoencoderKL, OracleVAEEncoder
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -98,3 +98,59 @@ def test_sd_vae_full_size_encode_vs_golden(side):
     noise = torch.randn(1, 4, side // 8, side // 8, generator=gen)
     z = nat.encode_latents(img.cuda(), noise=noise.cuda()).cpu()
     assert ((z - g["latents"]).norm() / g["latents"].norm()).item() < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------- decoder (f4)
+def test_native_autoencoder_names_match_oracle():
+    with torch.device("meta"):
+        a, b = OracleAutoencoderKL(**SD_VAE_CONFIG), NativeAutoencoderKL(**SD_VAE_CONFIG)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert {k: tuple(v.shape) for k, v in sa.items()} == {k: tuple(v.shape) for k, v in sb.items()}
+    assert sum(v.numel() for v in sa.values()) == 83653863                      # the SD VAE (diffusers AutoencoderKL), encoder + decoder
+    assert "decoder.up_blocks.0.upsamplers.0.conv.weight" in sa and "decoder.up_blocks.3.resnets.2.conv2.bias" in sa and "post_quant_conv.bias" in sa
+    assert "decoder.up_blocks.2.resnets.0.conv_shortcut.weight" in sa and "decoder.up_blocks.3.upsamplers.0.conv.weight" not in sa
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (24, 8)])
+def test_tiny_vae_decode_vs_oracle(backend, hw):
+    """``vae.decode(z, return_dict=False)[0]`` (pipe_hook.py:155) vs the fp32 oracle: relative L2 <= 2e-2 (bf16 activations); the
+    folded post_quant_conv is exact at the image border (compared on the border rows alone); slicing = the same images."""
+    ora = seeded_init_(OracleAutoencoderKL(**TINY_VAE_CONFIG), 4)
+    nat = NativeAutoencoderKL(**TINY_VAE_CONFIG)
+    nat.load_state_dict(ora.state_dict())
+    nat = nat.to(backend.device)
+    with torch.no_grad():
+        ora.post_quant_conv.bias.add_(0.5); nat.post_quant_conv.bias.add_(0.5)      # a bias large enough to show a border error
+    g = torch.Generator().manual_seed(21)
+    z = torch.randn(2, 4, *hw, generator=g)
+    with torch.no_grad():
+        ref = ora.decode(z)
+    out = nat.decode(backend.to(z), return_dict=False)[0].cpu()
+    assert out.shape == ref.shape == (2, 3, hw[0] * 2, hw[1] * 2) and out.dtype == torch.float32
+    assert ((out - ref).norm() / ref.norm()).item() < 2e-2
+    border = torch.cat([(out - ref)[..., :2, :].flatten(), (out - ref)[..., -2:, :].flatten(), (out - ref)[..., :, :2].flatten()])
+    rb = torch.cat([ref[..., :2, :].flatten(), ref[..., -2:, :].flatten(), ref[..., :, :2].flatten()])
+    assert (border.norm() / rb.norm()).item() < 2e-2
+    assert nat.decode(backend.to(z)).sample.shape == ref.shape
+    nat.enable_slicing()
+    assert torch.equal(nat.decode(backend.to(z)).sample.cpu(), out)
+    nat.disable_slicing(); nat.enable_tiling(); nat.disable_tiling()
+    with pytest.raises(ValueError):
+        nat.decode(backend.to(z[:, :3]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side", [256, 512])
+def test_sd_vae_full_size_decode_vs_golden(side):
+    """Full SD VAE decoder (49.5 M parameters, seeded weights) vs the oracle images committed in tests/golden/vae_decode_oracle.pt
+    (oracle/make_golden.py vae_dec): 16384 seeded pixel samples + the image norm (512 px), the whole image (256 px)."""
+    from oracle.make_golden import boundary_sample
+    g = torch.load(os.path.join(GOLD, "vae_decode_oracle.pt"))[side]
+    nat = seeded_init_(NativeAutoencoderKL(**SD_VAE_CONFIG), g["seed"]).to("cuda")
+    gen = torch.Generator().manual_seed(g["input_seed"])
+    z = torch.randn(1, 4, side // 8, side // 8, generator=gen)
+    img = nat.decode(z.cuda(), return_dict=False)[0].cpu()
+    vals, norm = boundary_sample(f"vae_dec_{side}", img, n=16384)
+    assert ((vals - g["samples"]).norm() / g["samples"].norm()).item() < 2e-2 and abs(norm - g["norm"]) / g["norm"] < 1e-2
+    if g["image"] is not None:
+        assert ((img - g["image"].float()).norm() / g["image"].float().norm()).item() < 2e-2
