@@ -76,8 +76,9 @@ class ControlNetHipPlugin(MultiPluginBlock):
         self.time_embedding = self.copy_block(host_model.time_embedding)
         self.down_blocks = self.copy_block(host_model.down_blocks)
         self.mid_block = self.copy_block(host_model.mid_block)
-        if getattr(host_model, "add_embedding", None) is not None:
-            raise NotImplementedError("hcp_diffusion_amd: ControlNet on an SDXL (text_time) host is not implemented")
+        # An SDXL host (addition_embed_type 'text_time') is copied the same way: the reference branch takes (sample, timestep,
+        # encoder_hidden_states) from the root pre-hook and never sees added_cond_kwargs, nor does it copy add_embedding
+        # (controlnet.py:19-25,88-97) — its time embedding carries no text_time term, and neither does this one.
 
         self.build_head(cond_block_channels)
         boc = block_out_channels

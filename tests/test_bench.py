@@ -20,20 +20,21 @@ def test_bench_refuses_a_world_that_is_not_one_rank_per_gpu():
 
 
 @pytest.mark.slow
-def test_bench_launcher_runs_two_ranks_end_to_end():
-    """`python bench.py --gpus 2` is its own launcher (re-executes under torch.distributed.run, one rank per device).  With the test switch
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_launcher_runs_n_ranks_end_to_end(n):
+    """`python bench.py --gpus N` is its own launcher (re-executes under torch.distributed.run, one rank per device).  With the test switch
     HCP_BENCH_BACKEND=emu the very same code path — exec, rendezvous on 127.0.0.1, process group, NativeTrainer with the exchange, timed
     loop, MAX over ranks, ONE JSON line from rank 0 — runs on the CPU interpreter with gloo: the first 2-rank execution of this file
     must not be the driver's."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(HCP_BENCH_BACKEND="emu", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", "--rank-lora", "4"],
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "1", "--rank-lora", "4"],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2
+    assert d["n_gpus"] == n and d["config"]["rccl_ranks"] == n and d["config"]["parallelism"] == f"dp{n}" and d["config"]["global_batch"] == n
     assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0 and "emu" in d["data"]
 
 

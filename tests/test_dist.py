@@ -237,7 +237,7 @@ def _variant_worker(rank, world, port, out, variant):
     from oracle.unet_sd15 import MICRO_CONFIG
     K._set_backend_for_tests(emu_cdll())
     x0, ehs, noise, t = _data()
-    sl = slice(rank, rank + 1)
+    sl = slice(rank % 2, rank % 2 + 1)             # (two distinct samples; worlds of 4 / 8 see each of them on half of the ranks)
     res = {}
     for name, kw in (("base", {}), ("var", VARIANTS[variant])):
         tr = _fullft(MICRO_CONFIG, **kw)
@@ -297,3 +297,30 @@ def test_sharded_exchange_variants(tmp_path, variant):
     assert moved > 0
     err = (var0 - base).norm().item() / moved
     assert err < (1e-4 if kw.get("grad_wire") != "bf16" else 5e-2), err
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("world,variant", [(4, "bf16_both"), (8, "bf16_both"), (8, "overlap")])
+def test_sharded_exchange_worlds_of_4_and_8(tmp_path, world, variant):
+    """the sharded exchange beyond two ranks, on gloo + the interpreter — chunk padding to world * 64 elements, slice
+    alignment of the 16-byte AdamW accesses (own = padded / world), the three-chunk early exchange and both bf16 wires with 4 and 8
+    owners: every rank ends with the same fp32 masters (after sync_masters() where the parameter wire is bf16), every rank computes with
+    the same bf16 operands before it, and the result agrees with the plain one-reduce-scatter fp32 path on the same world."""
+    port = 31200 + os.getpid() % 2000 + world * 3 + list(VARIANTS).index(variant)
+    mp.spawn(_variant_worker, args=(world, port, str(tmp_path), variant), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"v{r}.pt") for r in range(world)]
+    kw = VARIANTS[variant]
+    flat = lambda d: torch.cat([d[n].flatten() for n in sorted(d)])
+    base = flat(rs[0]["base"])
+    for r in rs[1:]:
+        assert torch.equal(flat(r["base"]), base) and torch.equal(flat(r["var"]), flat(rs[0]["var"]))
+        assert torch.equal(flat(r["var_before_sync"]).to(torch.bfloat16), flat(rs[0]["var_before_sync"]).to(torch.bfloat16))
+    # the slices the ranks own tile each part without gaps or overlaps, and start on 16-byte boundaries (4 fp32 = 16 B, 8 bf16 = 16 B)
+    for part in range(len(rs[0]["own"])):
+        spans = sorted(r["own"][part] for r in rs)
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1)) and all((lo % 8 == 0 and (hi - lo) % 64 == 0) for lo, hi in spans)
+    from oracle.unet_sd15 import MICRO_CONFIG, OracleUNet2DConditionModel, seeded_init_
+    init = flat({n: p.detach() for n, p in seeded_init_(OracleUNet2DConditionModel(**MICRO_CONFIG), 1).named_parameters()})
+    moved = (base - init).norm().item()
+    err = (flat(rs[0]["var"]) - base).norm().item() / moved
+    assert moved > 0 and err < (1e-4 if kw.get("grad_wire") != "bf16" else 5e-2), err

@@ -393,15 +393,19 @@ def test_sdxl_full_size_forward_and_lora_grads_vs_golden():
     assert len(bad) <= len(fp) // 100, bad
 
 
-def test_tiny_controlnet_train_step_vs_oracle(backend):
+@pytest.mark.parametrize("host", ["sd15", "sdxl"])
+def test_tiny_controlnet_train_step_vs_oracle(backend, host):
     """ControlNet branch (reference hcpdiff/models/controlnet.py, cfgs/plugins/plugin_controlnet.yaml): frozen host UNet,
     trainable deep copy of its encoder + cond_head + zero convs, wired in through the reference's hook layout; all branch
     gradients vs fp32 autograd of the oracle restatement, then clip + AdamW.  Zero convs get non-zero seeded values (a branch
-    "after some training"), otherwise every gradient upstream of them is exactly zero."""
+    "after some training"), otherwise every gradient upstream of them is exactly zero.  host = 'sdxl': a text_time host (three
+    down blocks, no attention in the first, added_cond_kwargs on the host call) — the branch is copied the same way and, like the
+    reference's (controlnet.py:19-25,88-97), carries no text_time term in its own time embedding."""
     from hcp_diffusion_amd.controlnet import make_controlnet
     from oracle.unet_sd15 import OracleControlNet
     dev = backend.device
-    cfg = TINY_CONFIG if backend.is_gpu else MICRO_CONFIG          # the interpreter gets the two-level miniature
+    from oracle.unet_sd15 import TINY_SDXL_CONFIG
+    cfg = TINY_SDXL_CONFIG if host == "sdxl" else TINY_CONFIG if backend.is_gpu else MICRO_CONFIG          # the interpreter gets the two-level miniature
     ora, nat = _pair(cfg, dev)
     ora.requires_grad_(False)
     torch.manual_seed(3)
@@ -425,11 +429,17 @@ def test_tiny_controlnet_train_step_vs_oracle(backend):
     x0 = torch.randn(B, 4, 8, 8, generator=g2); ehs = torch.randn(B, 24, cd, generator=g2)
     noise = torch.randn(B, 4, 8, 8, generator=g2); t = torch.tensor([30, 800]); cond = torch.rand(B, 3, 64, 64, generator=g2)
     xt = add_noise(x0, noise, t, ddpm_alphas_cumprod())
-    pred = ora(xt, t, ehs, control_residuals=ocn(xt, t, ehs, cond)).sample
+    added = None
+    if host == "sdxl":
+        added = dict(text_embeds=torch.randn(B, cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"], generator=g2),
+                     time_ids=torch.tensor([[64.0, 64.0, 0.0, 0.0, 64.0, 64.0]] * B))
+    okw = dict(added_cond_kwargs=added) if added else {}
+    pred = ora(xt, t, ehs, control_residuals=ocn(xt, t, ehs, cond), **okw).sample
     loss_o = F.mse_loss(pred, noise)
     loss_o.backward()
     tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
-    loss_n = tr.forward_backward(x0.to(dev), ehs.to(dev), None, None, dict(cond=cond.to(dev)))
+    nadded = {k: v.to(dev) for k, v in added.items()} if added else None
+    loss_n = tr.forward_backward(x0.to(dev), ehs.to(dev), None, nadded, dict(cond=cond.to(dev)))
     assert abs(loss_o.item() - loss_n.item()) / loss_o.item() < 2e-2
     po = dict(ocn.named_parameters())
     num = da = db = 0.0
@@ -445,8 +455,9 @@ def test_tiny_controlnet_train_step_vs_oracle(backend):
     assert tr.host_buckets[0].bucket.grads.abs().max().item() == 0.0
     plug.remove()
     with torch.no_grad():                                              # hooks gone: the host is the plain UNet again
-        y0 = nat(backend.to(xt), backend.to(t), backend.to(ehs)).sample.cpu()
-        assert ((y0 - ora(xt, t, ehs).sample).norm() / y0.norm()).item() < 2e-2
+        nkw = dict(added_cond_kwargs=nadded) if added else {}
+        y0 = nat(backend.to(xt), backend.to(t), backend.to(ehs), **nkw).sample.cpu()
+        assert ((y0 - ora(xt, t, ehs, **okw).sample).norm() / y0.norm()).item() < 2e-2
 
 
 def test_two_dataset_step_accumulates_like_reference(backend):
