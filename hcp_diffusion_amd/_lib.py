@@ -23,6 +23,8 @@ _PROTOTYPES = {
     "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, F, I, P, c_size_t, P]),
     # A, lda, B, ldb, L, E, Tout, D, ldd, M, N, K, bias, residual, ldr, workspace, workspace_bytes, stream
     "hcp_gemm_lora_bf16": (I, [P, I, P, I, P, P, P, P, I, I, I, I, P, P, I, P, c_size_t, P]),
+    # A, lda, B, ldb, L, E, Tout, HG, DHG, M, F, K, workspace, workspace_bytes, stream
+    "hcp_gemm_geglu_bwd_bf16": (I, [P, I, P, I, P, P, P, P, P, I, I, I, P, c_size_t, P]),
     "hcp_gemm_workspace_bytes": (c_size_t, [I, I]),
     # X1, C1, X2, C2, B, Hs, Ws, Ho, Wo, mode, stride, upsample, Wp, Cout, D, ldd, bias, rowbias, rowbias_ld,
     # residual, ldr, out_f32, workspace, workspace_bytes, stream

@@ -29,6 +29,7 @@ using namespace hcp_gemm;
 
 
 HCP_DEVICE void epilogue_store(const GemmParams& p, int m, int n, hcp_f32x4 v) {
+    if (p.geglu_hg) { epilogue_geglu_bwd(p, m, n, v); return; }
     v = v * p.alpha;
     if (p.bias) v += *(const hcp_f32x4*)(p.bias + n);
     if (p.rowbias) v += *(const hcp_f32x4*)(p.rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld + n);
@@ -710,6 +711,7 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WTN + j * 16 + 4 * fg;
             if (n >= p.N) continue;
+            if (p.geglu_hg) { epilogue_geglu_bwd(p, m, n, acc[i][j]); continue; }
             hcp_f32x4 v = acc[i][j] * p.alpha + bias_v[j];
             if (p.rowbias) v += rb_v[j];
             if (p.residual) {
@@ -940,6 +942,35 @@ int check_common(const GemmParams& p) {
     return 0;
 }
 
+// tile choice + launch of a fused-LoRA problem (p.L / p.E / p.Tout set): measured table, else the fallback rule; deep-K / small-M
+// shapes run as two launches (T GEMM, then split-K K-extension GEMM)
+int launch_lora_dispatched(GemmParams& p, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    int id = 4, nsplit = 1, ld = 0;
+    GemmParams q = p; q.K2 = 32;
+    if (!lookup_tuned(q, 3, &id, &nsplit, &ld)) {
+        // unseen shape: deep-K / small-M problems want split-K (two launches); otherwise fuse with a narrow-M tile
+        if (p.K >= 4096 && p.M <= 4096) id = -1;
+        else if ((long)p.M * p.N >= (long)4096 * 2560 && p.N % 160 == 0) id = 6;
+        else if (p.N % 160 == 0 && (long)p.M * p.N >= (long)4096 * 640) id = 4;
+        else id = 2;
+    }
+    if (g_force_cfg >= 0) id = g_force_cfg % 16;
+    p.loaders = g_force_loaders >= 0 ? g_force_loaders : deepest_ring(ld);
+    if (id == 7 || id == 10 || id == 11) id = 6;
+    if (id < 0) {
+        // two-launch form: T = A L^T, then D = A B^T + T E^T with the measured tile / split-K choice
+        HCP_REQUIRE(p.Tout, "hcp_gemm_lora_bf16: this shape runs as two launches and needs the T buffer");
+        GemmParams t = {};
+        t.A = p.A; t.lda = p.lda; t.B = p.L; t.ldb = p.K; t.M = p.M; t.N = 32; t.K = p.K; t.D = p.Tout; t.ldd = 32; t.alpha = 1.0f;
+        if (int e2 = dispatch_gemm<0, false>(t, (float*)workspace, workspace ? workspace_bytes : 0, stream)) return e2;
+        p.A2 = (const hcp_bf16*)p.Tout; p.lda2 = 32; p.B2 = p.E; p.ldb2 = 32; p.K2 = 32;
+        p.L = nullptr; p.E = nullptr; p.Tout = nullptr;
+        return dispatch_gemm<0, false>(p, (float*)workspace, workspace ? workspace_bytes : 0, stream);
+    }
+    p.nsplit = 1; p.kt_per_split = hcp_cdiv(p.K, BK); p.slabs = nullptr;
+    return launch_lora_by_id(id, p, stream);
+}
+
 }  // namespace
 
 #if defined(HCP_TOOLS)
@@ -1018,6 +1049,27 @@ HCP_API int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int
     return fast ? dispatch_gemm<2, true>(p, ws, wb, stream) : dispatch_gemm<2, false>(p, ws, wb, stream);
 }
 
+// FF-out input-gradient with the GEGLU backward in its epilogue:  dY_ff[M,F] = dY W (+ LoRA side path, as hcp_gemm_lora_bf16's
+// backward form: L = W_up^T, E = alpha W_down^T, Tout = U = dY W_up) is never written; with (h | g) = HG[M, 2F] of the forward
+//   DHG[m, n] = dY_ff * gelu(g),   DHG[m, F + n] = dY_ff * h * gelu'(g)
+// Replaces the input-gradient GEMM of FeedForward.net[2] followed by the GEGLU backward pass (diffusers GEGLU under
+// BasicTransformerBlock.ff, reference cfgs/unet_struct.txt:27-33; autograd of F.gelu / chunk).  L == NULL: plain host (no LoRA).
+HCP_API int hcp_gemm_geglu_bwd_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout,
+                                    const void* HG, void* DHG, int M, int F, int K, void* workspace, size_t workspace_bytes,
+                                    hipStream_t stream) {
+    GemmParams p = {};
+    p.A = (const hcp_bf16*)A; p.lda = lda; p.B = (const hcp_bf16*)B; p.ldb = ldb;
+    p.M = M; p.N = F; p.K = K; p.D = DHG; p.ldd = 2 * F; p.out_f32 = 0; p.alpha = 1.0f;
+    p.geglu_hg = (const hcp_bf16*)HG; p.geglu_ld = 2 * F;
+    HCP_REQUIRE(A && B && HG && DHG, "hcp_gemm_geglu_bwd_bf16: null operand");
+    HCP_REQUIRE((L == nullptr) == (E == nullptr), "hcp_gemm_geglu_bwd_bf16: L and E come together");
+    HCP_REQUIRE(lda % 8 == 0 && F % 8 == 0, "hcp_gemm_geglu_bwd_bf16: lda (%d) and F (%d) must be multiples of 8", lda, F);
+    if (int e = check_common(p)) return e;
+    if (!L) return dispatch_gemm<0, false>(p, (float*)workspace, workspace ? workspace_bytes : 0, stream);
+    p.L = (const hcp_bf16*)L; p.E = (const hcp_bf16*)E; p.Tout = (hcp_bf16*)Tout;
+    return launch_lora_dispatched(p, workspace, workspace_bytes, stream);
+}
+
 // Fused LoRA linear (forward AND input-gradient use the same entry point):
 //   T[M,32] = A[M,K] L[32,K]^T  (bf16-rounded, written to Tout if non-null)
 //   D[M,N]  = A B[N,K]^T + T E[N,32]^T + bias + residual
@@ -1035,28 +1087,5 @@ HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, c
     HCP_REQUIRE(A && B && D && L && E, "hcp_gemm_lora_bf16: null operand");
     HCP_REQUIRE(lda % 8 == 0, "hcp_gemm_lora_bf16: lda (%d) must be a multiple of 8", lda);
     if (int e = check_common(p)) return e;
-    int id = 4, nsplit = 1, ld = 0;
-    GemmParams q = p; q.K2 = 32;
-    if (!lookup_tuned(q, 3, &id, &nsplit, &ld)) {
-        // unseen shape: deep-K / small-M problems want split-K (two launches); otherwise fuse with a narrow-M tile
-        if (p.K >= 4096 && p.M <= 4096) id = -1;
-        else if ((long)p.M * p.N >= (long)4096 * 2560 && p.N % 160 == 0) id = 6;
-        else if (p.N % 160 == 0 && (long)p.M * p.N >= (long)4096 * 640) id = 4;
-        else id = 2;
-    }
-    if (g_force_cfg >= 0) id = g_force_cfg % 16;
-    p.loaders = g_force_loaders >= 0 ? g_force_loaders : deepest_ring(ld);
-    if (id == 7 || id == 10 || id == 11) id = 6;
-    if (id < 0) {
-        // two-launch form: T = A L^T, then D = A B^T + T E^T with the measured tile / split-K choice
-        HCP_REQUIRE(Tout, "hcp_gemm_lora_bf16: this shape runs as two launches and needs the T buffer");
-        GemmParams t = {};
-        t.A = p.A; t.lda = p.lda; t.B = p.L; t.ldb = p.K; t.M = p.M; t.N = 32; t.K = p.K; t.D = Tout; t.ldd = 32; t.alpha = 1.0f;
-        if (int e2 = dispatch_gemm<0, false>(t, (float*)workspace, workspace ? workspace_bytes : 0, stream)) return e2;
-        p.A2 = (const hcp_bf16*)Tout; p.lda2 = 32; p.B2 = p.E; p.ldb2 = 32; p.K2 = 32;
-        p.L = nullptr; p.E = nullptr; p.Tout = nullptr;
-        return dispatch_gemm<0, false>(p, (float*)workspace, workspace ? workspace_bytes : 0, stream);
-    }
-    p.nsplit = 1; p.kt_per_split = hcp_cdiv(p.K, BK); p.slabs = nullptr;
-    return launch_lora_by_id(id, p, stream);
+    return launch_lora_dispatched(p, workspace, workspace_bytes, stream);
 }

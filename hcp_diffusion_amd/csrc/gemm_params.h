@@ -31,12 +31,32 @@ struct GemmParams {
     // fused LoRA (LORA kernels): T = A L^T is accumulated next to the main tile from the same A tiles, rounded to
     // bf16, then D += T E^T as one extra k-step.  L [32,K] (ldl = K), E [N,32], Tout [M,32] (optional, for wgrad).
     const hcp_bf16* L; const hcp_bf16* E; hcp_bf16* Tout;
+    // GEGLU-backward epilogue (hcp_gemm_geglu_bwd_bf16): the product is dY_ff = d(h * gelu(g)) [M, N = F]; hg [M, 2F] holds the forward's
+    // (h | g); D is d(h | g) [M, 2F] (ldd = 2F): D[m, n] = v * gelu(g), D[m, F + n] = v * h * gelu'(g).  Null = ordinary epilogue.
+    const hcp_bf16* geglu_hg; int geglu_ld;
     int loaders;                    // 1: launch the loader-wave variant of the v2 kernel where one is instantiated (dispatch table / tools)
     int dbg;                        // tools/ablate_gemm.py: 1 = skip the DMA after the first tile, 2 = skip the MFMAs, 4 = skip LDS reads + MFMAs
     ConvDesc cv;
 };
 
 constexpr int BK = 64;
+
+// One 4-column piece of the GEGLU-backward epilogue (replaces the stand-alone geglu_bwd pass over dY_ff, h|g and d(h|g)).
+HCP_DEVICE void epilogue_geglu_bwd(const GemmParams& p, int m, int n, hcp_f32x4 v) {
+    const hcp_bf16* hp = p.geglu_hg + (size_t)m * p.geglu_ld + n;
+    const hcp_bf16x4 h = *(const hcp_bf16x4*)hp, g = *(const hcp_bf16x4*)(hp + p.N);
+    hcp_bf16x4 dh, dg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float hf = hcp_bf2f((unsigned short)h[q]), gf = hcp_bf2f((unsigned short)g[q]);
+        const float d = hcp_bf2f(hcp_f2bf(v[q] * p.alpha));                 // the two-kernel form rounds dY_ff to bf16 first: same values
+        dh[q] = (short)hcp_f2bf(d * hcp_gelu_erf(gf));
+        dg[q] = (short)hcp_f2bf(d * hf * hcp_gelu_erf_grad(gf));
+    }
+    hcp_bf16* dp = (hcp_bf16*)p.D + (size_t)m * p.ldd + n;
+    *(hcp_bf16x4*)dp = dh;
+    *(hcp_bf16x4*)(dp + p.N) = dg;
+}
 
 // gemm_pp.hip — the ping-pong main loop (two compute groups half a phase apart + 4 loader waves).  `p` arrives with tiles_m,
 // nsplit, kt_per_split and slabs set by the dispatcher; ring = depth of the LDS ring (2..4, lowered to what fits 160 KB).

@@ -445,6 +445,7 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + col0 + j * 16 + 4 * fg;
             if (n >= p.N) continue;
+            if (p.geglu_hg) { epilogue_geglu_bwd(p, m, n, acc[i][j]); continue; }
             hcp_f32x4 v = acc[i][j] * p.alpha + bias_v[j];
             if (p.rowbias) v += rb_v[j];
             if (p.residual) {

@@ -206,3 +206,10 @@ HCP_DEVICE float hcp_wave_max(float v) {
 HCP_DEVICE hcp_bf16x8 hcp_zero8() { hcp_bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
 HCP_DEVICE float hcp_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 HCP_DEVICE float hcp_silu(float x) { return x * hcp_sigmoid(x); }
+// exact (erf) GELU and its derivative: diffusers GEGLU's gate activation (reference cfgs/unet_struct.txt:28-30)
+HCP_DEVICE float hcp_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+HCP_DEVICE float hcp_gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

@@ -19,12 +19,8 @@ inline int pw_grid(long nvec) {
     return (int)g;
 }
 
-HCP_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-HCP_DEVICE float gelu_erf_grad(float x) {
-    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
-    return cdf + x * pdf;
-}
+HCP_DEVICE float gelu_erf(float x) { return hcp_gelu_erf(x); }
+HCP_DEVICE float gelu_erf_grad(float x) { return hcp_gelu_erf_grad(x); }
 
 HCP_KERNEL(256) geglu_fwd_kernel(const hcp_bf16* h, hcp_bf16* y, long M, int F) {
     const int fv = F / 8;

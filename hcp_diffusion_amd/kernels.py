@@ -120,6 +120,27 @@ def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True):
     return out, t
 
 
+def gemm_geglu_bwd(dy, wt, hg, *, l=None, e=None, want_t=True):
+    """d(h | g) [M, 2F] of  y = FFout(h * gelu(g))  from dy [M, C]: dY_ff = dy @ wt[F, C]^T (+ LoRA backward side path l [32, C], e [F, 32],
+    U = dy @ l^T returned) with the GEGLU backward applied in the GEMM epilogue — dY_ff itself is never stored.  hg [M, 2F] = the forward's (h | g)."""
+    _bf16_2d(dy, "dy"); _bf16_2d(wt, "wt"); _bf16_2d(hg, "hg")
+    M, C = dy.shape
+    Fd = wt.shape[0]
+    assert wt.shape[1] == C and hg.shape == (M, 2 * Fd) and hg.is_contiguous()
+    if TRACE is not None:
+        TRACE.append(("lora", M, Fd, C) if l is not None else ("gemm", M, Fd, C, 0))
+    dhg = torch.empty((M, 2 * Fd), dtype=BF16, device=dy.device)
+    u = None
+    if l is not None:
+        _bf16_2d(l, "l"); _bf16_2d(e, "e")
+        assert l.shape == (32, C) and e.shape == (Fd, 32) and l.is_contiguous() and e.is_contiguous()
+        u = torch.empty((M, 32), dtype=BF16, device=dy.device) if want_t else None
+    ws = _workspace(dy)
+    _chk(lib().hcp_gemm_geglu_bwd_bf16(_p(dy), dy.stride(0), _p(wt), wt.stride(0), _p(l), _p(e), _p(u), _p(hg), _p(dhg), M, Fd, C,
+                                       _p(ws), ws.numel(), _stream(dy)), "hcp_gemm_geglu_bwd_bf16")
+    return dhg, u
+
+
 def conv3x3(x1, wp, cout, *, x2=None, stride=1, upsample=False, mode=0, out_hw=None, bias=None, rowbias=None,
             residual=None, out_f32=False, a2=None, b2=None, pad=1):
     """3x3 convolution on NHWC bf16. mode 0: forward (wp = [cout][3][3][C1+C2]); mode 1: data gradient

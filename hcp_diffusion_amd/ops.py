@@ -503,6 +503,70 @@ class _GegluFn(torch.autograd.Function):
 geglu = _GegluFn.apply
 
 
+class _GegluLinearFn(torch.autograd.Function):
+    """y = FFout(h * gelu(g)) (+ residual) for (h | g) = hg, i.e. diffusers' FeedForward after its first projection
+    (GEGLU + Dropout(0) + Linear, cfgs/unet_struct.txt:27-33) as ONE autograd node: the forward is the GEGLU kernel + the (fused-LoRA) GEMM
+    as before; the backward runs the input-gradient GEMM with the GEGLU backward in its epilogue (hcp_gemm_geglu_bwd_bf16) — the
+    [M, 4C] gradient of the GEGLU output is never written or re-read, and the stand-alone geglu_bwd launch is gone.  Same arithmetic as
+    _GegluFn + _LinearFn (the epilogue rounds dY_ff to bf16 before the two products, as the two-kernel form does)."""
+
+    @staticmethod
+    def forward(ctx, hg, residual, w_down, w_up, host, lora, hw=None, hb=None):
+        shp = hg.shape
+        hg2 = hg.reshape(-1, shp[-1])
+        x2 = K.geglu_fwd(hg2)
+        res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
+        pk = host.packed()
+        T = None
+        if lora is not None:
+            lp = lora.packed()
+            y, T = K.gemm_lora(x2, pk.w, lp.ad, lp.bu, bias=pk.bias, residual=res2)
+        else:
+            y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2)
+        ctx.host, ctx.lora = host, lora
+        ctx.wg = current_wgrad()
+        ctx.train_w, ctx.train_b = hw is not None, hb is not None
+        ctx.save_for_backward(hg2, x2 if (lora is not None or hw is not None) else None, T)
+        ctx.hshape = shp
+        ctx.has_res = residual is not None
+        return y.view(*shp[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        hg2, x2, T = ctx.saved_tensors
+        host, lora = ctx.host, ctx.lora
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        pk = host.packed()
+        dhg = None
+        if lora is not None:
+            lp = lora.packed()
+            if ctx.needs_input_grad[0]:
+                dhg, U = K.gemm_geglu_bwd(dy2, pk.wt, hg2, l=lp.but, e=lp.adt)
+            else:
+                U = K.gemm(dy2, lp.but)
+            for blk, s0 in lora.members():
+                gd, gu = blk.grad_views()
+                ctx.wg.add(U, x2, gd, T, dy2, gu, blk.rank, blk.alpha_f, s0)
+        elif ctx.needs_input_grad[0]:
+            dhg, _ = K.gemm_geglu_bwd(dy2, pk.wt, hg2)
+        if ctx.train_w:
+            gw = grad_buffer(host.weight)
+            K.wgrad_linear(dy2, x2, gw.view(gw.shape[0], -1))
+        if ctx.train_b:
+            K.colsum(dy2, grad_buffer(host.bias))
+        if dhg is not None:
+            dhg = dhg.view(ctx.hshape)
+        return dhg, (dy if ctx.has_res else None), None, None, None, None, None, None
+
+
+def geglu_linear(hg, host, lora=None, residual=None):
+    wd = lora.layer.W_down if lora is not None else None
+    wu = lora.layer.W_up if lora is not None else None
+    return _GegluLinearFn.apply(hg, residual, wd, wu, host, lora, _tr(host.weight), _tr(host.bias))
+
+
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, heads, key_bias=None, causal=False):

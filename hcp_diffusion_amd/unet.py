@@ -157,6 +157,26 @@ def _fusable_linear(m):
     return host, blk
 
 
+_LAB_NO_GEGLU_FUSE = bool(os.environ.get("HCP_LAB_NO_GEGLU_FUSE"))      # same-box A/B switch (tools/lab): the two-node path
+
+
+def _ff_out_leaf(m):
+    """(host, lora block | None) when `m` — FeedForward's output projection — is a native HipLinear, bare or in a native single-block
+    LoRA container of rank <= 32 without active dropout, and nobody hooked it; else None (module-by-module path)."""
+    from .lora import LoraHipContainer
+    if isinstance(m, LoraHipContainer):
+        if (len(m.plugin_names) != 1 or m._forward_hooks or m._forward_pre_hooks or type(m._host) is not HipLinear
+                or m._host._forward_hooks or m._host._forward_pre_hooks):
+            return None
+        blk = m[m.plugin_names[0]]
+        if blk.wide or blk.host_type == "conv" or (blk.dropout.p > 0.0 and blk.training):
+            return None
+        return m._host, blk
+    if type(m) is HipLinear and not (m._forward_hooks or m._forward_pre_hooks):
+        return m, None
+    return None
+
+
 class CrossAttention(nn.Module):
     def __init__(self, dim, ctx_dim, heads):
         super().__init__()
@@ -239,6 +259,11 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), HipLinear(dim * 4, dim)])
 
     def forward(self, x, residual=None):
+        leaf = _ff_out_leaf(self.net[2]) if not (self.net[0]._forward_hooks or self.net[0]._forward_pre_hooks) and self.net[1].p == 0.0 else None
+        if leaf is not None and type(self.net[0]) is GEGLU and not _LAB_NO_GEGLU_FUSE:
+            # GEGLU + output projection as one autograd node: the GEGLU backward rides in the epilogue of the projection's
+            # input-gradient GEMM (ops._GegluLinearFn).  A hooked / foreign / dropout leaf keeps the module-by-module path below.
+            return ops.geglu_linear(self.net[0].proj(x), leaf[0], leaf[1], residual)
         h = self.net[0](x)
         return _call_res(self.net[2], h, residual) if residual is not None else self.net[2](h)
 

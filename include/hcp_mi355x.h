@@ -41,6 +41,12 @@ int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int l
 int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, void* D,
                        int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, void* workspace,
                        size_t workspace_bytes, hcpStream_t stream);
+/* FF-out input-gradient with the GEGLU backward in its epilogue: dY_ff = A B^T (+ the LoRA side path as hcp_gemm_lora_bf16's backward
+ * form: L = W_up^T, E = alpha W_down^T, Tout = dY W_up; L = E = NULL for a plain host) is never written; with (h | g) = HG[M, 2F] saved
+ * by the forward, DHG[m, n] = dY_ff gelu(g), DHG[m, F + n] = dY_ff h gelu'(g).  Replaces the dX GEMM of FeedForward.net[2] + the
+ * GEGLU backward pass (diffusers GEGLU in BasicTransformerBlock.ff, reference cfgs/unet_struct.txt:27-33 / autograd of F.gelu). */
+int hcp_gemm_geglu_bwd_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, const void* HG,
+                            void* DHG, int M, int F, int K, void* workspace, size_t workspace_bytes, hcpStream_t stream);
 /* fp32 split-K scratch (optional: workspace may be NULL, then small-M problems run unsplit). */
 size_t hcp_gemm_workspace_bytes(int M, int N);
 

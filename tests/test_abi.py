@@ -75,6 +75,7 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
     bad = {
         "hcp_conv3x3_bf16": (N, 8, N, 0, 1, 4, 4, 4, 4, 0, 1, 0, 1, N, 8, N, 8, N, N, 0, N, 0, 0, N, N, N, 0, N),
         "hcp_gemm_lora_bf16": (N, 8, N, 8, N, N, N, N, 8, 8, 8, 8, N, N, 0, N, 0, N),
+        "hcp_gemm_geglu_bwd_bf16": (N, 8, N, 8, N, N, N, N, N, 8, 8, 8, N, 0, N),
         "hcp_attention_fwd": (N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, 0, N),
         "hcp_attention_bwd": (N, N, N, N, N, N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, 0, N, 0, N),
         "hcp_groupnorm_silu_fwd": (N, N, N, N, N, N, 1, 16, 30, 32, 1e-5, 1, N),          # C % G != 0

@@ -878,3 +878,44 @@ def test_gemm_pingpong_variants(tbackend, cfg, ring):
         assert relerr(ol, ref_l) < 1e-2 and relerr(t, a.float() @ l.float().T) < 1e-2
     finally:
         L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1)
+
+
+def _geglu_bwd_ref(dff, hg, Fd):
+    h, g = hg.float()[:, :Fd], hg.float()[:, Fd:]
+    dff = dff.to(BF).float()
+    dgelu = 0.5 * (1 + torch.erf(g / 2 ** 0.5)) + g * torch.exp(-0.5 * g * g) / (2 * torch.pi) ** 0.5
+    return torch.cat([dff * F.gelu(g), dff * h * dgelu], 1)
+
+
+@pytest.mark.parametrize("lora", [False, True])
+def test_gemm_geglu_bwd_epilogue(tbackend, lora):
+    """hcp_gemm_geglu_bwd_bf16 == geglu_bwd(hg, dY W (+ LoRA side path)): the FF-out input gradient with the GEGLU backward in the GEMM
+    epilogue, through every main loop that can be dispatched for it (lock-step v2 with and without loader waves, ping-pong, the first
+    LDS-DMA loop for K % 64 != 0) and through split-K + reduce."""
+    to = tbackend.to
+    L = K.lib()
+    torch.manual_seed(31)
+    M, C, Fd = (200, 64, 320) if not tbackend.is_gpu else (4096, 640, 2560)
+    dy, wt, hg = rnd(M, C), rnd(Fd, C) * 0.2, rnd(M, 2 * Fd)
+    l, e = (rnd(32, C) * 0.2, rnd(Fd, 32) * 0.2) if lora else (None, None)
+    dff = dy.float() @ wt.float().T
+    u_ref = None
+    if lora:
+        u_ref = dy.float() @ l.float().T
+        dff = dff + u_ref.to(BF).float() @ e.float().T
+    ref = _geglu_bwd_ref(dff, hg, Fd)
+    kw = dict(l=to(l.contiguous()), e=to(e.contiguous())) if lora else {}
+    try:
+        for cfg, ld in ((-1, -1), (13 + 16, 0), (13 + 16, 4), (13 + 16, 12), (14 + 16, 11), (3 + 16, 0), (13 + 32, 12), (4 + 32, 0)):
+            L.hcp_debug_set_gemm_config(cfg); L.hcp_debug_set_gemm_loaders(ld)
+            out, u = K.gemm_geglu_bwd(to(dy), to(wt), to(hg), **kw)
+            assert out.shape == (M, 2 * Fd) and relerr(out, ref) < 1e-2, (cfg, ld)
+            if lora:
+                assert relerr(u, u_ref) < 1e-2
+        if not lora:                                        # K % 64 != 0: the first LDS-DMA loop (gemm_glds_kernel)
+            L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1)
+            dy2, wt2 = rnd(M, 40), rnd(Fd, 40) * 0.2
+            ref2 = _geglu_bwd_ref(dy2.float() @ wt2.float().T, hg, Fd)
+            assert relerr(K.gemm_geglu_bwd(to(dy2), to(wt2), to(hg))[0], ref2) < 1e-2
+    finally:
+        L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1)

@@ -62,6 +62,10 @@ int main(int argc, char** argv) {
     std::vector<Shape> shapes = {
         {"conv C320 @64x64 B4 (fwd)", 2, 16384, 320, 2880, 4, 64, 320, 0},
         {"conv C320 @64x64 B4 (dgrad)", 3, 16384, 320, 2880, 4, 64, 320, 0},
+        {"conv C320 @64x64 B4 fwd +residual", 2, 16384, 320, 2880, 4, 64, 320, 1},
+        {"conv C320 @64x64 B4 fwd +rowbias", 2, 16384, 320, 2880, 4, 64, 320, 2},
+        {"conv C320 @64x64 B4 fwd cold30 +rowbias", 2, 16384, 320, 2880, 4, 64, 320, 2},
+        {"conv C320 @64x64 B4 fwd cold30", 2, 16384, 320, 2880, 4, 64, 320, 0},
         {"gemm M16384 N320 K2880", 0, 16384, 320, 2880, 0, 0, 0, 0},
         {"gemm M16384 N320 K320 +res", 0, 16384, 320, 320, 0, 0, 0, 1},
         {"lora M16384 N320 K320 +res", 1, 16384, 320, 320, 0, 0, 0, 1},
@@ -106,7 +110,7 @@ int main(int argc, char** argv) {
     for (const Shape& s : shapes) {
         if (only && !strstr(s.name, only)) continue;
         const bool big = (double)s.M * s.N * s.K > 1e11;
-        const int nsets = big ? 2 : NSETS, reps = big ? 6 : REPS;
+        const int nsets = big ? 2 : strstr(s.name, "cold30") ? 30 : NSETS, reps = big ? 6 : strstr(s.name, "cold30") ? 60 : REPS;
         std::vector<void*> A(nsets), Bw(nsets), D(nsets), R(nsets);
         void *Lw = nullptr, *Ew = nullptr, *T = nullptr;
         const size_t a_elems = s.kind >= 2 ? (size_t)s.B * s.H * s.H * s.C : (size_t)s.M * s.K;
@@ -114,14 +118,15 @@ int main(int argc, char** argv) {
             A[i] = dev_random_bf16(a_elems, 1.0f);
             Bw[i] = dev_random_bf16((size_t)s.N * s.K, 0.05f);
             CK(hipMalloc(&D[i], (size_t)s.M * s.N * 2));
-            R[i] = s.res ? dev_random_bf16((size_t)s.M * s.N, 1.0f) : nullptr;
+            R[i] = s.res == 1 ? dev_random_bf16((size_t)s.M * s.N, 1.0f) : nullptr;
         }
         float* bias = dev_random_f32(s.N);
+        float* rowbias = s.res == 2 ? dev_random_f32((size_t)16 * s.N) : nullptr;
         if (s.kind == 1) { Lw = dev_random_bf16((size_t)32 * s.K, 0.05f); Ew = dev_random_bf16((size_t)s.N * 32, 0.05f); CK(hipMalloc(&T, (size_t)s.M * 32 * 2)); }
         auto run = [&](int i) -> int {
             if (s.kind == 0) return hcp_gemm_bf16(A[i], s.K, Bw[i], s.K, D[i], s.N, s.M, s.N, s.K, nullptr, 0, nullptr, 0, 0, bias, nullptr, 0, 1, R[i], s.N, 1.0f, 0, ws, ws_bytes, st);
             if (s.kind == 1) return hcp_gemm_lora_bf16(A[i], s.K, Bw[i], s.K, Lw, Ew, T, D[i], s.N, s.M, s.N, s.K, bias, R[i], s.N, ws, ws_bytes, st);
-            return hcp_conv3x3_bf16(A[i], s.C, nullptr, 0, s.B, s.H, s.H, s.H, s.H, s.kind == 2 ? 0 : 1, 1, 0, 1, Bw[i], s.N, D[i], s.N, bias, nullptr, 0, R[i], s.N, 0, nullptr, nullptr, ws, ws_bytes, st);
+            return hcp_conv3x3_bf16(A[i], s.C, nullptr, 0, s.B, s.H, s.H, s.H, s.H, s.kind == 2 ? 0 : 1, 1, 0, 1, Bw[i], s.N, D[i], s.N, bias, rowbias, s.N, R[i], s.N, 0, nullptr, nullptr, ws, ws_bytes, st);
         };
         const double flop = 2.0 * s.M * s.N * (s.K + (s.kind == 1 ? 32 : 0));
         printf("== %s  (%.1f GFLOP)\n", s.name, flop / 1e9);
@@ -159,6 +164,43 @@ int main(int argc, char** argv) {
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 times[v].push_back(ms * 1e3 / reps);
             }
+        if (argc > 2 && !strcmp(argv[2], "icache")) {          // the same launch timed alone (events around ONE launch) after itself vs after other kernels
+            hcp_debug_set_gemm_config(-1); hcp_debug_set_gemm_loaders(-1); hcp_debug_set_gemm_ablation(0);
+            void* xa = dev_random_bf16((size_t)4096 * 640, 1.0f); void* xb = dev_random_bf16((size_t)5120 * 640, 0.05f); void* xd; CK(hipMalloc(&xd, (size_t)4096 * 5120 * 2));
+            void* xl = dev_random_bf16((size_t)32 * 640, 0.05f); void* xe = dev_random_bf16((size_t)5120 * 32, 0.05f); void* xt; CK(hipMalloc(&xt, (size_t)4096 * 32 * 2));
+            auto others = [&]() {                             // three other kernel templates (fused-LoRA 128x160 v2, plain 64x160, split-K + reduce)
+                hcp_gemm_lora_bf16(xa, 640, xb, 640, xl, xe, xt, xd, 640, 4096, 640, 640, nullptr, nullptr, 0, ws, ws_bytes, st);
+                hcp_gemm_bf16(xa, 640, xb, 640, xd, 1280, 1024, 1280, 640, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0, 1.0f, 0, ws, ws_bytes, st);
+                hcp_gemm_bf16(xa, 640, xb, 640, xd, 320, 256, 320, 640, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0, 1.0f, 0, ws, ws_bytes, st);
+            };
+            for (int mode = 0; mode < 2; ++mode) {
+                std::vector<float> ts;
+                for (int i = 0; i < 60; ++i) {
+                    if (mode == 1) others(); else run((i + 1) % nsets);
+                    CK(hipEventRecord(e0, st));
+                    run(i % nsets);
+                    CK(hipEventRecord(e1, st));
+                    CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    ts.push_back(ms * 1e3f);
+                }
+                std::sort(ts.begin(), ts.end());
+                printf("   single launch between two events, %s: median %.1f us  min %.1f us\n", mode ? "after three OTHER kernels" : "after ITSELF", ts[ts.size() / 2], ts[0]);
+            }
+        }
+        if (argc > 2 && !strcmp(argv[2], "sustain")) {         // does the per-launch time drift under a SUSTAINED load (clock / power management)?
+            hcp_debug_set_gemm_config(-1); hcp_debug_set_gemm_loaders(-1); hcp_debug_set_gemm_ablation(0);
+            printf("   sustained (dispatched), us per launch in consecutive chunks of 400 launches:");
+            for (int c = 0; c < 12; ++c) {
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < 400; ++i) run(i % nsets);
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf(" %.1f", ms * 1e3 / 400);
+            }
+            printf("\n");
+        }
         for (size_t v = 0; v < variants.size(); ++v) {
             if (!ok[v]) continue;
             std::sort(times[v].begin(), times[v].end());
