@@ -629,6 +629,7 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
             hcp_barrier_keep_dma();                         // tile t+1 is in LDS, tile t is consumed
         }
         if (LORA) HCP_SYNC();                               // the compute waves' epilogue barrier
+        if (p.geglu_hg && p.nsplit == 1) { if (LORA) HCP_SYNC(); HCP_SYNC(); }       // ... and those of the GEGLU-backward tile
         return;
     }
     if (NLD == 0) { if (nprim > 0) issue(0); else if (has_ext) issue_ext(0); }
@@ -690,6 +691,17 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         }
         return;
     }
+    if (p.geglu_hg) {                                       // GEGLU-backward epilogue through LDS (gemm_params.h: geglu_tile_*)
+        static_assert((size_t)BM * geglu_tile_ld(BN) <= (size_t)2 * BUF_ELEMS, "the product tile fits the ring");
+        if (LORA) HCP_SYNC();                               // the LoRA tail's T / E images live in the same LDS
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) geglu_tile_put(lds, geglu_tile_ld(BN), wm * WTM + i * 16 + fr, wn * WTN + j * 16 + 4 * fg, acc[i][j], p.alpha);
+        HCP_SYNC();
+        geglu_tile_apply<BM, BN, NTC>(p, lds, m0, n0, tid_all);
+        return;
+    }
     // epilogue: ALL of the lane's bias / row-bias / residual loads are issued before the first store (one vmcnt wait instead
     // of one per 16x16 block: with K = 320 the serialized form cost as much as the whole main loop)
     if (!EARLY) load_epilogue_operands();
@@ -711,7 +723,6 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WTN + j * 16 + 4 * fg;
             if (n >= p.N) continue;
-            if (p.geglu_hg) { epilogue_geglu_bwd(p, m, n, acc[i][j]); continue; }
             hcp_f32x4 v = acc[i][j] * p.alpha + bias_v[j];
             if (p.rowbias) v += rb_v[j];
             if (p.residual) {

@@ -260,6 +260,7 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         hcp_barrier_only();                               // #2U
         hcp_barrier_only(); hcp_barrier_only();          // the exchange of the compute groups
         if (LORA) HCP_SYNC();                             // the compute waves' tail barrier
+        if (p.geglu_hg && p.nsplit == 1) { if (LORA) HCP_SYNC(); HCP_SYNC(); }       // ... and those of the GEGLU-backward tile
         return;
     }
 
@@ -427,6 +428,16 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         }
         return;
     }
+    if (p.geglu_hg) {                                       // GEGLU-backward epilogue through LDS (gemm_params.h: geglu_tile_*)
+        if (LORA) HCP_SYNC();                               // the LoRA tail's T image lives in the ring
+#pragma unroll
+        for (int i = 0; i < TMF; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) geglu_tile_put(ring, geglu_tile_ld(BN), frow0 + i * 16 + fr, col0 + j * 16 + 4 * fg, acc[i][j], p.alpha);
+        HCP_SYNC();
+        geglu_tile_apply<BM, BN, NTC>(p, ring, m0, n0, tid_all);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TMF; ++i) {
         const int m = m0 + frow0 + i * 16 + fr;
@@ -445,7 +456,6 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + col0 + j * 16 + 4 * fg;
             if (n >= p.N) continue;
-            if (p.geglu_hg) { epilogue_geglu_bwd(p, m, n, acc[i][j]); continue; }
             hcp_f32x4 v = acc[i][j] * p.alpha + bias_v[j];
             if (p.rowbias) v += rb_v[j];
             if (p.residual) {
