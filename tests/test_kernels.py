@@ -839,8 +839,7 @@ def test_gemm_loader_wave_variants(tbackend, cfg, stages):
         L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1)
 
 
-@pytest.mark.parametrize("ring", [2, 3, 4])
-@pytest.mark.parametrize("cfg", [13, 14, 15])
+@pytest.mark.parametrize("cfg,ring", [(13, 4), (13, 2), (14, 3), (15, 4)])
 def test_gemm_pingpong_variants(tbackend, cfg, ring):
     """gemm_pp_kernel (csrc/gemm_pp.hip): two compute groups half a phase apart + 4 loader waves; the groups split every K tile
     by k-step (partial sums exchanged through LDS); LDS ring of 2 / 3 / 4 K tiles.  Plain GEMM with

@@ -8,7 +8,7 @@ mkdir -p $out
 cd $root
 (timeout 1500 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1; echo "rc=$?" >> $out/gpu_tests.log)
 tail -2 $out/gpu_tests.log
-python bench.py > $out/bench_sd15.json 2> $out/bench_sd15.err
+python bench.py --steps 100 --warmup 20 > $out/bench_sd15.json 2> $out/bench_sd15.err
 for w in sdxl dreambooth controlnet sd15te; do
   python bench.py --workload $w --no-cpu-baseline > $out/bench_$w.json 2> $out/bench_$w.err
 done
@@ -19,6 +19,11 @@ python bench.py --seam --seam-graph --workload dreambooth > $out/bench_seam_grap
 bash tools/step_profile.sh $tag/step_sd15 > /dev/null 2>&1
 bash tools/step_profile.sh $tag/step_sdxl --workload sdxl > /dev/null 2>&1
 rm -rf $out/step_sd15 $out/step_sdxl          # the raw traces (tens of MB); the summaries stay
+# counter passes of the roofline kernels (one counter group per run, never combined with tracing domains) + the record bench.py reads
+bash tools/pmc_passes.sh $out/pmc -- python tools/pmc_roofline_target.py > /dev/null 2>&1
+python tools/pmc_summary.py $out/pmc > $out/pmc_summary.md 2>/dev/null
+python tools/pmc_roofline.py $out/pmc $out/pmc_roofline.json $out/step_sd15_summary.md > /dev/null 2>&1
+rm -rf $out/pmc/p*/*/*.db 2>/dev/null
 for f in $out/bench_*.json; do python - "$f" <<'PY'
 import json, sys
 try:

@@ -1,4 +1,4 @@
-"""tools/pmc_roofline.py PASSDIR [out.json]: per-launch HBM bytes and MFMA-busy of bench.py's roofline kernels from the
+"""tools/pmc_roofline.py PASSDIR [out.json [step_summary.md]]: per-launch HBM bytes and MFMA-busy of bench.py's roofline kernels from the
 rocprofv3 counter passes of tools/pmc_passes.sh (target tools/pmc_roofline_target.py) -> profiles/pmc_roofline.json, which
 bench.py reads for `roofline.traffic` (a profiler cannot run inside the benchmark process).
 HBM bytes = FETCH_SIZE x 1024 x 2 (gfx950: the counter tallies 128-byte requests as 64, MI355X_MICROARCH.md §HBM) + WRITE_SIZE x 1024."""
@@ -9,13 +9,34 @@ import subprocess
 import sys
 from collections import defaultdict
 
-KEYS = {"conv3x3_c320_64x64_b4": ("gemm_v2_kernel", "1, false"),      # MODE = 1 (forward conv), plain (no LoRA)
+KEYS = {"conv3x3_c320_64x64_b4": ("gemm_pp_kernel<128, 160, 1, false", ""),      # MODE = 1 (forward conv), plain (no LoRA), ping-pong loop
         "attn_fwd_b4_h8_n4096_d40": ("attn2_fwd_kernel<40", ""),
         "attn_dq_b4_h8_n4096_d40": ("attn2_bwd_dq_kernel<40", ""),
         "attn_dkv_b4_h8_n4096_d40": ("attn2_bwd_dkv_kernel<40", "")}
 
 
-def main(passdir, out):
+def in_step_averages(summary_md):
+    """avg us of the roofline kernels INSIDE the captured step, from the per-geometry table tools/prof_step_summary.py writes: the conv
+    template at 256 workgroups x 1 slab (C320 -> 320 at 64x64, B 4) and, for the attention templates, the geometry with the most time
+    (self-attention at 64x64)."""
+    rows = []
+    sec = False
+    for line in open(summary_md):
+        if "by launch geometry" in line:
+            sec = True
+            continue
+        if sec and line.startswith("|") and not line.startswith("| kernel") and not line.startswith("|---"):
+            c = [x.strip() for x in line.strip().strip("|").split("|")]
+            rows.append((c[0], int(c[1]), int(c[2]), float(c[5]), float(c[6])))
+    res = {}
+    for key, (a, b) in KEYS.items():
+        cand = [r for r in rows if a in r[0] and b in r[0] and (not key.startswith("conv") or (r[1] == 256 and r[2] == 1))]
+        if cand:
+            res[key] = max(cand, key=lambda r: r[4])[3]
+    return res
+
+
+def main(passdir, out, step_summary=None):
     vals = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(f"{passdir}/p*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -35,9 +56,14 @@ def main(passdir, out):
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
             e["mfma_busy"] = round(avg(v["SQ_VALU_MFMA_BUSY_CYCLES"]) / (avg(v["GRBM_GUI_ACTIVE"]) / 8 * 1024), 3)
         rec[key] = e
+    if step_summary:
+        for key, us in in_step_averages(step_summary).items():
+            if key in rec:
+                rec[key]["avg_launch_us_in_step"] = us
+                rec[key]["in_step_source"] = step_summary
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_roofline.json")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_roofline.json", sys.argv[3] if len(sys.argv) > 3 else None)

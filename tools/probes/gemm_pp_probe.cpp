@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
         {"pp 64x160 s2 ring4", 14 + 32, 12, 0},
     };
     if (ablate) variants = {
-        {"v2 128x160 ring4", 13 + 16, 4, 0}, {"v2 no DMA", 13 + 16, 4, 8}, {"v2 no reads no MFMA", 13 + 16, 4, 48}, {"v2 no MFMA", 13 + 16, 4, 16},
+        {"v2 128x160 ring4", 13 + 16, 4, 0}, {"v2 no stores", 13 + 16, 4, 64}, {"v2 no DMA", 13 + 16, 4, 8}, {"v2 no reads no MFMA", 13 + 16, 4, 48}, {"v2 no MFMA", 13 + 16, 4, 16},
         {"pp 128x160 ring4", 13 + 16, 12, 0}, {"pp no A", 13 + 16, 12, 0x100}, {"pp no B", 13 + 16, 12, 0x200}, {"pp no DMA", 13 + 16, 12, 0x300},
         {"pp no MFMA", 13 + 16, 12, 0x400}, {"pp barriers only", 13 + 16, 12, 0x800}, {"pp no DMA no MFMA", 13 + 16, 12, 0x700},
         {"pp nothing", 13 + 16, 12, 0xb00}, {"pp no A no MFMA", 13 + 16, 12, 0x500}, {"pp no B no MFMA", 13 + 16, 12, 0x600},

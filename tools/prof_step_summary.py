@@ -34,7 +34,7 @@ def main():
     by_shape = collections.defaultdict(lambda: [0, 0.0])      # GEMM family per (kernel template, workgroups x split-K slabs, threads)
     for s, e, n, shape in sel:
         agg[n][0] += 1; agg[n][1] += (e - s) / 1e3
-        if "gemm_" in n:
+        if "gemm_" in n or "attn2_" in n:
             by_shape[(n, shape)][0] += 1; by_shape[(n, shape)][1] += (e - s) / 1e3
     tot = sum(v[1] for v in agg.values())
     fam = collections.defaultdict(lambda: [0, 0.0])
@@ -51,9 +51,9 @@ def main():
     L += ["", "| kernel | launches / step | ms / step | avg us | % |", "|---|---|---|---|---|"]
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         L.append(f"| {n} | {c / steps:.1f} | {t / steps / 1e3:.3f} | {t / c:.1f} | {100 * t / tot:.1f} |")
-    L += ["", "GEMM family by launch geometry (one row = one problem shape class: tiles along M x N in `workgroups`, split-K slabs in `y`):", "",
+    L += ["", "GEMM family and attention by launch geometry (one row = one problem shape class: tiles along M x N in `workgroups`, split-K slabs in `y`):", "",
           "| kernel | workgroups | y | threads | launches / step | avg us | ms / step |", "|---|---|---|---|---|---|---|"]
-    for (n, (wgs, gy, thr)), (c, t) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:60]:
+    for (n, (wgs, gy, thr)), (c, t) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:90]:
         L.append(f"| {n} | {wgs} | {gy} | {thr} | {c / steps:.1f} | {t / c:.1f} | {t / steps / 1e3:.3f} |")
     open(out, "w").write("\n".join(L) + "\n")
     print("\n".join(L[:16]))
