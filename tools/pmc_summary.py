@@ -42,6 +42,20 @@ def main(out):
         lfrac = la / sb if sb == sb and sb and la == la else float("nan")
         print(f"| {k} | {avg(tr.get(k, [])):.1f} | {avg(dur[k]):.1f} | {mf:.3f} | {va:.3f} | {lfrac:.3f} | {bc:.3f} | "
               f"{avg(v.get('FETCH_SIZE', [])) * 1024 * 2 / 1e6:.1f} | {avg(v.get('WRITE_SIZE', [])) * 1024 / 1e6:.1f} |")
+    print()
+    print("Wave-cycle breakdown (fractions of SQ_WAVE_CYCLES; WAIT_ANY = parked at s_waitcnt / s_barrier, WAIT_INST_ANY = issue stall: pipe busy / "
+          "MFMA dependency; the passes come from different runs, so the three need not sum to exactly 1):")
+    print()
+    print("| kernel | ACTIVE_INST_ANY | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_VALU | WAIT_INST_LDS | per-launch us in the trace pass |")
+    print("|---|---|---|---|---|---|---|")
+    for k in sorted(vals, key=lambda k: -avg(dur[k])):
+        v = vals[k]
+        wc = avg(v.get("SQ_WAVE_CYCLES", []))
+        if not (wc == wc and wc) or "SQ_WAIT_ANY" not in v:
+            continue
+        fr = lambda name: avg(v.get(name, [])) / wc
+        print(f"| {k} | {fr('SQ_ACTIVE_INST_ANY'):.3f} | {fr('SQ_WAIT_ANY'):.3f} | {fr('SQ_WAIT_INST_ANY'):.3f} | {fr('SQ_ACTIVE_INST_VALU'):.3f} | "
+              f"{fr('SQ_WAIT_INST_LDS'):.3f} | {', '.join(f'{x:.1f}' for x in tr.get(k, []))} |")
 
 
 if __name__ == "__main__":
