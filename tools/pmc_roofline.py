@@ -44,6 +44,12 @@ def main(passdir, out, step_summary=None):
                 if a in r["Kernel_Name"] and b in r["Kernel_Name"]:
                     vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
                     vals[key]["_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    trace = defaultdict(list)                          # the kernel-trace pass of the same command (no counters attached)
+    for f in glob.glob(f"{passdir}/trace/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            for key, (a, b) in KEYS.items():
+                if a in r["Kernel_Name"] and b in r["Kernel_Name"]:
+                    trace[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     avg = lambda x: sum(x) / len(x)
     git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
     rec = {}
@@ -53,6 +59,9 @@ def main(passdir, out, step_summary=None):
         fetch, write = avg(v["FETCH_SIZE"]) * 1024 * 2, avg(v["WRITE_SIZE"]) * 1024
         e = {"hbm_bytes_per_launch": round(fetch + write), "hbm_fetch_bytes": round(fetch), "hbm_write_bytes": round(write),
              "us_under_pmc": round(avg(v["_us"]), 1), "git": git, "source": f"rocprofv3 --pmc passes, {passdir}"}
+        if trace.get(key):
+            e["us_rocprof_trace"] = round(avg(trace[key]), 1)
+            e["us_rocprof_trace_launches"] = [round(x, 1) for x in trace[key]]
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
             e["mfma_busy"] = round(avg(v["SQ_VALU_MFMA_BUSY_CYCLES"]) / (avg(v["GRBM_GUI_ACTIVE"]) / 8 * 1024), 3)
         rec[key] = e
