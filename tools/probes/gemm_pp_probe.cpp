@@ -81,6 +81,10 @@ int main(int argc, char** argv) {
         {"lora M1024 N10240 K1280", 1, 1024, 10240, 1280, 0, 0, 0, 0},
         {"lora M2048 N1280 K1280 +res (SDXL)", 1, 2048, 1280, 1280, 0, 0, 0, 1},
         {"lora M8192 N640 K640 +res (SDXL)", 1, 8192, 640, 640, 0, 0, 0, 1},
+        {"lora M2048 N1280 K1280 +res (SDXL) cold30", 1, 2048, 1280, 1280, 0, 0, 0, 1},
+        {"lora M4096 N640 K2560 +res cold30", 1, 4096, 640, 2560, 0, 0, 0, 1},
+        {"lora M1024 N1280 K1280 +res cold30", 1, 1024, 1280, 1280, 0, 0, 0, 1},
+        {"lora M16384 N320 K1280 +res cold30", 1, 16384, 320, 1280, 0, 0, 0, 1},
         {"gemm 4096^3", 0, 4096, 4096, 4096, 0, 0, 0, 0},
         {"gemm 8192^3", 0, 8192, 8192, 8192, 0, 0, 0, 0},
     };
