@@ -26,6 +26,11 @@ def emu_cdll():
         sys.path.insert(0, str(ROOT / "tests" / "emu"))
         from build_emu import build_emu
         _emu_cdll = ctypes.CDLL(str(build_emu()))
+        # HCP_EMU_DMA_LATE=1: the whole run under the interpreter's second LDS-DMA timing model (copies land at the wait that retires them,
+        # not at issue; tests/emu/hcp_emu.h) — `HCP_EMU_DMA_LATE=1 pytest -m "not gpu" tests/test_kernels.py` is the CPU race screen for
+        # every counted-vmcnt protocol; the default run keeps the early-landing model and one dedicated late-landing test
+        if os.environ.get("HCP_EMU_DMA_LATE") == "1":
+            _emu_cdll.hcp_debug_emu_dma_deferred(1)
     return _emu_cdll
 
 

@@ -45,8 +45,28 @@ static void to_main() { hcp_emu_ctx_switch(&g_cur->sp, g_main_sp); }
 void yield_barrier() { g_cur->state = ST_BARRIER; to_main(); }
 void wave_collective() { g_cur->state = ST_WAVE; to_main(); }
 
+int g_dma_deferred = 0;
+static const int kPend = 1024;
+void dma_push(void* dst, const void* src, int n) {
+    if (!g_dma_deferred) { if (src) memcpy(dst, src, n); else memset(dst, 0, n); return; }
+    Fiber* f = g_cur;
+    if (f->pend_n >= kPend) { fprintf(stderr, "hcp_emu: more than %d LDS-DMA copies in flight in one lane\n", kPend); abort(); }
+    Fiber::Pend& e = f->pend[f->pend_n++];
+    e.dst = (unsigned char*)dst; e.n = n;
+    if (src) memcpy(e.data, src, n); else memset(e.data, 0, n);      // the source is read at issue: kernel inputs do not change under a launch
+}
+void dma_drain(int keep) {
+    Fiber* f = g_cur;
+    if (f->pend_n <= keep) return;
+    const int land = f->pend_n - (keep > 0 ? keep : 0);
+    for (int i = 0; i < land; ++i) memcpy(f->pend[i].dst, f->pend[i].data, f->pend[i].n);      // loads return in order: the oldest land first
+    memmove(f->pend, f->pend + land, sizeof(Fiber::Pend) * (f->pend_n - land));
+    f->pend_n -= land;
+}
+
 static void trampoline() {
     (*g_body)();
+    dma_drain(0);
     g_cur->state = ST_DONE;
     to_main();
     fprintf(stderr, "hcp_emu: resumed a finished fibre\n");
@@ -140,6 +160,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
     while ((int)fb.size() < n) {
         Fiber f; memset(&f, 0, sizeof(f));
         f.stack = (char*)aligned_alloc(64, kStack);
+        f.pend = (Fiber::Pend*)malloc(sizeof(Fiber::Pend) * kPend);
         fb.push_back(f);
     }
     g_bdim = block; g_gdim = grid; g_smem = smem_buf; g_body = &body;
@@ -149,7 +170,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
         g_block = {bx, by, bz};
         for (int t = 0; t < n; ++t) {
             Fiber& f = fb[t];
-            f.lin = t; f.wave = t >> 6; f.lane = t & 63; f.state = ST_RUN;
+            f.lin = t; f.wave = t >> 6; f.lane = t & 63; f.state = ST_RUN; f.pend_n = 0;
             f.tid.x = t % block.x; f.tid.y = (t / block.x) % block.y; f.tid.z = t / (block.x * block.y);
             init_fiber(f);
         }
@@ -191,3 +212,6 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
     g_cur = nullptr;
 }
 }  // namespace hcp_emu
+
+// TEST ONLY: 1 = LDS-DMA copies land at the wait that retires them (latest the hardware allows), 0 = at issue (earliest).
+extern "C" __attribute__((visibility("default"))) int hcp_debug_emu_dma_deferred(int on) { hcp_emu::g_dma_deferred = on ? 1 : 0; return 0; }

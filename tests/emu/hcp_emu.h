@@ -29,7 +29,17 @@ struct Fiber {
     uint32_t out[16];
     int src_lane;
     char* stack;
+    struct Pend { unsigned char* dst; unsigned char data[16]; int n; }* pend;      // LDS-DMA writes issued and not yet landed (deferred mode)
+    int pend_n;
 };
+// LDS-DMA timing model.  0 (default): a copy lands the moment it is issued — the EARLIEST the hardware allows, which is what exposes
+// write-after-read hazards (a refill overwriting fragments still being read).  1: a copy lands only when its issuing lane executes the
+// wait that retires it (counted vmcnt: all but the N newest; HCP_SYNC / hcp_dma_wait_all: everything) — the LATEST the hardware allows,
+// which is what exposes read-after-write hazards (a tile read before the wait + barrier that publish it).  A counted-vmcnt / raw-barrier
+// protocol has to pass in both modes (tests/test_kernels.py::test_gemm_dma_protocols_under_late_landing).
+extern int g_dma_deferred;
+void dma_push(void* dst, const void* src, int n);       // src == nullptr: zeros (out-of-range lanes of a buffer load)
+void dma_drain(int keep);
 extern Fiber* g_cur;
 extern uint3_t g_block;
 extern dim3 g_bdim, g_gdim;
@@ -51,7 +61,7 @@ typedef void* hipStream_t;
 #define HCP_MEMBER inline
 #define HCP_KERNEL(maxthreads) static void
 #define HCP_DYN_SMEM(name) unsigned char* name = hcp_emu::g_smem
-#define HCP_SYNC() hcp_emu::yield_barrier()
+#define HCP_SYNC() (hcp_emu::dma_drain(0), hcp_emu::yield_barrier())      // __syncthreads() with LDS-DMA in flight carries vmcnt(0)
 #define HCP_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hcp_emu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
 
@@ -101,7 +111,7 @@ HCP_DEVICE hcp_bf16x4 hcp_lds_read_tr4(const unsigned short* p) {
 }
 // LDS-DMA (global_load_lds_dwordx4): lane l's 16 bytes land at wave_base + 16*l; the interpreter copies immediately.
 HCP_DEVICE void hcp_glds16(const void* gsrc, void* lds_wave_base) {
-    memcpy((unsigned char*)lds_wave_base + 16 * hcp_emu::g_cur->lane, gsrc, 16);
+    hcp_emu::dma_push((unsigned char*)lds_wave_base + 16 * hcp_emu::g_cur->lane, gsrc, 16);
 }
 struct hcp_rsrc { const unsigned char* base; unsigned nbytes; };
 #define HCP_BUF_OOB 0x80000000u
@@ -109,7 +119,7 @@ HCP_DEVICE hcp_rsrc hcp_make_rsrc(const void* base) { hcp_rsrc r; r.base = (cons
 HCP_DEVICE hcp_rsrc hcp_make_rsrc_n(const void* base, unsigned nbytes) { hcp_rsrc r; r.base = (const unsigned char*)base; r.nbytes = nbytes; return r; }
 HCP_DEVICE void hcp_buf_glds16(hcp_rsrc rsrc, unsigned voffset, void* lds_wave_base) {
     unsigned char* dst = (unsigned char*)lds_wave_base + 16 * hcp_emu::g_cur->lane;
-    if (voffset >= rsrc.nbytes || voffset + 16 > rsrc.nbytes) memset(dst, 0, 16); else memcpy(dst, rsrc.base + voffset, 16);
+    hcp_emu::dma_push(dst, (voffset >= rsrc.nbytes || voffset + 16 > rsrc.nbytes) ? nullptr : rsrc.base + voffset, 16);
 }
 HCP_DEVICE hcp_bf16x8 hcp_buf_load16(hcp_rsrc rsrc, unsigned voffset) {
     hcp_bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -130,19 +140,19 @@ struct hcp_desc4 { const unsigned char* base; unsigned nbytes; };
 HCP_DEVICE hcp_desc4 hcp_make_desc(const void* base, unsigned nbytes) { hcp_desc4 d; d.base = (const unsigned char*)base; d.nbytes = nbytes; return d; }
 HCP_DEVICE void hcp_dma16(hcp_desc4 d, unsigned voffset, void* lds_wave_base) {
     unsigned char* dst = (unsigned char*)lds_wave_base + 16 * hcp_emu::g_cur->lane;
-    if (voffset >= d.nbytes || voffset + 16 > d.nbytes) memset(dst, 0, 16); else memcpy(dst, d.base + voffset, 16);
+    hcp_emu::dma_push(dst, (voffset >= d.nbytes || voffset + 16 > d.nbytes) ? nullptr : d.base + voffset, 16);
 }
 template <int P> HCP_DEVICE void hcp_setprio() {}
 HCP_DEVICE void hcp_sched_fence() {}
-HCP_DEVICE void hcp_dma_wait_all() {}
+HCP_DEVICE void hcp_dma_wait_all() { hcp_emu::dma_drain(0); }
 HCP_DEVICE int hcp_uniform(int v) { return v; }
 HCP_DEVICE void hcp_force_ready(hcp_bf16x8&) {}
 HCP_DEVICE void hcp_force_ready(float&) {}
 #define HCP_DEVICE_GLOBAL static
-HCP_DEVICE void hcp_wait_vmcnt(int) {}                       // DMA is synchronous in the interpreter
+HCP_DEVICE void hcp_wait_vmcnt(int n) { hcp_emu::dma_drain(n); }
 HCP_DEVICE void hcp_barrier_keep_dma() { hcp_emu::yield_barrier(); }
 HCP_DEVICE void hcp_barrier_only() { hcp_emu::yield_barrier(); }
-template <int N> HCP_DEVICE void hcp_wait_vmcnt_c() {}
+template <int N> HCP_DEVICE void hcp_wait_vmcnt_c() { hcp_emu::dma_drain(N); }
 HCP_DEVICE bool hcp_all(bool pred) {
     int v = pred ? 1 : 0;
     for (int m = 32; m >= 1; m >>= 1) v &= hcp_shfl_xor_i(v, m);

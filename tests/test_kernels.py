@@ -918,3 +918,39 @@ def test_gemm_geglu_bwd_epilogue(tbackend, lora):
             assert relerr(K.gemm_geglu_bwd(to(dy2), to(wt2), to(hg))[0], ref2) < 1e-2
     finally:
         L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1)
+
+
+@pytest.mark.parametrize("cfg,ld", [(13, 4), (13, 3), (14, 1), (13, 12), (13, 10), (14, 11), (15, 12), (8, -1), (10, -1), (3, 0)])
+def test_gemm_dma_protocols_under_late_landing(cfg, ld):
+    """The interpreter's second LDS-DMA timing model (tests/emu/hcp_emu.h): a copy lands only when its issuing lane executes the wait that
+    retires it — the LATEST the hardware allows — instead of at issue.  Every main loop whose correctness rests on counted `vmcnt` waits
+    and raw barriers (loader-wave rings of 2 / 3 / 4 tiles, the 3-stage all-waves-load loop, the ping-pong loop with its part-wise
+    issue) must give the same answers: a fragment read that precedes the wait + barrier publishing its tile reads stale LDS here,
+    deterministically, where on the GPU it would pass whenever the copy happened to land first (guide: "place reads by the vmcnt /
+    barrier count, never by clean runs")."""
+    from conftest import emu_cdll
+    lib = emu_cdll()
+    K._set_backend_for_tests(lib)
+    torch.manual_seed(7)
+    M, N, Kd = 200, 320, 448                             # 7 K tiles: prologue, steady state and tail of every ring depth
+    a, b, a2, b2 = rnd(M, Kd), rnd(N, Kd), rnd(M, 32), rnd(N, 32)
+    bias, res = torch.randn(N), rnd(M, N)
+    ref = a.float() @ b.float().T + a2.float() @ b2.float().T + bias + res.float()
+    l, e = rnd(32, Kd) * 0.2, rnd(N, 32) * 0.2
+    ref_l = a.float() @ b.float().T + (a.float() @ l.float().T).to(BF).float() @ e.float().T + bias + res.float()
+    x1 = rnd(2, 6, 6, 128); w = rnd(64, 128, 3, 3) * 0.1
+    ref_c = F.conv2d(x1.permute(0, 3, 1, 2).float(), w.float(), padding=1).permute(0, 2, 3, 1)
+    try:
+        lib.hcp_debug_emu_dma_deferred(1)
+        lib.hcp_debug_set_gemm_loaders(ld); lib.hcp_debug_set_gemm_config(cfg + 16)
+        assert relerr(K.gemm(a, b, a2=a2, b2=b2, bias=bias, residual=res), ref) < 1e-2
+        assert relerr(K.conv3x3(x1, w.permute(0, 2, 3, 1).contiguous(), 64), ref_c) < 1e-2
+        lib.hcp_debug_set_gemm_config(cfg + 32)
+        assert relerr(K.gemm(a, b, a2=a2, b2=b2, bias=bias, residual=res), ref) < 1e-2
+        if cfg in (13, 14, 15, 8, 3):
+            lib.hcp_debug_set_gemm_config(cfg + 16)
+            assert relerr(K.gemm_lora(a, b, l.contiguous(), e.contiguous(), bias=bias, residual=res)[0], ref_l) < 1e-2
+    finally:
+        lib.hcp_debug_emu_dma_deferred(0)
+        lib.hcp_debug_set_gemm_config(-1); lib.hcp_debug_set_gemm_loaders(-1)
+        K._set_backend_for_tests(None)
