@@ -688,6 +688,17 @@ HCP_WAVES_PER_SIMD((dkv_waves<D, KT>())) HCP_KERNEL(256) attn2_bwd_dkv_kernel(At
     const int qfull = fr * G::RS + fg * 8;
     const int qtail = fr * G::RS + ((G::NFULL * 32 + fg * 8) < D ? G::NFULL * 32 + fg * 8 : D);
     const int tfrag = (4 * fg + (fr >> 2)) * G::RS + 4 * (fr & 3);
+    // the K / V fragments (and the keys' additive bias: one value per lane, loop invariant) are retired HERE, not at their first use
+    // inside the loop (where the compiler's vmcnt(0) would sit right behind each tile's DMA issue)
+    float kb2_t[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int key = k_base + t * 16 + fr;
+        kb2_t[t] = (KB && key < p.Nk && p.kbias) ? p.kbias[(size_t)b * p.kb_bs + key] * (RAW ? 1.0f / p.scale : LOG2E) : 0.f;
+        if (KB) hcp_force_ready(kb2_t[t]);
+#pragma unroll
+        for (int s = 0; s < G::NQK; ++s) { hcp_force_ready(kf[t][s]); hcp_force_ready(vf[t][s]); }
+    }
     hcp_dma_wait_all();
     HCP_SYNC();
 
@@ -697,9 +708,11 @@ HCP_WAVES_PER_SIMD((dkv_waves<D, KT>())) HCP_KERNEL(256) attn2_bwd_dkv_kernel(At
         const hcp_bf16* sG = sQ + G::IMG;
         const float* sL = (const float*)(sG + G::IMG);
         hcp_bf16* nxt = lds + ((it + 1 - it0) & 1) * BUF;
+        // (statistics load FIRST: the compiler guards the reuse of its destination register with s_waitcnt vmcnt(0), and behind the
+        //  DMA issue that wait would also drain the tile prefetch — the wave would sit out the whole L2 -> LDS latency every tile)
         if (it + 1 < nt) {
-            dma.issue(Qb + (size_t)(q0 + KVT) * p.q_rs, p.q_rs, dOb + (size_t)(q0 + KVT) * p.o_rs, p.o_rs, nvalid_q(q0 + KVT), nxt, wave);
             load_stats(q0 + KVT);
+            dma.issue(Qb + (size_t)(q0 + KVT) * p.q_rs, p.q_rs, dOb + (size_t)(q0 + KVT) * p.o_rs, p.o_rs, nvalid_q(q0 + KVT), nxt, wave);
         }
         hcp_bf16x8 pf[KT][2], df[KT][2];
 #pragma unroll
@@ -725,14 +738,16 @@ HCP_WAVES_PER_SIMD((dkv_waves<D, KT>())) HCP_KERNEL(256) attn2_bwd_dkv_kernel(At
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
                 const bool kok = k_base + t * 16 + fr < p.Nk;
-                const float kb2 = (KB && kok && p.kbias) ? p.kbias[(size_t)b * p.kb_bs + k_base + t * 16 + fr] * (RAW ? 1.0f / p.scale : LOG2E) : 0.f;
+                const float kb2 = kb2_t[t];
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
                     const int qt = 2 * hf + q2;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float pr = hcp_exp2((KB ? sc[t][q2][r] + kb2 : sc[t][q2][r]) * cs);
-                        if (!kok) pr = 0.f;                                                           // key past the end
+                        // A key past the end owns its lane's COLUMN of P / dS and nothing else: its (finite: K = V = 0) values only reach the
+                        // dK / dV rows of that key, which are never stored — no select per score on the unmasked path.
+                        if (KB && !kok) pr = 0.f;
                         if (KB && p.causal && k_base + t * 16 + fr > q0 + qt * 16 + 4 * fg + r) pr = 0.f;   // future key
                         sc[t][q2][r] = pr;
                         dp[t][q2][r] = pr * dp[t][q2][r];

@@ -126,3 +126,27 @@ def test_integration_doc_quotes_the_shipped_overlay():
     root = pathlib.Path(__file__).resolve().parent.parent
     yaml = (root / "cfgs" / "train" / "mi355x" / "lora_sd15_hip.yaml").read_text()
     assert yaml in (root / "INTEGRATION.md").read_text()
+
+
+def test_no_compiler_vmcnt_wait_drains_the_attention_tile_prefetch(tmp_path):
+    """ISA hygiene (found in round 4 in the dK/dV kernel): the LDS-DMA tile fills are inline asm, invisible to hipcc's waitcnt pass, but the
+    hardware counter is shared — a compiler-inserted `s_waitcnt vmcnt(N)` for some VGPR-destination load placed behind the DMA issue of a
+    loop iteration, with MFMA work still behind it, makes the wave sit out the whole L2 -> LDS latency every tile.  The unmasked kernels
+    (the ones every UNet step runs) must have none; tools/diag/loop_vmcnt_scan.py is the scanner."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = tmp_path / "attention.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I", os.path.join(root, "hcp_diffusion_amd", "csrc"),
+                    os.path.join(root, "hcp_diffusion_amd", "csrc", "attention.hip"), "-o", str(asm)], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "diag", "loop_vmcnt_scan.py"), str(asm)], capture_output=True, text=True)
+    flagged = [l for l in r.stdout.splitlines() if l.startswith("hcp_attn::")]
+    # masked / causal instantiations (KB = true) load the key bias per tile by design; <64, 2, false, 67> (non-pre-scaled d = 64 at 32 rows per
+    # wave: not on any training path) reloads one spilled DMA offset
+    bad = [l for l in flagged if ", true, 67" not in l and "attn2_bwd_dq_kernel<64, 2, false, 67>" not in l]
+    assert not bad, "\n".join(bad)
+    assert any("dkv" in l or "dq" in l or "fwd" in l for l in flagged) or not flagged
