@@ -299,6 +299,9 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bias_v[j] = hcp_buf_load16f(rbias, (unsigned)(n0 + col0 + j * 16 + 4 * fg) * 4u);
     };
+    // Rows past M need no select: their offset is >= the resource's num_records (ldr >= N), so the hardware range check returns zeros —
+    // and a `m < M ? offset : OOB` select here compiled to divergent branches with a WAW `s_waitcnt vmcnt(0)` between the loads: TMF
+    // serialised round trips in front of the main loop.  32-bit offsets: gemm_pp_launch rejects residuals of 2^31 bytes or more.
     auto load_residual = [&]() {
         const hcp_rsrc rres = hcp_make_rsrc_n(p.residual, p.residual ? (unsigned)(((size_t)(p.M - 1) * p.ldr + p.N) * 2) : 0u);
 #pragma unroll
@@ -306,7 +309,7 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
             const int m = m0 + frow0 + i * 16 + fr;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                res_v[i][j] = hcp_buf_load8(rres, m < p.M ? (unsigned)(((size_t)m * p.ldr + n0 + col0 + j * 16 + 4 * fg) * 2) : HCP_BUF_OOB);
+                res_v[i][j] = hcp_buf_load8(rres, ((unsigned)m * (unsigned)p.ldr + (unsigned)(n0 + col0 + j * 16 + 4 * fg)) * 2u);
         }
     };
 
