@@ -17,8 +17,9 @@ KEYS = {"conv3x3_c320_64x64_b4": ("gemm_pp_kernel<128, 160, 1, false", ""),     
 
 def in_step_averages(summary_md):
     """avg us of the roofline kernels INSIDE the captured step, from the per-geometry table tools/prof_step_summary.py writes: the conv
-    template at 256 workgroups x 1 slab (C320 -> 320 at 64x64, B 4) and, for the attention templates, the geometry with the most time
-    (self-attention at 64x64)."""
+    template at 256 workgroups x 1 slab — its FASTEST position cluster (that row also holds the C640 / C960 -> 320 convolutions of the up
+    blocks: K = 5760 / 8640; C320 -> 320 at 64x64, B 4 is the K = 2880 one) — and, for the attention templates, the geometry with the
+    most time and its SLOWEST cluster (self-attention at 64x64; the cross-attention launches share the row)."""
     rows = []
     sec = False
     for line in open(summary_md):
@@ -27,12 +28,14 @@ def in_step_averages(summary_md):
             continue
         if sec and line.startswith("|") and not line.startswith("| kernel") and not line.startswith("|---"):
             c = [x.strip() for x in line.strip().strip("|").split("|")]
-            rows.append((c[0], int(c[1]), int(c[2]), float(c[5]), float(c[6])))
+            cl = [float(x.split(" x")[0]) for x in c[7].split(" . ")] if len(c) > 7 and c[7] else []
+            rows.append((c[0], int(c[1]), int(c[2]), float(c[5]), float(c[6]), cl))
     res = {}
     for key, (a, b) in KEYS.items():
         cand = [r for r in rows if a in r[0] and b in r[0] and (not key.startswith("conv") or (r[1] == 256 and r[2] == 1))]
         if cand:
-            res[key] = max(cand, key=lambda r: r[4])[3]
+            r = max(cand, key=lambda r: r[4])
+            res[key] = (min(r[5]) if key.startswith("conv") else max(r[5])) if r[5] else r[3]
     return res
 
 
