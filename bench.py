@@ -168,6 +168,17 @@ def attention_roofline(dev):
         out["traffic_source"] = f"profiles/pmc_roofline.json ({rec.get('source', '?')})"
         if rec.get("avg_launch_us_in_step") is not None:
             out["avg_launch_us_in_step"] = rec["avg_launch_us_in_step"]
+    # the backward of the same problem (two launches: dQ, which also produces delta, then dK/dV), 2.5x the forward's FLOPs
+    outs = [K.attention_fwd(q, k, v, H, q_prescaled=True) for q, k, v in sets]
+    dos = [torch.randn(B, N, H * D, device=dev).to(torch.bfloat16) for _ in range(4)]
+    db = _time_rotating([(lambda i=i: K.attention_bwd(*sets[i], outs[i][0], dos[i % 4], outs[i][1], H, q_prescaled=True)) for i in range(len(sets))], rounds=2)
+    bwd = {"kernels": "attn2_bwd_dq_kernel<40,2> + attn2_bwd_dkv_kernel<40,2>", "avg_us_both_launches": round(db * 1e6, 1),
+           "achieved": round(2.5 * flops / db / 1e12, 1), "frac": round(2.5 * flops / db / MFMA_BF16_PEAK, 4)}
+    for key, name in (("attn_dq_b4_h8_n4096_d40", "dq"), ("attn_dkv_b4_h8_n4096_d40", "dkv")):
+        r2 = _pmc_record(key)
+        if r2:
+            bwd[name] = {"mfma_busy": r2.get("mfma_busy"), "us_rocprof_trace": r2.get("us_rocprof_trace"), "avg_launch_us_in_step": r2.get("avg_launch_us_in_step")}
+    out["backward"] = bwd
     return out
 
 
