@@ -45,7 +45,9 @@ HCP_DEVICE void wgrad_block(const WgradProb& pr, int M, int P, float scale, int 
         {
             int r = tid >> 2, c = (tid & 3) * 8;
             hcp_bf16x8 v = hcp_zero8();
-            if (m0 + r < me) v = *(const hcp_bf16x8*)(L + (size_t)(m0 + r) * ldl + c);
+            // only the 8-column pieces that hold this problem's rank slots [pcol0, pcol0 + P): a caller may hand in a column-offset view
+            // of a 32-wide T / U (several LoRA blocks on one host), whose last pieces would otherwise run past the row
+            if (m0 + r < me && c + 8 > pcol0 && c < pcol0 + P) v = *(const hcp_bf16x8*)(L + (size_t)(m0 + r) * ldl + c);
 #pragma unroll
             for (int i = 0; i < 8; ++i) sL[r * WG_LS + c + i] = (hcp_bf16)v[i];
         }

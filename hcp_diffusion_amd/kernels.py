@@ -191,9 +191,11 @@ def wgrad_linear(dy, x, dw):
                                      _stream(x)), "hcp_wgrad_linear_bf16")
 
 
-def wgrad_conv3x3(dy, x1, dw, *, x2=None, stride=1, upsample=False, cout=None):
+def wgrad_conv3x3(dy, x1, dw, *, x2=None, stride=1, upsample=False, cout=None, col0=0):
     """dw [Cout][3][3][Cw] fp32 contiguous (the channels_last storage of a [Cout,Cw,3,3] weight) += dY^T im2col(x1|x2).
-    dy [B,Ho,Wo,ldy] bf16 (ldy >= Cout, padded columns zero), x1/x2 the forward's NHWC inputs."""
+    dy [B,Ho,Wo,ldy] bf16 (ldy >= Cout, padded columns zero), x1/x2 the forward's NHWC inputs.  col0 (multiple of 8): the Cout columns
+    start at column col0 of dy — the rank slots of one of several LoRA blocks in a shared 32-wide U (the kernel only reads the 8-column
+    pieces that start below Cout, so col0 + round8(Cout) <= ldy keeps every read inside its row)."""
     assert dy.dtype == BF16 and x1.dtype == BF16 and dw.dtype == torch.float32 and dy.is_contiguous() and x1.is_contiguous()
     B, Hs, Ws, C1 = x1.shape
     C2 = 0
@@ -205,7 +207,9 @@ def wgrad_conv3x3(dy, x1, dw, *, x2=None, stride=1, upsample=False, cout=None):
     cw = dw.numel() // (cout * 9)
     assert dw.numel() == cout * 9 * cw and cw <= C1 + C2
     ws = _workspace(x1)
-    _chk(lib().hcp_wgrad_conv3x3_bf16(_p(dy), ldy, _p(x1), C1, _p(x2), C2, _p(dw), cw, B, Hs, Ws, Ho, Wo, cout, stride,
+    assert col0 % 8 == 0 and col0 + (cout + 7) // 8 * 8 <= ldy
+    dyp = ctypes.c_void_p(dy.data_ptr() + 2 * col0)
+    _chk(lib().hcp_wgrad_conv3x3_bf16(dyp, ldy, _p(x1), C1, _p(x2), C2, _p(dw), cw, B, Hs, Ws, Ho, Wo, cout, stride,
                                       1 if upsample else 0, _p(ws), ws.numel(), _stream(x1)), "hcp_wgrad_conv3x3_bf16")
 
 

@@ -32,10 +32,16 @@ class LoraHipContainer(PatchPluginContainer):
         if len(self.plugin_names) != 1:                # several blocks on one host: their rank slots side by side
             if self._multi is None or self._multi.names != tuple(self.plugin_names):
                 self._multi = MultiLora([self[n] for n in self.plugin_names], tuple(self.plugin_names))
+            last = self[self.plugin_names[-1]]         # the reference applies the LAST block's dropout (lora_base_patch.py:35)
+            drop = last.dropout.p > 0.0 and last.training
+            if self._multi.host_type == "conv":        # 3x3 host: T = conv3x3(x, [W_down_0; W_down_1; ...]) fills the shared rank slots
+                host = self._host
+                y = ops.conv3x3(x, host, x2=kwargs.pop("x2", None), rowbias=kwargs.pop("rowbias", None), residual=None if drop else residual,
+                                stride=host.stride[0], upsample=kwargs.pop("upsample", False), lora=self._multi, **kwargs)
+                return self._dropped(y, last, residual) if drop else y
             if kwargs:
                 raise NotImplementedError(f"LoraHipContainer: unsupported call arguments {list(kwargs)}")
-            last = self[self.plugin_names[-1]]         # the reference applies the LAST block's dropout (lora_base_patch.py:35)
-            if last.dropout.p > 0.0 and last.training:
+            if drop:
                 return self._dropped(ops.linear(x, self._host, self._multi, None), last, residual)
             return ops.linear(x, self._host, self._multi, residual)
         blk = self[self.plugin_names[0]]
@@ -211,14 +217,15 @@ class _LoraOperands:
 
 
 class MultiLora:
-    """Several LoRA blocks on ONE Linear host — the reference container sums ``get_weight()`` over all its plugins
-    (LoraPatchContainer.forward, lora_base_patch.py:20-27).  Natively: one fused-LoRA GEMM whose 32 rank slots hold the
-    blocks' factors side by side (sum of ranks, each padded to 8, must fit 32)."""
+    """Several LoRA blocks on ONE host — the reference container sums ``get_weight()`` over all its plugins
+    (LoraPatchContainer.forward, lora_base_patch.py:20-27).  Natively: one fused-LoRA GEMM (Linear host) or one skinny 3x3 convolution +
+    K-extension (3x3 conv host) whose 32 rank slots hold the blocks' factors side by side (sum of ranks, each padded to 8, must fit 32)."""
 
     def __init__(self, blocks, names):
         self.blocks, self.names = list(blocks), names
-        if any(b.host_type != "linear" or b.wide for b in self.blocks):
-            raise NotImplementedError("hcp_diffusion_amd: several LoRA blocks on one host need Linear hosts and ranks <= 32")
+        self.host_type = self.blocks[0].host_type
+        if any(b.host_type != self.host_type or b.wide for b in self.blocks):
+            raise NotImplementedError("hcp_diffusion_amd: several LoRA blocks on one host need ranks <= 32")
         self.slot_off, sl = [], 0
         for b in self.blocks:
             self.slot_off.append(sl); sl += 8 * ((b.rank + 7) // 8)
@@ -393,25 +400,29 @@ class LoraBucket:
         o.bu = img[2 * a:2 * a + c].view(n_total, RANK_SLOT); o.but = img[2 * a + c:2 * a + 2 * c].view(RANK_SLOT, n_total)
         return o
 
-    def _new_conv_images(self, b, cin, cout):
+    def _new_conv_images(self, b, cin, cout, slot0=0, into=None):
         """Operand images of a 3x3 conv LoRA block (zero padding written once) + the pack pieces that refresh them:
         ad [32][3][3][Cin] (T = conv3x3(x, W_down)), wdl [Cin][3][3][32] (its data gradient), bu [Cout][32] = alpha W_up,
-        but [32][Cout]."""
-        o = _LoraOperands()
-        img = torch.zeros(2 * RANK_SLOT * 9 * cin + 2 * RANK_SLOT * cout, dtype=BF16, device=self.device)
-        self._images.append(img)
-        a = RANK_SLOT * 9 * cin; c = RANK_SLOT * cout
-        o.ad = img[0:a].view(RANK_SLOT, 3, 3, cin); o.wdl = img[a:2 * a].view(cin, 3, 3, RANK_SLOT)
-        o.bu = img[2 * a:2 * a + c].view(cout, RANK_SLOT); o.but = img[2 * a + c:2 * a + 2 * c].view(RANK_SLOT, cout)
+        but [32][Cout].  slot0 / into: the block's factors go to rank slots [slot0, slot0 + r) of an EXISTING image set (several blocks
+        on one host, MultiLora): rows slot0.. of ad / but, columns slot0.. of wdl / bu."""
+        o = into
+        if o is None:
+            o = _LoraOperands()
+            img = torch.zeros(2 * RANK_SLOT * 9 * cin + 2 * RANK_SLOT * cout, dtype=BF16, device=self.device)
+            self._images.append(img)
+            a = RANK_SLOT * 9 * cin; c = RANK_SLOT * cout
+            o.ad = img[0:a].view(RANK_SLOT, 3, 3, cin); o.wdl = img[a:2 * a].view(cin, 3, 3, RANK_SLOT)
+            o.bu = img[2 * a:2 * a + c].view(cout, RANK_SLOT); o.but = img[2 * a + c:2 * a + 2 * c].view(RANK_SLOT, cout)
         r = b.layer.W_down.shape[0]
         wd = b.layer.W_down.permute(0, 2, 3, 1)            # physical [r][3][3][Cin] fp32
         assert wd.is_contiguous()
         tc = (cin + 63) // 64
         for tap in range(9):
-            self._conv_rows.append((wd.data_ptr() + 4 * tap * cin, o.ad.data_ptr() + 2 * tap * cin, o.wdl.data_ptr() + 2 * tap * RANK_SLOT,
+            self._conv_rows.append((wd.data_ptr() + 4 * tap * cin, o.ad.data_ptr() + 2 * (slot0 * 9 * cin + tap * cin),
+                                    o.wdl.data_ptr() + 2 * (tap * RANK_SLOT + slot0),
                                     r, cin, 9 * cin, 9 * cin, 9 * RANK_SLOT, self._conv_tiles, tc, 1.0))
             self._conv_tiles += tc                          # r <= 32 rows: one tile row
-        self._conv_rows.append((b.layer.W_up.data_ptr(), o.bu.data_ptr(), o.but.data_ptr(), cout, r, r, RANK_SLOT, cout,
+        self._conv_rows.append((b.layer.W_up.data_ptr(), o.bu.data_ptr() + 2 * slot0, o.but.data_ptr() + 2 * slot0 * cout, cout, r, r, RANK_SLOT, cout,
                                 self._conv_tiles, 1, b.alpha_f))
         self._conv_tiles += (cout + 63) // 64
         return o
@@ -481,6 +492,17 @@ class LoraBucket:
         """Shared operand images for several blocks on one host (MultiLora): same output columns, adjacent rank slots."""
         b0 = multi.blocks[0]
         k, n_out = b0.layer.W_down.shape[1], b0.layer.W_up.shape[0]
+        if multi.host_type == "conv":                      # one shared image set, every block's pack pieces aimed at its own slots
+            multi.ops = None
+            for b, s0 in zip(multi.blocks, multi.slot_off):
+                assert b._bucket is self
+                multi.ops = self._new_conv_images(b, k, n_out, slot0=s0, into=multi.ops)
+            import numpy as np
+            from .fullft import PIECE_DTYPE
+            arr = np.array(self._conv_rows, dtype=PIECE_DTYPE)
+            self._conv_pieces = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+            self.pack()
+            return
         multi.ops = self._new_images(k, n_out)
         for b, s0 in zip(multi.blocks, multi.slot_off):
             assert b._bucket is self

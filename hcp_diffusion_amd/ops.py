@@ -344,9 +344,11 @@ class _Conv3x3Fn(torch.autograd.Function):
         if lora is not None:       # U = dY (alpha W_up) [.,32]; dW_up = alpha dY^T T; dW_down = U^T im2col(x); dX += dgrad(U, W_down)
             lp = lora.packed()
             U = K.gemm(dy.view(-1, dy.shape[-1]), lp.but).view(*dy.shape[:-1], 32)
-            gd, gu = lora.grad_views()
-            K.lora_wgrad(T.view(-1, 32), dy.view(-1, dy.shape[-1]), gu, lora.rank, lora.alpha_f, True)
-            K.wgrad_conv3x3(U, x1, gd, x2=x2, stride=ctx.stride, upsample=ctx.upsample, cout=lora.rank)
+            T2 = T.view(-1, 32)
+            for blk, s0 in lora.members():             # one block, or several sharing the 32 rank slots (lora.MultiLora)
+                gd, gu = blk.grad_views()
+                K.lora_wgrad(T2[:, s0:], dy.view(-1, dy.shape[-1]), gu, blk.rank, blk.alpha_f, True)
+                K.wgrad_conv3x3(U, x1, gd, x2=x2, stride=ctx.stride, upsample=ctx.upsample, cout=blk.rank, col0=s0)
             if ctx.needs_input_grad[0]:
                 dl1 = K.conv3x3(U, lp.wdl[:C1], C1, mode=1, stride=ctx.stride, out_hw=hw)
             if ctx.c2 and ctx.needs_input_grad[1]:

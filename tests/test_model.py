@@ -601,6 +601,57 @@ def test_two_lora_blocks_on_one_host(backend):
     assert rel(y1, ref1.detach()) < 2e-2
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_two_lora_blocks_on_one_conv_host(backend, stride):
+    """Two cfg groups matching the same 3x3 conv -> lora_block_0 and lora_block_1 on one container (the reference sums their
+    get_weight(), lora_base_patch.py:20-27; LoCon factors lora_layers_patch.py:64-100).  Native: ONE skinny conv T = conv3x3(x, [W_down_0;
+    W_down_1]) fills adjacent rank slots, the host conv takes T as its K-extension, and each block's gradients are cut out of the shared
+    T / U by slot offset.  Checked against fp32 autograd on the merged weight."""
+    from hcp_diffusion_amd.layers import HipConv2d
+    dev = backend.device
+    torch.manual_seed(8)
+    cin, cout = 16, 24
+    parent = torch.nn.Module(); parent.conv = HipConv2d(cin, cout, 3, stride, 1).to(dev)
+    parent.requires_grad_(False)
+    b0 = LoraHipLayer.wrap_model(0, parent.conv, parent_block=parent, host_name="conv", rank=4, alpha=1.0)[""]
+    b1 = LoraHipLayer.wrap_model(1, parent.conv, parent_block=parent, host_name="conv", rank=8, alpha=4.0)[""]
+    assert type(parent.conv).__name__ == "LoraHipContainer" and parent.conv.plugin_names == ["lora_block_0", "lora_block_1"]
+    assert tuple(b1.layer.W_down.shape) == (8, cin, 3, 3) and tuple(b1.layer.W_up.shape) == (cout, 8, 1, 1)
+    with torch.no_grad():
+        b0.layer.W_up.normal_(0, 0.1); b1.layer.W_up.normal_(0, 0.1)
+    x = torch.randn(2, 6, 6, cin).to(torch.bfloat16)
+    Ho = 6 // stride
+    dy = torch.randn(2, Ho, Ho, cout).to(torch.bfloat16)
+    xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wd0, wu0, wd1, wu1 = (t.detach().cpu().clone().requires_grad_(True) for t in (b0.layer.W_down, b0.layer.W_up, b1.layer.W_down, b1.layer.W_up))
+    host = parent.conv._host
+    w_eff = (host.weight.detach().cpu().float() + float(b0.alpha) * torch.einsum("or,rikl->oikl", wu0[:, :, 0, 0], wd0)
+             + float(b1.alpha) * torch.einsum("or,rikl->oikl", wu1[:, :, 0, 0], wd1))
+    yr = torch.nn.functional.conv2d(xr, w_eff, host.bias.detach().cpu().float(), stride=stride, padding=1)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    xn = backend.to(x).requires_grad_(True)
+    y = parent.conv(xn)
+    y.backward(backend.to(dy))
+    rel = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    assert rel(y.detach().permute(0, 3, 1, 2), yr.detach()) < 2e-2 and rel(xn.grad.permute(0, 3, 1, 2), xr.grad) < 2e-2
+    for blk, gd, gu in ((b0, wd0.grad, wu0.grad), (b1, wd1.grad, wu1.grad)):
+        assert rel(blk.layer.W_down.grad, gd) < 2e-2 and rel(blk.layer.W_up.grad, gu) < 2e-2
+    # a second step after the factors moved: the shared operand images follow both blocks
+    with torch.no_grad():
+        b0.layer.W_down.mul_(0.5); b1.layer.W_up.mul_(2.0)
+    y2 = parent.conv(backend.to(x)).float().cpu()
+    w2 = (host.weight.detach().cpu().float() + float(b0.alpha) * torch.einsum("or,rikl->oikl", wu0[:, :, 0, 0], 0.5 * wd0)
+          + float(b1.alpha) * torch.einsum("or,rikl->oikl", 2.0 * wu1[:, :, 0, 0], wd1)).detach()
+    ref2 = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w2, host.bias.detach().cpu().float(), stride=stride, padding=1)
+    assert rel(y2.permute(0, 3, 1, 2), ref2) < 2e-2
+    b1.remove()
+    assert parent.conv.plugin_names == ["lora_block_0"]
+    y1 = parent.conv(backend.to(x)).float().cpu()
+    w1 = (host.weight.detach().cpu().float() + float(b0.alpha) * torch.einsum("or,rikl->oikl", wu0[:, :, 0, 0], 0.5 * wd0)).detach()
+    ref1 = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w1, host.bias.detach().cpu().float(), stride=stride, padding=1)
+    assert rel(y1.permute(0, 3, 1, 2), ref1) < 2e-2
+
+
 def test_gradient_checkpointing_matches_plain_backward(backend):
     """model.gradient_checkpointing: True (reference default, train_base.yaml:69; wrapper.py:39-49): same loss and LoRA
     gradients as the un-checkpointed step (segments recomputed by the same kernels)."""
