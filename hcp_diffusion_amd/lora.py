@@ -134,10 +134,10 @@ class LoraHipLayer(PatchPluginBlock):
             raise NotImplementedError("lora_hip: conv LoRA needs channel counts that are multiples of 8 (conv_in / conv_out are excluded)")
         if isinstance(rank, float):
             rank = max(round(out_f * rank), 1)            # fractional rank, lora_base_patch.py:105-106
-        if rank > RANK_SLOT and (conv3 or rank > 4 * RANK_SLOT):
-            raise NotImplementedError(f"lora_hip: rank {rank} is limited to {RANK_SLOT} on 3x3 conv hosts and {4 * RANK_SLOT} on Linear hosts")
-        # rank <= 32: one MFMA k-step of rank slots, fused into the host GEMM.  33..128: the side path runs as its own skinny
-        # GEMM (T = x W_down^T) and rides into the host GEMM as a K-extension of ceil(rank/32)*32 columns.
+        # rank <= 32: one MFMA k-step of rank slots, fused into the host GEMM.  Above (any rank: the reference's fractional ranks,
+        # lora_base_patch.py:105-106, reach half the layer width): the side path runs as its own skinny GEMM (T = x W_down^T) and rides
+        # into the host GEMM as a K-extension of ceil(rank/32)*32 columns (3x3 conv host: T = conv3x3(x, W_down) with ceil(rank/32)*32
+        # output channels, added to the host convolution's output by one more GEMM).
         self.wide = rank > RANK_SLOT
         self.rank_pad = (rank + RANK_SLOT - 1) // RANK_SLOT * RANK_SLOT
         self.host_type = "conv" if conv3 else "linear"   # a 1x1 conv is a Linear on channels-last tokens
@@ -406,25 +406,27 @@ class LoraBucket:
         but [32][Cout].  slot0 / into: the block's factors go to rank slots [slot0, slot0 + r) of an EXISTING image set (several blocks
         on one host, MultiLora): rows slot0.. of ad / but, columns slot0.. of wdl / bu."""
         o = into
+        rp = b.rank_pad if into is None else RANK_SLOT     # slots of the image set: 32, or the padded rank of a wide block (rank > 32)
         if o is None:
             o = _LoraOperands()
-            img = torch.zeros(2 * RANK_SLOT * 9 * cin + 2 * RANK_SLOT * cout, dtype=BF16, device=self.device)
+            img = torch.zeros(2 * rp * 9 * cin + 2 * rp * cout, dtype=BF16, device=self.device)
             self._images.append(img)
-            a = RANK_SLOT * 9 * cin; c = RANK_SLOT * cout
-            o.ad = img[0:a].view(RANK_SLOT, 3, 3, cin); o.wdl = img[a:2 * a].view(cin, 3, 3, RANK_SLOT)
-            o.bu = img[2 * a:2 * a + c].view(cout, RANK_SLOT); o.but = img[2 * a + c:2 * a + 2 * c].view(RANK_SLOT, cout)
+            a = rp * 9 * cin; c = rp * cout
+            o.ad = img[0:a].view(rp, 3, 3, cin); o.wdl = img[a:2 * a].view(cin, 3, 3, rp)
+            o.bu = img[2 * a:2 * a + c].view(cout, rp); o.but = img[2 * a + c:2 * a + 2 * c].view(rp, cout)
         r = b.layer.W_down.shape[0]
         wd = b.layer.W_down.permute(0, 2, 3, 1)            # physical [r][3][3][Cin] fp32
         assert wd.is_contiguous()
         tc = (cin + 63) // 64
         for tap in range(9):
             self._conv_rows.append((wd.data_ptr() + 4 * tap * cin, o.ad.data_ptr() + 2 * (slot0 * 9 * cin + tap * cin),
-                                    o.wdl.data_ptr() + 2 * (tap * RANK_SLOT + slot0),
-                                    r, cin, 9 * cin, 9 * cin, 9 * RANK_SLOT, self._conv_tiles, tc, 1.0))
-            self._conv_tiles += tc                          # r <= 32 rows: one tile row
-        self._conv_rows.append((b.layer.W_up.data_ptr(), o.bu.data_ptr() + 2 * slot0, o.but.data_ptr() + 2 * slot0 * cout, cout, r, r, RANK_SLOT, cout,
-                                self._conv_tiles, 1, b.alpha_f))
-        self._conv_tiles += (cout + 63) // 64
+                                    o.wdl.data_ptr() + 2 * (tap * rp + slot0),
+                                    r, cin, 9 * cin, 9 * cin, 9 * rp, self._conv_tiles, tc, 1.0))
+            self._conv_tiles += ((r + 63) // 64) * tc
+        tcu = (r + 63) // 64
+        self._conv_rows.append((b.layer.W_up.data_ptr(), o.bu.data_ptr() + 2 * slot0, o.but.data_ptr() + 2 * slot0 * cout, cout, r, r, rp, cout,
+                                self._conv_tiles, tcu, b.alpha_f))
+        self._conv_tiles += ((cout + 63) // 64) * tcu
         return o
 
     def _new_wide_images(self, b, k, n_out):

@@ -315,7 +315,13 @@ class _Conv3x3Fn(torch.autograd.Function):
     def forward(ctx, x1, x2, rowbias, residual, host, stride, upsample, hw=None, hb=None, lora=None, w_down=None, w_up=None):
         pk = host.packed()
         T = None
-        if lora is not None:       # LoCon side path: T = conv3x3(x, W_down) [.,32]; y = conv(x, W) + T (alpha W_up)^T as a K-extension
+        if lora is not None and getattr(lora, "wide", False):      # rank > 32: the side path's product joins through one more GEMM
+            lp = lora.packed()
+            rp = lora.rank_pad
+            T = K.conv3x3(x1, lp.ad, rp, x2=x2, stride=stride, upsample=upsample)
+            y0 = K.conv3x3(x1, pk.w, pk.cout, x2=x2, stride=stride, upsample=upsample, bias=pk.bias, rowbias=rowbias, residual=residual)
+            y = K.gemm(T.view(-1, rp), lp.bu, residual=y0.view(-1, pk.cout)).view_as(y0)
+        elif lora is not None:     # LoCon side path: T = conv3x3(x, W_down) [.,32]; y = conv(x, W) + T (alpha W_up)^T as a K-extension
             lp = lora.packed()
             T = K.conv3x3(x1, lp.ad, 32, x2=x2, stride=stride, upsample=upsample)
             y = K.conv3x3(x1, pk.w, pk.cout, x2=x2, stride=stride, upsample=upsample, bias=pk.bias, rowbias=rowbias, residual=residual,
@@ -343,11 +349,13 @@ class _Conv3x3Fn(torch.autograd.Function):
         dl1 = dl2 = None
         if lora is not None:       # U = dY (alpha W_up) [.,32]; dW_up = alpha dY^T T; dW_down = U^T im2col(x); dX += dgrad(U, W_down)
             lp = lora.packed()
-            U = K.gemm(dy.view(-1, dy.shape[-1]), lp.but).view(*dy.shape[:-1], 32)
-            T2 = T.view(-1, 32)
+            rp = lp.but.shape[0]                       # 32 rank slots, or the padded rank of a wide block
+            U = K.gemm(dy.view(-1, dy.shape[-1]), lp.but).view(*dy.shape[:-1], rp)
+            T2 = T.view(-1, rp)
             for blk, s0 in lora.members():             # one block, or several sharing the 32 rank slots (lora.MultiLora)
                 gd, gu = blk.grad_views()
-                K.lora_wgrad(T2[:, s0:], dy.view(-1, dy.shape[-1]), gu, blk.rank, blk.alpha_f, True)
+                for j in range(0, blk.rank, 32):       # dW_up = alpha dY^T T: 32 rank columns per launch of the skinny reduction kernel
+                    K.lora_wgrad(T2[:, s0 + j:], dy.view(-1, dy.shape[-1]), gu, min(32, blk.rank - j), blk.alpha_f, True, out_col0=j)
                 K.wgrad_conv3x3(U, x1, gd, x2=x2, stride=ctx.stride, upsample=ctx.upsample, cout=blk.rank, col0=s0)
             if ctx.needs_input_grad[0]:
                 dl1 = K.conv3x3(U, lp.wdl[:C1], C1, mode=1, stride=ctx.stride, out_hw=hw)

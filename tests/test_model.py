@@ -744,19 +744,23 @@ def test_from_pretrained_reads_diffusers_layout(tmp_path, cfg_name):
     assert nat.config.cross_attention_dim == cfg["cross_attention_dim"] and nat.dtype == torch.float32
 
 
-@pytest.mark.parametrize("rank", [48, 128])
+@pytest.mark.parametrize("rank", [48, 128, 200, 0.5])
 def test_lora_rank_above_one_slot_group(backend, rank):
-    """rank 33..128 on a Linear host: skinny side GEMM + K-extension instead of the fused 32-slot form; same reference arithmetic."""
+    """rank > 32 on a Linear host (any rank; 0.5 = the reference's fractional form, half the layer width: lora_base_patch.py:105-106):
+    skinny side GEMM + K-extension instead of the fused 32-slot form; same reference arithmetic."""
     from hcp_diffusion_amd.layers import HipLinear
     dev = backend.device
-    torch.manual_seed(rank)
-    parent = torch.nn.Module(); parent.fc = HipLinear(72, 40).to(dev)
+    torch.manual_seed(int(rank * 10))
+    nout = 40 if rank != 0.5 else 80
+    parent = torch.nn.Module(); parent.fc = HipLinear(72, nout).to(dev)
     parent.requires_grad_(False)
     blk = LoraHipLayer.wrap_model(0, parent.fc, parent_block=parent, host_name="fc", rank=rank, alpha=8.0)[""]
+    if rank == 0.5:
+        rank = 40
     assert tuple(blk.layer.W_down.shape) == (rank, 72) and abs(float(blk.alpha) - 8.0 / rank) < 1e-7
     with torch.no_grad():
         blk.layer.W_up.normal_(0, 0.1)
-    x = torch.randn(6, 9, 72).to(torch.bfloat16); dy = torch.randn(6, 9, 40).to(torch.bfloat16)
+    x = torch.randn(6, 9, 72).to(torch.bfloat16); dy = torch.randn(6, 9, nout).to(torch.bfloat16)
     wd, wu = (t.detach().cpu().clone().requires_grad_(True) for t in (blk.layer.W_down, blk.layer.W_up))
     xr = x.float().requires_grad_(True)
     yr = xr @ (parent.fc._host.weight.cpu() + float(blk.alpha) * (wu @ wd)).T + parent.fc._host.bias.cpu()
@@ -766,6 +770,38 @@ def test_lora_rank_above_one_slot_group(backend, rank):
     y.backward(backend.to(dy))
     rel = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
     assert rel(y.detach(), yr.detach()) < 2e-2 and rel(xn.grad, xr.grad) < 2e-2
+    assert rel(blk.layer.W_down.grad, wd.grad) < 2e-2 and rel(blk.layer.W_up.grad, wu.grad) < 2e-2
+
+
+@pytest.mark.parametrize("rank,stride", [(40, 1), (72, 2)])
+def test_conv_lora_rank_above_one_slot_group(backend, rank, stride):
+    """rank > 32 on a 3x3 conv host (LoCon with a wide rank, lora_layers_patch.py:64-100): T = conv3x3(x, W_down) with ceil(rank/32)*32
+    output channels, one more GEMM adds T (alpha W_up)^T to the host convolution; gradients through the same wgrad / dgrad kernels."""
+    from hcp_diffusion_amd.layers import HipConv2d
+    dev = backend.device
+    torch.manual_seed(rank)
+    cin, cout = 16, 24
+    parent = torch.nn.Module(); parent.conv = HipConv2d(cin, cout, 3, stride, 1).to(dev)
+    parent.requires_grad_(False)
+    blk = LoraHipLayer.wrap_model(0, parent.conv, parent_block=parent, host_name="conv", rank=rank, alpha=8.0)[""]
+    assert tuple(blk.layer.W_down.shape) == (rank, cin, 3, 3) and blk.wide
+    with torch.no_grad():
+        blk.layer.W_up.normal_(0, 0.1)
+    x = torch.randn(2, 6, 6, cin).to(torch.bfloat16)
+    Ho = 6 // stride
+    dy = torch.randn(2, Ho, Ho, cout).to(torch.bfloat16)
+    res = torch.randn(2, Ho, Ho, cout).to(torch.bfloat16)
+    xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wd, wu = (t.detach().cpu().clone().requires_grad_(True) for t in (blk.layer.W_down, blk.layer.W_up))
+    host = parent.conv._host
+    w_eff = host.weight.detach().cpu().float() + float(blk.alpha) * torch.einsum("or,rikl->oikl", wu[:, :, 0, 0], wd)
+    yr = torch.nn.functional.conv2d(xr, w_eff, host.bias.detach().cpu().float(), stride=stride, padding=1) + res.float().permute(0, 3, 1, 2)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    xn = backend.to(x).requires_grad_(True)
+    y = parent.conv(xn, residual=backend.to(res))
+    y.backward(backend.to(dy))
+    rel = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    assert rel(y.detach().permute(0, 3, 1, 2), yr.detach()) < 2e-2 and rel(xn.grad.permute(0, 3, 1, 2), xr.grad) < 2e-2
     assert rel(blk.layer.W_down.grad, wd.grad) < 2e-2 and rel(blk.layer.W_up.grad, wu.grad) < 2e-2
 
 
