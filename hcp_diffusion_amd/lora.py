@@ -430,7 +430,7 @@ class LoraBucket:
         return o
 
     def _new_wide_images(self, b, k, n_out):
-        """rank 33..128 on a Linear host: ad [Rp][K] = W_down, wdt [K][Rp] = W_down^T, bu [N][Rp] = alpha W_up,
+        """rank > 32 on a Linear host: ad [Rp][K] = W_down, wdt [K][Rp] = W_down^T, bu [N][Rp] = alpha W_up,
         but [Rp][N] = alpha W_up^T (Rp = rank padded to 32; padding stays zero), refreshed by two pack pieces."""
         o = _LoraOperands()
         rp, r = b.rank_pad, b.rank

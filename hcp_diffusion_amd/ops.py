@@ -122,7 +122,7 @@ class _LinearFn(torch.autograd.Function):
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
         pk = host.packed()
         T = None
-        if lora is not None and getattr(lora, "wide", False):      # rank 33..128: skinny side GEMM + K-extension
+        if lora is not None and getattr(lora, "wide", False):      # rank > 32: skinny side GEMM + K-extension
             lp = lora.packed()
             T = K.gemm(x2, lp.ad)
             y = K.gemm(x2, pk.w, a2=T, b2=lp.bu, bias=pk.bias, residual=res2)

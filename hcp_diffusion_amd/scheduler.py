@@ -12,11 +12,20 @@ from . import kernels as K
 
 class NativeDDPMScheduler:
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear"):
-        if beta_schedule != "scaled_linear":
-            raise NotImplementedError(f"beta_schedule {beta_schedule!r}: Stable Diffusion trains with 'scaled_linear'")
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                                       beta_schedule=beta_schedule, prediction_type="epsilon")
-        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        # the three schedules of diffusers' DDPMScheduler (published definitions; Stable Diffusion trains with 'scaled_linear')
+        if beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        elif beta_schedule == "squaredcos_cap_v2":         # Nichol & Dhariwal's cosine schedule, betas capped at 0.999
+            import math
+            bar = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+            betas = torch.tensor([min(1 - bar((i + 1) / num_train_timesteps) / bar(i / num_train_timesteps), 0.999)
+                                  for i in range(num_train_timesteps)], dtype=torch.float32)
+        else:
+            raise NotImplementedError(f"beta_schedule {beta_schedule!r}: 'scaled_linear', 'linear' and 'squaredcos_cap_v2' exist")
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self._acp_dev = {}
 

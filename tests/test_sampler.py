@@ -37,3 +37,32 @@ def test_sampler_loop_vs_oracle(backend):
     assert ((out - ref).norm() / ref.norm()).item() < 3e-2            # bf16 UNet, 4 accumulated guided steps
     out1 = s.sample(nat, backend.to(lat), backend.to(cond), None, num_inference_steps=2).cpu()       # no guidance: B-row forward
     assert torch.isfinite(out1).all() and out1.shape == lat.shape
+
+
+def test_ddpm_scheduler_beta_schedules(backend):
+    """Seam 4 (`model.noise_scheduler`, train_base.yaml:76): the three beta schedules of the DDPMScheduler the reference instantiates —
+    published definitions, checked against closed forms — and add_noise over each table through the native kernel."""
+    import math
+    from hcp_diffusion_amd.scheduler import NativeDDPMScheduler
+    sl = NativeDDPMScheduler()
+    assert torch.allclose(sl.alphas_cumprod, ddpm_alphas_cumprod(), atol=0, rtol=0)
+    lin = NativeDDPMScheduler(beta_schedule="linear", beta_start=1e-4, beta_end=0.02)
+    ref = torch.cumprod(1.0 - torch.linspace(1e-4, 0.02, 1000, dtype=torch.float64), 0)
+    assert (lin.alphas_cumprod.double() - ref).abs().max().item() < 1e-6
+    cos = NativeDDPMScheduler(beta_schedule="squaredcos_cap_v2")
+    bar = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+    # uncapped betas telescope: alphas_cumprod[i] = bar((i + 1) / T) / bar(0) until the 0.999 cap bites (only the very last steps)
+    for i in (0, 10, 500, 900):
+        assert abs(cos.alphas_cumprod[i].item() - bar((i + 1) / 1000) / bar(0)) < 1e-5
+    assert cos.alphas_cumprod[-1].item() > 0 and (cos.alphas_cumprod[1:] < cos.alphas_cumprod[:-1]).all()
+    g = torch.Generator().manual_seed(1)
+    x0, noise = torch.randn(3, 4, 8, 8, generator=g), torch.randn(3, 4, 8, 8, generator=g)
+    t = torch.tensor([0, 417, 999])
+    for sch in (sl, lin, cos):
+        a = sch.alphas_cumprod[t].view(-1, 1, 1, 1)
+        want = a.sqrt() * x0 + (1 - a).sqrt() * noise
+        got = sch.add_noise(backend.to(x0), backend.to(noise), backend.to(t)).cpu()
+        assert (got - want).abs().max().item() < 1e-5
+    import pytest
+    with pytest.raises(NotImplementedError):
+        NativeDDPMScheduler(beta_schedule="sigmoid")
