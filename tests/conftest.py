@@ -25,7 +25,9 @@ def emu_cdll():
     if _emu_cdll is None:
         sys.path.insert(0, str(ROOT / "tests" / "emu"))
         from build_emu import build_emu
-        _emu_cdll = ctypes.CDLL(str(build_emu()))
+        # HCP_EMU_LIB: another build of the interpreter library — e.g. the AddressSanitizer build of tools/diag/emu_asan.sh, under which
+        # every out-of-bounds global read / write of a kernel is a hard error (torch's CPU tensors are malloc'd: ASan red-zones them)
+        _emu_cdll = ctypes.CDLL(os.environ.get("HCP_EMU_LIB") or str(build_emu()))
         # HCP_EMU_DMA_LATE=1: the whole run under the interpreter's second LDS-DMA timing model (copies land at the wait that retires them,
         # not at issue; tests/emu/hcp_emu.h) — `HCP_EMU_DMA_LATE=1 pytest -m "not gpu" tests/test_kernels.py` is the CPU race screen for
         # every counted-vmcnt protocol; the default run keeps the early-landing model and one dedicated late-landing test
