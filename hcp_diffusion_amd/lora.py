@@ -224,13 +224,17 @@ class MultiLora:
     def __init__(self, blocks, names):
         self.blocks, self.names = list(blocks), names
         self.host_type = self.blocks[0].host_type
-        if any(b.host_type != self.host_type or b.wide for b in self.blocks):
-            raise NotImplementedError("hcp_diffusion_amd: several LoRA blocks on one host need ranks <= 32")
+        if any(b.host_type != self.host_type for b in self.blocks):
+            raise NotImplementedError("hcp_diffusion_amd: the LoRA blocks of one host must be of one kind")
         self.slot_off, sl = [], 0
         for b in self.blocks:
             self.slot_off.append(sl); sl += 8 * ((b.rank + 7) // 8)
-        if sl > RANK_SLOT:
-            raise NotImplementedError(f"hcp_diffusion_amd: LoRA blocks on one host need {sl} > {RANK_SLOT} rank slots")
+        # more than 32 slots in total (two rank-32 LoRAs stacked, a wide block among them, ...): the blocks share the WIDE form instead —
+        # one skinny side GEMM over all slots and a K-extension of ceil(slots / 32) * 32 columns (Linear hosts)
+        self.wide = sl > RANK_SLOT
+        self.rank_pad = (sl + RANK_SLOT - 1) // RANK_SLOT * RANK_SLOT
+        if self.wide and self.host_type != "linear":
+            raise NotImplementedError(f"hcp_diffusion_amd: LoRA blocks on one 3x3 conv host need {sl} > {RANK_SLOT} rank slots")
         buckets = {id(b._bucket) for b in self.blocks}
         if buckets == {id(None)}:
             LoraBucket(self.blocks)                        # stand-alone layers: one private bucket for the host's blocks
@@ -429,21 +433,24 @@ class LoraBucket:
         self._conv_tiles += ((cout + 63) // 64) * tcu
         return o
 
-    def _new_wide_images(self, b, k, n_out):
+    def _new_wide_images(self, b, k, n_out, slot0=0, into=None, rp=None):
         """rank > 32 on a Linear host: ad [Rp][K] = W_down, wdt [K][Rp] = W_down^T, bu [N][Rp] = alpha W_up,
-        but [Rp][N] = alpha W_up^T (Rp = rank padded to 32; padding stays zero), refreshed by two pack pieces."""
-        o = _LoraOperands()
-        rp, r = b.rank_pad, b.rank
-        img = torch.zeros(2 * rp * (k + n_out), dtype=BF16, device=self.device)
-        self._images.append(img)
-        a = rp * k; c = rp * n_out
-        o.ad = img[0:a].view(rp, k); o.wdt = img[a:2 * a].view(k, rp)
-        o.bu = img[2 * a:2 * a + c].view(n_out, rp); o.but = img[2 * a + c:2 * a + 2 * c].view(rp, n_out)
+        but [Rp][N] = alpha W_up^T (Rp = rank padded to 32; padding stays zero), refreshed by two pack pieces.  slot0 / into / rp: the
+        block's factors go to slots [slot0, slot0 + r) of an existing Rp-wide image set (several blocks on one host, MultiLora)."""
+        o = into
+        rp, r = (rp or b.rank_pad), b.rank
+        if o is None:
+            o = _LoraOperands()
+            img = torch.zeros(2 * rp * (k + n_out), dtype=BF16, device=self.device)
+            self._images.append(img)
+            a = rp * k; c = rp * n_out
+            o.ad = img[0:a].view(rp, k); o.wdt = img[a:2 * a].view(k, rp)
+            o.bu = img[2 * a:2 * a + c].view(n_out, rp); o.but = img[2 * a + c:2 * a + 2 * c].view(rp, n_out)
         tc = (k + 63) // 64
-        self._conv_rows.append((b.layer.W_down.data_ptr(), o.ad.data_ptr(), o.wdt.data_ptr(), r, k, k, k, rp, self._conv_tiles, tc, 1.0))
+        self._conv_rows.append((b.layer.W_down.data_ptr(), o.ad.data_ptr() + 2 * slot0 * k, o.wdt.data_ptr() + 2 * slot0, r, k, k, k, rp, self._conv_tiles, tc, 1.0))
         self._conv_tiles += ((r + 63) // 64) * tc
         tc = (r + 63) // 64
-        self._conv_rows.append((b.layer.W_up.data_ptr(), o.bu.data_ptr(), o.but.data_ptr(), n_out, r, r, rp, n_out, self._conv_tiles, tc, b.alpha_f))
+        self._conv_rows.append((b.layer.W_up.data_ptr(), o.bu.data_ptr() + 2 * slot0, o.but.data_ptr() + 2 * slot0 * n_out, n_out, r, r, rp, n_out, self._conv_tiles, tc, b.alpha_f))
         self._conv_tiles += ((n_out + 63) // 64) * tc
         return o
 
@@ -499,6 +506,17 @@ class LoraBucket:
             for b, s0 in zip(multi.blocks, multi.slot_off):
                 assert b._bucket is self
                 multi.ops = self._new_conv_images(b, k, n_out, slot0=s0, into=multi.ops)
+            import numpy as np
+            from .fullft import PIECE_DTYPE
+            arr = np.array(self._conv_rows, dtype=PIECE_DTYPE)
+            self._conv_pieces = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+            self.pack()
+            return
+        if multi.wide:                                     # shared wide images, every block's pack pieces aimed at its own slots
+            multi.ops = None
+            for b, s0 in zip(multi.blocks, multi.slot_off):
+                assert b._bucket is self
+                multi.ops = self._new_wide_images(b, k, n_out, slot0=s0, into=multi.ops, rp=multi.rank_pad)
             import numpy as np
             from .fullft import PIECE_DTYPE
             arr = np.array(self._conv_rows, dtype=PIECE_DTYPE)

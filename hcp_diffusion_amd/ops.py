@@ -153,11 +153,12 @@ class _LinearFn(torch.autograd.Function):
             U = K.gemm(dy2, lp.but)                    # dY (alpha W_up): [M, Rp]
             if ctx.needs_input_grad[0]:
                 dx = K.gemm(dy2, pk.wt, a2=U, b2=lp.wdt)
-            gd, gu = lora.grad_views()
-            for j in range(0, lora.rank, 32):          # 32 rank columns per launch of the skinny reduction kernel
-                pj = min(32, lora.rank - j)
-                K.lora_wgrad(U[:, j:j + 32], x2, gd[j:j + pj], pj, 1.0, False)                # dW_down = U^T x
-                K.lora_wgrad(T[:, j:j + 32], dy2, gu, pj, lora.alpha_f, True, out_col0=j)    # dW_up = alpha dY^T T
+            for blk, s0 in lora.members():             # one wide block, or several blocks sharing the wide slot range (lora.MultiLora)
+                gd, gu = blk.grad_views()
+                for j in range(0, blk.rank, 32):       # 32 rank columns per launch of the skinny reduction kernel
+                    pj = min(32, blk.rank - j)
+                    K.lora_wgrad(U[:, s0 + j:s0 + j + 32], x2, gd[j:j + pj], pj, 1.0, False)                # dW_down = U^T x
+                    K.lora_wgrad(T[:, s0 + j:s0 + j + 32], dy2, gu, pj, blk.alpha_f, True, out_col0=j)    # dW_up = alpha dY^T T
         elif lora is not None:
             lp = lora.packed()
             if ctx.needs_input_grad[0]:

@@ -601,6 +601,36 @@ def test_two_lora_blocks_on_one_host(backend):
     assert rel(y1, ref1.detach()) < 2e-2
 
 
+@pytest.mark.parametrize("ranks", [(32, 32), (40, 8), (16, 12, 8)])
+def test_lora_blocks_on_one_host_beyond_32_slots(backend, ranks):
+    """Stacked LoRA blocks whose ranks no longer fit one 32-slot group (two rank-32 LoRAs on one layer; a wide block among them): the
+    reference still just sums get_weight() (lora_base_patch.py:20-27); natively the blocks share the wide form — one skinny side GEMM over
+    all slots, K-extension of ceil(slots / 32) * 32 columns — and each block's gradients are cut out by slot offset."""
+    from hcp_diffusion_amd.layers import HipLinear
+    dev = backend.device
+    torch.manual_seed(sum(ranks))
+    parent = torch.nn.Module(); parent.fc = HipLinear(72, 40).to(dev)
+    parent.requires_grad_(False)
+    blks = [LoraHipLayer.wrap_model(i, parent.fc, parent_block=parent, host_name="fc", rank=r, alpha=float(2 + i))[""] for i, r in enumerate(ranks)]
+    assert parent.fc.plugin_names == [f"lora_block_{i}" for i in range(len(ranks))]
+    with torch.no_grad():
+        for b in blks:
+            b.layer.W_up.normal_(0, 0.1)
+    x = torch.randn(6, 9, 72).to(torch.bfloat16); dy = torch.randn(6, 9, 40).to(torch.bfloat16)
+    xr = x.float().requires_grad_(True)
+    fac = [(b.layer.W_down.detach().cpu().clone().requires_grad_(True), b.layer.W_up.detach().cpu().clone().requires_grad_(True)) for b in blks]
+    w_eff = parent.fc._host.weight.cpu() + sum(float(b.alpha) * (wu @ wd) for b, (wd, wu) in zip(blks, fac))
+    yr = xr @ w_eff.T + parent.fc._host.bias.cpu()
+    yr.backward(dy.float())
+    xn = backend.to(x).requires_grad_(True)
+    y = parent.fc(xn)
+    y.backward(backend.to(dy))
+    rel = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    assert rel(y.detach(), yr.detach()) < 2e-2 and rel(xn.grad, xr.grad) < 2e-2
+    for b, (wd, wu) in zip(blks, fac):
+        assert rel(b.layer.W_down.grad, wd.grad) < 2e-2 and rel(b.layer.W_up.grad, wu.grad) < 2e-2
+
+
 @pytest.mark.parametrize("stride", [1, 2])
 def test_two_lora_blocks_on_one_conv_host(backend, stride):
     """Two cfg groups matching the same 3x3 conv -> lora_block_0 and lora_block_1 on one container (the reference sums their
