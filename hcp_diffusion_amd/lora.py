@@ -29,6 +29,16 @@ class LoraHipContainer(PatchPluginContainer):
     _multi = None
 
     def forward(self, x, residual=None, **kwargs):
+        blocks = [self[n] for n in self.plugin_names]
+        b0 = blocks[0]
+        if b0.merged or (b0.host_type == "conv" and len(blocks) > 1 and
+                         (sum(8 * ((b.rank + 7) // 8) for b in blocks) > RANK_SLOT or any(b.wide for b in blocks))):
+            # conv_in / conv_out, or stacked blocks on a 3x3 conv whose ranks do not fit the 32 rank slots: the reference's merged-weight
+            # form through the host's own kernels (ops._MergedLoraFn) — any number of blocks, any ranks
+            last = blocks[-1]
+            drop = last.dropout.p > 0.0 and last.training
+            y = ops.merged_lora_call(self._host, blocks, x, residual=None if drop else residual, **kwargs)
+            return self._dropped(y, last, residual) if drop else y
         if len(self.plugin_names) != 1:                # several blocks on one host: their rank slots side by side
             if self._multi is None or self._multi.names != tuple(self.plugin_names):
                 self._multi = MultiLora([self[n] for n in self.plugin_names], tuple(self.plugin_names))
@@ -130,15 +140,17 @@ class LoraHipLayer(PatchPluginBlock):
             # Parameter (lora_layers_patch.py:41,85) -> "Boolean value of Tensor with more than one value is ambiguous"
             raise NotImplementedError("lora_hip: bias=True (the reference's own LoraLayer raises on it: lora_layers_patch.py:41)")
         out_f, in_f = host.weight.shape[0], host.weight.shape[1]
-        if conv3 and (in_f % 8 or out_f % 8 or type(host) is not HipConv2d):
-            raise NotImplementedError("lora_hip: conv LoRA needs channel counts that are multiples of 8 (conv_in / conv_out are excluded)")
+        # conv_in / conv_out (4 latent channels; their own NCHW <-> NHWC module classes): the side-path kernels want channel counts that
+        # are multiples of 8, so these two small layers run the reference's own arithmetic instead — host convolution on the MERGED weight
+        # W + sum alpha W_up W_down (lora_base_patch.py:20-35), factor gradients from the merged weight's gradient (ops.merged_lora_call)
+        self.merged = bool(conv3 and (in_f % 8 or out_f % 8 or type(host) is not HipConv2d))
         if isinstance(rank, float):
             rank = max(round(out_f * rank), 1)            # fractional rank, lora_base_patch.py:105-106
         # rank <= 32: one MFMA k-step of rank slots, fused into the host GEMM.  Above (any rank: the reference's fractional ranks,
         # lora_base_patch.py:105-106, reach half the layer width): the side path runs as its own skinny GEMM (T = x W_down^T) and rides
         # into the host GEMM as a K-extension of ceil(rank/32)*32 columns (3x3 conv host: T = conv3x3(x, W_down) with ceil(rank/32)*32
         # output channels, added to the host convolution's output by one more GEMM).
-        self.wide = rank > RANK_SLOT
+        self.wide = rank > RANK_SLOT and not self.merged
         self.rank_pad = (rank + RANK_SLOT - 1) // RANK_SLOT * RANK_SLOT
         self.host_type = "conv" if conv3 else "linear"   # a 1x1 conv is a Linear on channels-last tokens
         self.bias = bias
@@ -376,7 +388,7 @@ class LoraBucket:
             self._pgrads[id(b)] = tuple(views)
             if b.host_type == "conv":
                 self._gviews[id(b)] = (views[0].permute(0, 2, 3, 1), views[1].view(n_out, -1))     # [r][3][3][Cin], [Cout, r]
-                self._ops[id(b)] = self._new_conv_images(b, k, n_out)
+                self._ops[id(b)] = None if b.merged else self._new_conv_images(b, k, n_out)
             elif b.wide:
                 self._gviews[id(b)] = (views[0].view(views[0].shape[0], k), views[1].view(n_out, -1))
                 self._ops[id(b)] = self._new_wide_images(b, k, n_out)

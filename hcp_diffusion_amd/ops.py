@@ -686,6 +686,58 @@ class _ConcatFn(torch.autograd.Function):
 concat_channels = _ConcatFn.apply
 
 
+class _MergedLoraFn(torch.autograd.Function):
+    """LoRA on a host the side-path kernels do not serve (conv_in / conv_out: 4 latent channels): the reference's own arithmetic,
+    ``layer(x, W + sum_b alpha_b W_up_b W_down_b)`` (LoraPatchContainer.forward, lora_base_patch.py:20-35).  The host's forward runs on a
+    shadow of the host module whose weight is the merged fp32 tensor as a trainable leaf, so the host's own weight-gradient kernel
+    produces dW_eff; the factor gradients follow from it (dW_down = alpha W_up^T dW_eff, dW_up = alpha dW_eff W_down^T: two small
+    contractions on tensors of the layer's weight size) and go into the blocks' bucket views."""
+
+    @staticmethod
+    def forward(ctx, x, residual, x2, rowbias, host, blocks, upsample, *factors):
+        import copy
+        w_eff = host.weight.detach().clone()                   # keeps the 3x3 weight's channels_last storage
+        for b in blocks:
+            w_eff += b.alpha_f * torch.einsum("or,rikl->oikl", b.layer.W_up.detach()[:, :, 0, 0], b.layer.W_down.detach()).to(w_eff.dtype)
+        p = torch.nn.Parameter(w_eff, requires_grad=True)
+        shadow = copy.copy(host)
+        shadow._parameters = dict(host._parameters)
+        shadow._parameters["weight"] = p
+        shadow._pk = None
+        def leaf(t):                                           # the inner graph must not reach back into the outer one
+            if t is None:
+                return None
+            u = t.detach()
+            return u.requires_grad_(True) if t.requires_grad else u
+        with torch.enable_grad():
+            xin, rin, x2in, rbin = leaf(x), leaf(residual), leaf(x2), leaf(rowbias)
+            kw = {k: v for k, v in (("residual", rin), ("x2", x2in), ("rowbias", rbin)) if v is not None}
+            if upsample:
+                kw["upsample"] = True
+            y = shadow.forward(xin, **kw)                       # (conv_in / conv_out take the input alone)
+        ctx.inner = (xin, rin, x2in, rbin, y, p)
+        ctx.blocks = blocks
+        return y.detach()
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, rin, x2in, rbin, y, p = ctx.inner
+        torch.autograd.backward(y, dy)
+        g = p.grad
+        for b in ctx.blocks:
+            b.grad_views()                                     # (re-)attaches the factors' .grad views of the bucket
+            wu = b.layer.W_up.detach()[:, :, 0, 0]
+            b.layer.W_down.grad.add_(b.alpha_f * torch.einsum("or,oikl->rikl", wu, g))
+            b.layer.W_up.grad.add_((b.alpha_f * torch.einsum("oikl,rikl->or", g, b.layer.W_down.detach()))[:, :, None, None])
+        ctx.inner = None
+        gr = lambda t: t.grad if (t is not None and t.requires_grad) else None
+        return gr(xin), gr(rin), gr(x2in), gr(rbin), None, None, None, *([None] * len(ctx.blocks) * 2)
+
+
+def merged_lora_call(host, blocks, x, residual=None, x2=None, rowbias=None, upsample=False):
+    return _MergedLoraFn.apply(x, residual, x2, rowbias, host, blocks, upsample, *[p for b in blocks for p in (b.layer.W_down, b.layer.W_up)])
+
+
 class _SiluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -522,10 +522,12 @@ def test_conv_lora_layer_vs_reference_golden(backend, tag):
     assert torch.allclose(parent.conv._host.weight.cpu(), w_eff, atol=1e-5)
 
 
-def test_tiny_locon_train_step_vs_oracle(backend):
+@pytest.mark.parametrize("edge_convs", [False, True])
+def test_tiny_locon_train_step_vs_oracle(backend, edge_convs):
     """cfgs/train/examples/locon.yaml: LoRA on the attention / ff Linear layers AND on the resnets' convs, proj_in/out 1x1 convs
-    and the down/upsampler convs."""
-    pats_conv = [r"re:.*\.resnets$", r"re:.*\.proj_in$", r"re:.*\.proj_out$", r"re:.*\.conv$"]
+    and the down/upsampler convs.  edge_convs: conv_in / conv_out as well (4 latent channels: the merged-weight form, in the captured
+    trainer step like every other layer)."""
+    pats_conv = [r"re:.*\.resnets$", r"re:.*\.proj_in$", r"re:.*\.proj_out$", r"re:.*\.conv$"] + ([r"re:conv_in$", r"re:conv_out$"] if edge_convs else [])
     dev = backend.device
     ora, nat = _pair(TINY_CONFIG, dev)
     ora.requires_grad_(False)
@@ -631,8 +633,9 @@ def test_lora_blocks_on_one_host_beyond_32_slots(backend, ranks):
         assert rel(b.layer.W_down.grad, wd.grad) < 2e-2 and rel(b.layer.W_up.grad, wu.grad) < 2e-2
 
 
+@pytest.mark.parametrize("ranks", [(4, 8), (32, 8)])
 @pytest.mark.parametrize("stride", [1, 2])
-def test_two_lora_blocks_on_one_conv_host(backend, stride):
+def test_two_lora_blocks_on_one_conv_host(backend, stride, ranks):
     """Two cfg groups matching the same 3x3 conv -> lora_block_0 and lora_block_1 on one container (the reference sums their
     get_weight(), lora_base_patch.py:20-27; LoCon factors lora_layers_patch.py:64-100).  Native: ONE skinny conv T = conv3x3(x, [W_down_0;
     W_down_1]) fills adjacent rank slots, the host conv takes T as its K-extension, and each block's gradients are cut out of the shared
@@ -643,8 +646,9 @@ def test_two_lora_blocks_on_one_conv_host(backend, stride):
     cin, cout = 16, 24
     parent = torch.nn.Module(); parent.conv = HipConv2d(cin, cout, 3, stride, 1).to(dev)
     parent.requires_grad_(False)
-    b0 = LoraHipLayer.wrap_model(0, parent.conv, parent_block=parent, host_name="conv", rank=4, alpha=1.0)[""]
-    b1 = LoraHipLayer.wrap_model(1, parent.conv, parent_block=parent, host_name="conv", rank=8, alpha=4.0)[""]
+    # ranks (32, 8): 40 rank slots do not fit the 32 of one side path -> the container switches to the merged-weight form
+    b0 = LoraHipLayer.wrap_model(0, parent.conv, parent_block=parent, host_name="conv", rank=ranks[0], alpha=1.0)[""]
+    b1 = LoraHipLayer.wrap_model(1, parent.conv, parent_block=parent, host_name="conv", rank=ranks[1], alpha=4.0)[""]
     assert type(parent.conv).__name__ == "LoraHipContainer" and parent.conv.plugin_names == ["lora_block_0", "lora_block_1"]
     assert tuple(b1.layer.W_down.shape) == (8, cin, 3, 3) and tuple(b1.layer.W_up.shape) == (cout, 8, 1, 1)
     with torch.no_grad():
@@ -666,7 +670,20 @@ def test_two_lora_blocks_on_one_conv_host(backend, stride):
     assert rel(y.detach().permute(0, 3, 1, 2), yr.detach()) < 2e-2 and rel(xn.grad.permute(0, 3, 1, 2), xr.grad) < 2e-2
     for blk, gd, gu in ((b0, wd0.grad, wu0.grad), (b1, wd1.grad, wu1.grad)):
         assert rel(blk.layer.W_down.grad, gd) < 2e-2 and rel(blk.layer.W_up.grad, gu) < 2e-2
+    # the convolution's other operands (fused residual, per-sample row bias = the time embedding) through the same container call
+    res = torch.randn(2, Ho, Ho, cout).to(torch.bfloat16)
+    rb = torch.randn(2, cout)
+    rr = res.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    yk = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w_eff.detach(), host.bias.detach().cpu().float(), stride=stride, padding=1) \
+        + rr + rb[:, :, None, None]
+    yk.backward(dy.float().permute(0, 3, 1, 2))
+    rn = backend.to(res).requires_grad_(True)
+    y3 = parent.conv(backend.to(x), residual=rn, rowbias=backend.to(rb))
+    y3.backward(backend.to(dy))
+    assert rel(y3.detach().permute(0, 3, 1, 2), yk.detach()) < 2e-2 and rel(rn.grad.permute(0, 3, 1, 2), rr.grad) < 1e-2
     # a second step after the factors moved: the shared operand images follow both blocks
+    for blk in (b0, b1):
+        blk.layer.W_down.grad.zero_(); blk.layer.W_up.grad.zero_()
     with torch.no_grad():
         b0.layer.W_down.mul_(0.5); b1.layer.W_up.mul_(2.0)
     y2 = parent.conv(backend.to(x)).float().cpu()
@@ -833,6 +850,51 @@ def test_conv_lora_rank_above_one_slot_group(backend, rank, stride):
     rel = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
     assert rel(y.detach().permute(0, 3, 1, 2), yr.detach()) < 2e-2 and rel(xn.grad.permute(0, 3, 1, 2), xr.grad) < 2e-2
     assert rel(blk.layer.W_down.grad, wd.grad) < 2e-2 and rel(blk.layer.W_up.grad, wu.grad) < 2e-2
+
+
+@pytest.mark.parametrize("which", ["conv_in", "conv_out"])
+def test_lora_on_conv_in_and_conv_out(backend, which):
+    """LoRA on the UNet's first / last convolution (4 latent channels: not a shape of the side-path kernels): the reference's merged-weight
+    arithmetic (lora_base_patch.py:20-35) through the host's own kernels, TWO stacked blocks, against fp32 autograd on the merged weight."""
+    from hcp_diffusion_amd.layers import HipConvIn, HipConvOut
+    dev = backend.device
+    torch.manual_seed(3)
+    cin, cout = (4, 16) if which == "conv_in" else (16, 4)
+    parent = torch.nn.Module(); parent.c = (HipConvIn if which == "conv_in" else HipConvOut)(cin, cout, 3, 1, 1).to(dev)
+    parent.requires_grad_(False)
+    b0 = LoraHipLayer.wrap_model(0, parent.c, parent_block=parent, host_name="c", rank=4, alpha=1.0)[""]
+    b1 = LoraHipLayer.wrap_model(1, parent.c, parent_block=parent, host_name="c", rank=2, alpha=3.0)[""]
+    assert b0.merged and parent.c.plugin_names == ["lora_block_0", "lora_block_1"] and tuple(b0.layer.W_down.shape) == (4, cin, 3, 3)
+    with torch.no_grad():
+        b0.layer.W_up.normal_(0, 0.1); b1.layer.W_up.normal_(0, 0.1)
+    host = parent.c._host
+    fac = [(b.layer.W_down.detach().cpu().clone().requires_grad_(True), b.layer.W_up.detach().cpu().clone().requires_grad_(True)) for b in (b0, b1)]
+    w_eff = host.weight.detach().cpu().float() + sum(float(b.alpha) * torch.einsum("or,rikl->oikl", wu[:, :, 0, 0], wd) for b, (wd, wu) in zip((b0, b1), fac))
+    x = torch.randn(2, cin, 8, 8)
+    dy = torch.randn(2, cout, 8, 8)
+    xr = x.clone().requires_grad_(which == "conv_out")
+    yr = torch.nn.functional.conv2d(xr.to(torch.bfloat16).float() if which == "conv_in" else xr, w_eff, host.bias.detach().cpu().float(), padding=1)
+    yr.backward(dy if which == "conv_out" else dy.to(torch.bfloat16).float())
+    rel = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    if which == "conv_in":                       # NCHW latents in, NHWC bf16 activations out; the latents carry no gradient
+        y = parent.c(backend.to(x))
+        y.backward(backend.to(dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)))
+        assert rel(y.detach().permute(0, 3, 1, 2), yr.detach()) < 2e-2
+    else:                                        # NHWC bf16 in, NCHW fp32 `.sample` out
+        xn = backend.to(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)).requires_grad_(True)
+        xr2 = xn.detach().float().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+        yr = torch.nn.functional.conv2d(xr2, w_eff.detach(), host.bias.detach().cpu().float(), padding=1)
+        for wd, wu in fac:
+            wd.grad = None; wu.grad = None
+        w2 = host.weight.detach().cpu().float() + sum(float(b.alpha) * torch.einsum("or,rikl->oikl", wu[:, :, 0, 0], wd) for b, (wd, wu) in zip((b0, b1), fac))
+        yr = torch.nn.functional.conv2d(xr2, w2, host.bias.detach().cpu().float(), padding=1)
+        yr.backward(dy)
+        y = parent.c(xn)
+        y.backward(backend.to(dy))
+        assert rel(y.detach(), yr.detach()) < 2e-2 and rel(xn.grad.permute(0, 3, 1, 2), xr2.grad) < 2e-2
+    for b, (wd, wu) in zip((b0, b1), fac):
+        assert rel(b.layer.W_down.grad, wd.grad) < 3e-2 and rel(b.layer.W_up.grad, wu.grad) < 3e-2
+    assert host.weight.grad is None and not host.weight.requires_grad        # the frozen host stays untouched
 
 
 def test_lora_dropout_and_svd_init(backend):
