@@ -689,21 +689,33 @@ concat_channels = _ConcatFn.apply
 class _MergedLoraFn(torch.autograd.Function):
     """LoRA on a host the side-path kernels do not serve (conv_in / conv_out: 4 latent channels): the reference's own arithmetic,
     ``layer(x, W + sum_b alpha_b W_up_b W_down_b)`` (LoraPatchContainer.forward, lora_base_patch.py:20-35).  The host's forward runs on a
-    shadow of the host module whose weight is the merged fp32 tensor as a trainable leaf, so the host's own weight-gradient kernel
-    produces dW_eff; the factor gradients follow from it (dW_down = alpha W_up^T dW_eff, dW_up = alpha dW_eff W_down^T: two small
-    contractions on tensors of the layer's weight size) and go into the blocks' bucket views."""
+    shadow of the host module whose weight is the merged FP32 tensor as a trainable leaf (whatever the host's own dtype: a frozen bf16
+    host keeps its fp32 gradient path, and W + dW is rounded once, by the operand pack), so the host's own weight-gradient kernel produces
+    dW_eff; the factor gradients follow from it (dW_down = alpha W_up^T dW_eff, dW_up = alpha dW_eff W_down^T: two small contractions on
+    tensors of the layer's weight size) and go into the blocks' bucket views; a TRAINABLE host weight receives dW_eff as well (the
+    reference differentiates layer(x, host_weight + weight): both terms get the gradient).
+    Memory: W_eff and its gradient are two fp32 tensors of the host weight's size per call (a 1280 x 2560 x 3 x 3 host: 118 MB each)."""
 
     @staticmethod
-    def forward(ctx, x, residual, x2, rowbias, host, blocks, upsample, *factors):
-        import copy
-        w_eff = host.weight.detach().clone()                   # keeps the 3x3 weight's channels_last storage
+    def merged_weight(host, blocks):
+        w_eff = host.weight.detach().to(torch.float32, copy=True)        # keeps the 3x3 weight's channels_last storage
         for b in blocks:
-            w_eff += b.alpha_f * torch.einsum("or,rikl->oikl", b.layer.W_up.detach()[:, :, 0, 0], b.layer.W_down.detach()).to(w_eff.dtype)
-        p = torch.nn.Parameter(w_eff, requires_grad=True)
+            w_eff += b.alpha_f * torch.einsum("or,rikl->oikl", b.layer.W_up.detach()[:, :, 0, 0].float(), b.layer.W_down.detach().float())
+        return w_eff
+
+    @staticmethod
+    def shadow_of(host, w_eff, trainable):
+        import copy
         shadow = copy.copy(host)
         shadow._parameters = dict(host._parameters)
-        shadow._parameters["weight"] = p
+        shadow._parameters["weight"] = torch.nn.Parameter(w_eff, requires_grad=trainable)
         shadow._pk = None
+        return shadow
+
+    @staticmethod
+    def forward(ctx, x, residual, x2, rowbias, host, blocks, upsample, hw, *factors):
+        shadow = _MergedLoraFn.shadow_of(host, _MergedLoraFn.merged_weight(host, blocks), True)
+        p = shadow._parameters["weight"]
         def leaf(t):                                           # the inner graph must not reach back into the outer one
             if t is None:
                 return None
@@ -716,7 +728,7 @@ class _MergedLoraFn(torch.autograd.Function):
                 kw["upsample"] = True
             y = shadow.forward(xin, **kw)                       # (conv_in / conv_out take the input alone)
         ctx.inner = (xin, rin, x2in, rbin, y, p)
-        ctx.blocks = blocks
+        ctx.blocks, ctx.host, ctx.train_w = blocks, host, hw is not None
         return y.detach()
 
     @staticmethod
@@ -726,16 +738,43 @@ class _MergedLoraFn(torch.autograd.Function):
         g = p.grad
         for b in ctx.blocks:
             b.grad_views()                                     # (re-)attaches the factors' .grad views of the bucket
-            wu = b.layer.W_up.detach()[:, :, 0, 0]
+            wu = b.layer.W_up.detach()[:, :, 0, 0].float()
             b.layer.W_down.grad.add_(b.alpha_f * torch.einsum("or,oikl->rikl", wu, g))
-            b.layer.W_up.grad.add_((b.alpha_f * torch.einsum("oikl,rikl->or", g, b.layer.W_down.detach()))[:, :, None, None])
+            b.layer.W_up.grad.add_((b.alpha_f * torch.einsum("oikl,rikl->or", g, b.layer.W_down.detach().float()))[:, :, None, None])
+        if ctx.train_w:                                        # full fine-tune + LoRA on the same host: dW_host = dW_eff
+            hw = ctx.host.weight
+            if hw.dim() == 4 and tuple(hw.shape[2:]) == (3, 3):
+                grad_buffer(hw, conv3x3=True).add_(g.permute(0, 2, 3, 1))
+            else:
+                grad_buffer(hw).add_(g.view_as(hw))
         ctx.inner = None
         gr = lambda t: t.grad if (t is not None and t.requires_grad) else None
-        return gr(xin), gr(rin), gr(x2in), gr(rbin), None, None, None, *([None] * len(ctx.blocks) * 2)
+        return gr(xin), gr(rin), gr(x2in), gr(rbin), None, None, None, None, *([None] * len(ctx.blocks) * 2)
+
+
+_MERGED_EVAL_CACHE = {}   # id(host) -> (key, shadow): gradient-free calls (the sampler: one per denoising step) reuse W_eff and its operand pack
 
 
 def merged_lora_call(host, blocks, x, residual=None, x2=None, rowbias=None, upsample=False):
-    return _MergedLoraFn.apply(x, residual, x2, rowbias, host, blocks, upsample, *[p for b in blocks for p in (b.layer.W_down, b.layer.W_up)])
+    factors = [p for b in blocks for p in (b.layer.W_down, b.layer.W_up)]
+    needs = torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in (x, residual, x2, rowbias)) or
+                                          any(p.requires_grad for p in factors) or host.weight.requires_grad or
+                                          (host.bias is not None and host.bias.requires_grad))
+    if not needs:                                              # no inner autograd graph, no re-merge / re-pack while nothing changed
+        key = (host.weight._version, host.weight.data_ptr()) + tuple((p._version, p.data_ptr()) for p in factors) + tuple(b.alpha_f for b in blocks)
+        hit = _MERGED_EVAL_CACHE.get(id(host))
+        if hit is None or hit[0] != key or hit[2]() is not host:
+            import weakref
+            if len(_MERGED_EVAL_CACHE) >= 8:
+                _MERGED_EVAL_CACHE.pop(next(iter(_MERGED_EVAL_CACHE)))
+            hit = (key, _MergedLoraFn.shadow_of(host, _MergedLoraFn.merged_weight(host, blocks), False), weakref.ref(host))
+            _MERGED_EVAL_CACHE[id(host)] = hit
+        kw = {k: v for k, v in (("residual", residual), ("x2", x2), ("rowbias", rowbias)) if v is not None}
+        if upsample:
+            kw["upsample"] = True
+        with torch.no_grad():
+            return hit[1].forward(x, **kw)
+    return _MergedLoraFn.apply(x, residual, x2, rowbias, host, blocks, upsample, _tr(host.weight), *factors)
 
 
 class _SiluFn(torch.autograd.Function):

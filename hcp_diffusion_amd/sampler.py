@@ -38,10 +38,14 @@ class NativeDDIMSampler:
             added = {k: torch.cat([u[k], v]) if guided else v for k, v in added_cond_kwargs.items()}
         mask = None
         if encoder_attention_mask is not None:
-            if guided and encoder_attention_mask.shape[0] == 2 * B:
-                mask = encoder_attention_mask
-            else:
+            rows = encoder_attention_mask.shape[0]
+            if rows == 2 * B:                                      # reference order [negative prompts; prompts]
+                mask = encoder_attention_mask if guided else encoder_attention_mask[B:]      # unguided: the prompts' rows only
+            elif rows == B:
                 mask = torch.cat([encoder_attention_mask] * 2) if guided else encoder_attention_mask
+            else:
+                raise ValueError(f"encoder_attention_mask has {rows} rows for a batch of {B}: expected [B, L] or [2B, L] "
+                                 "([negative prompts; prompts])")
         ts = self.timesteps(num_inference_steps)
         ratio = self.num_train_timesteps // num_inference_steps
         for t in ts.tolist():

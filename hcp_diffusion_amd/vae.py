@@ -219,8 +219,8 @@ class NativeVAEEncoder(nn.Module):
 
     @classmethod
     def from_pretrained(cls, path, subfolder="vae", device="cuda"):
-        """A diffusers model directory (``<path>/vae/config.json`` + ``diffusion_pytorch_model.safetensors``): encoder and
-        quant_conv weights by name, decoder keys ignored."""
+        """A diffusers model directory (``<path>/vae/config.json`` + ``diffusion_pytorch_model.safetensors``): every tensor of THIS class
+        by name — encoder and quant_conv here (decoder keys ignored), all four parts for NativeAutoencoderKL."""
         from safetensors.torch import load_file
         root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
         cfg = json.load(open(os.path.join(root, "config.json")))
@@ -230,7 +230,7 @@ class NativeVAEEncoder(nn.Module):
         own = model.state_dict()
         missing = [k for k in own if k not in sd]
         if missing:
-            raise ValueError(f"VAE checkpoint lacks {len(missing)} encoder tensors, e.g. {missing[:3]}")
+            raise ValueError(f"VAE checkpoint lacks {len(missing)} tensors of {cls.__name__}, e.g. {missing[:3]}")
         model.load_state_dict({k: sd[k] for k in own})
         return model.to(device)
 
@@ -320,7 +320,8 @@ class NativeAutoencoderKL(NativeVAEEncoder):
     def _decoder_in(self):
         """conv_in composed with post_quant_conv: [C0][3][3][8] bf16 over the channels [z_0..z_{L-1} | 1 | 0..] (+ conv_in's own bias)."""
         ci, pq = self.decoder.conv_in, self.post_quant_conv
-        key = (ci.weight.data_ptr(), ci.weight._version, pq.weight.data_ptr(), pq.weight._version, pq.bias._version, str(ci.weight.device))
+        key = (ci.weight.data_ptr(), ci.weight._version, ci.bias.data_ptr(), ci.bias._version, pq.weight.data_ptr(), pq.weight._version,
+               pq.bias.data_ptr(), pq.bias._version, str(ci.weight.device))
         if self._dec_in is None or self._dec_in[0] != key:
             L = self.config["latent_channels"]
             if L + 1 > 8:
@@ -370,19 +371,3 @@ class NativeAutoencoderKL(NativeVAEEncoder):
         else:
             img = self._decode(z)
         return _DecoderOutput(img) if return_dict else (img,)
-
-    @classmethod
-    def from_pretrained(cls, path, subfolder="vae", device="cuda"):
-        """A diffusers model directory: every tensor by name (encoder, decoder, quant_conv, post_quant_conv)."""
-        from safetensors.torch import load_file
-        root = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
-        cfg = json.load(open(os.path.join(root, "config.json")))
-        keys = ("in_channels", "latent_channels", "block_out_channels", "layers_per_block", "norm_num_groups", "scaling_factor")
-        model = cls(**{k: cfg[k] for k in keys if k in cfg})
-        sd = load_file(os.path.join(root, "diffusion_pytorch_model.safetensors"))
-        own = model.state_dict()
-        missing = [k for k in own if k not in sd]
-        if missing:
-            raise ValueError(f"VAE checkpoint lacks {len(missing)} tensors, e.g. {missing[:3]}")
-        model.load_state_dict({k: sd[k] for k in own})
-        return model.to(device)

@@ -897,6 +897,50 @@ def test_lora_on_conv_in_and_conv_out(backend, which):
     assert host.weight.grad is None and not host.weight.requires_grad        # the frozen host stays untouched
 
 
+@pytest.mark.parametrize("host_mode", ["trainable", "bf16"])
+def test_merged_lora_host_gradient_and_bf16_host(backend, host_mode):
+    """the merged-weight fallback (a) hands dW_eff to a TRAINABLE host weight as well (the reference differentiates
+    layer(x, host_weight + weight), lora_base_patch.py:20-35: full fine-tune + LoRA on conv_in trains both), (b) builds its shadow weight
+    in fp32 so that a frozen bf16 host (the reference casts TE_unet to weight_dtype) does not trip the fp32 gradient buffer, and (c) a
+    gradient-free call (the sampler) reuses the merged weight until a factor changes."""
+    from hcp_diffusion_amd.layers import HipConvIn
+    dev = backend.device
+    torch.manual_seed(5)
+    cin, cout = 4, 16
+    parent = torch.nn.Module(); parent.c = HipConvIn(cin, cout, 3, 1, 1).to(dev)
+    parent.requires_grad_(host_mode == "trainable")
+    if host_mode == "bf16":
+        parent.c.to(torch.bfloat16)
+    blk = LoraHipLayer.wrap_model(0, parent.c, parent_block=parent, host_name="c", rank=4, alpha=2.0)[""]
+    with torch.no_grad():
+        blk.layer.W_up.normal_(0, 0.1)
+    host = parent.c._host
+    wd = blk.layer.W_down.detach().cpu().float().clone().requires_grad_(True)
+    wu = blk.layer.W_up.detach().cpu().float().clone().requires_grad_(True)
+    hw = host.weight.detach().cpu().float().clone().requires_grad_(True)
+    x = torch.randn(2, cin, 8, 8)
+    dy = torch.randn(2, cout, 8, 8).to(torch.bfloat16).float()
+    yr = torch.nn.functional.conv2d(x.to(torch.bfloat16).float(), hw + float(blk.alpha) * torch.einsum("or,rikl->oikl", wu[:, :, 0, 0], wd),
+                                    host.bias.detach().cpu().float(), padding=1)
+    yr.backward(dy)
+    y = parent.c(backend.to(x))
+    y.backward(backend.to(dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)))
+    rel = lambda a, b: ((a.float().cpu() - b).abs().max() / b.abs().max()).item()
+    assert rel(y.detach().permute(0, 3, 1, 2), yr.detach()) < 2e-2
+    assert rel(blk.layer.W_down.grad, wd.grad) < 3e-2 and rel(blk.layer.W_up.grad, wu.grad) < 3e-2
+    if host_mode == "trainable":
+        assert host.weight.grad is not None and rel(host.weight.grad, hw.grad) < 3e-2
+        assert host.bias.grad is not None and rel(host.bias.grad, dy.sum((0, 2, 3))) < 3e-2
+    else:
+        assert host.weight.grad is None
+    with torch.no_grad():                       # gradient-free calls: one merge, then cache hits until a factor changes
+        y1 = parent.c(backend.to(x)); y2 = parent.c(backend.to(x))
+        assert torch.equal(y1, y2) and rel(y1.permute(0, 3, 1, 2), yr.detach()) < 2e-2
+        blk.layer.W_up.mul_(2.0)
+        y3 = parent.c(backend.to(x))
+        assert not torch.equal(y1, y3)
+
+
 def test_lora_dropout_and_svd_init(backend):
     """dropout > 0: the reference drops the whole layer output (lora_base_patch.py:74) — eval mode is the identity, train mode
     zeroes ~p of the outputs and rescales the rest by 1/(1-p), gradients flow through the kept ones only.  svd_init: the factors

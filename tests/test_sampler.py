@@ -1,4 +1,5 @@
 """f4: CFG-batched forward + fused DDIM step vs the oracle restatement (oracle/sampler_ref.py)."""
+import pytest
 import torch
 
 from hcp_diffusion_amd import kernels as K
@@ -37,6 +38,14 @@ def test_sampler_loop_vs_oracle(backend):
     assert ((out - ref).norm() / ref.norm()).item() < 3e-2            # bf16 UNet, 4 accumulated guided steps
     out1 = s.sample(nat, backend.to(lat), backend.to(cond), None, num_inference_steps=2).cpu()       # no guidance: B-row forward
     assert torch.isfinite(out1).all() and out1.shape == lat.shape
+    # a [2B, L] key mask in the reference's order [negative prompts; prompts] on an UNGUIDED call uses the prompts' rows
+    # (not the negatives', not a shape error); any other row count is refused with a clear message
+    m_neg = torch.ones(2, 24, dtype=torch.bool); m_pos = torch.ones(2, 24, dtype=torch.bool); m_pos[:, 16:] = False
+    a = s.sample(nat, backend.to(lat), backend.to(cond), None, num_inference_steps=2, encoder_attention_mask=backend.to(torch.cat([m_neg, m_pos]))).cpu()
+    b = s.sample(nat, backend.to(lat), backend.to(cond), None, num_inference_steps=2, encoder_attention_mask=backend.to(m_pos)).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, out1)
+    with pytest.raises(ValueError, match="encoder_attention_mask"):
+        s.sample(nat, backend.to(lat), backend.to(cond), None, num_inference_steps=2, encoder_attention_mask=backend.to(torch.ones(3, 24, dtype=torch.bool)))
 
 
 def test_ddpm_scheduler_beta_schedules(backend):
