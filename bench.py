@@ -309,7 +309,8 @@ def main():
         torch.manual_seed(114514 + rank)
     else:
         text_encoder = None
-        if te:                                     # CLIP-L text encoder (cfgs/te_struct.txt), random init, lora_text_encoder rank 4 lr 1e-5
+        frozen_te_leg = (args.workload == "sd15" and world == 1 and not emu and not args.no_ckpt_line and not args.no_graph and not args.seam)
+        if te or frozen_te_leg:                    # CLIP-L text encoder (cfgs/te_struct.txt), random init; sd15te: + lora_text_encoder rank 4 lr 1e-5
             from hcp_diffusion_amd.text_encoder import NativeCLIPTextModel
             with torch.device("meta"):
                 text_encoder = NativeCLIPTextModel()
@@ -361,12 +362,11 @@ def main():
         if not emu:
             torch.cuda.synchronize()
 
-    if args.seam:
-        # What the reference's Trainer does with the native modules behind its seams (tests/test_reference_trainer.py runs its
-        # real code on the CPU interpreter; /root/reference does not exist on the GPU box, so the loop is restated here):
-        # TEUnetWrapper-style module call, MSE(reduction none).mean(), loss.backward(), accelerator.clip_grad_norm_,
-        # optimizer.step(), zero_grad(set_to_none=False), loss.item().
-        assert args.workload in ("sd15", "dreambooth") and world == 1
+    def seam_loop(graph, steps, warmup):
+        """What the reference's Trainer does with the native modules behind its seams (tests/test_reference_trainer.py runs its
+        real code on the CPU interpreter; /root/reference does not exist on the GPU box, so the loop is restated here):
+        TEUnetWrapper-style module call, MSE(reduction none).mean(), loss.backward(), accelerator.clip_grad_norm_,
+        optimizer.step(), zero_grad(set_to_none=False), loss.item().  graph: unet.enable_hip_graph().  -> (seconds, last loss)"""
         from hcp_diffusion_amd.optim import FusedAdamW
         from hcp_diffusion_amd.scheduler import NativeDDPMScheduler
         sched = NativeDDPMScheduler()
@@ -376,7 +376,7 @@ def main():
             params = [p for blk in tr.bucket.blocks for p in (blk.layer.W_down, blk.layer.W_up)]
         opt = (FusedAdamW if args.seam_optimizer == "fused" else torch.optim.AdamW)([dict(params=params, lr=(1e-6 if fullft else 1e-4) * B)], weight_decay=1e-3)
         crit = torch.nn.MSELoss(reduction="none")
-        if args.seam_graph:
+        if graph:
             unet.enable_hip_graph()
 
         def seam_step():
@@ -389,14 +389,18 @@ def main():
             opt.step()
             opt.zero_grad(set_to_none=False)
             return loss.item()
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             seam_step()
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             lv = seam_step()
         sync()
-        dt = time.perf_counter() - t0
+        return time.perf_counter() - t0, lv
+
+    if args.seam:
+        assert args.workload in ("sd15", "dreambooth") and world == 1
+        dt, lv = seam_loop(args.seam_graph, args.steps, args.warmup)
         print(json.dumps({"metric": ("training images/sec, SD1.5 full fine-tune (DreamBooth) 512px bs=%d" % B if fullft else "training images/sec, SD1.5 LoRA 512px bs=4") +
                                     ", native modules driven the reference trainer's way (eager seam)",
                           "value": round(B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -471,6 +475,36 @@ def main():
                                    "steps": k2, "note": "same workload with enable_gradient_checkpointing() (+1 forward per step)"}
             unet.disable_gradient_checkpointing()
             tr._graph_cache.clear()
+        if world == 1 and args.workload == "sd15" and tr.text_encoder is not None and not args.grad_ckpt:
+            # What TEUnetWrapper.forward does EVERY step (models/wrapper.py:14-30): the FROZEN text encoder runs inside the step on the
+            # batch's prompt ids; the headline feeds pre-computed states (north_star scopes the path to the UNet + LoRA).  Same trainer,
+            # same LoRA, no TE LoRA: the batch carries prompt_ids instead of encoder_hidden_states (its own captured graph).
+            try:                                   # (secondary legs never take the headline line down with them)
+                pid = torch.randint(0, 49406, (B, 77), device=dev); pid[:, 0] = 49406; pid[:, -1] = 49407
+                k3 = max(5, min(args.steps, 20))
+                for _ in range(3):
+                    tr.train_one_step(latents, None, None, added, plugin_input, pid)
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(k3):
+                    tr.train_one_step(latents, None, None, added, plugin_input, pid)
+                sync()
+                d3 = time.perf_counter() - t1
+                out["frozen_te_in_step"] = {"value": round(B * k3 / d3, 2), "unit": "images/sec", "ms_per_step": round(d3 / k3 * 1e3, 3), "steps": k3,
+                                            "note": "same step with the frozen native CLIP-L encoding prompt_ids [B,77] inside the captured step "
+                                                    "(TEUnetWrapper.forward, models/wrapper.py:20), no text-encoder LoRA"}
+            except Exception as e:                 # noqa: BLE001
+                out["frozen_te_in_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # ... and what a reference user gets who keeps the reference's OWN trainer loop over the native modules (INTEGRATION.md
+            # "Keeping the reference's loop"): eager trainer, unet.enable_hip_graph() as the mi355x overlay sets it.  LAST: it switches the module to graph replay.
+            try:
+                k4 = max(5, min(args.steps, 20))
+                d4, _ = seam_loop(True, k4, 5)
+                out["seam_graph"] = {"value": round(B * k4 / d4, 2), "unit": "images/sec", "ms_per_step": round(d4 / k4 * 1e3, 3), "steps": k4,
+                                     "note": "the reference Trainer's loop restated (train_ac.py:467-504: eager module call, clip_grad_norm_, fused "
+                                             "AdamW, zero_grad, loss.item() every step) over the native modules with unet.enable_hip_graph()"}
+            except Exception as e:                 # noqa: BLE001
+                out["seam_graph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if emu:
             out["data"] = "synthetic (HCP_BENCH_BACKEND=emu: launcher / rank plumbing check on the CPU interpreter, timings meaningless)"
             out["config"]["comm"] = "gloo via torch.distributed" if world > 1 else "none"

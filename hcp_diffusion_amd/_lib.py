@@ -22,9 +22,9 @@ _PROTOTYPES = {
     # residual, ldr, alpha, out_f32, workspace, workspace_bytes, stream
     "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, F, I, P, c_size_t, P]),
     # A, lda, B, ldb, L, E, Tout, D, ldd, M, N, K, bias, residual, ldr, workspace, workspace_bytes, stream
-    "hcp_gemm_lora_bf16": (I, [P, I, P, I, P, P, P, P, I, I, I, I, P, P, I, P, c_size_t, P]),
+    "hcp_gemm_lora_bf16": (I, [P, I, P, I, P, P, P, I, P, I, I, I, I, P, P, I, P, c_size_t, P]),
     # A, lda, B, ldb, L, E, Tout, HG, DHG, M, F, K, workspace, workspace_bytes, stream
-    "hcp_gemm_geglu_bwd_bf16": (I, [P, I, P, I, P, P, P, P, P, I, I, I, P, c_size_t, P]),
+    "hcp_gemm_geglu_bwd_bf16": (I, [P, I, P, I, P, P, P, I, P, P, I, I, I, P, c_size_t, P]),
     "hcp_gemm_workspace_bytes": (c_size_t, [I, I]),
     # X1, C1, X2, C2, B, Hs, Ws, Ho, Wo, mode, stride, upsample, Wp, Cout, D, ldd, bias, rowbias, rowbias_ld,
     # residual, ldr, out_f32, workspace, workspace_bytes, stream
@@ -80,9 +80,10 @@ _PROTOTYPES = {
     "hcp_vae_latent_sample": (I, [P, P, P, P, P, I, I, L, F, P]),
     "hcp_mse_masked_mean": (I, [P, P, P, I, P, P, P, I, I, I, F, P]),
     # L, ldl, R, ldr, out, ldo, M, P, Q, scale, transpose_out, stream
-    "hcp_lora_wgrad": (I, [P, I, P, I, P, I, I, I, I, F, I, P]),
+    "hcp_lora_wgrad": (I, [P, I, I, P, I, P, I, I, I, I, F, I, P]),
     # U, x, ldx, K, grad_down, T, dY, ldy, N, grad_up, M, r, scale, stream
-    "hcp_lora_wgrad_pair": (I, [P, P, I, I, P, P, P, I, I, P, I, I, F, P]),
+    "hcp_lora_wgrad_pair": (I, [P, I, P, I, I, P, P, I, P, I, I, P, I, I, F, P]),
+    "hcp_split_hi_lo_bf16": (I, [P, P, c_long, I, P]),
     "hcp_lora_wgrad_group_geometry": (I, [I, I, I, P, P, P]),
     "hcp_lora_wgrad_group_desc_bytes": (I, []),
     "hcp_lora_wgrad_grouped": (I, [P, I, I, P]),

@@ -303,14 +303,20 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
         constexpr int TS2 = 40;
         hcp_bf16* lt = lds;
         hcp_bf16* le = lds + BM * TS2;
+        hcp_bf16* lt2 = le + BN * TS2;                      // split T (p.ldt == 64): the residual image T_lo
+        const bool split = p.ldt == 64;
+        const int ldt = split ? 64 : 32;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            hcp_bf16x4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(tacc[i][q]);
+            hcp_bf16x4 o, o2;
+            lora_t_split(tacc[i], o, o2);
             const int ml = wm * WTM + i * 16 + fr;
             *(hcp_bf16x4*)(lt + ml * TS2 + wn * 16 + 4 * fg) = o;
-            if (tile_n == 0 && p.Tout && m0 + ml < p.M) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * 32 + wn * 16 + 4 * fg) = o;
+            if (split) *(hcp_bf16x4*)(lt2 + ml * TS2 + wn * 16 + 4 * fg) = o2;
+            if (tile_n == 0 && p.Tout && m0 + ml < p.M) {
+                *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * ldt + wn * 16 + 4 * fg) = o;
+                if (split) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * ldt + 32 + wn * 16 + 4 * fg) = o2;
+            }
         }
         for (int c = tid; c < BN * 4; c += NT) {
             const int r = c >> 2, q = c & 3;
@@ -328,6 +334,14 @@ HCP_KERNEL(64 * WGM * WGN) gemm_glds_kernel(GemmParams p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
+        if (split) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ft[i] = *(const hcp_bf16x8*)(lt2 + (wm * WTM + i * 16 + fr) * TS2 + fg * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
+        }
     }
 
 #pragma unroll
@@ -649,14 +663,20 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         constexpr int TS2 = 40;
         hcp_bf16* lt = lds;
         hcp_bf16* le = EARLY ? le_early : lds + BM * TS2;
+        hcp_bf16* lt2 = lds + BM * TS2 + (EARLY ? 0 : BN * TS2);   // split T (p.ldt == 64): the residual image T_lo
+        const bool split = p.ldt == 64;
+        const int ldt = split ? 64 : 32;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            hcp_bf16x4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(tacc[i][q]);
+            hcp_bf16x4 o, o2;
+            lora_t_split(tacc[i], o, o2);
             const int ml = wm * WTM + i * 16 + fr;
             *(hcp_bf16x4*)(lt + ml * TS2 + wn * 16 + 4 * fg) = o;
-            if (tile_n == 0 && p.Tout && m0 + ml < p.M) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * 32 + wn * 16 + 4 * fg) = o;
+            if (split) *(hcp_bf16x4*)(lt2 + ml * TS2 + wn * 16 + 4 * fg) = o2;
+            if (tile_n == 0 && p.Tout && m0 + ml < p.M) {
+                *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * ldt + wn * 16 + 4 * fg) = o;
+                if (split) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * ldt + 32 + wn * 16 + 4 * fg) = o2;
+            }
         }
         if (!EARLY) {
             for (int c = tid_all; c < BN * 4; c += NTC) {
@@ -676,6 +696,14 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
+        if (split) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ft[i] = *(const hcp_bf16x8*)(lt2 + (wm * WTM + i * 16 + fr) * TS2 + fg * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
+        }
     }
 
     if (p.nsplit > 1) {
@@ -774,7 +802,7 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
             constexpr size_t stage = (size_t)(BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
             constexpr size_t eimg = (LORA && NLD > 0) ? (size_t)BN * 32 * sizeof(hcp_bf16) : 0;   // loader variant: the E rows, behind the ring
             size_t smem = 2 * stage;
-            const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);
+            const size_t tail = (size_t)(2 * BM + BN) * 40 * sizeof(hcp_bf16);   // fused-LoRA tail images: T_hi, E, T_lo
             if (LORA && smem < tail) smem = tail;
             [[maybe_unused]] const dim3 grid(p.tiles_m * tiles_n, p.nsplit);
             if constexpr (NLD > 0) {
@@ -801,7 +829,7 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
     }
     {
         size_t smem = (size_t)NSTAGE * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
-        const size_t tail = (size_t)(BM + BN) * 40 * sizeof(hcp_bf16);      // fused-LoRA tail images
+        const size_t tail = (size_t)(2 * BM + BN) * 40 * sizeof(hcp_bf16);  // fused-LoRA tail images: T_hi, E, T_lo
         if (LORA && smem < tail) smem = tail;
         HCP_LAUNCH((gemm_glds_kernel<BM, BN, WGM, WGN, MODE, FAST, LORA, NSTAGE>), dim3(p.tiles_m * tiles_n, p.nsplit),
                    dim3(64 * WGM * WGN), smem, stream, p);
@@ -971,11 +999,15 @@ int launch_lora_dispatched(GemmParams& p, void* workspace, size_t workspace_byte
     if (id < 0) {
         // two-launch form: T = A L^T, then D = A B^T + T E^T with the measured tile / split-K choice
         HCP_REQUIRE(p.Tout, "hcp_gemm_lora_bf16: this shape runs as two launches and needs the T buffer");
+        // (split T, ldt = 64: this form keeps the bf16-rounded T — its T is a GEMM output of its own; the residual half of Tout is zeroed so
+        //  that the weight-gradient kernel reads one format)
+        const int ldt = p.ldt == 64 ? 64 : 32;
+        if (ldt == 64 && hcp_memset_async(p.Tout, 0, (size_t)p.M * 64 * sizeof(hcp_bf16), stream)) return hcp_set_error("hcp_gemm_lora_bf16: memset failed");
         GemmParams t = {};
-        t.A = p.A; t.lda = p.lda; t.B = p.L; t.ldb = p.K; t.M = p.M; t.N = 32; t.K = p.K; t.D = p.Tout; t.ldd = 32; t.alpha = 1.0f;
+        t.A = p.A; t.lda = p.lda; t.B = p.L; t.ldb = p.K; t.M = p.M; t.N = 32; t.K = p.K; t.D = p.Tout; t.ldd = ldt; t.alpha = 1.0f;
         if (int e2 = dispatch_gemm<0, false>(t, (float*)workspace, workspace ? workspace_bytes : 0, stream)) return e2;
-        p.A2 = (const hcp_bf16*)p.Tout; p.lda2 = 32; p.B2 = p.E; p.ldb2 = 32; p.K2 = 32;
-        p.L = nullptr; p.E = nullptr; p.Tout = nullptr;
+        p.A2 = (const hcp_bf16*)p.Tout; p.lda2 = ldt; p.B2 = p.E; p.ldb2 = 32; p.K2 = 32;
+        p.L = nullptr; p.E = nullptr; p.Tout = nullptr; p.ldt = 0;
         return dispatch_gemm<0, false>(p, (float*)workspace, workspace ? workspace_bytes : 0, stream);
     }
     p.nsplit = 1; p.kt_per_split = hcp_cdiv(p.K, BK); p.slabs = nullptr;
@@ -1065,7 +1097,7 @@ HCP_API int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int
 //   DHG[m, n] = dY_ff * gelu(g),   DHG[m, F + n] = dY_ff * h * gelu'(g)
 // Replaces the input-gradient GEMM of FeedForward.net[2] followed by the GEGLU backward pass (diffusers GEGLU under
 // BasicTransformerBlock.ff, reference cfgs/unet_struct.txt:27-33; autograd of F.gelu / chunk).  L == NULL: plain host (no LoRA).
-HCP_API int hcp_gemm_geglu_bwd_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout,
+HCP_API int hcp_gemm_geglu_bwd_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, int ldt,
                                     const void* HG, void* DHG, int M, int F, int K, void* workspace, size_t workspace_bytes,
                                     hipStream_t stream) {
     GemmParams p = {};
@@ -1077,25 +1109,30 @@ HCP_API int hcp_gemm_geglu_bwd_bf16(const void* A, int lda, const void* B, int l
     HCP_REQUIRE(lda % 8 == 0 && F % 8 == 0, "hcp_gemm_geglu_bwd_bf16: lda (%d) and F (%d) must be multiples of 8", lda, F);
     if (int e = check_common(p)) return e;
     if (!L) return dispatch_gemm<0, false>(p, (float*)workspace, workspace ? workspace_bytes : 0, stream);
-    p.L = (const hcp_bf16*)L; p.E = (const hcp_bf16*)E; p.Tout = (hcp_bf16*)Tout;
+    HCP_REQUIRE(ldt == 32 || ldt == 64, "hcp_gemm_geglu_bwd_bf16: ldt (%d) is 32 (bf16 U) or 64 (split U: hi | lo)", ldt);
+    p.L = (const hcp_bf16*)L; p.E = (const hcp_bf16*)E; p.Tout = (hcp_bf16*)Tout; p.ldt = ldt;
     return launch_lora_dispatched(p, workspace, workspace_bytes, stream);
 }
 
 // Fused LoRA linear (forward AND input-gradient use the same entry point):
-//   T[M,32] = A[M,K] L[32,K]^T  (bf16-rounded, written to Tout if non-null)
+//   T[M,32] = A[M,K] L[32,K]^T  (fp32 accumulator)
 //   D[M,N]  = A B[N,K]^T + T E[N,32]^T + bias + residual
+// ldt = 32: T enters the product (and Tout [M,32], if non-null) rounded to bf16.  ldt = 64 ("split"): T is carried as T_hi = bf16(T) and
+// T_lo = bf16(T - T_hi) — 16 mantissa bits, the rank-r intermediate of the side path no longer sets the precision of y, dX or of the
+// factor gradients — D gets T_hi E^T + T_lo E^T and Tout [M,64] = (T_hi | T_lo) for hcp_lora_wgrad*.
 // forward : A = x,  B = W,   L = W_down (rank-padded), E = alpha*W_up   -> y,  T = x W_down^T   (for dW_up)
 // backward: A = dY, B = W^T, L = W_up^T,               E = alpha*W_down^T -> dX, T = dY W_up    (for dW_down)
 // One launch replaces LoraPatchContainer.forward's weight merge + mm (reference lora_base_patch.py:20-35,61-74).
-HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, void* D,
+HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, int ldt, void* D,
                                int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, void* workspace,
                                size_t workspace_bytes, hipStream_t stream) {
     GemmParams p = {};
     p.A = (const hcp_bf16*)A; p.lda = lda; p.B = (const hcp_bf16*)B; p.ldb = ldb;
     p.M = M; p.N = N; p.K = K; p.D = D; p.ldd = ldd; p.out_f32 = 0;
     p.bias = bias; p.residual = (const hcp_bf16*)residual; p.ldr = ldr; p.alpha = 1.0f;
-    p.L = (const hcp_bf16*)L; p.E = (const hcp_bf16*)E; p.Tout = (hcp_bf16*)Tout;
+    p.L = (const hcp_bf16*)L; p.E = (const hcp_bf16*)E; p.Tout = (hcp_bf16*)Tout; p.ldt = ldt;
     HCP_REQUIRE(A && B && D && L && E, "hcp_gemm_lora_bf16: null operand");
+    HCP_REQUIRE(ldt == 32 || ldt == 64, "hcp_gemm_lora_bf16: ldt (%d) is 32 (bf16 T) or 64 (split T: hi | lo)", ldt);
     HCP_REQUIRE(lda % 8 == 0, "hcp_gemm_lora_bf16: lda (%d) must be a multiple of 8", lda);
     if (int e = check_common(p)) return e;
     return launch_lora_dispatched(p, workspace, workspace_bytes, stream);

@@ -29,8 +29,11 @@ struct GemmParams {
     int nsplit; int kt_per_split;   // split-K over the primary K tiles (grid.y)
     float* slabs;                   // [nsplit][M][N] fp32 partials when nsplit > 1
     // fused LoRA (LORA kernels): T = A L^T is accumulated next to the main tile from the same A tiles, rounded to
-    // bf16, then D += T E^T as one extra k-step.  L [32,K] (ldl = K), E [N,32], Tout [M,32] (optional, for wgrad).
-    const hcp_bf16* L; const hcp_bf16* E; hcp_bf16* Tout;
+    // bf16, then D += T E^T as one extra k-step.  L [32,K] (ldl = K), E [N,32], Tout [M,ldt] (optional, for wgrad).
+    // ldt = 64 ("split" T): the fp32 T leaves the accumulator as TWO bf16 images, T_hi = bf16(T) and T_lo = bf16(T - T_hi) (16 mantissa
+    // bits between them); the K-extension adds T_hi E^T + T_lo E^T (one more MFMA per output block) and Tout gets T_hi in columns
+    // 0..31, T_lo in columns 32..63 for the weight-gradient kernel.  ldt = 32 (or 0): the bf16-rounded T only.
+    const hcp_bf16* L; const hcp_bf16* E; hcp_bf16* Tout; int ldt;
     // GEGLU-backward epilogue (hcp_gemm_geglu_bwd_bf16): the product is dY_ff = d(h * gelu(g)) [M, N = F]; hg [M, 2F] holds the forward's
     // (h | g); D is d(h | g) [M, 2F] (ldd = 2F): D[m, n] = v * gelu(g), D[m, F + n] = v * h * gelu'(g).  Null = ordinary epilogue.
     const hcp_bf16* geglu_hg; int geglu_ld;
@@ -40,6 +43,16 @@ struct GemmParams {
 };
 
 constexpr int BK = 64;
+
+// One accumulator quad of the fused-LoRA T tile -> its bf16 image(s): hi = bf16(t), lo = bf16(t - hi) (the rounding residual).
+HCP_DEVICE void lora_t_split(const hcp_f32x4& t, hcp_bf16x4& hi, hcp_bf16x4& lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned short h = hcp_f2bf(t[q]);
+        hi[q] = (short)h;
+        lo[q] = (short)hcp_f2bf(t[q] - hcp_bf2f(h));
+    }
+}
 
 // One 4-column piece of the GEGLU-backward epilogue (replaces the stand-alone geglu_bwd pass over dY_ff, h|g and d(h|g)).
 HCP_DEVICE void epilogue_geglu_bwd(const GemmParams& p, int m, int n, hcp_f32x4 v) {

@@ -396,14 +396,20 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         // T (bf16-rounded) and E = alpha * W_up rows of this N tile meet in LDS; one extra k-step adds T E^T
         constexpr int TS2 = 40;
         hcp_bf16* lt = ring;
+        hcp_bf16* lt2 = ring + BM * TS2;                    // split T (p.ldt == 64): the residual image T_lo
+        const bool split = p.ldt == 64;
+        const int ldt = split ? 64 : 32;
 #pragma unroll
         for (int i = 0; i < TMF; ++i) {
-            hcp_bf16x4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(tacc[i][q]);
+            hcp_bf16x4 o, o2;
+            lora_t_split(tacc[i], o, o2);
             const int ml = frow0 + i * 16 + fr;
             *(hcp_bf16x4*)(lt + ml * TS2 + gn * 16 + 4 * fg) = o;
-            if (tile_n == 0 && p.Tout && m0 + ml < p.M) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * 32 + gn * 16 + 4 * fg) = o;
+            if (split) *(hcp_bf16x4*)(lt2 + ml * TS2 + gn * 16 + 4 * fg) = o2;
+            if (tile_n == 0 && p.Tout && m0 + ml < p.M) {
+                *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * ldt + gn * 16 + 4 * fg) = o;
+                if (split) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * ldt + 32 + gn * 16 + 4 * fg) = o2;
+            }
         }
         if (!EARLY && p.nsplit == 1) load_residual();
         HCP_SYNC();
@@ -416,6 +422,14 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         for (int i = 0; i < TMF; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
+        if (split) {
+#pragma unroll
+            for (int i = 0; i < TMF; ++i) ft[i] = *(const hcp_bf16x8*)(lt2 + (frow0 + i * 16 + fr) * TS2 + fg * 8);
+#pragma unroll
+            for (int i = 0; i < TMF; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = hcp_mfma16(fe[j], ft[i], acc[i][j]);
+        }
     }
 
     if (p.nsplit > 1) {
@@ -483,7 +497,7 @@ int launch_pp(GemmParams& p, int ring, hipStream_t stream) {
     constexpr size_t eimg = LORA ? (size_t)BN * 32 * sizeof(hcp_bf16) : 0;
     constexpr int TMF = BM / 64;
     constexpr size_t xchg = (size_t)8 * TMF * (BN / 32) * 64 * 16 + (LORA ? (size_t)8 * TMF * 64 * 16 : 0);   // the groups' exchange area
-    constexpr size_t tail = LORA ? (size_t)BM * 40 * sizeof(hcp_bf16) : 0;
+    constexpr size_t tail = LORA ? (size_t)2 * BM * 40 * sizeof(hcp_bf16) : 0;   // T_hi and T_lo images
     constexpr size_t floor_ = xchg > tail ? xchg : tail;
     constexpr size_t cap = 160 * 1024;
     const dim3 grid(p.tiles_m * hcp_cdiv(p.N, BN), p.nsplit);

@@ -18,7 +18,9 @@ constexpr int WG_LS = 32 + 2;     // LDS row stride of the L tile
 
 // out[p, q] (+)= scale * sum_m L[m, p] * R[m, q]      p < P (<= 32), q < Q
 // transpose_out: element (p,q) lives at out[q * ldo + p] instead of out[p * ldo + q]
-struct WgradProb { const hcp_bf16* L; int ldl; const hcp_bf16* R; int ldr; float* out; int ldo; int Q; int transpose_out; int pcol0; };
+// lo: 0, or the column offset (32) of the residual half of a split L = (L_hi | L_lo) (hcp_gemm_lora_bf16 with ldt = 64): the product then
+// is (L_hi + L_lo)^T R — both halves ride the same staged R tile, two MFMAs per output block instead of one.
+struct WgradProb { const hcp_bf16* L; int ldl; int lo; const hcp_bf16* R; int ldr; float* out; int ldo; int Q; int transpose_out; int pcol0; };
 
 HCP_DEVICE void wgrad_block(const WgradProb& pr, int M, int P, float scale, int rows_per_split, int qtile, int split) {
     const hcp_bf16* L = pr.L; const int ldl = pr.ldl; const hcp_bf16* R = pr.R; const int ldr = pr.ldr;
@@ -28,6 +30,8 @@ HCP_DEVICE void wgrad_block(const WgradProb& pr, int M, int P, float scale, int 
     HCP_DYN_SMEM(smem);
     hcp_bf16* sL = (hcp_bf16*)smem;              // [WG_BM][WG_LS]
     hcp_bf16* sR = sL + WG_BM * WG_LS;           // [WG_BM][WG_RS]
+    hcp_bf16* sL2 = sR + WG_BM * WG_RS;          // [WG_BM][WG_LS]: the residual half of a split L
+    const int lo = pr.lo;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q0 = qtile * WG_BQ;
     const int mb = split * rows_per_split;
@@ -47,9 +51,16 @@ HCP_DEVICE void wgrad_block(const WgradProb& pr, int M, int P, float scale, int 
             hcp_bf16x8 v = hcp_zero8();
             // only the 8-column pieces that hold this problem's rank slots [pcol0, pcol0 + P): a caller may hand in a column-offset view
             // of a 32-wide T / U (several LoRA blocks on one host), whose last pieces would otherwise run past the row
-            if (m0 + r < me && c + 8 > pcol0 && c < pcol0 + P) v = *(const hcp_bf16x8*)(L + (size_t)(m0 + r) * ldl + c);
+            const bool live = m0 + r < me && c + 8 > pcol0 && c < pcol0 + P;
+            if (live) v = *(const hcp_bf16x8*)(L + (size_t)(m0 + r) * ldl + c);
 #pragma unroll
             for (int i = 0; i < 8; ++i) sL[r * WG_LS + c + i] = (hcp_bf16)v[i];
+            if (lo) {
+                hcp_bf16x8 v2 = hcp_zero8();
+                if (live) v2 = *(const hcp_bf16x8*)(L + (size_t)(m0 + r) * ldl + lo + c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sL2[r * WG_LS + c + i] = (hcp_bf16)v2[i];
+            }
         }
         // stage R tile: 64 rows x 128 cols = 1024 chunks
 #pragma unroll
@@ -78,6 +89,16 @@ HCP_DEVICE void wgrad_block(const WgradProb& pr, int M, int P, float scale, int 
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = hcp_mfma16(fa[i], fb[j], acc[i][j]);
+            if (lo) {                                                      // (workgroup-uniform)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fa[i][e] = (short)sL2[(kb + e) * WG_LS + i * 16 + fr];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = hcp_mfma16(fa[i], fb[j], acc[i][j]);
+            }
         }
         HCP_SYNC();
     }
@@ -105,7 +126,7 @@ HCP_KERNEL(256) lora_wgrad_kernel(WgradProb pr0, WgradProb pr1, int M, int P, fl
 // One launch for the weight gradients of MANY LoRA layers (all 160 of an SD1.5 step): workgroup -> (layer, problem,
 // column tile, token split) through a prefix table.  144-byte descriptors, device array:
 struct WgradGroupDesc {
-    WgradProb down;        // grad_down[r,K] += s U^T x      (56 bytes each)
+    WgradProb down;        // grad_down[r,K] += s U^T x      (56 bytes each: {L, ldl, lo, R, ldr, pad, out, ldo, Q, transpose_out, pcol0})
     WgradProb up;          // grad_up[N,r]  += s dY^T T
     int M, P; float scale; int rows_per_split;
     int qt, splits;        // grid shape of this layer: qt column tiles x splits token ranges x 2 problems
@@ -139,7 +160,7 @@ struct LoraPackDesc {
     int K, N, r;
     float alpha;
     int slot0, n0, Ntot, bu_ld;   // placement inside a (possibly shared) operand image; images are zero-initialised once.
-                                  // bu_ld: row stride of `bu` in elements (0 = 32); adt / but may be null (image not wanted)
+                                  // bu_ld: row stride of `bu` in elements (0 = 32); ad / adt / but may be null (image not wanted)
 };
 
 HCP_KERNEL(256) lora_pack_kernel(const LoraPackDesc* descs) {
@@ -152,7 +173,7 @@ HCP_KERNEL(256) lora_pack_kernel(const LoraPackDesc* descs) {
         int k = k0 + kk;
         float w = d.w_down[(size_t)pp * d.K + k];
         if (d.adt) d.adt[(size_t)k * 32 + d.slot0 + pp] = hcp_f2bf(w * d.alpha);
-        d.ad[(size_t)(d.slot0 + pp) * d.K + k] = hcp_f2bf(w);
+        if (d.ad) d.ad[(size_t)(d.slot0 + pp) * d.K + k] = hcp_f2bf(w);
     }
     const int bu_ld = d.bu_ld ? d.bu_ld : 32;
     const int nper = (d.N + nchunk - 1) / nchunk, n0 = chunk * nper;
@@ -166,7 +187,35 @@ HCP_KERNEL(256) lora_pack_kernel(const LoraPackDesc* descs) {
     }
 }
 
+// fp32 [M, C] -> bf16 [M, 2C] = (hi | lo), hi = bf16(v), lo = bf16(v - hi): the split form of a T / U that was produced by a GEMM of
+// its own (lora.CtxBatch: every cross-attention layer's x W_down^T from one launch) instead of inside a fused-LoRA kernel.
+HCP_KERNEL(256) split_hi_lo_kernel(const float* src, hcp_bf16* dst, long M, int C) {
+    const int cv = C / 4;
+    const long total = M * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / cv; const int c = (int)(i - m * cv) * 4;
+        const hcp_f32x4 v = *(const hcp_f32x4*)(src + m * C + c);
+        hcp_bf16x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned short h = hcp_f2bf(v[q]);
+            hi[q] = (short)h; lo[q] = (short)hcp_f2bf(v[q] - hcp_bf2f(h));
+        }
+        *(hcp_bf16x4*)(dst + m * 2 * C + c) = hi;
+        *(hcp_bf16x4*)(dst + m * 2 * C + C + c) = lo;
+    }
+}
+
 }  // namespace
+
+// dst[M, 2C] (bf16) = (bf16(src) | bf16(src - bf16(src))) for src [M, C] fp32, C % 4 == 0: a rank-r LoRA intermediate (T = x W_down^T,
+// U = dY W_up; reference lora_base_patch.py:61-74 never rounds it) carried to 16 mantissa bits as two bf16 MFMA operands.
+HCP_API int hcp_split_hi_lo_bf16(const float* src, void* dst, long M, int C, hipStream_t stream) {
+    HCP_REQUIRE(src && dst && M > 0 && C > 0 && C % 4 == 0, "hcp_split_hi_lo_bf16: bad arguments (C %% 4 == 0)");
+    long g = (M * (C / 4) + 255) / 256; if (g > 2048) g = 2048;
+    HCP_LAUNCH(split_hi_lo_kernel, dim3((int)g), dim3(256), 0, stream, src, (hcp_bf16*)dst, M, C);
+    HCP_LAUNCH_CHECK("split_hi_lo");
+}
 
 static int wgrad_launch(const WgradProb& a, const WgradProb& b, int nprob, int M, int P, float scale, hipStream_t stream) {
     const int qmax = nprob == 2 && b.Q > a.Q ? b.Q : a.Q;
@@ -177,7 +226,7 @@ static int wgrad_launch(const WgradProb& a, const WgradProb& b, int nprob, int M
     if (splits < 1) splits = 1;
     int rows = hcp_cdiv(hcp_cdiv(M, splits), WG_BM) * WG_BM;
     splits = hcp_cdiv(M, rows);
-    size_t smem = (size_t)(WG_BM * WG_LS + WG_BM * WG_RS) * sizeof(hcp_bf16);
+    size_t smem = (size_t)(2 * WG_BM * WG_LS + WG_BM * WG_RS) * sizeof(hcp_bf16);
     HCP_LAUNCH(lora_wgrad_kernel, dim3(qt, splits, nprob), dim3(256), smem, stream, a, b, M, P, scale, rows);
     HCP_LAUNCH_CHECK("lora_wgrad");
 }
@@ -186,23 +235,27 @@ static int wgrad_launch(const WgradProb& a, const WgradProb& b, int nprob, int M
 //   [p, q] += scale * sum_m L[m,p] R[m,q],  L:[M,32] bf16 (ldl), R:[M,Q] bf16 (ldr), p < P <= 32.
 // dW_down: L = U = dY W_up, R = x, out = grad[r,K] (transpose_out=0, ldo=K)
 // dW_up  : L = T = x W_down^T, R = dY, out = grad[N,r] (transpose_out=1, ldo=r)
-HCP_API int hcp_lora_wgrad(const void* L, int ldl, const void* R, int ldr, float* out, int ldo, int M, int P, int Q,
+// l_lo: 0, or the column offset of L's residual half (a split T / U of hcp_gemm_lora_bf16, ldt = 64: l_lo = 32, ldl = 64).
+HCP_API int hcp_lora_wgrad(const void* L, int ldl, int l_lo, const void* R, int ldr, float* out, int ldo, int M, int P, int Q,
                            float scale, int transpose_out, hipStream_t stream) {
     HCP_REQUIRE(L && R && out && M > 0 && Q > 0, "hcp_lora_wgrad: bad arguments");
     HCP_REQUIRE(P > 0 && P <= 32 && ldl % 8 == 0 && ldl >= 32 && ldr % 8 == 0 && Q % 8 == 0, "hcp_lora_wgrad: P<=32, ldl>=32, 8-aligned leading dims required");
-    WgradProb a = {(const hcp_bf16*)L, ldl, (const hcp_bf16*)R, ldr, out, ldo, Q, transpose_out, 0};
+    HCP_REQUIRE(l_lo == 0 || (l_lo % 8 == 0 && l_lo >= 32 && ldl >= l_lo + 32), "hcp_lora_wgrad: l_lo (%d) must leave 32 columns inside ldl (%d)", l_lo, ldl);
+    WgradProb a = {(const hcp_bf16*)L, ldl, l_lo, (const hcp_bf16*)R, ldr, out, ldo, Q, transpose_out, 0};
     return wgrad_launch(a, a, 1, M, P, scale, stream);
 }
 
 // Both LoRA weight gradients of one layer in ONE launch:
 //   grad_down[r,K] += scale * U^T x   (U = dY W_up [M,32], x [M,K])
 //   grad_up  [N,r] += scale * dY^T T  (T = x W_down^T [M,32], dY [M,N])
-HCP_API int hcp_lora_wgrad_pair(const void* U, const void* x, int ldx, int K, float* grad_down, const void* T, const void* dY,
+// ldu / ldt: 32 (bf16 U / T) or 64 (split: hi | lo, as hcp_gemm_lora_bf16 writes them with ldt = 64).
+HCP_API int hcp_lora_wgrad_pair(const void* U, int ldu, const void* x, int ldx, int K, float* grad_down, const void* T, int ldt, const void* dY,
                                 int ldy, int N, float* grad_up, int M, int r, float scale, hipStream_t stream) {
     HCP_REQUIRE(U && x && grad_down && T && dY && grad_up && M > 0 && K > 0 && N > 0, "hcp_lora_wgrad_pair: bad arguments");
     HCP_REQUIRE(r > 0 && r <= 32 && ldx % 8 == 0 && ldy % 8 == 0 && K % 8 == 0 && N % 8 == 0, "hcp_lora_wgrad_pair: r<=32, 8-aligned dims required");
-    WgradProb a = {(const hcp_bf16*)U, 32, (const hcp_bf16*)x, ldx, grad_down, K, K, 0, 0};
-    WgradProb b = {(const hcp_bf16*)T, 32, (const hcp_bf16*)dY, ldy, grad_up, r, N, 1, 0};
+    HCP_REQUIRE((ldu == 32 || ldu == 64) && (ldt == 32 || ldt == 64), "hcp_lora_wgrad_pair: ldu (%d) / ldt (%d) are 32 or 64 (split)", ldu, ldt);
+    WgradProb a = {(const hcp_bf16*)U, ldu, ldu == 64 ? 32 : 0, (const hcp_bf16*)x, ldx, grad_down, K, K, 0, 0};
+    WgradProb b = {(const hcp_bf16*)T, ldt, ldt == 64 ? 32 : 0, (const hcp_bf16*)dY, ldy, grad_up, r, N, 1, 0};
     return wgrad_launch(a, b, 2, M, r, scale, stream);
 }
 
@@ -225,7 +278,7 @@ HCP_API int hcp_lora_wgrad_group_desc_bytes(void) { return (int)sizeof(WgradGrou
 // WgradGroupDesc above; host builders: hcp_diffusion_amd/ops.py), total_blocks = sum of the per-layer workgroup counts.
 HCP_API int hcp_lora_wgrad_grouped(const void* descs, int count, int total_blocks, hipStream_t stream) {
     HCP_REQUIRE(descs && count > 0 && total_blocks > 0, "hcp_lora_wgrad_grouped: bad arguments");
-    size_t smem = (size_t)(WG_BM * WG_LS + WG_BM * WG_RS) * sizeof(hcp_bf16);
+    size_t smem = (size_t)(2 * WG_BM * WG_LS + WG_BM * WG_RS) * sizeof(hcp_bf16);
     HCP_LAUNCH(lora_wgrad_grouped_kernel, dim3(total_blocks), dim3(256), smem, stream, (const WgradGroupDesc*)descs, count);
     HCP_LAUNCH_CHECK("lora_wgrad_grouped");
 }

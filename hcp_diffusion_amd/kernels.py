@@ -5,6 +5,7 @@ kernel on torch's *current* stream.  Nothing here computes with torch ops.
 """
 import ctypes
 import math
+import os
 import torch
 
 from . import _lib
@@ -99,8 +100,20 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, r
     return out
 
 
+# Split T: the fused-LoRA GEMMs hand the rank-r intermediate T = x W_down^T (forward) / U = dY W_up (backward) on as
+# TWO bf16 images, hi = bf16(T) and lo = bf16(T - hi) — [M, 64] = (hi | lo) — instead of one rounded copy; the K-extension and the
+# weight-gradient kernel consume both.  False restores the bf16-rounded [M, 32] T (lab A/B: HCP_LAB_NO_T_SPLIT=1).
+T_SPLIT = os.environ.get("HCP_LAB_NO_T_SPLIT") != "1"
+
+
+def t_lo(t):
+    """Column offset of the residual half of a T / U that came out of gemm_lora / gemm_geglu_bwd (0: bf16-rounded T only)."""
+    return 32 if (t is not None and T_SPLIT and t.shape[1] == 64 and t.stride(0) == 64) else 0
+
+
 def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True):
-    """(D, T): T[M,32] = a @ l[32,K]^T (bf16);  D[M,N] = a @ b[N,K]^T + T @ e[N,32]^T + bias + residual — one launch."""
+    """(D, T): T = a @ l[32,K]^T;  D[M,N] = a @ b[N,K]^T + T @ e[N,32]^T + bias + residual — one launch.
+    T_SPLIT: T [M,64] = (bf16(T) | bf16(T - bf16(T))) and the product takes both halves; else T [M,32] rounded to bf16."""
     _bf16_2d(a, "a"); _bf16_2d(b, "b"); _bf16_2d(l, "l"); _bf16_2d(e, "e")
     M, Kd = a.shape
     N = b.shape[0]
@@ -108,13 +121,14 @@ def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True):
     if TRACE is not None:
         TRACE.append(("lora", M, N, Kd))
     out = torch.empty((M, N), dtype=BF16, device=a.device)
-    t = torch.empty((M, 32), dtype=BF16, device=a.device) if want_t else None
+    ldt = 64 if T_SPLIT else 32
+    t = torch.empty((M, ldt), dtype=BF16, device=a.device) if want_t else None
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     if residual is not None:
         _bf16_2d(residual, "residual"); assert residual.shape == (M, N)
     ws = _workspace(a)
-    _chk(lib().hcp_gemm_lora_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(l), _p(e), _p(t), _p(out), N, M, N, Kd, _p(bias),
+    _chk(lib().hcp_gemm_lora_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(l), _p(e), _p(t), ldt, _p(out), N, M, N, Kd, _p(bias),
                                   _p(residual), residual.stride(0) if residual is not None else 0, _p(ws), ws.numel(), _stream(a)),
          "hcp_gemm_lora_bf16")
     return out, t
@@ -134,9 +148,9 @@ def gemm_geglu_bwd(dy, wt, hg, *, l=None, e=None, want_t=True):
     if l is not None:
         _bf16_2d(l, "l"); _bf16_2d(e, "e")
         assert l.shape == (32, C) and e.shape == (Fd, 32) and l.is_contiguous() and e.is_contiguous()
-        u = torch.empty((M, 32), dtype=BF16, device=dy.device) if want_t else None
+        u = torch.empty((M, 64 if T_SPLIT else 32), dtype=BF16, device=dy.device) if want_t else None
     ws = _workspace(dy)
-    _chk(lib().hcp_gemm_geglu_bwd_bf16(_p(dy), dy.stride(0), _p(wt), wt.stride(0), _p(l), _p(e), _p(u), _p(hg), _p(dhg), M, Fd, C,
+    _chk(lib().hcp_gemm_geglu_bwd_bf16(_p(dy), dy.stride(0), _p(wt), wt.stride(0), _p(l), _p(e), _p(u), 64 if T_SPLIT else 32, _p(hg), _p(dhg), M, Fd, C,
                                        _p(ws), ws.numel(), _stream(dy)), "hcp_gemm_geglu_bwd_bf16")
     return dhg, u
 
@@ -541,16 +555,26 @@ def mse_masked_mean(pred, target, mask=None, weight=1.0, want_grad=True, sample_
     return loss, grad
 
 
-def lora_wgrad(L, R, out, P, scale, transpose_out, out_col0=0):
+def split_hi_lo(src):
+    """fp32 [M, C] -> bf16 [M, 2C] = (bf16(src) | bf16(src - bf16(src))): the split form of a rank-r intermediate (T_SPLIT)."""
+    assert src.dtype == torch.float32 and src.dim() == 2 and src.is_contiguous() and src.shape[1] % 4 == 0
+    M, C = src.shape
+    dst = torch.empty((M, 2 * C), dtype=BF16, device=src.device)
+    _chk(lib().hcp_split_hi_lo_bf16(_p(src), _p(dst), M, C, _stream(src)), "hcp_split_hi_lo_bf16")
+    return dst
+
+
+def lora_wgrad(L, R, out, P, scale, transpose_out, out_col0=0, lo=0):
     """out (fp32, atomically accumulated) += scale * L[:, :P]^T @ R ; transpose_out writes out[q, out_col0 + p]
-    (out_col0: first rank column of a 32-wide block when the rank exceeds one slot group)."""
+    (out_col0: first rank column of a 32-wide block when the rank exceeds one slot group).  lo: column offset of the residual half of a
+    split L (t_lo(L)), 0 = none."""
     _bf16_2d(L, "L"); _bf16_2d(R, "R")
     M, Q = R.shape
     assert L.shape[0] == M and out.dtype == torch.float32 and out.is_contiguous()
     assert out_col0 == 0 or transpose_out
     ldo = out.shape[1]
     ptr = ctypes.c_void_p(out.data_ptr() + 4 * out_col0)
-    _chk(lib().hcp_lora_wgrad(_p(L), L.stride(0), _p(R), R.stride(0), ptr, ldo, M, P, Q, float(scale),
+    _chk(lib().hcp_lora_wgrad(_p(L), L.stride(0), int(lo), _p(R), R.stride(0), ptr, ldo, M, P, Q, float(scale),
                               1 if transpose_out else 0, _stream(L)), "hcp_lora_wgrad")
 
 
@@ -558,15 +582,16 @@ def lora_wgrad_pair(U, x, grad_down, T, dy, grad_up, r, scale):
     _bf16_2d(U, "U"); _bf16_2d(x, "x"); _bf16_2d(T, "T"); _bf16_2d(dy, "dy")
     M, Kd = x.shape
     N = dy.shape[1]
-    assert U.shape == (M, 32) and T.shape == (M, 32) and U.is_contiguous() and T.is_contiguous()
+    assert U.shape in ((M, 32), (M, 64)) and T.shape in ((M, 32), (M, 64)) and U.is_contiguous() and T.is_contiguous()      # 64: split (hi | lo)
     assert grad_down.shape == (r, Kd) and grad_up.shape == (N, r) and grad_down.is_contiguous() and grad_up.is_contiguous()
-    _chk(lib().hcp_lora_wgrad_pair(_p(U), _p(x), x.stride(0), Kd, _p(grad_down), _p(T), _p(dy), dy.stride(0), N, _p(grad_up), M, r,
-                                   float(scale), _stream(x)), "hcp_lora_wgrad_pair")
+    _chk(lib().hcp_lora_wgrad_pair(_p(U), U.shape[1], _p(x), x.stride(0), Kd, _p(grad_down), _p(T), T.shape[1], _p(dy), dy.stride(0), N,
+                                   _p(grad_up), M, r, float(scale), _stream(x)), "hcp_lora_wgrad_pair")
 
 
 def lora_wgrad_grouped(items):
-    """items: list of (U, x, grad_down, T, dy, grad_up, r, scale[, slot0]) — every layer's LoRA weight gradients, ONE launch.
-    dy, U and T may be column-slice views (row stride = their stride(0)); slot0 = first rank column of the layer in U / T."""
+    """items: list of (U, x, grad_down, T, dy, grad_up, r, scale[, slot0[, u_lo, t_lo]]) — every layer's LoRA weight gradients, ONE launch.
+    dy, U and T may be column-slice views (row stride = their stride(0)); slot0 = first rank column of the layer in U / T;
+    u_lo / t_lo = column offset of the residual half of a split U / T (t_lo(.)), 0 = none."""
     import struct
     L = lib()
     assert L.hcp_lora_wgrad_group_desc_bytes() == 144
@@ -576,12 +601,13 @@ def lora_wgrad_grouped(items):
     for item in items:
         (U, x, gd, T, dy, gu, r, scale) = item[:8]
         slot0 = item[8] if len(item) > 8 else 0          # first rank column of this layer inside U / T (fused groups)
+        ulo, tlo = (item[9], item[10]) if len(item) > 10 else (0, 0)
         M, Kd = x.shape
         N = dy.shape[1]
         nb = L.hcp_lora_wgrad_group_geometry(M, Kd, N, ctypes.byref(qt), ctypes.byref(sp), ctypes.byref(rows))
         assert U.stride(1) == 1 and T.stride(1) == 1 and U.stride(0) % 8 == 0 and T.stride(0) % 8 == 0
-        buf += struct.pack("<Qi4xQi4xQiiii", U.data_ptr(), U.stride(0), x.data_ptr(), x.stride(0), gd.data_ptr(), Kd, Kd, 0, slot0)
-        buf += struct.pack("<Qi4xQi4xQiiii", T.data_ptr(), T.stride(0), dy.data_ptr(), dy.stride(0), gu.data_ptr(), r, N, 1, slot0)
+        buf += struct.pack("<QiiQi4xQiiii", U.data_ptr(), U.stride(0), ulo, x.data_ptr(), x.stride(0), gd.data_ptr(), Kd, Kd, 0, slot0)
+        buf += struct.pack("<QiiQi4xQiiii", T.data_ptr(), T.stride(0), tlo, dy.data_ptr(), dy.stride(0), gu.data_ptr(), r, N, 1, slot0)
         buf += struct.pack("<iifiiiii", M, r, float(scale), rows.value, qt.value, sp.value, begin, 0)
         begin += nb
     dev = items[0][1].device

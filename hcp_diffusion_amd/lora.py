@@ -316,9 +316,12 @@ class CtxBatch:
         self.bucket = buckets[0] if buckets else None
         assert all(b is self.bucket for b in buckets), "one LoRA bucket per model"
         self.k2 = RANK_SLOT * len(self.groups) if self.bucket is not None else 0
+        # split T (kernels.T_SPLIT): T_all travels as (hi | lo) — 2 * k2 extension columns against [BU | BU]
+        self.split = bool(K.T_SPLIT and self.k2)
+        self.kext = self.k2 * (2 if self.split else 1)
         dev = self.groups[0].hosts[0].weight.device
         self.ad_all = torch.zeros(max(self.k2, 1), self.k, dtype=BF16, device=dev) if self.k2 else None
-        self.b_cat = torch.zeros(self.n_total, self.k + self.k2, dtype=BF16, device=dev)       # [W_all | BU]: padding stays zero forever
+        self.b_cat = torch.zeros(self.n_total, self.k + self.kext, dtype=BF16, device=dev)     # [W_all | BU (| BU)]: padding stays zero forever
         # backward: U_all = dY_all BUT^T, every layer's dY W_up in ONE deep-K GEMM (block-diagonal again)
         self.but_all = torch.zeros(max(self.k2, 1), self.n_total, dtype=BF16, device=dev) if self.k2 else None
         self._host_key = None
@@ -503,8 +506,13 @@ class LoraBucket:
                                                 batch.ad_all.data_ptr() + 2 * RANK_SLOT * gi * k, 0,
                                                 batch.b_cat.data_ptr() + 2 * (batch.k + RANK_SLOT * gi),
                                                 batch.but_all.data_ptr() + 2 * RANK_SLOT * gi * batch.n_total, k, n_out, r, b.alpha_f * c,
-                                                s0, goff + n0, batch.n_total, batch.k + batch.k2)
+                                                s0, goff + n0, batch.n_total, batch.k + batch.kext)
                 self._desc_count += 1
+                if batch.split:                            # the second copy of alpha W_up, against the residual half of T_all
+                    self._desc_bytes += struct.pack("<6Q3if4i", b.layer.W_down.data_ptr(), b.layer.W_up.data_ptr(), 0, 0,
+                                                    batch.b_cat.data_ptr() + 2 * (batch.k + batch.k2 + RANK_SLOT * gi), 0, k, n_out, r,
+                                                    b.alpha_f * c, s0, goff + n0, batch.n_total, batch.k + batch.kext)
+                    self._desc_count += 1
         self._images += [batch.b_cat, batch.but_all]
         self._upload_descs()
         self.pack()

@@ -35,12 +35,14 @@ class WgradContext:
         self.items, self.keep = [], []            # grouped: pending operands / what the last grouped launch keeps alive (hipGraph replays)
         self.stream, self.side_keep = None, []
 
-    def add(self, U, x2, gd, T, dy2, gu, rank, alpha, slot0=0):
+    def add(self, U, x2, gd, T, dy2, gu, rank, alpha, slot0=0, ulo=0, tlo=0):
+        """ulo / tlo: column offset of the residual half of a split U / T (K.t_lo: the fused-LoRA GEMMs' [M, 64] = (hi | lo)), 0 = none."""
         if self.grouped:
-            self.items.append((U, x2, gd, T, dy2, gu, rank, alpha, slot0))
+            self.items.append((U, x2, gd, T, dy2, gu, rank, alpha, slot0, ulo, tlo))
             return
-        if slot0 != 0 or not dy2.is_contiguous():     # member of a fused group: the grouped entry point handles slots / strides
-            self.keep = [K.lora_wgrad_grouped([(U, x2, gd, T, dy2, gu, rank, alpha, slot0)])]
+        if slot0 != 0 or not dy2.is_contiguous() or (ulo != 0) != (U.shape[1] == 64) or (tlo != 0) != (T.shape[1] == 64):
+            # member of a fused group (or mixed formats): the grouped entry point handles slots / strides
+            self.keep = [K.lora_wgrad_grouped([(U, x2, gd, T, dy2, gu, rank, alpha, slot0, ulo, tlo)])]
             return
         if not (self.side and x2.is_cuda):
             K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
@@ -167,7 +169,7 @@ class _LinearFn(torch.autograd.Function):
                 U = K.gemm(dy2, lp.but)
             for blk, s0 in lora.members():             # one block, or several sharing the 32 rank slots (lora.MultiLora)
                 gd, gu = blk.grad_views()
-                ctx.wg.add(U, x2, gd, T, dy2, gu, blk.rank, blk.alpha_f, s0)
+                ctx.wg.add(U, x2, gd, T, dy2, gu, blk.rank, blk.alpha_f, s0, K.t_lo(U), K.t_lo(T))
         elif ctx.needs_input_grad[0]:
             dx = K.gemm(dy2, pk.wt)
         if ctx.train_w:                                # dW[N,K] += dY^T X (nn.Linear [N,K]; 1x1 conv [N,K,1,1] = same memory)
@@ -228,7 +230,7 @@ class _LinearGroupFn(torch.autograd.Function):
             for blk, n0, s0, host, sc_ in zip(g.blocks, g.n_off, g.slot_off, g.hosts, g.out_scale):
                 if blk is not None:
                     gd, gu = blk.grad_views()
-                    ctx.wg.add(U, x2, gd, T, dy2[:, n0:n0 + host.weight.shape[0]], gu, blk.rank, blk.alpha_f * sc_, s0)
+                    ctx.wg.add(U, x2, gd, T, dy2[:, n0:n0 + host.weight.shape[0]], gu, blk.rank, blk.alpha_f * sc_, s0, K.t_lo(U), K.t_lo(T))
         elif ctx.needs_input_grad[0]:
             dx = K.gemm(dy2, wt)
         if dx is not None:
@@ -247,7 +249,10 @@ class _CtxKVFn(torch.autograd.Function):
         x2 = x.reshape(-1, shp[-1])
         ad_all, b_cat = batch.operands()
         T_all = None
-        if ad_all is not None:
+        if ad_all is not None and batch.split:
+            T_all = K.split_hi_lo(K.gemm(x2, ad_all, out_f32=True))  # [M, 2 * 32 G] = (hi | lo) of every layer's x W_down^T (fp32 accumulator)
+            y = K.gemm(K.concat_channels(x2, T_all), b_cat)          # [M, sum N_g]; b_cat = [W_all | BU | BU]
+        elif ad_all is not None:
             T_all = K.gemm(x2, ad_all)                               # [M, 32 G]: every layer's x W_down^T
             y = K.gemm(K.concat_channels(x2, T_all), b_cat)          # [M, sum N_g]
         else:
@@ -274,7 +279,7 @@ class _CtxKVFn(torch.autograd.Function):
         U_all = None
         if joint:                                                     # every layer's U = dY W_up in ONE deep-K GEMM (block-diagonal operand)
             batch.operands()
-            U_all = K.gemm(dall, batch.but_all)                       # [M, 32 G]
+            U_all = K.split_hi_lo(K.gemm(dall, batch.but_all, out_f32=True)) if batch.split else K.gemm(dall, batch.but_all)   # [M, 32 G] (x 2: hi | lo)
         for gi, (g, off, d) in enumerate(zip(batch.groups, batch.n_off, dkvs)):
             if d is None or not g.has_lora:
                 continue
@@ -284,7 +289,8 @@ class _CtxKVFn(torch.autograd.Function):
             for blk, n0, s0, host, sc_ in zip(g.blocks, g.n_off, g.slot_off, g.hosts, g.out_scale):
                 if blk is not None:
                     gd, gu = blk.grad_views()
-                    ctx.wg.add(U, x2, gd, T, sl[:, n0:n0 + host.weight.shape[0]], gu, blk.rank, blk.alpha_f * sc_, s0)
+                    ctx.wg.add(U, x2, gd, T, sl[:, n0:n0 + host.weight.shape[0]], gu, blk.rank, blk.alpha_f * sc_, s0,
+                               batch.k2 if (joint and batch.split) else 0, batch.k2 if batch.split else 0)
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
@@ -559,7 +565,7 @@ class _GegluLinearFn(torch.autograd.Function):
                 U = K.gemm(dy2, lp.but)
             for blk, s0 in lora.members():
                 gd, gu = blk.grad_views()
-                ctx.wg.add(U, x2, gd, T, dy2, gu, blk.rank, blk.alpha_f, s0)
+                ctx.wg.add(U, x2, gd, T, dy2, gu, blk.rank, blk.alpha_f, s0, K.t_lo(U), K.t_lo(T))
         elif ctx.needs_input_grad[0]:
             dhg, _ = K.gemm_geglu_bwd(dy2, pk.wt, hg2)
         if ctx.train_w:

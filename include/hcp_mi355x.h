@@ -37,16 +37,20 @@ int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int l
 /* Fused LoRA linear, forward and input-gradient: T = A L^T (rank slot 32, written to Tout if non-NULL),
  * D = A B^T + T E^T + bias + residual in ONE launch (the block accumulates its T tile from the A tiles it streams);
  * deep-K / small-M shapes run as two launches (T GEMM, then split-K K-extension GEMM) and then require Tout.
+ * ldt = 32: T is rounded to bf16 (Tout [M,32]).  ldt = 64: "split" T — the fp32 accumulator leaves as T_hi = bf16(T) and
+ * T_lo = bf16(T - T_hi), the product takes both (D += T_hi E^T + T_lo E^T) and Tout [M,64] = (T_hi | T_lo) for hcp_lora_wgrad*:
+ * the rank-r intermediate keeps 16 mantissa bits, as the reference's merged-weight form never rounds it at all
+ * (the two-launch form keeps the rounded T and zeroes the residual half).
  * Replaces LoraPatchContainer.forward's weight merge + mm (lora_base_patch.py:20-35,61-74). */
-int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, void* D,
+int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, int ldt, void* D,
                        int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, void* workspace,
                        size_t workspace_bytes, hcpStream_t stream);
 /* FF-out input-gradient with the GEGLU backward in its epilogue: dY_ff = A B^T (+ the LoRA side path as hcp_gemm_lora_bf16's backward
  * form: L = W_up^T, E = alpha W_down^T, Tout = dY W_up; L = E = NULL for a plain host) is never written; with (h | g) = HG[M, 2F] saved
  * by the forward, DHG[m, n] = dY_ff gelu(g), DHG[m, F + n] = dY_ff h gelu'(g).  Replaces the dX GEMM of FeedForward.net[2] + the
  * GEGLU backward pass (diffusers GEGLU in BasicTransformerBlock.ff, reference cfgs/unet_struct.txt:27-33 / autograd of F.gelu). */
-int hcp_gemm_geglu_bwd_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, const void* HG,
-                            void* DHG, int M, int F, int K, void* workspace, size_t workspace_bytes, hcpStream_t stream);
+int hcp_gemm_geglu_bwd_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, int ldt,
+                            const void* HG, void* DHG, int M, int F, int K, void* workspace, size_t workspace_bytes, hcpStream_t stream);
 /* fp32 split-K scratch (optional: workspace may be NULL, then small-M problems run unsplit). */
 size_t hcp_gemm_workspace_bytes(int M, int N);
 
@@ -170,11 +174,15 @@ int hcp_mse_masked_mean(const float* pred, const float* target, const float* mas
 
 /* out[p,q] (+)= scale * sum_m L[m,p] R[m,q]  (fp32 atomics): the rank-r LoRA weight gradients
  * dW_down = alpha (dY W_up)^T x, dW_up = alpha dY^T (x W_down^T) (autograd of lora_base_patch.py:61-74). */
-int hcp_lora_wgrad(const void* L, int ldl, const void* R, int ldr, float* out, int ldo, int M, int P, int Q, float scale,
+/* l_lo: 0, or the column offset of the residual half of a split L = (L_hi | L_lo) (hcp_gemm_lora_bf16 with ldt = 64: l_lo = 32): the
+ * product is then (L_hi + L_lo)^T R. */
+int hcp_lora_wgrad(const void* L, int ldl, int l_lo, const void* R, int ldr, float* out, int ldo, int M, int P, int Q, float scale,
                    int transpose_out, hcpStream_t stream);
-/* both gradients of one LoRA layer in one launch: grad_down[r,K] += s U^T x ; grad_up[N,r] += s dY^T T */
-int hcp_lora_wgrad_pair(const void* U, const void* x, int ldx, int K, float* grad_down, const void* T, const void* dY, int ldy,
-                        int N, float* grad_up, int M, int r, float scale, hcpStream_t stream);
+/* both gradients of one LoRA layer in one launch: grad_down[r,K] += s U^T x ; grad_up[N,r] += s dY^T T  (ldu / ldt: 32, or 64 = split) */
+int hcp_lora_wgrad_pair(const void* U, int ldu, const void* x, int ldx, int K, float* grad_down, const void* T, int ldt, const void* dY,
+                        int ldy, int N, float* grad_up, int M, int r, float scale, hcpStream_t stream);
+/* dst[M,2C] bf16 = (bf16(src) | bf16(src - bf16(src))), src [M,C] fp32: the split form of a T / U produced by a GEMM of its own */
+int hcp_split_hi_lo_bf16(const float* src, void* dst, long M, int C, hcpStream_t stream);
 /* the weight gradients of MANY LoRA layers in one launch (descriptor layout: csrc/lora.hip WgradGroupDesc, 144 B) */
 int hcp_lora_wgrad_group_geometry(int M, int K, int N, int* qt, int* splits, int* rows_per_split);
 int hcp_lora_wgrad_group_desc_bytes(void);

@@ -74,8 +74,8 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
     N = None
     bad = {
         "hcp_conv3x3_bf16": (N, 8, N, 0, 1, 4, 4, 4, 4, 0, 1, 0, 1, N, 8, N, 8, N, N, 0, N, 0, 0, N, N, N, 0, N),
-        "hcp_gemm_lora_bf16": (N, 8, N, 8, N, N, N, N, 8, 8, 8, 8, N, N, 0, N, 0, N),
-        "hcp_gemm_geglu_bwd_bf16": (N, 8, N, 8, N, N, N, N, N, 8, 8, 8, N, 0, N),
+        "hcp_gemm_lora_bf16": (N, 8, N, 8, N, N, N, 32, N, 8, 8, 8, 8, N, N, 0, N, 0, N),
+        "hcp_gemm_geglu_bwd_bf16": (N, 8, N, 8, N, N, N, 32, N, N, 8, 8, 8, N, 0, N),
         "hcp_attention_fwd": (N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, 0, N),
         "hcp_attention_bwd": (N, N, N, N, N, N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, 0, N, 0, N),
         "hcp_groupnorm_silu_fwd": (N, N, N, N, N, N, 1, 16, 30, 32, 1e-5, 1, N),          # C % G != 0
@@ -87,7 +87,7 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
         "hcp_wgrad_conv3x3_bf16": (N, 8, N, 8, N, 0, N, 8, 1, 4, 4, 4, 4, 8, 1, 0, N, 0, N),
         "hcp_colsum_bf16": (N, 8, N, 8, 8, 8, 8, N),
         "hcp_pack_weights": (N, 0, 0, N),
-        "hcp_lora_wgrad": (N, 8, N, 8, N, 8, 8, 40, 8, 1.0, 0, N),                           # P > 32
+        "hcp_lora_wgrad": (N, 8, 0, N, 8, N, 8, 8, 40, 8, 1.0, 0, N),                           # P > 32
         "hcp_sumsq_f32": (N, 0, N, N),
         "hcp_adamw_clip_fused": (N, N, N, N, 0, N, 0.9, 0.999, 1e-8, 0.0, N, 1.0, 1.0, N, N),
         "hcp_ema_update": (N, N, 0, N, 1.0, 0.6, 0.99, N),

@@ -357,6 +357,73 @@ def test_sd15_full_size_batch4_blocks_and_full_lora_gradient_vs_golden():
     assert cos > 0.999 and abs(flat.norm().item() - g["grad_norm"]) / g["grad_norm"] < 2e-2
 
 
+def _per_block_errors(ora, nat, to_dev, xt, t, ehs, **fwd_kw):
+    """TRUE per-block errors (SURVEY.md §8c "rel-L2 <= 1e-2 per block"): every down / mid / up block of the NATIVE model is fed the
+    ORACLE's input of that block — hidden state and, for the up blocks, the skip tensors (forward pre-hooks swap them in during ONE
+    native forward; the time embedding and prompt states stay the native model's own: they are not block outputs) — and its output
+    is compared with the oracle block's output on the same input.  Nothing accumulates from block to block."""
+    names = ([f"down_blocks.{i}" for i in range(len(ora.down_blocks))] + ["mid_block"] + [f"up_blocks.{i}" for i in range(len(ora.up_blocks))])
+    o_mod, n_mod = dict(ora.named_modules()), dict(nat.named_modules())
+    rec, got, hooks = {}, {}, []
+    for nm in names:
+        hooks.append(o_mod[nm].register_forward_hook(lambda m, a, out, nm=nm: rec.__setitem__(nm, (a, out))))
+    with torch.no_grad():
+        ora(xt, t, ehs, **fwd_kw)
+    for h in hooks:
+        h.remove()
+    nhwc = lambda y: to_dev(y.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16))
+    hooks = []
+    for nm in names:
+        def pre(mod, args, nm=nm):
+            a = rec[nm][0]
+            if nm.startswith("up_blocks"):                       # (h, skips, temb, ctx)
+                return (nhwc(a[0]), tuple(nhwc(s) for s in a[1])) + tuple(args[2:])
+            return (nhwc(a[0]),) + tuple(args[1:])               # (h, temb, ctx)
+        hooks.append(n_mod[nm].register_forward_pre_hook(pre))
+        hooks.append(n_mod[nm].register_forward_hook(lambda m, a, out, nm=nm: got.__setitem__(nm, out[0] if isinstance(out, tuple) else out)))
+    with torch.no_grad():
+        nat(to_dev(xt), to_dev(t), to_dev(ehs), **{k: ({kk: to_dev(vv) for kk, vv in v.items()} if isinstance(v, dict) else to_dev(v)) for k, v in fwd_kw.items()})
+    for h in hooks:
+        h.remove()
+    errs = {}
+    for nm in names:
+        ref = rec[nm][1][0] if isinstance(rec[nm][1], tuple) else rec[nm][1]
+        y = got[nm].permute(0, 3, 1, 2).float().cpu()
+        errs[nm] = ((y - ref).norm() / ref.norm()).item()
+    return errs
+
+
+def test_per_block_error_tiny(backend):
+    """The per-block harness on the interpreter (TINY config): oracle block input -> native block, <= 1e-2 per block."""
+    ora, nat = _pair(TINY_CONFIG, backend.device)
+    g = torch.load(os.path.join(GOLD, "tiny_unet_oracle.pt"))
+    xt = add_noise(g["x0"], g["noise"], g["t"], ddpm_alphas_cumprod())
+    errs = _per_block_errors(ora, nat, backend.to, xt, g["t"], g["ehs"])
+    assert len(errs) == len(ora.down_blocks) + 1 + len(ora.up_blocks) and max(errs.values()) < 1e-2, errs
+
+
+@pytest.mark.gpu
+def test_sd15_full_size_batch4_true_per_block_error():
+    """SURVEY.md §8(c) says rel-L2 <= 1e-2 PER BLOCK; the golden-fixture test above can only bound the CUMULATIVE error
+    (its fixtures hold samples of the oracle's boundaries, not the 21 MB tensors a block would need as input).  Here the fp32 oracle
+    itself runs on the host cores (full SD1.5, B = 4, 64x64 latents, the benchmark shape, timesteps 10/250/500/999) and every native
+    block gets the oracle's input of that block: nine blocks, each <= 1e-2 on its own."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle.make_golden import sd15_b4_inputs
+    K._set_backend_for_tests(None)
+    dev = torch.device("cuda:0")
+    ora = seeded_init_(OracleUNet2DConditionModel(), 1)
+    with torch.device("meta"):
+        nat = NativeUNet2DConditionModel()
+    nat = seeded_init_(nat.to_empty(device=dev), 1)
+    x0, ehs, noise, t = sd15_b4_inputs()
+    xt = add_noise(x0, noise, t, ddpm_alphas_cumprod())
+    errs = _per_block_errors(ora, nat, lambda v: v.to(dev), xt, t, ehs)
+    print("[b4 per-block rel-L2] " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert len(errs) == 9 and max(errs.values()) < 1e-2, errs
+
+
 @pytest.mark.gpu
 def test_sdxl_full_size_forward_and_lora_grads_vs_golden():
     """Full SDXL-base architecture (2.567 B params, seeded init), batch 1, 64x64 latents, 77x2048 context + text_time
