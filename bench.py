@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--no-ckpt-line", action="store_true", help="skip the secondary grad-ckpt-on measurement (profiling runs)")
     ap.add_argument("--overlap", action="store_true", help="LoRA wgrad kernels on a side stream (measured slower)")
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="one wgrad launch per layer instead of one grouped launch")
+    ap.add_argument("--wgrad-chunk", type=int, default=int(os.environ.get("HCP_WGRAD_CHUNK", "0")),
+                    help="cut the grouped LoRA weight-gradient launch into pieces of this many layers, launched on a parallel branch as "
+                         "backward produces their operands (0 = one launch at the end of backward)")
     ap.add_argument("--grad-ckpt", action="store_true", help="enable_gradient_checkpointing() as the reference defaults to "
                     "(train_base.yaml:69): +1 forward per step; a secondary line, the headline runs without (288 GB HBM)")
     ap.add_argument("--seam", action="store_true", help="secondary line: time the step the way the REFERENCE's Trainer drives the native "
@@ -290,6 +293,7 @@ def main():
     if args.grad_ckpt:
         unet.enable_gradient_checkpointing()
     plugin_input = None
+    frozen_te_leg = False
     xkw = dict(overlap_exchange=args.exchange != "plain", **(dict(grad_wire="bf16", param_wire="bf16") if args.exchange == "overlap-bf16" else {}))
     if os.environ.get("HCP_BENCH_FORCE_SHARD") == "1" and world == 1:      # lab: the sharded machinery's own cost (casts, chunked launches,
         xkw["shard_optimizer"] = "force"                                   # side-stream branch) on one GPU, collectives = copies
@@ -310,13 +314,14 @@ def main():
     else:
         text_encoder = None
         frozen_te_leg = (args.workload == "sd15" and world == 1 and not emu and not args.no_ckpt_line and not args.no_graph and not args.seam)
-        if te or frozen_te_leg:                    # CLIP-L text encoder (cfgs/te_struct.txt), random init; sd15te: + lora_text_encoder rank 4 lr 1e-5
+
+        def build_clip():                          # CLIP-L text encoder (cfgs/te_struct.txt), random init
             from hcp_diffusion_amd.text_encoder import NativeCLIPTextModel
             with torch.device("meta"):
-                text_encoder = NativeCLIPTextModel()
-            text_encoder = text_encoder.to_empty(device=dev)
+                enc = NativeCLIPTextModel()
+            enc = enc.to_empty(device=dev)
             with torch.no_grad():
-                for name, p in text_encoder.named_parameters():
+                for name, p in enc.named_parameters():
                     if "embedding" in name:
                         p.normal_(0, 0.02)
                     elif p.dim() > 1:
@@ -325,9 +330,12 @@ def main():
                         p.fill_(1.0)
                     else:
                         p.zero_()
+            return enc
+        if te:                                     # sd15te: + lora_text_encoder rank 4 lr 1e-5 (the frozen-TE secondary leg of the headline
+            text_encoder = build_clip()            # builds its encoder AFTER the headline loop: the timed process is the one of rounds 1-4)
         tr = NativeTrainer(unet, [dict(layers=LORA_PATTERNS, rank=args.rank_lora, lr=1e-4)], lr=1e-4, weight_decay=1e-3,
                            scale_lr_factor=args.batch * world, use_graph=not args.no_graph, overlap_wgrad=args.overlap,
-                           grouped_wgrad=not args.no_grouped_wgrad, text_encoder=text_encoder,
+                           grouped_wgrad=not args.no_grouped_wgrad, wgrad_chunk_layers=args.wgrad_chunk, text_encoder=text_encoder,
                            lora_te_cfg=[dict(layers=[r"re:.*self_attn$", r"re:.*mlp$"], rank=4, lr=1e-5)] if te else None, comm=comm)
         torch.manual_seed(114514 + rank)           # set_seed(seed + local_rank), train_ac.py:128
         buckets = [tr.bucket] + ([tr.te_bucket] if te else [])
@@ -475,7 +483,8 @@ def main():
                                    "steps": k2, "note": "same workload with enable_gradient_checkpointing() (+1 forward per step)"}
             unet.disable_gradient_checkpointing()
             tr._graph_cache.clear()
-        if world == 1 and args.workload == "sd15" and tr.text_encoder is not None and not args.grad_ckpt:
+        if world == 1 and args.workload == "sd15" and frozen_te_leg and not args.grad_ckpt:
+            tr.text_encoder = build_clip().requires_grad_(False).eval()       # frozen: no TE LoRA, NativeTrainer only calls it under no_grad
             # What TEUnetWrapper.forward does EVERY step (models/wrapper.py:14-30): the FROZEN text encoder runs inside the step on the
             # batch's prompt ids; the headline feeds pre-computed states (north_star scopes the path to the UNet + LoRA).  Same trainer,
             # same LoRA, no TE LoRA: the batch carries prompt_ids instead of encoder_hidden_states (its own captured graph).

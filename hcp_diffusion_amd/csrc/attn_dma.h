@@ -136,42 +136,12 @@ constexpr int VAR_PRE = 512;      // forward: Q arrives pre-multiplied by scale*
 constexpr int VAR_LSUM = 2048;    // forward: lazy rescale from the ROW SUMS instead of a per-score maximum (exact fallback on exp2 overflow)
 constexpr int VAR_PRODUCT = VAR_XCD | VAR_ONES | VAR_RAW;
 
-#if defined(HCP_EMU)
-#define HCP_WAVES_PER_SIMD(n)
-#else
-#define HCP_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
-#endif
 
 template <int D, int QT> constexpr int fwd_waves() { return D > 80 ? 2 : (QT == 2 ? (D == 40 ? 4 : 3) : 4); }   // per SIMD
 template <bool V> struct BoolC { static constexpr bool value = V; };
 template <int V> struct IntC { static constexpr int value = V; };
 
-// Maximum of a lane's 16 scores.  ONE asm statement: fmaxf() on MFMA results makes hipcc canonicalise every operand first
-// (v_max x, x: +16 VALU per 16 scores), and a bare asm v_max3 reading an MFMA result is a hazard hipcc does not pad (guide §5.7
-// item 2: XDL write -> VALU read needs wait states; the stale read showed up on hardware as spurious rescales).  The leading
-// s_nop's cover the longest case once per 16 scores; VALU -> VALU dependencies inside are interlocked by hardware.
-HCP_DEVICE float max16(const hcp_f32x4 (&s)[4]) {
-#if defined(HCP_EMU)
-    float m = s[0][0];
-    for (int k = 0; k < 4; ++k) for (int r = 0; r < 4; ++r) m = fmaxf(m, s[k][r]);
-    return m;
-#else
-    float r, t1, t2;
-    asm volatile("s_nop 7\n\ts_nop 3\n\t"
-                 "v_max3_f32 %0, %3, %4, %5\n\t"
-                 "v_max3_f32 %1, %6, %7, %8\n\t"
-                 "v_max3_f32 %2, %9, %10, %11\n\t"
-                 "v_max3_f32 %0, %0, %1, %2\n\t"
-                 "v_max3_f32 %1, %12, %13, %14\n\t"
-                 "v_max3_f32 %2, %15, %16, %17\n\t"
-                 "v_max3_f32 %0, %0, %1, %2\n\t"
-                 "v_max_f32 %0, %0, %18"
-                 : "=&v"(r), "=&v"(t1), "=&v"(t2)
-                 : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][3]),
-                   "v"(s[2][0]), "v"(s[2][1]), "v"(s[2][2]), "v"(s[2][3]), "v"(s[3][0]), "v"(s[3][1]), "v"(s[3][2]), "v"(s[3][3]));
-    return r;
-#endif
-}
+// (the per-lane maximum of 16 fresh MFMA results is hcp_max16, hcp_device.h: one asm statement, see there)
 
 // ------------------------------------------------------------------------------------------ forward
 template <int D, int QT, bool KB, int VAR, int NW = 4>
@@ -329,7 +299,7 @@ HCP_WAVES_PER_SIMD((fwd_waves<D, QT>())) HCP_KERNEL(64 * NW) attn2_fwd_kernel(At
                     for (int kt = 0; kt < 4; ++kt) sc[t][kt] -= delta;
                 }
             }
-            const float mx = (EXACT || FIRST) ? max16(sc[t]) : 0.f;
+            const float mx = (EXACT || FIRST) ? hcp_max16(sc[t]) : 0.f;
             // Lazy rescale: the scores are already relative to the reference max m_i; while no lane of the wave sees one above
             // 2^6 nothing is rescaled.
             if (FIRST || (EXACT && !hcp_all(mx <= rescale_thr))) {

@@ -33,15 +33,13 @@ constexpr int SW_NBUF = 4;        // {K | V} image pairs in the LDS ring: tiles 
 // scheduling pipeline of one fast iteration: N x { 1 MFMA, NT transcendental, NV plain VALU, ND LDS reads }
 template <int N, int NT, int NV, int ND>
 HCP_DEVICE void sw_interleave() {
-#if !defined(HCP_EMU)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
-        if (NT) __builtin_amdgcn_sched_group_barrier(0x400, NT, 0);     // TRANS (v_exp_f32)
-        if (NV) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);     // VALU
-        if (ND) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);     // DS read
+        hcp_sched_group<0x008, 1>();                      // MFMA
+        if (NT) hcp_sched_group<0x400, NT ? NT : 1>();    // TRANS (v_exp_f32)
+        if (NV) hcp_sched_group<0x002, NV ? NV : 1>();    // VALU
+        if (ND) hcp_sched_group<0x100, ND ? ND : 1>();    // DS read
     }
-#endif
 }
 
 // f(IntC<I>{}) for I = 0 .. N-1 (the chunk index must be a constant expression: sched_group_barrier takes immediates)
@@ -50,24 +48,7 @@ HCP_DEVICE void sw_static_for(F&& f) {
     if constexpr (I < N) { f(IntC<I>{}); sw_static_for<I + 1, N>(f); }
 }
 
-// Maximum of a lane's 8 scores (one 32-key half tile of one 16-row block); see max16 in attn_dma.h for why this is one asm statement.
-HCP_DEVICE float max8(const hcp_f32x4 (&s)[2]) {
-#if defined(HCP_EMU)
-    float m = s[0][0];
-    for (int k = 0; k < 2; ++k) for (int r = 0; r < 4; ++r) m = fmaxf(m, s[k][r]);
-    return m;
-#else
-    float r, t1;
-    asm volatile("s_nop 7\n\ts_nop 3\n\t"
-                 "v_max3_f32 %0, %2, %3, %4\n\t"
-                 "v_max3_f32 %1, %5, %6, %7\n\t"
-                 "v_max3_f32 %0, %0, %1, %8\n\t"
-                 "v_max_f32 %0, %0, %9"
-                 : "=&v"(r), "=&v"(t1)
-                 : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][3]));
-    return r;
-#endif
-}
+// (the per-lane maximum of 8 fresh MFMA results is hcp_max8, hcp_device.h)
 
 // The pipeline's unit is a HALF tile (32 keys = one k-step of the PV MFMA): two score half-tiles + two packed-P half-tiles per wave are
 // 48 registers (a whole 64-key tile in flight twice needed 96 and spilled at the 256-register budget of two waves per SIMD).
@@ -264,7 +245,7 @@ HCP_WAVES_PER_SIMD(WPS) HCP_KERNEL(64 * NW) attn4_fwd_kernel(AttnParams p) {
         if (hh >= first_dead) mask_dead(hh, sc[0]);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            float rm = max8(sc[0][t]);
+            float rm = hcp_max8(sc[0][t]);
             rm = fmaxf(rm, hcp_shfl_xor(rm, 16));
             rm = fmaxf(rm, hcp_shfl_xor(rm, 32));
             float delta = first ? rm : fmaxf(rm, 0.f);

@@ -11,24 +11,21 @@
 // RCCL is bound at run time (dlopen, preferring the copy PyTorch-ROCm already mapped so the process holds one RCCL): the
 // kernel library itself has no link-time dependency on it and single-GPU users never load it.  The unique id travels
 // between ranks by whatever side channel the host has (the Python side uses the torch.distributed store).
+// (The CPU interpreter build of the tests does not compile this file: tests/emu/hcp_emu_comm.cpp provides the same entry points for a
+// world of one.)
 #include "hcp_common.h"
 
-#if !defined(HCP_EMU)
 #include <dlfcn.h>
 #include <rccl/rccl.h>
-#endif
 #include <stdlib.h>
 
 namespace {
 
 struct HcpComm {
     int rank, world;
-#if !defined(HCP_EMU)
     ncclComm_t nccl;
-#endif
 };
 
-#if !defined(HCP_EMU)
 struct Rccl {
     void* so = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -77,9 +74,6 @@ int to_nccl(int dtype, ncclDataType_t* out) {
     if (dtype == 1) { *out = ncclBfloat16; return 0; }
     return hcp_set_error("hcp comm: dtype %d unsupported (0 = fp32, 1 = bf16)", dtype);
 }
-#endif
-
-[[maybe_unused]] size_t dtype_bytes(int dtype) { return dtype == 1 ? 2 : 4; }
 
 }  // namespace
 
@@ -88,17 +82,12 @@ int to_nccl(int dtype, ncclDataType_t* out) {
 // Rank 0 creates the rendezvous token (128 bytes) that every rank passes to hcp_comm_init.
 HCP_API int hcp_comm_unique_id(void* out128) {
     HCP_REQUIRE(out128, "hcp_comm_unique_id: null pointer");
-#if defined(HCP_EMU)
-    memset(out128, 0, HCP_COMM_UNIQUE_ID_BYTES);
-    return 0;
-#else
     if (int e = rccl_ready("hcp_comm_unique_id")) return e;
     static_assert(sizeof(ncclUniqueId) == HCP_COMM_UNIQUE_ID_BYTES, "unique id size");
     ncclUniqueId id;
     HCP_NCCL(rccl()->GetUniqueId(&id), "hcp_comm_unique_id");
     memcpy(out128, &id, sizeof(id));
     return 0;
-#endif
 }
 
 // Collective: all `world` ranks call it with the same token; the calling thread's current HIP device is the rank's GPU.
@@ -108,9 +97,6 @@ HCP_API int hcp_comm_init(int rank, int world, const void* unique_id128, void** 
     HcpComm* c = (HcpComm*)calloc(1, sizeof(HcpComm));
     HCP_REQUIRE(c, "hcp_comm_init: out of host memory");
     c->rank = rank; c->world = world;
-#if defined(HCP_EMU)
-    if (world != 1) { free(c); return hcp_set_error("hcp_comm_init: the interpreter build has no RCCL (world must be 1)"); }
-#else
     if (int e = rccl_ready("hcp_comm_init")) { free(c); return e; }
     ncclUniqueId id;
     memcpy(&id, unique_id128, sizeof(id));
@@ -119,7 +105,6 @@ HCP_API int hcp_comm_init(int rank, int world, const void* unique_id128, void** 
         free(c);
         return hcp_set_error("hcp_comm_init: RCCL error %d (%s)", (int)r, rccl()->GetErrorString ? rccl()->GetErrorString(r) : "?");
     }
-#endif
     *comm_out = c;
     return 0;
 }
@@ -127,9 +112,7 @@ HCP_API int hcp_comm_init(int rank, int world, const void* unique_id128, void** 
 HCP_API int hcp_comm_destroy(void* comm) {
     if (!comm) return 0;
     HcpComm* c = (HcpComm*)comm;
-#if !defined(HCP_EMU)
     if (c->nccl) HCP_NCCL(rccl()->CommDestroy(c->nccl), "hcp_comm_destroy");
-#endif
     free(c);
     return 0;
 }
@@ -142,14 +125,10 @@ HCP_API int hcp_allreduce_flat(void* comm, void* buf, size_t count, int dtype, h
     HCP_REQUIRE(comm && (buf || count == 0), "hcp_allreduce_flat: null pointer");
     HcpComm* c = (HcpComm*)comm;
     if (count == 0) return 0;
-#if defined(HCP_EMU)
-    return c->world == 1 ? 0 : hcp_set_error("hcp_allreduce_flat: no RCCL in the interpreter build");
-#else
     ncclDataType_t dt;
     if (int e = to_nccl(dtype, &dt)) return e;
     HCP_NCCL(rccl()->AllReduce(buf, buf, count, dt, ncclSum, c->nccl, stream), "hcp_allreduce_flat");
     return 0;
-#endif
 }
 
 // recv[0 .. recv_count) <- sum over ranks of send[rank*recv_count .. (rank+1)*recv_count); send holds world*recv_count elements.
@@ -157,16 +136,10 @@ HCP_API int hcp_reduce_scatter_flat(void* comm, const void* send, void* recv, si
     HCP_REQUIRE(comm && ((send && recv) || recv_count == 0), "hcp_reduce_scatter_flat: null pointer");
     HcpComm* c = (HcpComm*)comm;
     if (recv_count == 0) return 0;
-#if defined(HCP_EMU)
-    if (c->world != 1) return hcp_set_error("hcp_reduce_scatter_flat: no RCCL in the interpreter build");
-    if (send != recv && hcp_memcpy_async(recv, send, recv_count * dtype_bytes(dtype), stream)) return hcp_set_error("hcp_reduce_scatter_flat: copy failed");
-    return 0;
-#else
     ncclDataType_t dt;
     if (int e = to_nccl(dtype, &dt)) return e;
     HCP_NCCL(rccl()->ReduceScatter(send, recv, recv_count, dt, ncclSum, c->nccl, stream), "hcp_reduce_scatter_flat");
     return 0;
-#endif
 }
 
 // recv[r*send_count .. (r+1)*send_count) <- rank r's send[0 .. send_count); recv holds world*send_count elements
@@ -175,14 +148,8 @@ HCP_API int hcp_allgather_flat(void* comm, const void* send, void* recv, size_t 
     HCP_REQUIRE(comm && ((send && recv) || send_count == 0), "hcp_allgather_flat: null pointer");
     HcpComm* c = (HcpComm*)comm;
     if (send_count == 0) return 0;
-#if defined(HCP_EMU)
-    if (c->world != 1) return hcp_set_error("hcp_allgather_flat: no RCCL in the interpreter build");
-    if (send != recv && hcp_memcpy_async(recv, send, send_count * dtype_bytes(dtype), stream)) return hcp_set_error("hcp_allgather_flat: copy failed");
-    return 0;
-#else
     ncclDataType_t dt;
     if (int e = to_nccl(dtype, &dt)) return e;
     HCP_NCCL(rccl()->AllGather(send, recv, send_count, dt, c->nccl, stream), "hcp_allgather_flat");
     return 0;
-#endif
 }

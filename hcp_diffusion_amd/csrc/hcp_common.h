@@ -26,24 +26,7 @@ extern "C" int hcp_set_error(const char* fmt, ...);
         if (!(cond)) return hcp_set_error(__VA_ARGS__); \
     } while (0)
 
-#if defined(HCP_EMU)
-#define HCP_LAUNCH_CHECK(name) return 0
-static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
-static inline int hcp_memcpy_async(void* d, const void* s, size_t n, hipStream_t) { memmove(d, s, n); return 0; }
-#else
-#define HCP_LAUNCH_CHECK(name)                                                        \
-    do {                                                                              \
-        hipError_t e_ = hipGetLastError();                                            \
-        if (e_ != hipSuccess) return hcp_set_error("%s: %s", name, hipGetErrorString(e_)); \
-        return 0;                                                                     \
-    } while (0)
-static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t s) {
-    return hipMemsetAsync(p, v, n, s) == hipSuccess ? 0 : -1;
-}
-static inline int hcp_memcpy_async(void* d, const void* src, size_t n, hipStream_t s) {
-    return hipMemcpyAsync(d, src, n, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1;
-}
-#endif
+// (HCP_LAUNCH_CHECK, hcp_memset_async, hcp_memcpy_async: hcp_device.h — the interpreter build has its own in tests/emu/hcp_emu.h)
 
 static inline int hcp_cdiv(int a, int b) { return (a + b - 1) / b; }
 typedef unsigned short hcp_bf16;  // raw bf16 bits

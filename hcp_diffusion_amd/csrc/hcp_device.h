@@ -175,6 +175,56 @@ HCP_DEVICE void hcp_barrier_only() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// Exact occupancy request for the attention kernels (their register budgets are planned per waves-per-SIMD).
+#define HCP_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+// Maximum of a lane's 16 (8) fresh MFMA results.  ONE asm statement: fmaxf() on MFMA results makes hipcc canonicalise every operand first
+// (v_max x, x: +16 VALU per 16 scores), and a bare asm v_max3 reading an MFMA result is a hazard hipcc does not pad (guide §5.7 item 2:
+// XDL write -> VALU read needs wait states; the stale read showed up on hardware as spurious rescales).  The leading s_nop's cover the
+// longest case once per call; VALU -> VALU dependencies inside are interlocked by hardware.
+HCP_DEVICE float hcp_max16(const hcp_f32x4 (&s)[4]) {
+    float r, t1, t2;
+    asm volatile("s_nop 7\n\ts_nop 3\n\t"
+                 "v_max3_f32 %0, %3, %4, %5\n\t"
+                 "v_max3_f32 %1, %6, %7, %8\n\t"
+                 "v_max3_f32 %2, %9, %10, %11\n\t"
+                 "v_max3_f32 %0, %0, %1, %2\n\t"
+                 "v_max3_f32 %1, %12, %13, %14\n\t"
+                 "v_max3_f32 %2, %15, %16, %17\n\t"
+                 "v_max3_f32 %0, %0, %1, %2\n\t"
+                 "v_max_f32 %0, %0, %18"
+                 : "=&v"(r), "=&v"(t1), "=&v"(t2)
+                 : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][3]),
+                   "v"(s[2][0]), "v"(s[2][1]), "v"(s[2][2]), "v"(s[2][3]), "v"(s[3][0]), "v"(s[3][1]), "v"(s[3][2]), "v"(s[3][3]));
+    return r;
+}
+HCP_DEVICE float hcp_max8(const hcp_f32x4 (&s)[2]) {
+    float r, t1;
+    asm volatile("s_nop 7\n\ts_nop 3\n\t"
+                 "v_max3_f32 %0, %2, %3, %4\n\t"
+                 "v_max3_f32 %1, %5, %6, %7\n\t"
+                 "v_max3_f32 %0, %0, %1, %8\n\t"
+                 "v_max_f32 %0, %0, %9"
+                 : "=&v"(r), "=&v"(t1)
+                 : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]), "v"(s[1][3]));
+    return r;
+}
+// Host side of a launch: status of the launch just issued (the C-ABI convention: 0 / <0 + hcp_last_error()), stream-ordered fill / copy.
+#define HCP_IS_EMULATED 0
+extern "C" int hcp_set_error(const char* fmt, ...);
+#define HCP_LAUNCH_CHECK(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) return hcp_set_error("%s: %s", name, hipGetErrorString(e_)); \
+        return 0;                                                                     \
+    } while (0)
+static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t s) {
+    return hipMemsetAsync(p, v, n, s) == hipSuccess ? 0 : -1;
+}
+static inline int hcp_memcpy_async(void* d, const void* src, size_t n, hipStream_t s) {
+    return hipMemcpyAsync(d, src, n, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1;
+}
+// One slot of a scheduling pipeline: the next N instructions of class MASK (0x008 MFMA, 0x400 TRANS, 0x002 VALU, 0x100 DS read).
+template <int MASK, int N> HCP_DEVICE void hcp_sched_group() { __builtin_amdgcn_sched_group_barrier(MASK, N, 0); }
 #endif  // HCP_EMU
 
 // ---------------------------------------------------------------- bf16 helpers (bit-exact RNE)

@@ -15,12 +15,6 @@ extern "C" int hcp_set_error(const char* fmt, ...) {
 HCP_API const char* hcp_last_error(void) { return g_err; }
 
 // 1 when this object was built by tests/emu (CPU interpreter), 0 for the gfx950 product library.
-HCP_API int hcp_is_emulated(void) {
-#if defined(HCP_EMU)
-    return 1;
-#else
-    return 0;
-#endif
-}
+HCP_API int hcp_is_emulated(void) { return HCP_IS_EMULATED; }
 
 HCP_API int hcp_abi_version(void) { return 1; }

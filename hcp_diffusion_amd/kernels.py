@@ -100,10 +100,13 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, r
     return out
 
 
-# Split T: the fused-LoRA GEMMs hand the rank-r intermediate T = x W_down^T (forward) / U = dY W_up (backward) on as
-# TWO bf16 images, hi = bf16(T) and lo = bf16(T - hi) — [M, 64] = (hi | lo) — instead of one rounded copy; the K-extension and the
-# weight-gradient kernel consume both.  False restores the bf16-rounded [M, 32] T (lab A/B: HCP_LAB_NO_T_SPLIT=1).
-T_SPLIT = os.environ.get("HCP_LAB_NO_T_SPLIT") != "1"
+# Split T: the fused-LoRA GEMMs can hand the rank-r intermediate T = x W_down^T (forward) / U = dY W_up (backward) on
+# as TWO bf16 images, hi = bf16(T) and lo = bf16(T - hi) — [M, 64] = (hi | lo) — instead of one rounded copy; the K-extension and the
+# weight-gradient kernel then consume both (16 mantissa bits of the fp32 accumulator).  OPT-IN (HCP_T_SPLIT=1, or set this attribute
+# before the model is built): measured on MI355X (profiles/r5_ab_t_split.md) it leaves the SDXL configs[3] error ratios against the
+# reference's own bf16 mode where they were (flat 1.46 vs 1.45, worst class 2.15 vs 2.18, prediction 1.29 vs 1.29) — the rank-r
+# intermediates are NOT where the native step differs from autocast — and costs +1.0 % (SD1.5) / +1.5 % (SDXL) of the step.
+T_SPLIT = os.environ.get("HCP_T_SPLIT") == "1"
 
 
 def t_lo(t):

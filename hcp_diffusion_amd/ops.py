@@ -30,8 +30,12 @@ BF16 = torch.bfloat16
 
 
 class WgradContext:
-    def __init__(self, grouped=False, side_stream=False):
+    def __init__(self, grouped=False, side_stream=False, chunk_layers=0):
+        """chunk_layers > 0 (with grouped): the grouped launch is cut into pieces of that many layers, and every piece but the last is
+        launched on a SIDE stream as soon as its layers' operands exist (an event on the dX chain's stream) — under hipGraph capture a
+        parallel branch next to the rest of the dX chain, whose latency-bound kernels leave most of the chip idle; join() at the end."""
         self.grouped, self.side = bool(grouped), bool(side_stream)
+        self.chunk = int(chunk_layers) if grouped else 0
         self.items, self.keep = [], []            # grouped: pending operands / what the last grouped launch keeps alive (hipGraph replays)
         self.stream, self.side_keep = None, []
 
@@ -39,6 +43,8 @@ class WgradContext:
         """ulo / tlo: column offset of the residual half of a split U / T (K.t_lo: the fused-LoRA GEMMs' [M, 64] = (hi | lo)), 0 = none."""
         if self.grouped:
             self.items.append((U, x2, gd, T, dy2, gu, rank, alpha, slot0, ulo, tlo))
+            if self.chunk and len(self.items) >= self.chunk and x2.is_cuda:
+                self._launch_chunk_on_side_stream()
             return
         if slot0 != 0 or not dy2.is_contiguous() or (ulo != 0) != (U.shape[1] == 64) or (tlo != 0) != (T.shape[1] == 64):
             # member of a fused group (or mixed formats): the grouped entry point handles slots / strides
@@ -55,6 +61,18 @@ class WgradContext:
         with torch.cuda.stream(self.stream):
             K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
         self.side_keep.append((U, x2, T, dy2))        # the allocator must not recycle these before the side kernel ran
+
+    def _launch_chunk_on_side_stream(self):
+        dev = self.items[0][1].device
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        ev = torch.cuda.Event()
+        ev.record()                                   # after the dX kernel of the chunk's last layer: every U of the chunk is complete
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            keep = K.lora_wgrad_grouped(self.items)
+        self.side_keep.append((keep, self.items))     # operands stay alive until join(): the allocator must not hand them out before the branch ran
+        self.items = []
 
     def flush(self):
         """grouped: all collected layers' weight gradients as one launch."""

@@ -157,6 +157,7 @@ def _fusable_linear(m):
     return host, blk
 
 
+_LAB_FP32_STREAM = False          # lab probe, see BasicTransformerBlock.forward
 _LAB_NO_GEGLU_FUSE = bool(os.environ.get("HCP_LAB_NO_GEGLU_FUSE"))      # same-box A/B switch (tools/lab): the two-node path
 
 
@@ -280,6 +281,15 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, context):
         context, key_bias = context if isinstance(context, tuple) else (context, None)   # (states, additive key mask)
+        if _LAB_FP32_STREAM and not torch.is_grad_enabled():
+            # LAB PROBE (tools/diag/sdxl_stream_probe.py; forward only, torch ops): the residual stream of the transformer blocks in fp32 —
+            # what the reference's LoRA layers produce under autocast (their mm(...) + fp32 bias promotes to_out / ff.net.2 outputs to fp32,
+            # lora_layers_patch.py:50-55).  Measures what a native fp32 stream would buy before any kernel is written.
+            ln = lambda m, v: torch.nn.functional.layer_norm(v, (v.shape[-1],), m.weight.float(), m.bias.float(), m.eps).to(BF16)
+            x32 = x.float()
+            x32 = x32 + self.attn1(ln(self.norm1, x32)).float()
+            x32 = x32 + self.attn2(ln(self.norm2, x32), context, key_bias=key_bias).float()
+            return x32 + self.ff(ln(self.norm3, x32)).float()
         h, x = self.norm1(x, fork=True)                        # (LN(x), x): the fork fuses the residual-gradient add
         x = self.attn1(h, residual=x)
         h, x = self.norm2(x, fork=True)
@@ -305,6 +315,8 @@ class Transformer2DModel(nn.Module):
         h = self.proj_in(h.view(B, H * W, C)) if isinstance(self.proj_in, nn.Linear) else self.proj_in(h).view(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
+        if h.dtype != BF16:                                    # (lab probe: fp32 residual stream)
+            h = h.to(BF16)
         if isinstance(self.proj_out, nn.Linear):
             return _call_res(self.proj_out, h, x.view(B, H * W, C)).view(B, H, W, C)
         return _call_res(self.proj_out, h.view(B, H, W, C), x)
@@ -603,6 +615,12 @@ class NativeUNet2DConditionModel(nn.Module):
         if bool(added_cond_kwargs) != text_time:
             raise ValueError("hcp_diffusion_amd: added_cond_kwargs={text_embeds,time_ids} is required by (and only by) a UNet with "
                              "addition_embed_type='text_time' (SDXL; reference models/wrapper.py:66-73)")
+        if sample.dtype == torch.float16 or encoder_hidden_states.dtype == torch.float16 or \
+                (sample.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16):
+            # the reference's default mixed_precision (cfgs/train/train_base.yaml:2, train_ac.py:116-123): no fp16 operand packing and no
+            # loss-scale handling exist on this path — refuse instead of computing in another precision than the config names
+            raise NotImplementedError("hcp_diffusion_amd: mixed_precision 'fp16' is not supported by the native MI355X path (bf16 compute, fp32 "
+                                      "accumulation / masters): set mixed_precision: 'bf16' (INTEGRATION.md, Precision)")
         B = sample.shape[0]
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], dtype=torch.int64, device=sample.device)

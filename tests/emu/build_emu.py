@@ -23,7 +23,8 @@ def build_emu(force=False):
     import sys
     sys.path.insert(0, str(HERE.parent.parent))
     from hcp_diffusion_amd.build import SOURCES
-    srcs = [CSRC / s for s in SOURCES] + [HERE / "hcp_emu.cpp"]
+    # comm.hip (RCCL) is the one product source the interpreter does not compile: hcp_emu_comm.cpp stands in for a world of one rank
+    srcs = [CSRC / s for s in SOURCES if s != "comm.hip"] + [HERE / "hcp_emu.cpp", HERE / "hcp_emu_comm.cpp"]
     deps = srcs + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [HERE / "hcp_emu.h"]
     if not force and LIB.exists() and all(d.stat().st_mtime <= LIB.stat().st_mtime for d in deps):
         return LIB

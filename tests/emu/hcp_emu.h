@@ -144,6 +144,22 @@ HCP_DEVICE void hcp_dma16(hcp_desc4 d, unsigned voffset, void* lds_wave_base) {
 }
 template <int P> HCP_DEVICE void hcp_setprio() {}
 HCP_DEVICE void hcp_sched_fence() {}
+#define HCP_IS_EMULATED 1
+#define HCP_LAUNCH_CHECK(name) return 0
+static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline int hcp_memcpy_async(void* d, const void* s, size_t n, hipStream_t) { memmove(d, s, n); return 0; }
+#define HCP_WAVES_PER_SIMD(n)
+template <int MASK, int N> HCP_DEVICE void hcp_sched_group() {}
+HCP_DEVICE float hcp_max16(const hcp_f32x4 (&s)[4]) {
+    float m = s[0][0];
+    for (int k = 0; k < 4; ++k) for (int r = 0; r < 4; ++r) m = fmaxf(m, s[k][r]);
+    return m;
+}
+HCP_DEVICE float hcp_max8(const hcp_f32x4 (&s)[2]) {
+    float m = s[0][0];
+    for (int k = 0; k < 2; ++k) for (int r = 0; r < 4; ++r) m = fmaxf(m, s[k][r]);
+    return m;
+}
 HCP_DEVICE void hcp_dma_wait_all() { hcp_emu::dma_drain(0); }
 HCP_DEVICE int hcp_uniform(int v) { return v; }
 HCP_DEVICE void hcp_force_ready(hcp_bf16x8&) {}

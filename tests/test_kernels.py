@@ -571,10 +571,12 @@ def test_snr_weighted_loss(backend, kind):
     assert abs(loss.item() - float(ref)) <= 1e-4 * abs(float(ref))
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("M,Kd,N,r", [(100, 64, 72, 4), (300, 320, 40, 8), (40, 4096, 72, 4), (16384, 320, 2560, 8), (4096, 2560, 640, 16)])
-def test_lora_wgrad_and_pack(backend, M, Kd, N, r):
+def test_lora_wgrad_and_pack(backend, M, Kd, N, r, split, monkeypatch):
     if not backend.is_gpu and M > 1000:
         pytest.skip("large shape: GPU only")
+    monkeypatch.setattr(K, "T_SPLIT", split)             # both forms of the rank-r intermediate: bf16-rounded [M, 32] / split (hi | lo) [M, 64]
     import ctypes
     import struct
     torch.manual_seed(M)

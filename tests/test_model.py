@@ -163,10 +163,16 @@ def test_sdxl_structure_matches_public_config():
         NativeUNet2DConditionModel(**TINY_SDXL_CONFIG)(torch.zeros(1, 4, 8, 8), torch.zeros(1).long(), torch.zeros(1, 77, 64))
 
 
-def test_tiny_sdxl_lora_train_step_vs_oracle(backend):
+@pytest.mark.parametrize("t_split", [False, True])
+def test_tiny_sdxl_lora_train_step_vs_oracle(backend, t_split, monkeypatch):
     """SDXL-structured miniature (3 levels, DownBlock2D first, transformer depth 1/1/2, head_dim 64, linear projections,
-    text_time additional embedding, rank-16 LoRA as in BASELINE.json configs[3])."""
+    text_time additional embedding, rank-16 LoRA as in BASELINE.json configs[3]).  t_split: the opt-in (hi | lo) form of the rank-r
+    intermediates (kernels.T_SPLIT) through every path that carries them — fused linear / group GEMMs, GEGLU backward epilogue, the
+    batched cross-attention K|V projection."""
+    monkeypatch.setattr(K, "T_SPLIT", t_split)
     lo, ln, go, tr, wr = _train_step_pair(TINY_SDXL_CONFIG, backend, 16, (2, 4, 8, 8), 77, 64, pooled_dim=64)
+    cb = getattr(tr.unet, "_ctx_batch", None)            # (key, CtxBatch or None, groups)
+    assert cb is not None and cb[1] is not None and cb[1].split == t_split
     assert abs(lo - ln) / abs(lo) < 2e-2
     assert F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.999
     # three rank-16 blocks do not fit one 32-wide slot group: self-attention runs as q alone + k|v together (the pre-scaled-Q kernels)
@@ -355,6 +361,22 @@ def test_sd15_full_size_batch4_blocks_and_full_lora_gradient_vs_golden():
     cos = (flat.double() @ ref.double() / (flat.double().norm() * ref.double().norm())).item()      # fp64: 3M-term dot product
     print(f"[b4] worst block rel-L2 {max(worst.values()):.2e}, LoRA gradient cosine {cos:.5f}, norm {flat.norm().item():.5f} vs {g['grad_norm']:.5f}")
     assert cos > 0.999 and abs(flat.norm().item() - g["grad_norm"]) / g["grad_norm"] < 2e-2
+
+
+def test_fp16_mixed_precision_is_refused_loudly(backend):
+    """The reference's DEFAULT mixed_precision is 'fp16' (cfgs/train/train_base.yaml:2, train_ac.py:116-123); the native path is bf16-only
+    and says so at the first UNet call instead of silently computing in another precision (Precision)."""
+    _, nat = _pair(TINY_CONFIG, backend.device)
+    g = torch.load(os.path.join(GOLD, "tiny_unet_oracle.pt"))
+    with pytest.raises(NotImplementedError, match="mixed_precision 'fp16'"):
+        nat(backend.to(g["x0"].half()), backend.to(g["t"]), backend.to(g["ehs"]))
+    with pytest.raises(NotImplementedError, match="mixed_precision 'fp16'"):
+        nat(backend.to(g["x0"]), backend.to(g["t"]), backend.to(g["ehs"].half()))
+    if backend.is_gpu:
+        with torch.autocast("cuda", dtype=torch.float16), pytest.raises(NotImplementedError, match="mixed_precision 'fp16'"):
+            nat(backend.to(g["x0"]), backend.to(g["t"]), backend.to(g["ehs"]))
+        with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():            # the supported mode is untouched
+            assert torch.isfinite(nat(backend.to(g["x0"]), backend.to(g["t"]), backend.to(g["ehs"])).sample).all()
 
 
 def _per_block_errors(ora, nat, to_dev, xt, t, ehs, **fwd_kw):

@@ -191,7 +191,7 @@ HCP_WAVES_PER_SIMD(WPS) HCP_KERNEL(64 * NW) attn3_fwd_kernel(AttnParams p) {
         }
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const float mx = max16(sc[t]);
+            const float mx = hcp_max16(sc[t]);
             if (FIRST || !hcp_all(mx <= rescale_thr)) {
                 float rm = fmaxf(mx, hcp_shfl_xor(mx, 16));
                 rm = fmaxf(rm, hcp_shfl_xor(rm, 32));                   // row maximum of this tile, relative to m_i
