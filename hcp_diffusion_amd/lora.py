@@ -26,10 +26,15 @@ class LoraHipContainer(PatchPluginContainer):
     """Stands where the host Linear / Conv2d stood (reference LoraPatchContainer, lora_base_patch.py:19-35)."""
     supports_fused_residual = True
 
-    _multi = None
+    _multis = None        # {plugin-name tuple: MultiLora}: the shared operand images of several blocks on this host
 
     def forward(self, x, residual=None, **kwargs):
-        blocks = [self[n] for n in self.plugin_names]
+        return self._run(tuple(self.plugin_names), x, residual, **kwargs)
+
+    def _run(self, names, x, residual=None, **kwargs):
+        """The host layer with the LoRA blocks `names` (plugin names of this container) applied — all of them for the plain container;
+        one branch's for DAPPHipContainer."""
+        blocks = [self[n] for n in names]
         b0 = blocks[0]
         if b0.merged or (b0.host_type == "conv" and len(blocks) > 1 and
                          (sum(8 * ((b.rank + 7) // 8) for b in blocks) > RANK_SLOT or any(b.wide for b in blocks))):
@@ -39,22 +44,25 @@ class LoraHipContainer(PatchPluginContainer):
             drop = last.dropout.p > 0.0 and last.training
             y = ops.merged_lora_call(self._host, blocks, x, residual=None if drop else residual, **kwargs)
             return self._dropped(y, last, residual) if drop else y
-        if len(self.plugin_names) != 1:                # several blocks on one host: their rank slots side by side
-            if self._multi is None or self._multi.names != tuple(self.plugin_names):
-                self._multi = MultiLora([self[n] for n in self.plugin_names], tuple(self.plugin_names))
-            last = self[self.plugin_names[-1]]         # the reference applies the LAST block's dropout (lora_base_patch.py:35)
+        if len(names) != 1:                            # several blocks on one host: their rank slots side by side
+            multi = self._multis.get(names) if self._multis else None
+            if multi is None:
+                if self._multis is None:
+                    self._multis = {}
+                multi = self._multis[names] = MultiLora(blocks, names)
+            last = blocks[-1]                          # the reference applies the LAST block's dropout (lora_base_patch.py:35)
             drop = last.dropout.p > 0.0 and last.training
-            if self._multi.host_type == "conv":        # 3x3 host: T = conv3x3(x, [W_down_0; W_down_1; ...]) fills the shared rank slots
+            if multi.host_type == "conv":              # 3x3 host: T = conv3x3(x, [W_down_0; W_down_1; ...]) fills the shared rank slots
                 host = self._host
                 y = ops.conv3x3(x, host, x2=kwargs.pop("x2", None), rowbias=kwargs.pop("rowbias", None), residual=None if drop else residual,
-                                stride=host.stride[0], upsample=kwargs.pop("upsample", False), lora=self._multi, **kwargs)
+                                stride=host.stride[0], upsample=kwargs.pop("upsample", False), lora=multi, **kwargs)
                 return self._dropped(y, last, residual) if drop else y
             if kwargs:
                 raise NotImplementedError(f"LoraHipContainer: unsupported call arguments {list(kwargs)}")
             if drop:
-                return self._dropped(ops.linear(x, self._host, self._multi, None), last, residual)
-            return ops.linear(x, self._host, self._multi, residual)
-        blk = self[self.plugin_names[0]]
+                return self._dropped(ops.linear(x, self._host, multi, None), last, residual)
+            return ops.linear(x, self._host, multi, residual)
+        blk = blocks[0]
         drop = blk.dropout.p > 0.0 and blk.training
         if blk.host_type == "conv":                    # 3x3 host: same keyword surface as HipConv2d.forward
             host = self._host
@@ -222,6 +230,49 @@ class LoraHipLayer(PatchPluginBlock):
     def members(self):
         """[(block, first rank slot)] — one entry for a single block, several for MultiLora."""
         return [(self, 0)]
+
+
+class DAPPHipContainer(LoraHipContainer):
+    """Native twin of the reference's DAPPPatchContainer (lora_layers_patch.py:102-135, DreamArtist++): the batch is [negative half;
+    positive half]; the first half runs the host with the summed 'n'-branch blocks, the second with the 'p'-branch blocks, and the halves
+    are concatenated again.  Each half is the ordinary fused-LoRA call of LoraHipContainer on that branch's blocks (their rank slots side
+    by side when a branch holds several).  Like the reference, both branches need at least one block (its `host_weight + None` raises
+    otherwise, lora_base_patch.py:74), and the LAST plugin's dropout acts on both halves."""
+
+    def forward(self, x, residual=None, **kwargs):
+        names = {"p": tuple(n for n in self.plugin_names if self[n].branch == "p"),
+                 "n": tuple(n for n in self.plugin_names if self[n].branch == "n")}
+        if not names["p"] or not names["n"]:
+            raise ValueError("dapp_hip: a host needs at least one 'p' and one 'n' branch block (the reference adds None to the host weight "
+                             "otherwise, lora_layers_patch.py:131-133)")
+        if kwargs:
+            raise NotImplementedError(f"dapp_hip: unsupported call arguments {list(kwargs)}")
+        B = x.shape[0] // 2
+        last = self.plugin_names[-1]                    # post_forward of the LAST plugin (its dropout), lora_layers_patch.py:132-133
+        order = lambda ns: tuple(n for n in ns if n != last) + ((last,) if last in ns else ())
+        rn, rp = (residual[:B], residual[B:]) if residual is not None else (None, None)
+        y_n = self._run(order(names["n"]), x[:B], rn)
+        y_p = self._run(order(names["p"]), x[B:], rp)
+        return torch.cat([y_n, y_p], dim=0)
+
+
+class DAPPHipLayer(LoraHipLayer):
+    """``lora_layer_map['dapp_hip']``: LoraHipLayer with a ``branch`` ('p' / 'n'), reference DAPPLayer (lora_layers_patch.py:137-141).
+    (The reference's own DAPPLayer derives from LoraBlock, which has no LinearLayer / Conv2dLayer classes, and cannot be constructed as
+    shipped; the semantics implemented are those of its container.)"""
+    container_cls = DAPPHipContainer
+
+    def __init__(self, lora_id, host, rank=1, dropout=0.1, alpha=1.0, bias=False, alpha_auto_scale=True, branch="p", **kwargs):
+        if branch not in ("p", "n"):
+            raise ValueError(f"dapp_hip: branch must be 'p' or 'n', got {branch!r}")
+        super().__init__(lora_id, host, rank, dropout, alpha, bias=bias, alpha_auto_scale=alpha_auto_scale, **kwargs)
+        self.branch = branch
+
+    @classmethod
+    def wrap_layer(cls, lora_id, layer, rank=1, dropout=0.0, alpha=1.0, svd_init=False, bias=False, mask=None, branch="p", **kwargs):
+        blk = cls(lora_id, layer, rank, dropout, alpha, bias=bias, branch=branch, **kwargs)
+        blk.init_weights(svd_init)
+        return blk
 
 
 class _LoraOperands:
@@ -607,11 +658,12 @@ class LoraBucket:
         return self.params.numel()
 
 
-lora_layer_map = {"lora_hip": LoraHipLayer, "lora": LoraHipLayer}
+lora_layer_map = {"lora_hip": LoraHipLayer, "lora": LoraHipLayer, "dapp_hip": DAPPHipLayer, "dapp": DAPPHipLayer}
 
 try:  # register with the reference's registry when it is importable (seam 2)
     from hcpdiff.models.lora_layers_patch import lora_layer_map as _ref_map   # pragma: no cover
     _ref_map.setdefault("lora_hip", LoraHipLayer)                              # pragma: no cover
+    _ref_map.setdefault("dapp_hip", DAPPHipLayer)                              # pragma: no cover
 except Exception:  # noqa: BLE001
     pass
 

@@ -12,7 +12,8 @@ mkdir -p "$out" /tmp/asan_logs
 cxx=/opt/rocm/lib/llvm/bin/clang++
 rt=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 objs=""
-for s in $(python -c "import sys; sys.path.insert(0, '$root'); from hcp_diffusion_amd.build import SOURCES; print(' '.join(SOURCES))"); do
+# (comm.hip binds RCCL and is the one product source the interpreter does not compile: tests/emu/hcp_emu_comm.cpp stands in, as in build_emu.py)
+for s in $(python -c "import sys; sys.path.insert(0, '$root'); from hcp_diffusion_amd.build import SOURCES; print(' '.join(x for x in SOURCES if x != 'comm.hip'))"); do
   o=$out/${s%.hip}.o; objs="$objs $o"
   if [ ! -f "$o" ] || [ -n "$(find "$root/hcp_diffusion_amd/csrc" "$root/tests/emu" -newer "$o" \( -name '*.h' -o -name '*.inc' -o -name "$s" \) | head -1)" ]; then
     $cxx -x c++ -std=c++17 -O1 -g -fPIC -DHCP_EMU -DHCP_TOOLS -ffp-contract=off -fsanitize=address -fno-omit-frame-pointer -shared-libasan \
@@ -22,8 +23,10 @@ for s in $(python -c "import sys; sys.path.insert(0, '$root'); from hcp_diffusio
 done
 $cxx -x c++ -std=c++17 -O1 -g -fPIC -DHCP_EMU -DHCP_TOOLS -fsanitize=address -fno-omit-frame-pointer -shared-libasan -fvisibility=hidden \
      -I"$root/tests/emu" -I"$root/hcp_diffusion_amd/csrc" -c "$root/tests/emu/hcp_emu.cpp" -o "$out/hcp_emu.o" &
+$cxx -x c++ -std=c++17 -O1 -g -fPIC -DHCP_EMU -DHCP_TOOLS -fsanitize=address -fno-omit-frame-pointer -shared-libasan -fvisibility=hidden \
+     -I"$root/tests/emu" -I"$root/hcp_diffusion_amd/csrc" -c "$root/tests/emu/hcp_emu_comm.cpp" -o "$out/hcp_emu_comm.o" &
 wait
-$cxx -shared -fPIC -fsanitize=address -shared-libasan -o "$out/libhcp_emu_asan.so" $objs "$out/hcp_emu.o"
+$cxx -shared -fPIC -fsanitize=address -shared-libasan -o "$out/libhcp_emu_asan.so" $objs "$out/hcp_emu.o" "$out/hcp_emu_comm.o"
 cd "$root"
 args=("$@")
 [ ${#args[@]} -eq 0 ] && args=(tests/test_kernels.py tests/test_model.py tests/test_vae.py tests/test_text_encoder.py tests/test_trainer.py tests/test_sampler.py tests/test_graphed.py tests/test_ckpt.py -n 8)
