@@ -386,6 +386,10 @@ def main():
         crit = torch.nn.MSELoss(reduction="none")
         if graph:
             unet.enable_hip_graph()
+        nancheck, seen_bad, calls = os.environ.get("HCP_BENCH_NANCHECK") == "1", [], []
+        import gc
+        if os.environ.get("HCP_BENCH_GC") == "off":
+            gc.disable()
 
         def seam_step():
             noise = torch.randn_like(latents)
@@ -393,9 +397,39 @@ def main():
             pred = unet(sched.add_noise(latents, noise, t), t, ehs).sample
             loss = crit(pred.float(), noise.float()).mean()
             loss.backward()
+            if nancheck and not fullft:                              # lab (HCP_BENCH_NANCHECK=1): first step whose prediction / LoRA gradients are not finite
+                ok = (bool(torch.isfinite(pred).all()), bool(torch.isfinite(tr.bucket.grads).all()), bool(torch.isfinite(tr.bucket.params).all()))
+                if not all(ok) and not seen_bad:
+                    seen_bad.append(1)
+                    print(f"[nancheck] call {len(calls)}: finite(pred, grads, params) = {ok}, t = {t.tolist()}, loss {float(loss)}", file=sys.stderr, flush=True)
+                calls.append(1)
+                gn_ = float(tr.bucket.grads.norm())
+                if gn_ > 1e2 and len(seen_bad) < 3:                     # a finite but absurd gradient: name the tensors that carry it
+                    seen_bad.append(2)
+                    rows = []
+                    for path, blk in tr.lora_group.plugin_dict.items():
+                        for nm, p_ in (("W_down", blk.layer.W_down), ("W_up", blk.layer.W_up)):
+                            if p_.grad is not None:
+                                g_ = p_.grad.float()
+                                n_ = float(g_.norm())
+                                if n_ > 1.0:
+                                    big = (g_.abs() > 1.0)
+                                    idx = big.nonzero()
+                                    rows.append((n_, path, nm, tuple(p_.shape), int(big.sum()), idx[:4].tolist(), g_[big][:4].tolist(), blk.rank, blk.alpha_f))
+                    rows.sort(reverse=True)
+                    print(f"[nancheck] call {len(calls) - 1}: |g| {gn_:.4e}; tensors with |grad| > 1: {len(rows)}", file=sys.stderr, flush=True)
+                    for r_ in rows[:6]:
+                        print("   ", r_, file=sys.stderr, flush=True)
+                    flat = tr.bucket.grads
+                    bigf = (flat.abs() > 1.0).nonzero().flatten()
+                    print(f"    flat bucket: {bigf.numel()} elements > 1 at offsets {bigf[:8].tolist()} .. {bigf[-4:].tolist()} of {flat.numel()}", file=sys.stderr, flush=True)
+                if os.environ.get("HCP_BENCH_NANCHECK_VERBOSE") == "1":
+                    print(f"[call {len(calls) - 1}] loss {float(loss):.5f} |g| {float(tr.bucket.grads.norm()):.4e} |p| {float(tr.bucket.params.norm()):.6f}", file=sys.stderr, flush=True)
             torch.nn.utils.clip_grad_norm_(params, 1.0)              # accelerator.clip_grad_norm_(TE_unet.trainable_parameters(), ...), train_ac.py:485-490
             opt.step()
             opt.zero_grad(set_to_none=False)
+            if os.environ.get("HCP_BENCH_GC") == "every":
+                gc.collect()
             return loss.item()
         for _ in range(warmup):
             seam_step()
@@ -409,6 +443,8 @@ def main():
     if args.seam:
         assert args.workload in ("sd15", "dreambooth") and world == 1
         dt, lv = seam_loop(args.seam_graph, args.steps, args.warmup)
+        if lv != lv or abs(lv) == float("inf"):
+            raise RuntimeError(f"bench.py --seam: the training loss after the timed loop is not finite ({lv}): the measurement is void")
         print(json.dumps({"metric": ("training images/sec, SD1.5 full fine-tune (DreamBooth) 512px bs=%d" % B if fullft else "training images/sec, SD1.5 LoRA 512px bs=4") +
                                     ", native modules driven the reference trainer's way (eager seam)",
                           "value": round(B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -430,6 +466,9 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = tmax.item()
     loss_v = float(loss.item())
+    if loss_v != loss_v or abs(loss_v) == float("inf"):
+        # (round 5: NaN losses in some graph-replay runs went unnoticed for three rounds because nobody read this field — LAB_NOTEBOOK)
+        raise RuntimeError(f"bench.py: the training loss after the timed loop is not finite ({loss_v}): the measurement is void")
     if rank == 0:
         ips = world * B * args.steps / dt
         out = {
@@ -508,7 +547,9 @@ def main():
             # "Keeping the reference's loop"): eager trainer, unet.enable_hip_graph() as the mi355x overlay sets it.  LAST: it switches the module to graph replay.
             try:
                 k4 = max(5, min(args.steps, 20))
-                d4, _ = seam_loop(True, k4, 5)
+                d4, lv4 = seam_loop(True, k4, 5)
+                if lv4 != lv4:
+                    raise RuntimeError("non-finite loss")
                 out["seam_graph"] = {"value": round(B * k4 / d4, 2), "unit": "images/sec", "ms_per_step": round(d4 / k4 * 1e3, 3), "steps": k4,
                                      "note": "the reference Trainer's loop restated (train_ac.py:467-504: eager module call, clip_grad_norm_, fused "
                                              "AdamW, zero_grad, loss.item() every step) over the native modules with unet.enable_hip_graph()"}

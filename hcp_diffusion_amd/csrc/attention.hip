@@ -68,10 +68,11 @@ int launch_dq(AttnParams& p, int B, hipStream_t stream) {
     else HCP_LAUNCH((attn2_bwd_dq_kernel<D, QT, false, VAR_PRODUCT>), dim3(n), dim3(256), fwd_smem<D>(), stream, p);
     HCP_LAUNCH_CHECK("attn_bwd_dq");
 }
+// few key tiles (cross-attention: 77 keys): split the query loop of the dK/dV kernel so the grid still fills the chip; the partial sums
+// meet in fp32 accumulators in the workspace (cleared by the dQ kernel in front, AttnParams::zero_ptr)
 template <int D, int KT>
-int launch_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t stream) {
+void plan_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes) {
     const int nkv = hcp_cdiv(p.Nk, 64 * KT);
-    // few key tiles (cross-attention: 77 keys): split the query loop so the grid still fills the chip
     const int nqt = hcp_cdiv(p.Nq, KVT);
     int qsplit = 1;
     const long base = (long)nkv * p.H * B;
@@ -81,14 +82,20 @@ int launch_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t str
         const int min_tiles = ovr ? ((g_attn_cfg >> 8) & 255) : kMinQTilesPerSplit;
         const int target = ovr ? 256 * ((g_attn_cfg >> 16) & 15) : kSplitTargetWgs;
         qsplit = (int)((target + base - 1) / base);
-        if (qsplit > nqt / min_tiles) qsplit = nqt / min_tiles;       // >= min_tiles query tiles per workgroup, else memset + convert dominate
+        if (qsplit > nqt / min_tiles) qsplit = nqt / min_tiles;       // >= min_tiles query tiles per workgroup, else clear + convert dominate
         if (qsplit < 2) qsplit = 1;
     }
     p.qsplit = qsplit;
+    p.zero_ptr = nullptr; p.zero_n4 = 0;
     if (qsplit > 1) {
         p.dk32 = ws; p.dv32 = ws + (size_t)B * p.Nk * p.H * D;
-        if (hcp_memset_async(ws, 0, need, stream)) return hcp_set_error("attention_bwd: memset failed");
+        p.zero_ptr = ws; p.zero_n4 = (long)(need / 16);               // (H * D is a multiple of 8: need is a multiple of 16 bytes)
     }
+}
+template <int D, int KT>
+int launch_dkv(AttnParams& p, int B, hipStream_t stream) {
+    const int nkv = hcp_cdiv(p.Nk, 64 * KT);
+    const int qsplit = p.qsplit;
     const int n = nkv * qsplit * p.H * B;
     if (p.kbias || p.causal) HCP_LAUNCH((attn2_bwd_dkv_kernel<D, KT, true, VAR_PRODUCT>), dim3(n), dim3(256), dkv_smem<D>(), stream, p);
     else if (p.pre) HCP_LAUNCH((attn2_bwd_dkv_kernel<D, KT, false, VAR_PRE_BASE>), dim3(n), dim3(256), dkv_smem<D>(), stream, p);
@@ -133,12 +140,14 @@ int run_bwd(AttnParams& p, int B, float* ws, size_t ws_bytes, hipStream_t stream
     // measured on MI355X: 32 rows per wave pay off once the grid has >= 512 such workgroups
     bool wq = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nq, 128) >= 512, wk = kWide<D> && (long)B * p.H * hcp_cdiv(p.Nk, 128) >= 512;
     if (g_attn_cfg >= 0 && !(g_attn_cfg & 16)) { wq = kWide<D> && (g_attn_cfg & 2); wk = kWide<D> && (g_attn_cfg & 4); }
+    if constexpr (kWide<D>) { if (wk) plan_dkv<D, 2>(p, B, ws, ws_bytes); else plan_dkv<D, 1>(p, B, ws, ws_bytes); }
+    else plan_dkv<D, 1>(p, B, ws, ws_bytes);
     int e;
     if constexpr (kWide<D>) { e = wq ? launch_dq<D, 2>(p, B, stream) : launch_dq<D, 1>(p, B, stream); }
     else e = launch_dq<D, 1>(p, B, stream);
     if (e) return e;
-    if constexpr (kWide<D>) { return wk ? launch_dkv<D, 2>(p, B, ws, ws_bytes, stream) : launch_dkv<D, 1>(p, B, ws, ws_bytes, stream); }
-    return launch_dkv<D, 1>(p, B, ws, ws_bytes, stream);
+    if constexpr (kWide<D>) { return wk ? launch_dkv<D, 2>(p, B, stream) : launch_dkv<D, 1>(p, B, stream); }
+    return launch_dkv<D, 1>(p, B, stream);
 }
 
 int attn_check(const AttnParams& p, int B, int D) {

@@ -44,6 +44,11 @@ struct AttnParams {
     // dK/dV kernel: the query loop may be split over workgroups that accumulate into fp32 buffers
     int qsplit;
     float* dk32; float* dv32;       // [B, Nk, H*D] fp32 accumulators when qsplit > 1
+    // The dQ kernel, which runs in front of the dK/dV kernel on the same stream, clears those accumulators (zero_n4 16-byte pieces from
+    // zero_ptr, spread over its workgroups): no hipMemsetAsync node between the two kernels (round 5: under hipGraph replay the memset
+    // node in front of the query-split dK/dV kernel intermittently left stale workspace contents in the accumulators — absurd
+    // to_k / to_v LoRA gradients on the 64x64 cross-attention layers from some replay on, tools/diag/nan_hunt.py).
+    float* zero_ptr; long zero_n4;
 };
 
 constexpr int KVT = 64;            // keys (or queries, in the dK/dV kernel) per tile
@@ -442,6 +447,10 @@ HCP_WAVES_PER_SIMD((dq_waves<D, QT>())) HCP_KERNEL(256) attn2_bwd_dq_kernel(Attn
     const float cs = RAW ? c2 : 1.0f;
 
     for (int i = tid * 8; i < 2 * BUF; i += 256 * 8) *(hcp_bf16x8*)(lds + i) = hcp_zero8();
+    if (p.zero_n4) {                                  // (workgroup-uniform) the query-split dK/dV accumulators of the kernel behind this one
+        const hcp_f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        for (long i = (long)blockIdx.x * 256 + tid; i < p.zero_n4; i += (long)gridDim.x * 256) ((hcp_f32x4*)p.zero_ptr)[i] = z4;
+    }
     TileDma<D> dma;
     dma.init(wave, lane, p.k_rs, p.v_rs);
     const int nt = (p.Nk + KVT - 1) / KVT;

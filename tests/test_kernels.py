@@ -220,6 +220,63 @@ def test_attention_fwd_bwd(backend, case):
     assert relerr(dq, dq_ref) < 2e-2 and relerr(dk, dk_ref) < 2e-2 and relerr(dv, dv_ref) < 2e-2
 
 
+def test_attention_query_split_dkv_clears_its_own_accumulators(tbackend):
+    """Long query / short key (cross-attention): the dK/dV kernel splits its query loop over workgroups that add into fp32 accumulators
+    in the SHARED workspace (the split-K slabs of the GEMMs live there too).  The dQ kernel in front clears them — no hipMemsetAsync node
+    (round 5: under hipGraph replay that memset intermittently left stale workspace contents in the sums; tools/diag/nan_hunt.py).  The
+    workspace is poisoned with NaN bit patterns before every call; forced here on a small shape through the tools hook."""
+    B, H, Nq, Nk, D = (1, 1, 520, 77, 40) if not tbackend.is_gpu else (4, 8, 4096, 77, 40)
+    torch.manual_seed(3)
+    q, k, v, do = rnd(B, Nq, H * D), rnd(B, Nk, H * D), rnd(B, Nk, H * D), rnd(B, Nq, H * D)
+    o_ref, lse_ref, dq_ref, dk_ref, dv_ref = attn_ref(q, k, v, H, do)
+    to = tbackend.to
+    K.lib().hcp_debug_set_attention_config(16 | (2 << 8) | (1 << 16))      # keep the rows-per-wave heuristic; >= 2 query tiles per split, 256 target workgroups
+    try:
+        o, lse = K.attention_fwd(to(q), to(k), to(v), H)
+        for _ in range(3):
+            K._workspace(o).view(torch.int32).fill_(-1)                     # 0xFFFFFFFF: NaN as fp32
+            dq, dk, dv = K.attention_bwd(to(q), to(k), to(v), o, to(do), lse, H)
+            assert torch.isfinite(dk.float()).all() and torch.isfinite(dv.float()).all()
+            assert relerr(dq, dq_ref) < 2e-2 and relerr(dk, dk_ref) < 2e-2 and relerr(dv, dv_ref) < 2e-2
+    finally:
+        K.lib().hcp_debug_set_attention_config(-1)
+
+
+@pytest.mark.gpu
+def test_attention_query_split_backward_replayed_as_a_hipgraph():
+    """Regression (round 5): the 64x64 cross-attention backward (B4 H8, 4096 queries x 77 keys: query-split dK/dV with fp32 atomics into the
+    shared workspace) captured in a hipGraph and replayed 200 times with the workspace re-poisoned between replays.  With a
+    hipMemsetAsync NODE clearing the accumulators, replays of the training step intermittently summed onto stale workspace contents
+    (absurd to_k / to_v LoRA gradients, NaN losses in bench.py --seam --seam-graph); the dQ kernel clears them now."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    K._set_backend_for_tests(None)
+    dev = torch.device("cuda:0")
+    B, H, Nq, Nk, D = 4, 8, 4096, 77, 40
+    torch.manual_seed(5)
+    q, k, v, do = (rnd(B, n, H * D).to(dev) for n in (Nq, Nk, Nk, Nq))
+    o, lse = K.attention_fwd(q, k, v, H)
+    ws = K._workspace(o).view(torch.int32)
+    dq0, dk0, dv0 = K.attention_bwd(q, k, v, o, do, lse, H)
+    out = tuple(torch.empty_like(t) for t in (q, k, v))
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        K.attention_bwd(q, k, v, o, do, lse, H, out=out)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            K.gemm(q.view(-1, H * D), k.view(-1, H * D)[:64].contiguous())           # a GEMM in front, as in the step (its split-K slabs share the workspace)
+            K.attention_bwd(q, k, v, o, do, lse, H, out=out)
+    torch.cuda.current_stream().wait_stream(s)
+    for i in range(200):
+        ws.fill_(-1)                                                                  # NaN bit patterns wherever nobody writes
+        g.replay()
+        if i % 20 == 19:
+            torch.cuda.synchronize()
+            assert torch.isfinite(out[1].float()).all() and torch.isfinite(out[2].float()).all(), i
+            assert relerr(out[1], dk0.float().cpu()) < 1e-3 and relerr(out[2], dv0.float().cpu()) < 1e-3 and relerr(out[0], dq0.float().cpu()) < 1e-6, i
+
+
 @pytest.mark.parametrize("cfg", [0, 7, 8, 15])
 def test_attention_rows_per_wave_variants(tbackend, cfg):
     """16- and 32-rows-per-wave and 4- / 8-wave-workgroup instantiations of forward / dQ / dK,dV agree with the reference

@@ -33,3 +33,4 @@ except Exception as e:
     print(sys.argv[1], "unreadable", e)
 PY
 done
+if grep -l '"final_loss": NaN' $out/bench_*.json $out/*.log 2>/dev/null; then echo "!!! NaN final_loss in the files above"; else echo "no NaN final_loss in any bench line"; fi
