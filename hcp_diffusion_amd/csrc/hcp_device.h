@@ -221,8 +221,9 @@ extern "C" int hcp_set_error(const char* fmt, ...);
 // atomics", and under hipGraph replay a memset NODE in that position intermittently let the adding kernel see stale contents (round 5:
 // garbage dK / dV sums of the query-split cross-attention backward from some replay on — tools/diag/nan_hunt.py; eager streams never
 // showed it).  A kernel node orders against its neighbours like any other launch of the step.  n must be a multiple of 4 bytes.
-template <int UNUSED>
-__global__ void __launch_bounds__(256) hcp_fill32_kernel(unsigned* p, unsigned v, size_t n4) {
+// (internal linkage: every translation unit registers its OWN copy with its own code object — one shared host stub registered by eleven
+//  modules would leave the choice of the module to the runtime)
+static __global__ void __launch_bounds__(256) hcp_fill32_kernel(unsigned* p, unsigned v, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t s) {
@@ -232,7 +233,7 @@ static inline int hcp_memset_async(void* p, int v, size_t n, hipStream_t s) {
     const size_t n4 = n / 4;
     size_t g = (n4 + 255) / 256; if (g > 1024) g = 1024;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(hcp_fill32_kernel<0>, dim3((unsigned)g), dim3(256), 0, s, (unsigned*)p, w, n4);
+    hipLaunchKernelGGL(hcp_fill32_kernel, dim3((unsigned)g), dim3(256), 0, s, (unsigned*)p, w, n4);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 static inline int hcp_memcpy_async(void* d, const void* src, size_t n, hipStream_t s) {

@@ -274,7 +274,8 @@ def test_attention_query_split_backward_replayed_as_a_hipgraph():
         if i % 20 == 19:
             torch.cuda.synchronize()
             assert torch.isfinite(out[1].float()).all() and torch.isfinite(out[2].float()).all(), i
-            assert relerr(out[1], dk0.float().cpu()) < 1e-3 and relerr(out[2], dv0.float().cpu()) < 1e-3 and relerr(out[0], dq0.float().cpu()) < 1e-6, i
+            # (dK / dV: fp32 atomics in a different order each replay, then one bf16 rounding; dQ is deterministic)
+            assert relerr(out[1], dk0.float().cpu()) < 1e-2 and relerr(out[2], dv0.float().cpu()) < 1e-2 and relerr(out[0], dq0.float().cpu()) < 1e-6, i
 
 
 @pytest.mark.parametrize("cfg", [0, 7, 8, 15])
