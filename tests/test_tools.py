@@ -44,12 +44,12 @@ def test_step_summary_clusters_launch_positions(tmp_path):
 
 
 def test_committed_step_summary_carries_the_clusters():
-    """profiles/r4_step_kernel_summary.md (what bench.py's avg_launch_us_in_step is read from) has the position column, and the
+    """profiles/r5_step_kernel_summary.md (what bench.py's avg_launch_us_in_step is read from) has the position column, and the
     committed roofline record agrees with it."""
     import json
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_roofline
-    rec = pmc_roofline.in_step_averages(os.path.join(ROOT, "profiles", "r4_step_kernel_summary.md"))
+    rec = pmc_roofline.in_step_averages(os.path.join(ROOT, "profiles", "r5_step_kernel_summary.md"))
     js = json.load(open(os.path.join(ROOT, "profiles", "pmc_roofline.json")))
     assert set(rec) >= {"conv3x3_c320_64x64_b4", "attn_fwd_b4_h8_n4096_d40", "attn_dq_b4_h8_n4096_d40", "attn_dkv_b4_h8_n4096_d40"}
     for k, v in rec.items():
