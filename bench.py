@@ -387,9 +387,6 @@ def main():
         if graph:
             unet.enable_hip_graph()
         nancheck, seen_bad, calls = os.environ.get("HCP_BENCH_NANCHECK") == "1", [], []
-        import gc
-        if os.environ.get("HCP_BENCH_GC") == "off":
-            gc.disable()
 
         def seam_step():
             noise = torch.randn_like(latents)
@@ -428,8 +425,6 @@ def main():
             torch.nn.utils.clip_grad_norm_(params, 1.0)              # accelerator.clip_grad_norm_(TE_unet.trainable_parameters(), ...), train_ac.py:485-490
             opt.step()
             opt.zero_grad(set_to_none=False)
-            if os.environ.get("HCP_BENCH_GC") == "every":
-                gc.collect()
             return loss.item()
         for _ in range(warmup):
             seam_step()
