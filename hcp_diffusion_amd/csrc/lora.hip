@@ -13,8 +13,26 @@ namespace {
 
 constexpr int WG_BQ = 128;        // columns of R per block
 constexpr int WG_BM = 64;         // token rows per LDS tile
-constexpr int WG_RS = WG_BQ + 2;  // LDS row stride (bf16) of the R tile: 65 dwords -> conflict-free u16 gathers
-constexpr int WG_LS = 32 + 2;     // LDS row stride of the L tile
+// Row strides (bf16 elements) of the two row-major LDS images: an odd number of 16-byte granules (17 / 5), so that the 16-byte staging
+// stores stay aligned and the transposed fragment reads of four consecutive rows fall on distinct banks (the attention images' rule,
+// tools/attn_lab/bank_model.py).
+constexpr int WG_RS = WG_BQ + 8;
+constexpr int WG_LS = 32 + 8;
+
+HCP_DEVICE hcp_bf16x8 wg_join8(hcp_bf16x4 a, hcp_bf16x4 b) {
+    hcp_bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = a[i]; r[4 + i] = b[i]; }
+    return r;
+}
+// MFMA operand whose k-slots run down 32 token ROWS of a row-major image, for the 16 columns starting at `col`: two ds_read_b64_tr_b16
+// (hcp_lds_read_tr4: lane group fg receives rows 4 fg .. 4 fg + 3 of a 16-row block) — the same row -> k-slot order for the L and the R
+// image, so the products pair the same tokens.  (Round 5: the fragments were gathered with 16 ds_read_u16 per operand and the tiles
+// staged with 8 ds_write_b16 per 16 bytes; the LDS instruction stream, not HBM, set the kernel's time.)
+HCP_DEVICE hcp_bf16x8 wg_frag(const hcp_bf16* img, int rs, int row0, int col, int fr, int fg) {
+    const hcp_bf16* a = img + (row0 + 4 * fg + (fr >> 2)) * rs + col + 4 * (fr & 3);
+    return wg_join8(hcp_lds_read_tr4(a), hcp_lds_read_tr4(a + 16 * rs));
+}
 
 // out[p, q] (+)= scale * sum_m L[m, p] * R[m, q]      p < P (<= 32), q < Q
 // transpose_out: element (p,q) lives at out[q * ldo + p] instead of out[p * ldo + q]
@@ -53,13 +71,11 @@ HCP_DEVICE void wgrad_block(const WgradProb& pr, int M, int P, float scale, int 
             // of a 32-wide T / U (several LoRA blocks on one host), whose last pieces would otherwise run past the row
             const bool live = m0 + r < me && c + 8 > pcol0 && c < pcol0 + P;
             if (live) v = *(const hcp_bf16x8*)(L + (size_t)(m0 + r) * ldl + c);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sL[r * WG_LS + c + i] = (hcp_bf16)v[i];
+            *(hcp_bf16x8*)(sL + r * WG_LS + c) = v;
             if (lo) {
                 hcp_bf16x8 v2 = hcp_zero8();
                 if (live) v2 = *(const hcp_bf16x8*)(L + (size_t)(m0 + r) * ldl + lo + c);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) sL2[r * WG_LS + c + i] = (hcp_bf16)v2[i];
+                *(hcp_bf16x8*)(sL2 + r * WG_LS + c) = v2;
             }
         }
         // stage R tile: 64 rows x 128 cols = 1024 chunks
@@ -69,31 +85,23 @@ HCP_DEVICE void wgrad_block(const WgradProb& pr, int M, int P, float scale, int 
             int r = cidx >> 4, c = (cidx & 15) * 8;
             hcp_bf16x8 v = hcp_zero8();
             if (m0 + r < me && q0 + c < Q) v = *(const hcp_bf16x8*)(R + (size_t)(m0 + r) * ldr + q0 + c);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sR[r * WG_RS + c + i] = (hcp_bf16)v[i];
+            *(hcp_bf16x8*)(sR + r * WG_RS + c) = v;
         }
         HCP_SYNC();
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int kb = ks * 32 + fg * 8;   // this lane's 8 token rows
+        for (int ks = 0; ks < 2; ++ks) {                                   // two k-steps of 32 token rows
             hcp_bf16x8 fa[2], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) fa[i] = wg_frag(sL, WG_LS, ks * 32, i * 16, fr, fg);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) fa[i][e] = (short)sL[(kb + e) * WG_LS + i * 16 + fr];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) fb[j][e] = (short)sR[(kb + e) * WG_RS + wave * 32 + j * 16 + fr];
+            for (int j = 0; j < 2; ++j) fb[j] = wg_frag(sR, WG_RS, ks * 32, wave * 32 + j * 16, fr, fg);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = hcp_mfma16(fa[i], fb[j], acc[i][j]);
             if (lo) {                                                      // (workgroup-uniform)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) fa[i][e] = (short)sL2[(kb + e) * WG_LS + i * 16 + fr];
+                for (int i = 0; i < 2; ++i) fa[i] = wg_frag(sL2, WG_LS, ks * 32, i * 16, fr, fg);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
