@@ -36,6 +36,7 @@ def test_bench_launcher_runs_n_ranks_end_to_end(n):
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["config"]["rccl_ranks"] == n and d["config"]["parallelism"] == f"dp{n}" and d["config"]["global_batch"] == n
     assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0 and "emu" in d["data"]
+    assert d["loss_finite"] is True and d["final_loss"] > 0 and "invalid" not in d        # (round 5: the line says itself whether its loss was finite)
 
 
 @pytest.mark.slow
@@ -83,8 +84,9 @@ def test_bench_json_line_contract():
     assert len(lines) == 1, "exactly ONE JSON line"
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline"):
+              "data", "config", "roofline", "loss_finite"):
         assert k in d, k
+    assert d["loss_finite"] is True and "invalid" not in d
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "images/sec" and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "SD1.5" in d["config"]["workload"] and d["config"]["global_batch"] == 4
