@@ -18,6 +18,8 @@ _PROTOTYPES = {
     "hcp_last_error": (c_char_p, []),
     "hcp_is_emulated": (I, []),
     "hcp_abi_version": (I, []),
+    # line, bucket, nb, stride, workgroups, stream
+    "hcp_selfcheck_atomics": (I, [P, P, I, I, I, P]),
     # A, lda, B, ldb, D, ldd, M, N, K, A2, lda2, B2, ldb2, K2, bias, rowbias, rowbias_ld, rows_per_group,
     # residual, ldr, alpha, out_f32, workspace, workspace_bytes, stream
     "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, F, I, P, c_size_t, P]),
@@ -79,14 +81,15 @@ _PROTOTYPES = {
     "hcp_softmax_rows": (I, [P, L, P, L, I, I, F, P]),
     "hcp_vae_latent_sample": (I, [P, P, P, P, P, I, I, L, F, P]),
     "hcp_mse_masked_mean": (I, [P, P, P, I, P, P, P, I, I, I, F, P]),
-    # L, ldl, R, ldr, out, ldo, M, P, Q, scale, transpose_out, stream
-    "hcp_lora_wgrad": (I, [P, I, I, P, I, P, I, I, I, I, F, I, P]),
-    # U, x, ldx, K, grad_down, T, dY, ldy, N, grad_up, M, r, scale, stream
-    "hcp_lora_wgrad_pair": (I, [P, I, P, I, I, P, P, I, P, I, I, P, I, I, F, P]),
+    # L, ldl, l_lo, R, ldr, out, ldo, M, P, Q, scale, transpose_out, workspace, workspace_bytes, stream
+    "hcp_lora_wgrad": (I, [P, I, I, P, I, P, I, I, I, I, F, I, P, c_size_t, P]),
+    # U, ldu, x, ldx, K, grad_down, T, ldt, dY, ldy, N, grad_up, M, r, scale, workspace, workspace_bytes, stream
+    "hcp_lora_wgrad_pair": (I, [P, I, P, I, I, P, P, I, P, I, I, P, I, I, F, P, c_size_t, P]),
     "hcp_split_hi_lo_bf16": (I, [P, P, c_long, I, P]),
-    "hcp_lora_wgrad_group_geometry": (I, [I, I, I, P, P, P]),
+    "hcp_lora_wgrad_group_geometry": (I, [I, I, I, I, I, P, P, P, P]),
     "hcp_lora_wgrad_group_desc_bytes": (I, []),
-    "hcp_lora_wgrad_grouped": (I, [P, I, I, P]),
+    # descs, count, total_blocks, total_tiles, slab_units, workspace, workspace_bytes, stream
+    "hcp_lora_wgrad_grouped": (I, [P, I, I, I, c_long, P, c_size_t, P]),
     "hcp_lora_pack": (I, [P, I, P]),
     "hcp_lora_pack_desc_bytes": (I, []),
     "hcp_sumsq_f32": (I, [P, L, P, P]),
@@ -120,13 +123,23 @@ TOOLS_SYMBOLS = tuple(_TOOLS_PROTOTYPES)
 TOOLS_LIB_PATH = Path(__file__).resolve().parent / "libhcp_mi355x_tools.so"
 
 
+ABI_VERSION = 2          # include/hcp_mi355x.h HCP_ABI_VERSION: bumped whenever an exported signature or descriptor layout changes
+
+
 class HcpError(RuntimeError):
     pass
 
 
 def bind(cdll):
-    """Attach argtypes/restype for every exported symbol; raises AttributeError if one is missing.  The tuning hooks are
+    """Attach argtypes/restype for every exported symbol; raises AttributeError if one is missing, HcpError when the library was
+    built from another revision of the header (a stale .so would take shifted arguments silently).  The tuning hooks are
     bound when the library has them (tools / interpreter builds)."""
+    cdll.hcp_abi_version.restype = I
+    cdll.hcp_abi_version.argtypes = []
+    got = cdll.hcp_abi_version()
+    if got != ABI_VERSION:
+        raise HcpError(f"{getattr(cdll, '_name', 'library')}: hcp_abi_version() = {got}, these bindings are for ABI {ABI_VERSION} "
+                       "(rebuild with `python -m hcp_diffusion_amd.build`)")
     for name, (res, args) in _PROTOTYPES.items():
         fn = getattr(cdll, name)
         fn.restype = res

@@ -15,14 +15,20 @@
 namespace {
 using namespace hcp_attn;
 
-// fp32 accumulators of the query-split dK/dV pass -> bf16 outputs (token-major, strided)
+// fp32 slabs of the query-split dK/dV pass (one per split, [B, Nk, C] each), added in split order -> bf16 outputs (token-major, strided)
 HCP_KERNEL(256) attn_dkv_convert_kernel(AttnParams p, int B, int C) {
     const int cv = C / 4;
     const long total = (long)B * p.Nk * cv;
+    const size_t slab = (size_t)B * p.Nk * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % cv) * 4; long r = i / cv; const int n = (int)(r % p.Nk); const int b = (int)(r / p.Nk);
-        const hcp_f32x4 k4 = *(const hcp_f32x4*)(p.dk32 + ((size_t)b * p.Nk + n) * C + c);
-        const hcp_f32x4 v4 = *(const hcp_f32x4*)(p.dv32 + ((size_t)b * p.Nk + n) * C + c);
+        const size_t e = ((size_t)b * p.Nk + n) * C + c;
+        hcp_f32x4 k4 = *(const hcp_f32x4*)(p.dk32 + e);
+        hcp_f32x4 v4 = *(const hcp_f32x4*)(p.dv32 + e);
+        for (int s = 1; s < p.qsplit; ++s) {
+            const hcp_f32x4 ks = *(const hcp_f32x4*)(p.dk32 + s * slab + e); k4 += ks;
+            const hcp_f32x4 vs = *(const hcp_f32x4*)(p.dv32 + s * slab + e); v4 += vs;
+        }
         hcp_bf16x4 wk, wv;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { wk[q] = (short)hcp_f2bf(k4[q]); wv[q] = (short)hcp_f2bf(v4[q]); }
@@ -68,29 +74,26 @@ int launch_dq(AttnParams& p, int B, hipStream_t stream) {
     else HCP_LAUNCH((attn2_bwd_dq_kernel<D, QT, false, VAR_PRODUCT>), dim3(n), dim3(256), fwd_smem<D>(), stream, p);
     HCP_LAUNCH_CHECK("attn_bwd_dq");
 }
-// few key tiles (cross-attention: 77 keys): split the query loop of the dK/dV kernel so the grid still fills the chip; the partial sums
-// meet in fp32 accumulators in the workspace (cleared by the dQ kernel in front, AttnParams::zero_ptr)
+// few key tiles (cross-attention: 77 keys): split the query loop of the dK/dV kernel so the grid still fills the chip; every split leaves
+// its partial sums as an fp32 slab in the workspace and the convert kernel adds them in split order (no atomics, nothing to clear)
 template <int D, int KT>
 void plan_dkv(AttnParams& p, int B, float* ws, size_t ws_bytes) {
     const int nkv = hcp_cdiv(p.Nk, 64 * KT);
     const int nqt = hcp_cdiv(p.Nq, KVT);
     int qsplit = 1;
     const long base = (long)nkv * p.H * B;
-    const size_t need = (size_t)2 * B * p.Nk * p.H * D * sizeof(float);
-    if (base < 256 && nqt >= 8 && ws && ws_bytes >= need) {
+    const size_t need1 = (size_t)2 * B * p.Nk * p.H * D * sizeof(float);          // one split's dK + dV slab
+    if (base < 256 && nqt >= 8 && ws && ws_bytes >= 2 * need1) {
         const bool ovr = g_attn_cfg >= 0 && (g_attn_cfg >> 8);                    // tools: bits 8-15 min tiles, bits 16-19 target / 256
         const int min_tiles = ovr ? ((g_attn_cfg >> 8) & 255) : kMinQTilesPerSplit;
         const int target = ovr ? 256 * ((g_attn_cfg >> 16) & 15) : kSplitTargetWgs;
         qsplit = (int)((target + base - 1) / base);
-        if (qsplit > nqt / min_tiles) qsplit = nqt / min_tiles;       // >= min_tiles query tiles per workgroup, else clear + convert dominate
+        if (qsplit > nqt / min_tiles) qsplit = nqt / min_tiles;       // >= min_tiles query tiles per workgroup, else the slabs + convert dominate
+        if ((size_t)qsplit > ws_bytes / need1) qsplit = (int)(ws_bytes / need1);
         if (qsplit < 2) qsplit = 1;
     }
     p.qsplit = qsplit;
-    p.zero_ptr = nullptr; p.zero_n4 = 0;
-    if (qsplit > 1) {
-        p.dk32 = ws; p.dv32 = ws + (size_t)B * p.Nk * p.H * D;
-        p.zero_ptr = ws; p.zero_n4 = (long)(need / 16);               // (H * D is a multiple of 8: need is a multiple of 16 bytes)
-    }
+    if (qsplit > 1) { p.dk32 = ws; p.dv32 = ws + (size_t)qsplit * B * p.Nk * p.H * D; }
 }
 template <int D, int KT>
 int launch_dkv(AttnParams& p, int B, hipStream_t stream) {

@@ -41,14 +41,14 @@ struct AttnParams {
     int causal;                     // 1: key k is visible to query q only if k <= q (CLIP text encoder); KB instantiations only
     int pre;                        // 1: Q holds Q * scale*log2(e) (its projection's weights carry the factor); `scale` then only names the factor
     int B;
-    // dK/dV kernel: the query loop may be split over workgroups that accumulate into fp32 buffers
+    // dK/dV kernel: the query loop may be split over `qsplit` workgroups per key block.  Round 6: every split STORES its fp32 partial into
+    // its own slab — dk32 / dv32 [qsplit][B, Nk, H*D], each element written exactly once — and the convert kernel behind adds the slabs
+    // in split order: no atomics, nothing to clear, the same bits on every run.  (Rounds 2-5 added the partials with fp32 atomics into
+    // one accumulator: cleared by a hipMemsetAsync that, as a hipGraph memset NODE, intermittently let the adding kernel see stale
+    // workspace contents — absurd to_k / to_v LoRA gradients on the 64x64 cross-attention layers, tools/diag/nan_hunt.py — then by the dQ
+    // kernel in front.)
     int qsplit;
-    float* dk32; float* dv32;       // [B, Nk, H*D] fp32 accumulators when qsplit > 1
-    // The dQ kernel, which runs in front of the dK/dV kernel on the same stream, clears those accumulators (zero_n4 16-byte pieces from
-    // zero_ptr, spread over its workgroups): no hipMemsetAsync node between the two kernels (round 5: under hipGraph replay the memset
-    // node in front of the query-split dK/dV kernel intermittently left stale workspace contents in the accumulators — absurd
-    // to_k / to_v LoRA gradients on the 64x64 cross-attention layers from some replay on, tools/diag/nan_hunt.py).
-    float* zero_ptr; long zero_n4;
+    float* dk32; float* dv32;
 };
 
 constexpr int KVT = 64;            // keys (or queries, in the dK/dV kernel) per tile
@@ -447,10 +447,6 @@ HCP_WAVES_PER_SIMD((dq_waves<D, QT>())) HCP_KERNEL(256) attn2_bwd_dq_kernel(Attn
     const float cs = RAW ? c2 : 1.0f;
 
     for (int i = tid * 8; i < 2 * BUF; i += 256 * 8) *(hcp_bf16x8*)(lds + i) = hcp_zero8();
-    if (p.zero_n4) {                                  // (workgroup-uniform) the query-split dK/dV accumulators of the kernel behind this one
-        const hcp_f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        for (long i = (long)blockIdx.x * 256 + tid; i < p.zero_n4; i += (long)gridDim.x * 256) ((hcp_f32x4*)p.zero_ptr)[i] = z4;
-    }
     TileDma<D> dma;
     dma.init(wave, lane, p.k_rs, p.v_rs);
     const int nt = (p.Nk + KVT - 1) / KVT;
@@ -758,15 +754,16 @@ HCP_WAVES_PER_SIMD((dkv_waves<D, KT>())) HCP_KERNEL(256) attn2_bwd_dkv_kernel(At
     for (int t = 0; t < KT; ++t) {
         const int row = k_base + t * 16 + fr;
         if (row >= p.Nk) continue;
-        if (p.qsplit > 1) {
-            float* k32 = p.dk32 + ((size_t)b * p.Nk + row) * (p.H * D) + h * D;
-            float* v32 = p.dv32 + ((size_t)b * p.Nk + row) * (p.H * D) + h * D;
+        if (p.qsplit > 1) {                               // this split's own slab: plain 16-byte stores, summed by attn_dkv_convert_kernel
+            const size_t slab = (size_t)qs * p.B * p.Nk * (p.H * D);
+            float* k32 = p.dk32 + slab + ((size_t)b * p.Nk + row) * (p.H * D) + h * D;
+            float* v32 = p.dv32 + slab + ((size_t)b * p.Nk + row) * (p.H * D) + h * D;
 #pragma unroll
             for (int d = 0; d < G::NDV; ++d) {
                 const int col = d * 16 + 4 * fg;
                 if (col < D) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { hcp_atomic_add(k32 + col + r, dk[t][d][r] * kscale); hcp_atomic_add(v32 + col + r, dv[t][d][r]); }
+                    *(hcp_f32x4*)(k32 + col) = dk[t][d] * kscale;
+                    *(hcp_f32x4*)(v32 + col) = dv[t][d];
                 }
             }
             continue;

@@ -52,7 +52,8 @@ BF16 = torch.bfloat16
 
 _WS = {}
 _WGTAB = {}
-_WS_BYTES = 128 << 20
+_WS_BYTES = 256 << 20
+WGRAD_GRID_BLOCKS = int(os.environ.get("HCP_LAB_WGRAD_BLOCKS", 16384))      # workgroups the grouped LoRA weight-gradient launch aims at
 
 
 def _workspace(t):
@@ -60,9 +61,31 @@ def _workspace(t):
     key = (t.device.type, t.device.index)
     ws = _WS.get(key)
     if ws is None:
-        ws = torch.empty(_WS_BYTES if t.is_cuda else (4 << 20), dtype=torch.uint8, device=t.device)
+        ws = torch.empty(_WS_BYTES if t.is_cuda else (16 << 20), dtype=torch.uint8, device=t.device)
         _WS[key] = ws
     return ws
+
+
+def atomics_selfcheck(device, workgroups=2048, nb=4099, stride=37):
+    """Exact check of the device's fp32 atomic adds (hcp_selfcheck_atomics): raises HcpError when a sum of small integers is wrong.
+    One launch of `workgroups` x 256 threads, two small device buffers, one synchronising read-back: ~1 ms.  Called by smoke(), bench.py and
+    the GPU tests before they trust any number (every cross-workgroup sum left in the library — loss, gradient norm, bias / affine
+    gradients, the query-split dK / dV — goes through this instruction)."""
+    dev = torch.device(device)
+    line = torch.empty(16, dtype=torch.float32, device=dev)
+    bucket = torch.empty(nb * stride, dtype=torch.float32, device=dev)
+    _chk(lib().hcp_selfcheck_atomics(_p(line), _p(bucket), nb, stride, workgroups, _stream(line)), "hcp_selfcheck_atomics")
+    w = torch.arange(workgroups, dtype=torch.int64).view(-1, 1)
+    t = torch.arange(256, dtype=torch.int64).view(1, -1)
+    want_b = torch.zeros(nb, dtype=torch.int64).index_add_(0, ((37 * w + 101 * t) % nb).flatten(), ((t & 3) + 1).expand(workgroups, 256).flatten())
+    want_l = workgroups * 16 * ((torch.arange(16) & 3) + 1)
+    got_l, got_b = line.cpu().double(), bucket.cpu()[::stride].double()
+    bad_l = int((got_l != want_l.double()).sum()); bad_b = int((got_b != want_b.double()).sum())
+    if bad_l or bad_b:
+        worst = float(((got_b - want_b.double()).abs() / want_b.double().clamp(min=1)).max())
+        raise _lib.HcpError(f"fp32 atomics self-check FAILED on {dev}: {bad_l}/16 words of the shared line and {bad_b}/{nb} strided words differ "
+                            f"from the exact integer sums (worst relative error {worst:.3g}); no result of this device can be trusted")
+    return True
 
 
 TRACE = None        # tools/autotune.py: a list collects the (kind, shape...) key of every GEMM-family launch
@@ -568,7 +591,7 @@ def split_hi_lo(src):
 
 
 def lora_wgrad(L, R, out, P, scale, transpose_out, out_col0=0, lo=0):
-    """out (fp32, atomically accumulated) += scale * L[:, :P]^T @ R ; transpose_out writes out[q, out_col0 + p]
+    """out (fp32) += scale * L[:, :P]^T @ R (partial slabs in the workspace + an ordered reduce: no atomics); transpose_out writes out[q, out_col0 + p]
     (out_col0: first rank column of a 32-wide block when the rank exceeds one slot group).  lo: column offset of the residual half of a
     split L (t_lo(L)), 0 = none."""
     _bf16_2d(L, "L"); _bf16_2d(R, "R")
@@ -577,8 +600,9 @@ def lora_wgrad(L, R, out, P, scale, transpose_out, out_col0=0, lo=0):
     assert out_col0 == 0 or transpose_out
     ldo = out.shape[1]
     ptr = ctypes.c_void_p(out.data_ptr() + 4 * out_col0)
+    ws = _workspace(L)
     _chk(lib().hcp_lora_wgrad(_p(L), L.stride(0), int(lo), _p(R), R.stride(0), ptr, ldo, M, P, Q, float(scale),
-                              1 if transpose_out else 0, _stream(L)), "hcp_lora_wgrad")
+                              1 if transpose_out else 0, _p(ws), ws.numel(), _stream(L)), "hcp_lora_wgrad")
 
 
 def lora_wgrad_pair(U, x, grad_down, T, dy, grad_up, r, scale):
@@ -587,32 +611,49 @@ def lora_wgrad_pair(U, x, grad_down, T, dy, grad_up, r, scale):
     N = dy.shape[1]
     assert U.shape in ((M, 32), (M, 64)) and T.shape in ((M, 32), (M, 64)) and U.is_contiguous() and T.is_contiguous()      # 64: split (hi | lo)
     assert grad_down.shape == (r, Kd) and grad_up.shape == (N, r) and grad_down.is_contiguous() and grad_up.is_contiguous()
+    ws = _workspace(x)
     _chk(lib().hcp_lora_wgrad_pair(_p(U), U.shape[1], _p(x), x.stride(0), Kd, _p(grad_down), _p(T), T.shape[1], _p(dy), dy.stride(0), N,
-                                   _p(grad_up), M, r, float(scale), _stream(x)), "hcp_lora_wgrad_pair")
+                                   _p(grad_up), M, r, float(scale), _p(ws), ws.numel(), _stream(x)), "hcp_lora_wgrad_pair")
 
 
 def lora_wgrad_grouped(items):
-    """items: list of (U, x, grad_down, T, dy, grad_up, r, scale[, slot0[, u_lo, t_lo]]) — every layer's LoRA weight gradients, ONE launch.
+    """items: list of (U, x, grad_down, T, dy, grad_up, r, scale[, slot0[, u_lo, t_lo]]) — every layer's LoRA weight gradients as ONE
+    partial-tile launch + ONE ordered reduce (no atomics: a step's LoRA gradients are bit-reproducible).
     dy, U and T may be column-slice views (row stride = their stride(0)); slot0 = first rank column of the layer in U / T;
-    u_lo / t_lo = column offset of the residual half of a split U / T (t_lo(.)), 0 = none."""
+    u_lo / t_lo = column offset of the residual half of a split U / T (t_lo(.)), 0 = none.
+    A gradient tensor named twice (a layer that ran twice in the forward) is taken by a second call on the same stream: inside one
+    call the reduce adds into the bucket without atomics."""
+    seen, first, rest = set(), [], []
+    for item in items:
+        key = (item[2].data_ptr(), item[5].data_ptr())
+        (rest if key in seen else first).append(item)
+        seen.add(key)
+    if rest:
+        a = lora_wgrad_grouped(first)
+        b = lora_wgrad_grouped(rest)
+        return a + b
     import struct
     L = lib()
-    assert L.hcp_lora_wgrad_group_desc_bytes() == 144
-    qt, sp, rows = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert L.hcp_lora_wgrad_group_desc_bytes() == 152
+    qt0, qt1, sp, rows = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     buf = bytearray()
-    begin = 0
+    begin = tiles = units = 0
+    target = max(8, min(256, WGRAD_GRID_BLOCKS // len(items)))     # the layers share one grid: a few thousand workgroups fill the chip
     for item in items:
         (U, x, gd, T, dy, gu, r, scale) = item[:8]
         slot0 = item[8] if len(item) > 8 else 0          # first rank column of this layer inside U / T (fused groups)
         ulo, tlo = (item[9], item[10]) if len(item) > 10 else (0, 0)
         M, Kd = x.shape
         N = dy.shape[1]
-        nb = L.hcp_lora_wgrad_group_geometry(M, Kd, N, ctypes.byref(qt), ctypes.byref(sp), ctypes.byref(rows))
+        nb = L.hcp_lora_wgrad_group_geometry(M, Kd, N, r, target, ctypes.byref(qt0), ctypes.byref(qt1), ctypes.byref(sp), ctypes.byref(rows))
         assert U.stride(1) == 1 and T.stride(1) == 1 and U.stride(0) % 8 == 0 and T.stride(0) % 8 == 0
         buf += struct.pack("<QiiQi4xQiiii", U.data_ptr(), U.stride(0), ulo, x.data_ptr(), x.stride(0), gd.data_ptr(), Kd, Kd, 0, slot0)
         buf += struct.pack("<QiiQi4xQiiii", T.data_ptr(), T.stride(0), tlo, dy.data_ptr(), dy.stride(0), gu.data_ptr(), r, N, 1, slot0)
-        buf += struct.pack("<iifiiiii", M, r, float(scale), rows.value, qt.value, sp.value, begin, 0)
+        buf += struct.pack("<iifiiiiiii", M, r, float(scale), rows.value, qt0.value, qt1.value, sp.value, begin, units, tiles)
         begin += nb
+        tiles += qt0.value + qt1.value
+        if sp.value > 1:
+            units += nb * r                           # a workgroup's slab: r x 128 floats (a layer with one token range writes its gradient itself)
     dev = items[0][1].device
     src = torch.frombuffer(buf, dtype=torch.uint8)
     if dev.type == "cuda":
@@ -643,7 +684,8 @@ def lora_wgrad_grouped(items):
         host, table = slot["host"], slot["table"]
     else:
         host, table = src, src.clone()
-    _chk(L.hcp_lora_wgrad_grouped(_p(table), len(items), begin, _stream(table)), "hcp_lora_wgrad_grouped")
+    ws = _workspace(items[0][1])
+    _chk(L.hcp_lora_wgrad_grouped(_p(table), len(items), begin, tiles, units, _p(ws), ws.numel(), _stream(table)), "hcp_lora_wgrad_grouped")
     return host, table
 
 

@@ -24,7 +24,16 @@ typedef struct ihipStream_t* hcpStream_t; /* == hipStream_t */
 
 const char* hcp_last_error(void);
 int hcp_is_emulated(void); /* 0 for the product library */
+/* Revision of this header.  hcp_abi_version() returns the value the library was built with; a binding made for another revision must
+ * refuse to call it (hcp_diffusion_amd/_lib.py does).  1: rounds 1-5.  2: round 6 — workspace arguments on the LoRA weight-gradient
+ * entry points (slabs + ordered reduce instead of fp32 atomics), 152-byte grouped descriptors; earlier in-place argument insertions
+ * (ldt on hcp_gemm_lora_bf16 / hcp_gemm_geglu_bwd_bf16, l_lo, ldu / ldt) are covered by the same bump. */
+#define HCP_ABI_VERSION 2
 int hcp_abi_version(void);
+/* Device self-check of the fp32 atomic path (no reference counterpart: the reference's sums are torch's).  workgroups x 256 threads add
+ * small integers into line[16] and into bucket[i * stride], i < nb (both cleared here first); exact expected values:
+ * line[j] = workgroups * 16 * ((j & 3) + 1), bucket[i * stride] = sum of ((t & 3) + 1) over (w, t) with (37 w + 101 t) % nb == i. */
+int hcp_selfcheck_atomics(float* line, float* bucket, int nb, int stride, int workgroups, hcpStream_t stream);
 
 /* D[M,N] = alpha*(A[M,K] B[N,K]^T + A2[M,K2] B2[N,K2]^T) + bias[N] + rowbias[m/rows_per_group, :] + residual[M,N]
  * Replaces nn.Linear / 1x1 nn.Conv2d forward and input-gradient of the UNet, and the LoRA container's
@@ -177,16 +186,23 @@ int hcp_mse_masked_mean(const float* pred, const float* target, const float* mas
 /* l_lo: 0, or the column offset of the residual half of a split L = (L_hi | L_lo) (hcp_gemm_lora_bf16 with ldt = 64: l_lo = 32): the
  * product is then (L_hi + L_lo)^T R. */
 int hcp_lora_wgrad(const void* L, int ldl, int l_lo, const void* R, int ldr, float* out, int ldo, int M, int P, int Q, float scale,
-                   int transpose_out, hcpStream_t stream);
+                   int transpose_out, void* workspace, size_t workspace_bytes, hcpStream_t stream);
 /* both gradients of one LoRA layer in one launch: grad_down[r,K] += s U^T x ; grad_up[N,r] += s dY^T T  (ldu / ldt: 32, or 64 = split) */
 int hcp_lora_wgrad_pair(const void* U, int ldu, const void* x, int ldx, int K, float* grad_down, const void* T, int ldt, const void* dY,
-                        int ldy, int N, float* grad_up, int M, int r, float scale, hcpStream_t stream);
+                        int ldy, int N, float* grad_up, int M, int r, float scale, void* workspace, size_t workspace_bytes,
+                        hcpStream_t stream);
 /* dst[M,2C] bf16 = (bf16(src) | bf16(src - bf16(src))), src [M,C] fp32: the split form of a T / U produced by a GEMM of its own */
 int hcp_split_hi_lo_bf16(const float* src, void* dst, long M, int C, hcpStream_t stream);
-/* the weight gradients of MANY LoRA layers in one launch (descriptor layout: csrc/lora.hip WgradGroupDesc, 144 B) */
-int hcp_lora_wgrad_group_geometry(int M, int K, int N, int* qt, int* splits, int* rows_per_split);
+/* the weight gradients of MANY LoRA layers in two launches: partial tiles, ordered reduce (descriptor layout: csrc/lora.hip
+ * WgradGroupDesc, 152 B; total_tiles = sum of qt_down + qt_up; slab_units = sum of blocks * P over the layers with more than one
+ * token range: the workspace holds slab_units * 512 bytes; a layer with one range adds its tile itself).
+ * No atomics anywhere on this path: every gradient element is summed in a fixed order by one thread (ABI 2; ABI 1 accumulated the
+ * partials with fp32 atomics and took no workspace). */
+int hcp_lora_wgrad_group_geometry(int M, int K, int N, int P, int target_blocks, int* qt_down, int* qt_up, int* splits,
+                                  int* rows_per_split);
 int hcp_lora_wgrad_group_desc_bytes(void);
-int hcp_lora_wgrad_grouped(const void* descs, int count, int total_blocks, hcpStream_t stream);
+int hcp_lora_wgrad_grouped(const void* descs, int count, int total_blocks, int total_tiles, long slab_units, void* workspace,
+                           size_t workspace_bytes, hcpStream_t stream);
 /* fp32 LoRA factors -> the four bf16 operand layouts, all layers in one launch (descs: device array, 80 B each, see
  * hcp_lora_pack_desc_bytes(): {const float* w_down; const float* w_up; bf16* ad; bf16* adt; bf16* bu; bf16* but; int K; int N; int r;
  * float alpha; int slot0; int n0; int Ntot; int bu_ld;} — slot0 / n0 / Ntot place a layer inside operand images shared by a fused

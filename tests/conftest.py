@@ -46,6 +46,33 @@ class Backend:
         return t.to(self.device)
 
 
+_gpu_checked = False
+
+
+def gpu_box_check():
+    """Once per GPU test session: print what box this is and run the exact fp32-atomics self-check of the product library
+    (kernels.atomics_selfcheck) — a box whose atomic adds are wrong fails HERE, with its identity in the log, instead of in nine
+    unrelated-looking tests (profiles/r5_gpu_tests_run_with_9_failures.txt)."""
+    global _gpu_checked
+    if _gpu_checked:
+        return
+    _gpu_checked = True
+    from hcp_diffusion_amd import kernels
+    sys.path.insert(0, str(ROOT / "tools"))
+    try:
+        from box_info import box_info
+        print(f"\n[box] {box_info()}")
+    except Exception as e:  # noqa: BLE001 - identification is best effort
+        print(f"\n[box] identification failed: {e}")
+    prev = kernels._backend
+    kernels._set_backend_for_tests(None)
+    try:
+        kernels.atomics_selfcheck("cuda:0")
+        print("[box] fp32 atomics self-check: exact")
+    finally:
+        kernels._backend = prev
+
+
 @pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
 def backend(request):
     """'emu': kernels interpreted on the CPU (tiny shapes, logic check);  'gpu': the gfx950 product library."""
@@ -53,6 +80,7 @@ def backend(request):
     if request.param == "gpu":
         if not torch.cuda.is_available():
             pytest.skip("no GPU visible")
+        gpu_box_check()
         kernels._set_backend_for_tests(None)      # product path: libhcp_mi355x.so, fails loudly if missing
         assert kernels.lib().hcp_is_emulated() == 0
     else:
@@ -69,6 +97,7 @@ def tbackend(request):
     if request.param == "gpu":
         if not torch.cuda.is_available():
             pytest.skip("no GPU visible")
+        gpu_box_check()
         kernels._set_backend_for_tests(_lib.load_tools())
         assert kernels.lib().hcp_is_emulated() == 0
     else:

@@ -33,7 +33,20 @@ def test_product_library_exports_every_declared_symbol():
     for s in header_symbols():
         assert hasattr(lib, s), f"{s} missing from libhcp_mi355x.so"
     lib.hcp_is_emulated.restype = ctypes.c_int
-    assert lib.hcp_is_emulated() == 0 and lib.hcp_abi_version() == 1
+    declared = int(re.search(r"#define HCP_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "hcp_mi355x.h")).read()).group(1))
+    assert lib.hcp_is_emulated() == 0 and lib.hcp_abi_version() == declared == _lib.ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi_revision():
+    """A stale .so would take shifted arguments silently: bind() compares hcp_abi_version() with its own revision."""
+    class Stale:
+        _name = "stale.so"
+        class hcp_abi_version:                      # noqa: N801 - stands in for a ctypes function pointer
+            restype = None; argtypes = None
+            def __new__(cls):
+                return _lib.ABI_VERSION - 1
+    with pytest.raises(_lib.HcpError, match="hcp_abi_version"):
+        _lib.bind(Stale)
 
 
 def test_product_library_has_no_tuning_hooks_but_the_tools_build_does():
@@ -87,7 +100,9 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
         "hcp_wgrad_conv3x3_bf16": (N, 8, N, 8, N, 0, N, 8, 1, 4, 4, 4, 4, 8, 1, 0, N, 0, N),
         "hcp_colsum_bf16": (N, 8, N, 8, 8, 8, 8, N),
         "hcp_pack_weights": (N, 0, 0, N),
-        "hcp_lora_wgrad": (N, 8, 0, N, 8, N, 8, 8, 40, 8, 1.0, 0, N),                           # P > 32
+        "hcp_lora_wgrad": (N, 8, 0, N, 8, N, 8, 8, 40, 8, 1.0, 0, N, 0, N),                     # P > 32
+        "hcp_lora_wgrad_pair": (N, 48, N, 8, 8, N, N, 32, N, 8, 8, N, 8, 8, 1.0, N, 0, N),
+        "hcp_lora_wgrad_grouped": (N, 1, 1, 1, 1, N, 0, N),                                    # null table / no workspace
         "hcp_sumsq_f32": (N, 0, N, N),
         "hcp_adamw_clip_fused": (N, N, N, N, 0, N, 0.9, 0.999, 1e-8, 0.0, N, 1.0, 1.0, N, N),
         "hcp_ema_update": (N, N, 0, N, 1.0, 0.6, 0.99, N),

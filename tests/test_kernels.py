@@ -5,6 +5,7 @@ masking and fragment layouts without a GPU) and, under `-m gpu`, on the gfx950 p
 Tolerances are stated per test: fp32-output kernels must match to accumulation-order noise (1e-5 relative to the
 tensor max), bf16-output kernels to bf16 rounding (<= 1e-2 relative to the tensor max).
 """
+import ctypes
 import math
 import os
 
@@ -696,6 +697,20 @@ def test_lora_wgrad_and_pack(backend, M, Kd, N, r, split, monkeypatch):
     assert relerr(gd2, wdr.grad) < 2e-2 and relerr(gu2, wur.grad) < 2e-2
 
 
+def test_atomics_selfcheck(backend):
+    """hcp_selfcheck_atomics: 2048 x 256 integer adds into one shared line and into strided words are EXACT, and the wrapper notices a
+    device that gets them wrong (simulated by asking for a check against the wrong number of workgroups)."""
+    assert K.atomics_selfcheck(backend.device)
+    assert K.atomics_selfcheck(backend.device, workgroups=300, nb=257, stride=5)
+    real = K.lib().hcp_selfcheck_atomics
+    try:
+        K.lib().hcp_selfcheck_atomics = lambda line, bucket, nb, stride, wg, st: real(line, bucket, nb, stride, wg - 1, st)
+        with pytest.raises(Exception, match="self-check FAILED"):
+            K.atomics_selfcheck(backend.device, workgroups=64, nb=257, stride=5)
+    finally:
+        K.lib().hcp_selfcheck_atomics = real
+
+
 def test_adamw_clip(backend):
     torch.manual_seed(0)
     to = backend.to
@@ -776,6 +791,55 @@ def test_lora_wgrad_grouped(backend):
     keep = K.lora_wgrad_grouped(items)
     for it, (rd, ru) in zip(items, refs):
         assert relerr(it[2], rd) < 2e-2 and relerr(it[5], ru) < 2e-2
+    del keep
+
+
+@pytest.mark.parametrize("M,Kd,N,r,slot0", [(1100, 200, 72, 4, 0), (1500, 136, 264, 5, 3), (2200, 64, 520, 8, 8), (400, 72, 64, 4, 0)])
+def test_lora_wgrad_slabs_are_ordered_sums_without_atomics(backend, M, Kd, N, r, slot0):
+    """Round 6: several token ranges per layer leave their partial tiles as slabs, a second kernel adds them in split order — the
+    three entry points ADD into the gradient (the bucket is cleared once per step), give the same bits on every run, and a rank that is
+    not a multiple of 4 / a slot offset take the scalar paths of the reduce."""
+    torch.manual_seed(M)
+    to = backend.to
+    dev = backend.device
+    U, T, x, dy = rnd(M, 32), rnd(M, 32), rnd(M, Kd), rnd(M, N)
+    rd = 0.5 * U.float()[:, slot0:slot0 + r].T @ x.float()
+    ru = 0.5 * dy.float().T @ T.float()[:, slot0:slot0 + r]
+    qt0, qt1, sp, rows = (ctypes.c_int() for _ in range(4))
+    K.lib().hcp_lora_wgrad_group_geometry(M, Kd, N, r, 256, ctypes.byref(qt0), ctypes.byref(qt1), ctypes.byref(sp), ctypes.byref(rows))
+    assert (sp.value > 1) == (M >= 2 * 64 * r), "the case list is meant to cover both the slab and the direct form"
+    runs = []
+    for rep in range(2):
+        gd = torch.full((r, Kd), 0.25, device=dev); gu = torch.full((N, r), -0.5, device=dev)
+        keep = K.lora_wgrad_grouped([(to(U), to(x), gd, to(T), to(dy), gu, r, 0.5, slot0)])
+        assert relerr(gd - 0.25, rd) < 2e-2 and relerr(gu + 0.5, ru) < 2e-2
+        runs.append((gd.cpu().clone(), gu.cpu().clone()))
+        del keep
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    if slot0 == 0:
+        gd = torch.full((r, Kd), 0.25, device=dev); gu = torch.full((N, r), -0.5, device=dev)
+        K.lora_wgrad_pair(to(U), to(x), gd, to(T), to(dy), gu, r, 0.5)
+        assert relerr(gd - 0.25, rd) < 2e-2 and relerr(gu + 0.5, ru) < 2e-2
+        gd1 = torch.full((r, Kd), 0.25, device=dev); gu1 = torch.full((N, r), -0.5, device=dev)
+        K.lora_wgrad(to(U), to(x), gd1, r, 0.5, False); K.lora_wgrad(to(T), to(dy), gu1, r, 0.5, True)
+        assert relerr(gd1 - 0.25, rd) < 2e-2 and relerr(gu1 + 0.5, ru) < 2e-2
+
+
+def test_lora_wgrad_grouped_takes_a_gradient_named_twice_in_two_passes(backend):
+    """The reduce adds without atomics, so one call must not hold two descriptors for the same gradient rows: the wrapper runs the
+    second use as a second pass on the stream (a layer that ran twice in one forward)."""
+    torch.manual_seed(3)
+    to = backend.to
+    dev = backend.device
+    M, Kd, N, r = 1100, 64, 72, 4
+    gd = torch.zeros(r, Kd, device=dev); gu = torch.zeros(N, r, device=dev)
+    items, rd, ru = [], 0, 0
+    for _ in range(2):
+        U, T, x, dy = rnd(M, 32), rnd(M, 32), rnd(M, Kd), rnd(M, N)
+        items.append((to(U), to(x), gd, to(T), to(dy), gu, r, 1.0))
+        rd = rd + U.float()[:, :r].T @ x.float(); ru = ru + dy.float().T @ T.float()[:, :r]
+    keep = K.lora_wgrad_grouped(items)
+    assert relerr(gd, rd) < 2e-2 and relerr(gu, ru) < 2e-2
     del keep
 
 

@@ -225,6 +225,58 @@ def test_graph_cache_per_latent_shape():
 
 
 @pytest.mark.gpu
+def test_graph_trainer_300_step_soak_tracks_eager_on_the_real_architecture():
+    """The test that would have caught the round-3 NaN (a memset node in front of an atomics kernel, wrong from SOME replay on): the
+    captured step of NativeTrainer replayed 300 times on the full SD1.5 architecture at 64x64 latents — the only size at which the
+    query-split cross-attention backward, the split-K GEMMs and the multi-range LoRA weight gradients all run — against the same 300
+    steps eager, same weights, same noise / timestep stream.  Every 50th loss within 1e-3 (relative), final LoRA within 1e-3 of the
+    update's norm... measured on MI355X: see the message printed with -rP."""
+    dev = _gpu()
+    from hcp_diffusion_amd.unet import NativeUNet2DConditionModel as U
+    B, steps, every = 2, 300, 50
+    res = []
+    for use_graph in (False, True):
+        torch.manual_seed(7)
+        with torch.device("meta"):
+            unet = U()
+        unet = unet.to_empty(device=dev)
+        g = torch.Generator(device=dev).manual_seed(99)
+        with torch.no_grad():
+            for name, p in unet.named_parameters():
+                if p.dim() > 1:
+                    p.copy_(torch.randn(p.shape, generator=g, device=dev) * p[0].numel() ** -0.5)
+                elif "norm" in name and name.endswith("weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+        tr = NativeTrainer(unet, [dict(layers=[r"re:.*\.attn.?$", r"re:.*\.ff$"], rank=8, lr=1e-4)], lr=1e-4, use_graph=use_graph)
+        with torch.no_grad():
+            for blk in tr.bucket.blocks:
+                blk.layer.W_up.copy_(torch.randn(blk.layer.W_up.shape, generator=g, device=dev) * 0.02)
+        tr.bucket.pack()
+        p0 = tr.bucket.params.clone()
+        lat = torch.randn(B, 4, 64, 64, generator=g, device=dev)
+        ehs = torch.randn(B, 77, 768, generator=g, device=dev).to(torch.bfloat16)
+        torch.manual_seed(123); torch.cuda.manual_seed(123)           # make_noise draws from torch's device generator
+        losses = []
+        for i in range(steps):
+            loss = tr.train_one_step(lat, ehs)
+            if (i + 1) % every == 0:
+                losses.append(float(loss.item()))
+        torch.cuda.synchronize()
+        res.append((losses, (tr.bucket.params - p0).clone()))
+        del tr, unet
+        torch.cuda.empty_cache()
+    (le, de), (lg, dg) = res
+    rel = [abs(a - b) / abs(a) for a, b in zip(le, lg)]
+    upd = ((de - dg).norm() / de.norm()).item()
+    print(f"soak: eager losses {[round(v, 5) for v in le]}  graph losses {[round(v, 5) for v in lg]}  max rel {max(rel):.2e}  LoRA update diff {upd:.2e}")
+    assert all(v == v and abs(v) != float("inf") for v in le + lg)
+    assert max(rel) < 1e-3, (le, lg)
+    assert upd < 2e-2, upd
+
+
+@pytest.mark.gpu
 def test_unet_hip_graph_under_a_plain_trainer_loop_matches_eager():
     """unet.enable_hip_graph(): an ordinary eager loop (module call, loss.backward(), clip, torch AdamW, zero_grad) — what the
     reference's Trainer.train_one_step does — replays captured forward / backward graphs and follows the eager trajectory; the
