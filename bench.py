@@ -12,6 +12,7 @@ Rank 0 prints ONE JSON line.  The `cpu_baseline` leg (N=1 only) times the oracle
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -182,7 +183,10 @@ def attention_roofline(dev):
     return out
 
 
-def main():
+def main(emu=False):
+    """emu=True is passed only by tests/emu/bench_emu.py, which has pointed hcp_diffusion_amd.kernels at the CPU interpreter build first: the
+    same launcher, rank plumbing, trainer and JSON line with gloo and a two-level miniature UNet, so that the first multi-rank run of
+    this file is not the one on the driver's 8-GPU node.  Timings of such a run mean nothing and the line says so."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -199,9 +203,8 @@ def main():
     ap.add_argument("--no-ckpt-line", action="store_true", help="skip the secondary grad-ckpt-on measurement (profiling runs)")
     ap.add_argument("--overlap", action="store_true", help="LoRA wgrad kernels on a side stream (measured slower)")
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="one wgrad launch per layer instead of one grouped launch")
-    ap.add_argument("--wgrad-chunk", type=int, default=int(os.environ.get("HCP_WGRAD_CHUNK", "0")),
-                    help="cut the grouped LoRA weight-gradient launch into pieces of this many layers, launched on a parallel branch as "
-                         "backward produces their operands (0 = one launch at the end of backward)")
+    ap.add_argument("--residual-stream", choices=["auto", "on", "off"], default="auto",
+                    help="(hi | lo) residual stream of the transformer blocks (unet.set_residual_stream): auto = stacks of >= 2 blocks (SDXL)")
     ap.add_argument("--grad-ckpt", action="store_true", help="enable_gradient_checkpointing() as the reference defaults to "
                     "(train_base.yaml:69): +1 forward per step; a secondary line, the headline runs without (288 GB HBM)")
     ap.add_argument("--seam", action="store_true", help="secondary line: time the step the way the REFERENCE's Trainer drives the native "
@@ -226,7 +229,7 @@ def main():
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
         os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -234,15 +237,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
-    # TEST SWITCH (tests/test_bench.py only; never set by the driver): the same launcher, rank plumbing, trainer and JSON line on
-    # the CPU interpreter build of the kernels with gloo and a two-level miniature UNet — so that the first multi-rank run of this file
-    # is not the one on the driver's 8-GPU node.  Timings of such a run mean nothing and the line says so.
-    emu = os.environ.get("HCP_BENCH_BACKEND") == "emu"
-    if emu:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
-        from conftest import emu_cdll
-        from hcp_diffusion_amd import kernels as _K
-        _K._set_backend_for_tests(emu_cdll())
+    if emu:                                        # tests/emu/bench_emu.py (the launcher / rank plumbing on the CPU interpreter): see main()'s docstring
         dev = torch.device("cpu")
         args.no_graph, args.no_cpu_baseline, args.no_ckpt_line = True, True, True
         if world > 1:
@@ -260,6 +255,18 @@ def main():
     if world > 1:
         assert torch.distributed.get_world_size() == args.gpus
 
+    if not emu:
+        # which box is this, and do its fp32 atomic adds add?  (one box of round 5 gave wrong sums in every atomics-based
+        # kernel for the length of a process; a run on such a box stops here, with the box's identity in the log)
+        from hcp_diffusion_amd import kernels as _K
+        if rank == 0:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            try:
+                from box_info import box_info
+                print(f"[bench] box: {json.dumps(box_info(local_rank))}", file=sys.stderr, flush=True)
+            except Exception as e:  # noqa: BLE001 - identification only
+                print(f"[bench] box identification failed: {e}", file=sys.stderr, flush=True)
+        _K.atomics_selfcheck(dev)
     from hcp_diffusion_amd.comm import make_comm
     from hcp_diffusion_amd.trainer import NativeTrainer
     from hcp_diffusion_amd.unet import SDXL_CONFIG, NativeUNet2DConditionModel
@@ -292,6 +299,8 @@ def main():
                 p.zero_()
     if args.grad_ckpt:
         unet.enable_gradient_checkpointing()
+    if args.residual_stream != "auto":
+        unet.set_residual_stream(args.residual_stream == "on")
     plugin_input = None
     frozen_te_leg = False
     xkw = dict(overlap_exchange=args.exchange != "plain", **(dict(grad_wire="bf16", param_wire="bf16") if args.exchange == "overlap-bf16" else {}))
@@ -335,7 +344,7 @@ def main():
             text_encoder = build_clip()            # builds its encoder AFTER the headline loop: the timed process is the one of rounds 1-4)
         tr = NativeTrainer(unet, [dict(layers=LORA_PATTERNS, rank=args.rank_lora, lr=1e-4)], lr=1e-4, weight_decay=1e-3,
                            scale_lr_factor=args.batch * world, use_graph=not args.no_graph, overlap_wgrad=args.overlap,
-                           grouped_wgrad=not args.no_grouped_wgrad, wgrad_chunk_layers=args.wgrad_chunk, text_encoder=text_encoder,
+                           grouped_wgrad=not args.no_grouped_wgrad, text_encoder=text_encoder,
                            lora_te_cfg=[dict(layers=[r"re:.*self_attn$", r"re:.*mlp$"], rank=4, lr=1e-5)] if te else None, comm=comm)
         torch.manual_seed(114514 + rank)           # set_seed(seed + local_rank), train_ac.py:128
         buckets = [tr.bucket] + ([tr.te_bucket] if te else [])
@@ -386,42 +395,12 @@ def main():
         crit = torch.nn.MSELoss(reduction="none")
         if graph:
             unet.enable_hip_graph()
-        nancheck, seen_bad, calls = os.environ.get("HCP_BENCH_NANCHECK") == "1", [], []
-
         def seam_step():
             noise = torch.randn_like(latents)
             t = torch.randint(0, 1000, (B,), device=dev).long()
             pred = unet(sched.add_noise(latents, noise, t), t, ehs).sample
             loss = crit(pred.float(), noise.float()).mean()
             loss.backward()
-            if nancheck and not fullft:                              # lab (HCP_BENCH_NANCHECK=1): first step whose prediction / LoRA gradients are not finite
-                ok = (bool(torch.isfinite(pred).all()), bool(torch.isfinite(tr.bucket.grads).all()), bool(torch.isfinite(tr.bucket.params).all()))
-                if not all(ok) and not seen_bad:
-                    seen_bad.append(1)
-                    print(f"[nancheck] call {len(calls)}: finite(pred, grads, params) = {ok}, t = {t.tolist()}, loss {float(loss)}", file=sys.stderr, flush=True)
-                calls.append(1)
-                gn_ = float(tr.bucket.grads.norm())
-                if gn_ > 1e2 and len(seen_bad) < 3:                     # a finite but absurd gradient: name the tensors that carry it
-                    seen_bad.append(2)
-                    rows = []
-                    for path, blk in tr.lora_group.plugin_dict.items():
-                        for nm, p_ in (("W_down", blk.layer.W_down), ("W_up", blk.layer.W_up)):
-                            if p_.grad is not None:
-                                g_ = p_.grad.float()
-                                n_ = float(g_.norm())
-                                if n_ > 1.0:
-                                    big = (g_.abs() > 1.0)
-                                    idx = big.nonzero()
-                                    rows.append((n_, path, nm, tuple(p_.shape), int(big.sum()), idx[:4].tolist(), g_[big][:4].tolist(), blk.rank, blk.alpha_f))
-                    rows.sort(reverse=True)
-                    print(f"[nancheck] call {len(calls) - 1}: |g| {gn_:.4e}; tensors with |grad| > 1: {len(rows)}", file=sys.stderr, flush=True)
-                    for r_ in rows[:6]:
-                        print("   ", r_, file=sys.stderr, flush=True)
-                    flat = tr.bucket.grads
-                    bigf = (flat.abs() > 1.0).nonzero().flatten()
-                    print(f"    flat bucket: {bigf.numel()} elements > 1 at offsets {bigf[:8].tolist()} .. {bigf[-4:].tolist()} of {flat.numel()}", file=sys.stderr, flush=True)
-                if os.environ.get("HCP_BENCH_NANCHECK_VERBOSE") == "1":
-                    print(f"[call {len(calls) - 1}] loss {float(loss):.5f} |g| {float(tr.bucket.grads.norm()):.4e} |p| {float(tr.bucket.params.norm()):.6f}", file=sys.stderr, flush=True)
             torch.nn.utils.clip_grad_norm_(params, 1.0)              # accelerator.clip_grad_norm_(TE_unet.trainable_parameters(), ...), train_ac.py:485-490
             opt.step()
             opt.zero_grad(set_to_none=False)
@@ -438,7 +417,7 @@ def main():
     if args.seam:
         assert args.workload in ("sd15", "dreambooth") and world == 1
         dt, lv = seam_loop(args.seam_graph, args.steps, args.warmup)
-        if lv != lv or abs(lv) == float("inf"):
+        if not math.isfinite(lv):
             raise RuntimeError(f"bench.py --seam: the training loss after the timed loop is not finite ({lv}): the measurement is void")
         print(json.dumps({"metric": ("training images/sec, SD1.5 full fine-tune (DreamBooth) 512px bs=%d" % B if fullft else "training images/sec, SD1.5 LoRA 512px bs=4") +
                                     ", native modules driven the reference trainer's way (eager seam)",
@@ -464,7 +443,7 @@ def main():
     # (round 5: NaN losses in some graph-replay runs went unnoticed for three rounds because nobody read `final_loss` — LAB_NOTEBOOK.
     #  The line now says so itself: `loss_finite`, and `invalid` when it is not — such a run's timing is void, the exp2-overflow
     #  fallback of the attention forward alone makes its steps slower)
-    loss_ok = loss_v == loss_v and abs(loss_v) != float("inf")
+    loss_ok = math.isfinite(loss_v)
     if not loss_ok:
         print(f"bench.py: the training loss after the timed loop is not finite ({loss_v}): the measurement is void", file=sys.stderr, flush=True)
     if rank == 0:
@@ -474,7 +453,7 @@ def main():
                       ("training images/sec (whole node), SD1.5 full fine-tune (DreamBooth) 512px bs=%d/GPU" % B) if fullft else
                       ("training images/sec (whole node), SD1.5 + ControlNet branch training 512px bs=%d/GPU" % B) if cnet else
                       ("training images/sec (whole node), SD1.5 LoRA on UNet + text encoder 512px bs=%d/GPU" % B) if te else
-                      "training images/sec (whole node), SD1.5 LoRA 512px bs=4/GPU", "value": round(ips, 2), "unit": "images/sec",
+                      "training images/sec (whole node), SD1.5 LoRA 512px bs=4/GPU", "value": round(ips, 2) if loss_ok else None, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("SDXL-base UNet LoRA rank=%d bf16, bs=%d/GPU, 1024x1024 (128x128 latents), 77x2048 context + text_time "
@@ -546,7 +525,7 @@ def main():
             try:
                 k4 = max(5, min(args.steps, 20))
                 d4, lv4 = seam_loop(True, k4, 5)
-                if lv4 != lv4:
+                if not math.isfinite(lv4):
                     raise RuntimeError("non-finite loss")
                 out["seam_graph"] = {"value": round(B * k4 / d4, 2), "unit": "images/sec", "ms_per_step": round(d4 / k4 * 1e3, 3), "steps": k4,
                                      "note": "the reference Trainer's loop restated (train_ac.py:467-504: eager module call, clip_grad_norm_, fused "
@@ -569,6 +548,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if not loss_ok:                                # a void measurement must not read as a result: value is null, exit code 3
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

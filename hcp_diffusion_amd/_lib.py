@@ -21,10 +21,10 @@ _PROTOTYPES = {
     # line, bucket, nb, stride, workgroups, stream
     "hcp_selfcheck_atomics": (I, [P, P, I, I, I, P]),
     # A, lda, B, ldb, D, ldd, M, N, K, A2, lda2, B2, ldb2, K2, bias, rowbias, rowbias_ld, rows_per_group,
-    # residual, ldr, alpha, out_f32, workspace, workspace_bytes, stream
-    "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, F, I, P, c_size_t, P]),
-    # A, lda, B, ldb, L, E, Tout, D, ldd, M, N, K, bias, residual, ldr, workspace, workspace_bytes, stream
-    "hcp_gemm_lora_bf16": (I, [P, I, P, I, P, P, P, I, P, I, I, I, I, P, P, I, P, c_size_t, P]),
+    # residual, ldr, residual_lo, D_lo, alpha, out_f32, workspace, workspace_bytes, stream
+    "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, P, P, F, I, P, c_size_t, P]),
+    # A, lda, B, ldb, L, E, Tout, ldt, D, ldd, M, N, K, bias, residual, ldr, residual_lo, D_lo, workspace, workspace_bytes, stream
+    "hcp_gemm_lora_bf16": (I, [P, I, P, I, P, P, P, I, P, I, I, I, I, P, P, I, P, P, P, c_size_t, P]),
     # A, lda, B, ldb, L, E, Tout, HG, DHG, M, F, K, workspace, workspace_bytes, stream
     "hcp_gemm_geglu_bwd_bf16": (I, [P, I, P, I, P, P, P, I, P, P, I, I, I, P, c_size_t, P]),
     "hcp_gemm_workspace_bytes": (c_size_t, [I, I]),
@@ -40,8 +40,10 @@ _PROTOTYPES = {
     "hcp_groupnorm_silu_fwd": (I, [P, P, P, P, P, P, I, I, I, I, F, I, P]),
     # x, dy, gamma, beta, stats, addend, dx, ws, B, HW, C, G, silu, stream
     "hcp_groupnorm_silu_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
-    "hcp_layernorm_fwd": (I, [P, P, P, P, P, I, I, F, P]),
-    "hcp_layernorm_bwd": (I, [P, P, P, P, P, P, I, I, P]),
+    # x, x_lo, gamma, beta, y, stats, M, C, eps, stream
+    "hcp_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
+    # x, x_lo, dy, gamma, stats, addend, addend_lo, dx, dx_lo, M, C, stream
+    "hcp_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P]),
     "hcp_geglu_fwd": (I, [P, P, L, I, P]),
     "hcp_geglu_bwd": (I, [P, P, P, L, I, P]),
     "hcp_add_bf16": (I, [P, P, P, L, P]),
@@ -123,7 +125,7 @@ TOOLS_SYMBOLS = tuple(_TOOLS_PROTOTYPES)
 TOOLS_LIB_PATH = Path(__file__).resolve().parent / "libhcp_mi355x_tools.so"
 
 
-ABI_VERSION = 2          # include/hcp_mi355x.h HCP_ABI_VERSION: bumped whenever an exported signature or descriptor layout changes
+ABI_VERSION = 3          # include/hcp_mi355x.h HCP_ABI_VERSION: bumped whenever an exported signature or descriptor layout changes
 
 
 class HcpError(RuntimeError):
@@ -176,10 +178,6 @@ def load():
     global _lib
     if _lib is None:
         import torch  # noqa: F401  torch must map ITS libamdhip64 first: our .so then binds to the same HIP runtime
-        lab = os.environ.get("HCP_LAB_LIB")                  # lab A/B runs: another BUILD of the same library (never a fallback)
-        if lab:
-            _lib = bind(ctypes.CDLL(lab))
-            return _lib
         if not LIB_PATH.exists():
             raise HcpError(
                 f"{LIB_PATH} not found: build it with `python -m hcp_diffusion_amd.build` "

@@ -37,15 +37,10 @@ HCP_DEVICE void epilogue_store(const GemmParams& p, int m, int n, hcp_f32x4 v) {
         hcp_bf16x4 r = *(const hcp_bf16x4*)(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)r[q]);
+        add_residual_lo(p, m, n, v);
     }
-    if (p.out_f32) {
-        *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
-    } else {
-        hcp_bf16x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(v[q]);
-        *(hcp_bf16x4*)((hcp_bf16*)p.D + (size_t)m * p.ldd + n) = o;
-    }
+    if (p.out_f32) *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
+    else store_hi_lo(p, m, n, v);
 }
 
 // MODE: 0 plain A, 1 conv forward gather, 2 conv data-gradient gather.  FAST: hoisted im2col addressing.
@@ -756,18 +751,13 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
             if (p.residual) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)res_v[i][j][q]);
+                add_residual_lo(p, m, n, v);
             }
 #if defined(HCP_TOOLS)
             if ((p.dbg & 64) && v[0] != 12345.678f) continue;      // ablation: no output stores (the compare keeps the math alive)
 #endif
-            if (p.out_f32) {
-                *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
-            } else {
-                hcp_bf16x4 o;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(v[q]);
-                *(hcp_bf16x4*)((hcp_bf16*)p.D + (size_t)m * p.ldd + n) = o;
-            }
+            if (p.out_f32) *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
+            else store_hi_lo(p, m, n, v);
         }
     }
 }
@@ -1044,14 +1034,17 @@ HCP_API size_t hcp_gemm_workspace_bytes(int M, int N) { return (size_t)16 * M * 
 HCP_API int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int ldd, int M, int N, int K,
                           const void* A2, int lda2, const void* B2, int ldb2, int K2, const float* bias,
                           const float* rowbias, int rowbias_ld, int rows_per_group, const void* residual, int ldr,
-                          float alpha, int out_f32, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                          const void* residual_lo, void* D_lo, float alpha, int out_f32, void* workspace, size_t workspace_bytes,
+                          hipStream_t stream) {
     GemmParams p = {};
     p.A = (const hcp_bf16*)A; p.lda = lda; p.B = (const hcp_bf16*)B; p.ldb = ldb;
     p.A2 = (const hcp_bf16*)A2; p.lda2 = lda2; p.B2 = (const hcp_bf16*)B2; p.ldb2 = ldb2; p.K2 = K2;
     p.M = M; p.N = N; p.K = K; p.D = D; p.ldd = ldd; p.out_f32 = out_f32;
     p.bias = bias; p.rowbias = rowbias; p.rowbias_ld = rowbias_ld; p.rows_per_group = rows_per_group;
     p.residual = (const hcp_bf16*)residual; p.ldr = ldr; p.alpha = alpha;
+    p.residual_lo = (const hcp_bf16*)residual_lo; p.D_lo = (hcp_bf16*)D_lo;
     HCP_REQUIRE(A && B && D, "hcp_gemm_bf16: null operand");
+    HCP_REQUIRE((!residual_lo || residual) && (!D_lo || !out_f32), "hcp_gemm_bf16: residual_lo needs residual; D_lo needs a bf16 output");
     HCP_REQUIRE(lda % 8 == 0, "hcp_gemm_bf16: lda (%d) must be a multiple of 8", lda);
     if (int e = check_common(p)) return e;
     return dispatch_gemm<0, false>(p, (float*)workspace, workspace ? workspace_bytes : 0, stream);
@@ -1124,14 +1117,16 @@ HCP_API int hcp_gemm_geglu_bwd_bf16(const void* A, int lda, const void* B, int l
 // backward: A = dY, B = W^T, L = W_up^T,               E = alpha*W_down^T -> dX, T = dY W_up    (for dW_down)
 // One launch replaces LoraPatchContainer.forward's weight merge + mm (reference lora_base_patch.py:20-35,61-74).
 HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, int ldt, void* D,
-                               int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, void* workspace,
-                               size_t workspace_bytes, hipStream_t stream) {
+                               int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, const void* residual_lo,
+                               void* D_lo, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     GemmParams p = {};
     p.A = (const hcp_bf16*)A; p.lda = lda; p.B = (const hcp_bf16*)B; p.ldb = ldb;
     p.M = M; p.N = N; p.K = K; p.D = D; p.ldd = ldd; p.out_f32 = 0;
     p.bias = bias; p.residual = (const hcp_bf16*)residual; p.ldr = ldr; p.alpha = 1.0f;
     p.L = (const hcp_bf16*)L; p.E = (const hcp_bf16*)E; p.Tout = (hcp_bf16*)Tout; p.ldt = ldt;
+    p.residual_lo = (const hcp_bf16*)residual_lo; p.D_lo = (hcp_bf16*)D_lo;
     HCP_REQUIRE(A && B && D && L && E, "hcp_gemm_lora_bf16: null operand");
+    HCP_REQUIRE(!residual_lo || residual, "hcp_gemm_lora_bf16: residual_lo needs residual");
     HCP_REQUIRE(ldt == 32 || ldt == 64, "hcp_gemm_lora_bf16: ldt (%d) is 32 (bf16 T) or 64 (split T: hi | lo)", ldt);
     HCP_REQUIRE(lda % 8 == 0, "hcp_gemm_lora_bf16: lda (%d) must be a multiple of 8", lda);
     if (int e = check_common(p)) return e;

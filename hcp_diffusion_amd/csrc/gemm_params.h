@@ -24,6 +24,11 @@ struct GemmParams {
     const float* bias;
     const float* rowbias; int rowbias_ld; int rows_per_group;
     const hcp_bf16* residual; int ldr;
+    // (hi | lo) residual stream (round 6): the transformer blocks' residual stream carried as TWO bf16 tensors, x = hi + lo with
+    // hi = bf16(x) and lo = bf16(x - hi) — 16 mantissa bits, what the reference's LoRA layers keep by promoting their output to fp32
+    // (mm(...) [bf16] + bias [fp32], lora_layers_patch.py:50-57).  residual_lo (same ldr, needs residual) is added in fp32 with the
+    // rest of the epilogue; D_lo (same ldd, bf16 output only) receives bf16(v - bf16(v)) next to D = bf16(v).  Null = plain bf16.
+    const hcp_bf16* residual_lo; hcp_bf16* D_lo;
     float alpha;
     int tiles_m;
     int nsplit; int kt_per_split;   // split-K over the primary K tiles (grid.y)
@@ -52,6 +57,27 @@ HCP_DEVICE void lora_t_split(const hcp_f32x4& t, hcp_bf16x4& hi, hcp_bf16x4& lo)
         hi[q] = (short)h;
         lo[q] = (short)hcp_f2bf(t[q] - hcp_bf2f(h));
     }
+}
+
+// The output quad of an epilogue: D = bf16(v) and, when the launch carries a lo image, D_lo = bf16(v - D).
+HCP_DEVICE void store_hi_lo(const GemmParams& p, int m, int n, const hcp_f32x4& v) {
+    hcp_bf16x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(v[q]);
+    *(hcp_bf16x4*)((hcp_bf16*)p.D + (size_t)m * p.ldd + n) = o;
+    if (p.D_lo) {
+        hcp_bf16x4 l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) l[q] = (short)hcp_f2bf(v[q] - hcp_bf2f((unsigned short)o[q]));
+        *(hcp_bf16x4*)(p.D_lo + (size_t)m * p.ldd + n) = l;
+    }
+}
+// v += residual_lo[m, n .. n+3] (requested where it is used: the lo image is read once, behind the main loop)
+HCP_DEVICE void add_residual_lo(const GemmParams& p, int m, int n, hcp_f32x4& v) {
+    if (!p.residual_lo) return;
+    const hcp_bf16x4 r = *(const hcp_bf16x4*)(p.residual_lo + (size_t)m * p.ldr + n);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)r[q]);
 }
 
 // One 4-column piece of the GEGLU-backward epilogue (replaces the stand-alone geglu_bwd pass over dY_ff, h|g and d(h|g)).

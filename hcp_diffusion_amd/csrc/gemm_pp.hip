@@ -478,15 +478,10 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
             if (p.residual) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)res_v[i][j][q]);
+                add_residual_lo(p, m, n, v);
             }
-            if (p.out_f32) {
-                *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
-            } else {
-                hcp_bf16x4 o;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(v[q]);
-                *(hcp_bf16x4*)((hcp_bf16*)p.D + (size_t)m * p.ldd + n) = o;
-            }
+            if (p.out_f32) *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
+            else store_hi_lo(p, m, n, v);
         }
     }
 }

@@ -441,29 +441,34 @@ GNSlab gn_slab_geom(int HW, int C, int G) {
 // NV = 16-byte vectors per lane (C <= 512 NV): the row is loaded ONCE into registers — mean, variance and the normalised output
 // (backward: both reductions and dx) come from there; the first version re-read the row from L1/L2 for every pass, three
 // dependent memory round trips per wave for a 640-byte row.
-template <int NV>
-HCP_KERNEL(256) ln_fwd_kernel(const hcp_bf16* x, const float* gamma, const float* beta, hcp_bf16* y, float* stats,
+template <int NV, bool HL>
+HCP_KERNEL(256) ln_fwd_kernel(const hcp_bf16* x, const hcp_bf16* x_lo, const float* gamma, const float* beta, hcp_bf16* y, float* stats,
                               int M, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool live = row < M;
     const hcp_bf16* xr = x + (size_t)(live ? row : 0) * C;
     const int nch = C / 8;
-    hcp_bf16x8 v[NV];
+    hcp_bf16x8 v[NV], vl[HL ? NV : 1];                  // vl (HL): the lo image of a (hi | lo) residual stream
 #pragma unroll
-    for (int u = 0; u < NV; ++u) { const int j = lane + 64 * u; v[u] = j < nch ? *(const hcp_bf16x8*)(xr + j * 8) : hcp_zero8(); }
+    for (int u = 0; u < NV; ++u) {
+        const int j = lane + 64 * u;
+        v[u] = j < nch ? *(const hcp_bf16x8*)(xr + j * 8) : hcp_zero8();
+        if (HL) vl[u] = j < nch ? *(const hcp_bf16x8*)(x_lo + (size_t)(live ? row : 0) * C + j * 8) : hcp_zero8();
+    }
+#define HCP_LN_X(u_, i_) (HL ? hcp_bf2f((unsigned short)v[u_][i_]) + hcp_bf2f((unsigned short)vl[HL ? u_ : 0][i_]) : hcp_bf2f((unsigned short)v[u_][i_]))
     float s = 0.f;
 #pragma unroll
     for (int u = 0; u < NV; ++u)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += hcp_bf2f((unsigned short)v[u][i]);
+        for (int i = 0; i < 8; ++i) s += HCP_LN_X(u, i);
     const float mean = hcp_wave_sum(s) / C;
     float q = 0.f;
 #pragma unroll
     for (int u = 0; u < NV; ++u)
         if (lane + 64 * u < nch) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { float d = hcp_bf2f((unsigned short)v[u][i]) - mean; q += d * d; }
+            for (int i = 0; i < 8; ++i) { float d = HCP_LN_X(u, i) - mean; q += d * d; }
         }
     const float rstd = 1.0f / sqrtf(hcp_wave_sum(q) / C + eps);
     if (!live) return;
@@ -479,22 +484,22 @@ HCP_KERNEL(256) ln_fwd_kernel(const hcp_bf16* x, const float* gamma, const float
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float g = i < 4 ? g0[i] : g1[i - 4], bb = i < 4 ? b0[i] : b1[i - 4];
-            o[i] = (short)hcp_f2bf((hcp_bf2f((unsigned short)v[u][i]) - mean) * rstd * g + bb);
+            o[i] = (short)hcp_f2bf((HCP_LN_X(u, i) - mean) * rstd * g + bb);
         }
         *(hcp_bf16x8*)(yr + j * 8) = o;
     }
 }
 
-template <int NV>
-HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float* gamma, const float* stats,
-                              const hcp_bf16* addend, hcp_bf16* dx, int M, int C) {
+template <int NV, bool HL>
+HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* x_lo, const hcp_bf16* dy, const float* gamma, const float* stats,
+                              const hcp_bf16* addend, const hcp_bf16* addend_lo, hcp_bf16* dx, hcp_bf16* dx_lo, int M, int C) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool live = row < M;
     const size_t off = (size_t)(live ? row : 0) * C;
     const float mean = stats[(size_t)(live ? row : 0) * 2], rstd = stats[(size_t)(live ? row : 0) * 2 + 1];
     const int nch = C / 8;
-    hcp_bf16x8 v[NV], d[NV], ad[NV];
+    hcp_bf16x8 v[NV], d[NV], ad[NV], vl[HL ? NV : 1], adl[HL ? NV : 1];      // HL: lo images of a (hi | lo) residual stream (each optional)
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int j = lane + 64 * u;
@@ -502,6 +507,10 @@ HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float
         v[u] = ok ? *(const hcp_bf16x8*)(x + off + j * 8) : hcp_zero8();
         d[u] = ok ? *(const hcp_bf16x8*)(dy + off + j * 8) : hcp_zero8();                   // dy = 0: padding lanes add nothing
         ad[u] = (ok && addend) ? *(const hcp_bf16x8*)(addend + off + j * 8) : hcp_zero8();
+        if (HL) {
+            vl[u] = (ok && x_lo) ? *(const hcp_bf16x8*)(x_lo + off + j * 8) : hcp_zero8();
+            adl[u] = (ok && addend_lo) ? *(const hcp_bf16x8*)(addend_lo + off + j * 8) : hcp_zero8();
+        }
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -510,7 +519,7 @@ HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float
         if (j >= nch) continue;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float xh = (hcp_bf2f((unsigned short)v[u][i]) - mean) * rstd;
+            float xh = (HCP_LN_X(u, i) - mean) * rstd;
             float dxh = hcp_bf2f((unsigned short)d[u][i]) * gamma[j * 8 + i];
             s1 += dxh; s2 += dxh * xh;
         }
@@ -521,16 +530,21 @@ HCP_KERNEL(256) ln_bwd_kernel(const hcp_bf16* x, const hcp_bf16* dy, const float
     for (int u = 0; u < NV; ++u) {
         const int j = lane + 64 * u;
         if (j >= nch) continue;
-        hcp_bf16x8 o;
+        hcp_bf16x8 o, ol;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float xh = (hcp_bf2f((unsigned short)v[u][i]) - mean) * rstd;
+            float xh = (HCP_LN_X(u, i) - mean) * rstd;
             float dxh = hcp_bf2f((unsigned short)d[u][i]) * gamma[j * 8 + i];
-            o[i] = (short)hcp_f2bf(rstd * (dxh - c1 - xh * c2) + hcp_bf2f((unsigned short)ad[u][i]));
+            float g = rstd * (dxh - c1 - xh * c2) + hcp_bf2f((unsigned short)ad[u][i]);
+            if (HL) g += hcp_bf2f((unsigned short)adl[u][i]);
+            o[i] = (short)hcp_f2bf(g);
+            if (HL) ol[i] = (short)hcp_f2bf(g - hcp_bf2f((unsigned short)o[i]));
         }
         *(hcp_bf16x8*)(dx + off + j * 8) = o;
+        if (HL && dx_lo) *(hcp_bf16x8*)(dx_lo + off + j * 8) = ol;
     }
 }
+#undef HCP_LN_X
 
 // Affine-parameter gradients (full fine-tuning: every norm's weight/bias is trainable — DreamBooth.yaml:6-10):
 //   dgamma[c] += sum_rows dz * xhat ; dbeta[c] += sum_rows dz ;  dz = dy [* silu'(xhat gamma + beta)]
@@ -670,25 +684,31 @@ HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* g
     HCP_LAUNCH_CHECK("groupnorm_bwd");
 }
 
-HCP_API int hcp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int C,
+HCP_API int hcp_layernorm_fwd(const void* x, const void* x_lo, const float* gamma, const float* beta, void* y, float* stats, int M, int C,
                               float eps, hipStream_t stream) {
     HCP_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 4096, "hcp_layernorm_fwd: bad shape M=%d C=%d (C: multiple of 8 up to 4096)", M, C);
     HCP_REQUIRE(x && gamma && beta && y && stats, "hcp_layernorm_fwd: null pointer");
-#define HCP_LN_FWD(NV_) HCP_LAUNCH(ln_fwd_kernel<NV_>, dim3(hcp_cdiv(M, 4)), dim3(256), 0, stream, (const hcp_bf16*)x, gamma, beta, \
-                                   (hcp_bf16*)y, stats, M, C, eps)
-    if (C <= 512) HCP_LN_FWD(1); else if (C <= 1024) HCP_LN_FWD(2); else if (C <= 2048) HCP_LN_FWD(4); else HCP_LN_FWD(8);
+#define HCP_LN_FWD(NV_, HL_) HCP_LAUNCH((ln_fwd_kernel<NV_, HL_>), dim3(hcp_cdiv(M, 4)), dim3(256), 0, stream, (const hcp_bf16*)x, \
+                                        (const hcp_bf16*)x_lo, gamma, beta, (hcp_bf16*)y, stats, M, C, eps)
+    if (x_lo) { if (C <= 512) HCP_LN_FWD(1, true); else if (C <= 1024) HCP_LN_FWD(2, true); else if (C <= 2048) HCP_LN_FWD(4, true); else HCP_LN_FWD(8, true); }
+    else { if (C <= 512) HCP_LN_FWD(1, false); else if (C <= 1024) HCP_LN_FWD(2, false); else if (C <= 2048) HCP_LN_FWD(4, false); else HCP_LN_FWD(8, false); }
 #undef HCP_LN_FWD
     HCP_LAUNCH_CHECK("layernorm_fwd");
 }
 
 // dx = layer_norm_backward(dy) [+ addend]   (addend: gradient arriving on the residual path of a pre-norm block)
-HCP_API int hcp_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, const void* addend,
-                              void* dx, int M, int C, hipStream_t stream) {
+// (hi | lo) residual stream: x_lo, addend_lo, dx_lo each optional — the row is x + x_lo, the skip gradient addend + addend_lo, and
+// the result g leaves as dx = bf16(g), dx_lo = bf16(g - dx).
+HCP_API int hcp_layernorm_bwd(const void* x, const void* x_lo, const void* dy, const float* gamma, const float* stats, const void* addend,
+                              const void* addend_lo, void* dx, void* dx_lo, int M, int C, hipStream_t stream) {
     HCP_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 4096, "hcp_layernorm_bwd: bad shape M=%d C=%d (C: multiple of 8 up to 4096)", M, C);
     HCP_REQUIRE(x && dy && gamma && stats && dx, "hcp_layernorm_bwd: null pointer");
-#define HCP_LN_BWD(NV_) HCP_LAUNCH(ln_bwd_kernel<NV_>, dim3(hcp_cdiv(M, 4)), dim3(256), 0, stream, (const hcp_bf16*)x, (const hcp_bf16*)dy, \
-                                   gamma, stats, (const hcp_bf16*)addend, (hcp_bf16*)dx, M, C)
-    if (C <= 512) HCP_LN_BWD(1); else if (C <= 1024) HCP_LN_BWD(2); else if (C <= 2048) HCP_LN_BWD(4); else HCP_LN_BWD(8);
+    HCP_REQUIRE(!addend_lo || addend, "hcp_layernorm_bwd: addend_lo needs addend");
+#define HCP_LN_BWD(NV_, HL_) HCP_LAUNCH((ln_bwd_kernel<NV_, HL_>), dim3(hcp_cdiv(M, 4)), dim3(256), 0, stream, (const hcp_bf16*)x, \
+                                        (const hcp_bf16*)x_lo, (const hcp_bf16*)dy, gamma, stats, (const hcp_bf16*)addend,       \
+                                        (const hcp_bf16*)addend_lo, (hcp_bf16*)dx, (hcp_bf16*)dx_lo, M, C)
+    if (x_lo || addend_lo || dx_lo) { if (C <= 512) HCP_LN_BWD(1, true); else if (C <= 1024) HCP_LN_BWD(2, true); else if (C <= 2048) HCP_LN_BWD(4, true); else HCP_LN_BWD(8, true); }
+    else { if (C <= 512) HCP_LN_BWD(1, false); else if (C <= 1024) HCP_LN_BWD(2, false); else if (C <= 2048) HCP_LN_BWD(4, false); else HCP_LN_BWD(8, false); }
 #undef HCP_LN_BWD
     HCP_LAUNCH_CHECK("layernorm_bwd");
 }

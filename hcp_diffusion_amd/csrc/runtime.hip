@@ -17,7 +17,7 @@ HCP_API const char* hcp_last_error(void) { return g_err; }
 // 1 when this object was built by tests/emu (CPU interpreter), 0 for the gfx950 product library.
 HCP_API int hcp_is_emulated(void) { return HCP_IS_EMULATED; }
 
-HCP_API int hcp_abi_version(void) { return 2; }   // include/hcp_mi355x.h HCP_ABI_VERSION; _lib.py refuses any other value
+HCP_API int hcp_abi_version(void) { return 3; }   // include/hcp_mi355x.h HCP_ABI_VERSION; _lib.py refuses any other value
 
 // ---- device self-check of the fp32 atomic path (round 6) ----------------------------------------------------------------------------
 // Every kernel of the library that still ADDS across workgroups (the loss and sum-of-squares scalars, bias / norm-affine column sums,

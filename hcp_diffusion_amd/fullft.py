@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
+from . import ops
 from .layers import HipConv2d, HipLinear
 
 PIECE_DTYPE = np.dtype([("src", "<u8"), ("dst_rm", "<u8"), ("dst_tr", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("src_ld", "<i4"),
@@ -135,4 +136,5 @@ class HostBucket:
                     break
         if self._n_pieces:
             K.pack_weights(self._pieces, self._n_pieces, self._tiles)
+        ops.invalidate_merged_cache()
         self._packed_ver = self._version()

@@ -53,7 +53,7 @@ BF16 = torch.bfloat16
 _WS = {}
 _WGTAB = {}
 _WS_BYTES = 256 << 20
-WGRAD_GRID_BLOCKS = int(os.environ.get("HCP_LAB_WGRAD_BLOCKS", 16384))      # workgroups the grouped LoRA weight-gradient launch aims at
+WGRAD_GRID_BLOCKS = 16384      # workgroups the grouped LoRA weight-gradient launch aims at (tools/lab/wgrad_grouped_bench.py sweeps it)
 
 
 def _workspace(t):
@@ -91,9 +91,17 @@ def atomics_selfcheck(device, workgroups=2048, nb=4099, stride=37):
 TRACE = None        # tools/autotune.py: a list collects the (kind, shape...) key of every GEMM-family launch
 
 
+def _lo_pair(residual, residual_lo, want_lo, M, N, dev):
+    """Checks of the (hi | lo) residual-stream arguments shared by gemm / gemm_lora; returns the lo output tensor (or None)."""
+    if residual_lo is not None:
+        assert residual is not None and residual_lo.dtype == BF16 and residual_lo.shape == (M, N) and residual_lo.stride() == residual.stride()
+    return torch.empty((M, N), dtype=BF16, device=dev) if want_lo else None
+
+
 def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, residual=None, alpha=1.0,
-         out_f32=False, out=None):
-    """out[M,N] = alpha*(a[M,K] @ b[N,K]^T + a2 @ b2^T) + bias + rowbias[m // rows_per_group] + residual."""
+         out_f32=False, out=None, residual_lo=None, want_lo=False):
+    """out[M,N] = alpha*(a[M,K] @ b[N,K]^T + a2 @ b2^T) + bias + rowbias[m // rows_per_group] + residual.
+    (hi | lo) residual stream: residual_lo joins the sum in fp32; want_lo returns (out, out_lo) with out_lo = bf16(v - bf16(v))."""
     _bf16_2d(a, "a"); _bf16_2d(b, "b")
     M, K = a.shape
     N = b.shape[0]
@@ -115,12 +123,14 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, r
     if residual is not None:
         _bf16_2d(residual, "residual"); assert residual.shape == (M, N)
     ws = _workspace(a)
+    assert not want_lo or (out.dtype == BF16 and out.is_contiguous())
+    out_lo = _lo_pair(residual, residual_lo, want_lo, M, N, a.device)
     _chk(lib().hcp_gemm_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K,
                              _p(a2), a2.stride(0) if a2 is not None else 0, _p(b2), b2.stride(0) if b2 is not None else 0,
                              K2, _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, rows_per_group,
-                             _p(residual), residual.stride(0) if residual is not None else 0, float(alpha),
+                             _p(residual), residual.stride(0) if residual is not None else 0, _p(residual_lo), _p(out_lo), float(alpha),
                              1 if out.dtype == torch.float32 else 0, _p(ws), ws.numel(), _stream(a)), "hcp_gemm_bf16")
-    return out
+    return (out, out_lo) if want_lo else out
 
 
 # Split T: the fused-LoRA GEMMs can hand the rank-r intermediate T = x W_down^T (forward) / U = dY W_up (backward) on
@@ -137,8 +147,9 @@ def t_lo(t):
     return 32 if (t is not None and T_SPLIT and t.shape[1] == 64 and t.stride(0) == 64) else 0
 
 
-def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True):
+def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True, residual_lo=None, want_lo=False):
     """(D, T): T = a @ l[32,K]^T;  D[M,N] = a @ b[N,K]^T + T @ e[N,32]^T + bias + residual — one launch.
+    (hi | lo) residual stream (see gemm): residual_lo; want_lo returns ((D, D_lo), T).
     T_SPLIT: T [M,64] = (bf16(T) | bf16(T - bf16(T))) and the product takes both halves; else T [M,32] rounded to bf16."""
     _bf16_2d(a, "a"); _bf16_2d(b, "b"); _bf16_2d(l, "l"); _bf16_2d(e, "e")
     M, Kd = a.shape
@@ -154,10 +165,12 @@ def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True):
     if residual is not None:
         _bf16_2d(residual, "residual"); assert residual.shape == (M, N)
     ws = _workspace(a)
+    out_lo = _lo_pair(residual, residual_lo, want_lo, M, N, a.device)
     _chk(lib().hcp_gemm_lora_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(l), _p(e), _p(t), ldt, _p(out), N, M, N, Kd, _p(bias),
-                                  _p(residual), residual.stride(0) if residual is not None else 0, _p(ws), ws.numel(), _stream(a)),
+                                  _p(residual), residual.stride(0) if residual is not None else 0, _p(residual_lo), _p(out_lo),
+                                  _p(ws), ws.numel(), _stream(a)),
          "hcp_gemm_lora_bf16")
-    return out, t
+    return ((out, out_lo) if want_lo else out), t
 
 
 def gemm_geglu_bwd(dy, wt, hg, *, l=None, e=None, want_t=True):
@@ -363,22 +376,31 @@ def layernorm_affine_grad(x, dy, stats, dgamma, dbeta):
          "hcp_layernorm_affine_grad")
 
 
-def layernorm_fwd(x, gamma, beta, eps):
+def _lo_like(t, ref):
+    assert t is None or (t.dtype == BF16 and t.is_contiguous() and t.numel() == ref.numel())
+    return t
+
+
+def layernorm_fwd(x, gamma, beta, eps, x_lo=None):
+    """x_lo: the lo image of a (hi | lo) residual stream — the row normalised is x + x_lo."""
     assert x.dtype == BF16 and x.is_contiguous()
     C = x.shape[-1]; M = x.numel() // C
     y = torch.empty_like(x)
     stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
-    _chk(lib().hcp_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), M, C, float(eps), _stream(x)), "hcp_layernorm_fwd")
+    _chk(lib().hcp_layernorm_fwd(_p(x), _p(_lo_like(x_lo, x)), _p(gamma), _p(beta), _p(y), _p(stats), M, C, float(eps), _stream(x)), "hcp_layernorm_fwd")
     return y, stats
 
 
-def layernorm_bwd(x, dy, gamma, stats, addend=None):
+def layernorm_bwd(x, dy, gamma, stats, addend=None, x_lo=None, addend_lo=None, want_lo=False):
+    """want_lo: returns (dx, dx_lo) = (bf16(g), bf16(g - bf16(g))) for g = ln_backward(dy) + addend + addend_lo."""
     assert x.is_contiguous() and dy.is_contiguous() and dy.dtype == BF16
     assert addend is None or (addend.dtype == BF16 and addend.is_contiguous() and addend.numel() == x.numel())
     C = x.shape[-1]; M = x.numel() // C
     dx = torch.empty_like(x)
-    _chk(lib().hcp_layernorm_bwd(_p(x), _p(dy), _p(gamma), _p(stats), _p(addend), _p(dx), M, C, _stream(x)), "hcp_layernorm_bwd")
-    return dx
+    dx_lo = torch.empty_like(x) if want_lo else None
+    _chk(lib().hcp_layernorm_bwd(_p(x), _p(_lo_like(x_lo, x)), _p(dy), _p(gamma), _p(stats), _p(addend), _p(_lo_like(addend_lo, x)), _p(dx),
+                                 _p(dx_lo), M, C, _stream(x)), "hcp_layernorm_bwd")
+    return (dx, dx_lo) if want_lo else dx
 
 
 def geglu_fwd(h):

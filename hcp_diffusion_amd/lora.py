@@ -607,6 +607,7 @@ class LoraBucket:
         if self._conv_pieces is not None:                  # conv (LoCon) blocks: the grouped convert/transpose kernel
             K.pack_weights(self._conv_pieces, len(self._conv_rows), self._conv_tiles)
         self._packed_version = self.params._version
+        ops.invalidate_merged_cache()                      # merged-weight hosts cache W + dW for gradient-free calls
         for b in self.blocks:                              # each factor's own counter too: an optimizer steps through the Parameters,
             b._pk_ver = (b.layer.W_down._version, b.layer.W_up._version)   # whose `.data` views do not share the bucket's version counter
 

@@ -30,12 +30,8 @@ BF16 = torch.bfloat16
 
 
 class WgradContext:
-    def __init__(self, grouped=False, side_stream=False, chunk_layers=0):
-        """chunk_layers > 0 (with grouped): the grouped launch is cut into pieces of that many layers, and every piece but the last is
-        launched on a SIDE stream as soon as its layers' operands exist (an event on the dX chain's stream) — under hipGraph capture a
-        parallel branch next to the rest of the dX chain, whose latency-bound kernels leave most of the chip idle; join() at the end."""
+    def __init__(self, grouped=False, side_stream=False):
         self.grouped, self.side = bool(grouped), bool(side_stream)
-        self.chunk = int(chunk_layers) if grouped else 0
         self.items, self.keep = [], []            # grouped: pending operands / what the last grouped launch keeps alive (hipGraph replays)
         self.stream, self.side_keep = None, []
 
@@ -43,8 +39,6 @@ class WgradContext:
         """ulo / tlo: column offset of the residual half of a split U / T (K.t_lo: the fused-LoRA GEMMs' [M, 64] = (hi | lo)), 0 = none."""
         if self.grouped:
             self.items.append((U, x2, gd, T, dy2, gu, rank, alpha, slot0, ulo, tlo))
-            if self.chunk and len(self.items) >= self.chunk and x2.is_cuda:
-                self._launch_chunk_on_side_stream()
             return
         if slot0 != 0 or not dy2.is_contiguous() or (ulo != 0) != (U.shape[1] == 64) or (tlo != 0) != (T.shape[1] == 64):
             # member of a fused group (or mixed formats): the grouped entry point handles slots / strides
@@ -61,18 +55,6 @@ class WgradContext:
         with torch.cuda.stream(self.stream):
             K.lora_wgrad_pair(U, x2, gd, T, dy2, gu, rank, alpha)
         self.side_keep.append((U, x2, T, dy2))        # the allocator must not recycle these before the side kernel ran
-
-    def _launch_chunk_on_side_stream(self):
-        dev = self.items[0][1].device
-        if self.stream is None:
-            self.stream = torch.cuda.Stream(device=dev)
-        ev = torch.cuda.Event()
-        ev.record()                                   # after the dX kernel of the chunk's last layer: every U of the chunk is complete
-        self.stream.wait_event(ev)
-        with torch.cuda.stream(self.stream):
-            keep = K.lora_wgrad_grouped(self.items)
-        self.side_keep.append((keep, self.items))     # operands stay alive until join(): the allocator must not hand them out before the branch ran
-        self.items = []
 
     def flush(self):
         """grouped: all collected layers' weight gradients as one launch."""
@@ -136,31 +118,41 @@ class _LinearFn(torch.autograd.Function):
     LoraPatchContainer.forward / LoraBlock.post_forward (lora_base_patch.py:20-35,68-74)."""
 
     @staticmethod
-    def forward(ctx, x, residual, w_down, w_up, host, lora, out_f32=False, hw=None, hb=None):
+    def forward(ctx, x, residual, w_down, w_up, host, lora, out_f32=False, hw=None, hb=None, residual_lo=None, stream=False):
+        """stream: the residual is a (hi | lo) residual stream (residual, residual_lo — lo may be None where the stream starts) and the
+        result is the pair (y_hi, y_lo); their gradients come back as a pair too and pass to the residual inputs as they are."""
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
+        lo2 = residual_lo.reshape(-1, residual_lo.shape[-1]) if residual_lo is not None else None
         pk = host.packed()
         T = None
         if lora is not None and getattr(lora, "wide", False):      # rank > 32: skinny side GEMM + K-extension
             lp = lora.packed()
             T = K.gemm(x2, lp.ad)
-            y = K.gemm(x2, pk.w, a2=T, b2=lp.bu, bias=pk.bias, residual=res2)
+            y = K.gemm(x2, pk.w, a2=T, b2=lp.bu, bias=pk.bias, residual=res2, residual_lo=lo2, want_lo=stream)
         elif lora is not None:
             lp = lora.packed()
-            y, T = K.gemm_lora(x2, pk.w, lp.ad, lp.bu, bias=pk.bias, residual=res2)
+            y, T = K.gemm_lora(x2, pk.w, lp.ad, lp.bu, bias=pk.bias, residual=res2, residual_lo=lo2, want_lo=stream)
         else:
-            y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2, out_f32=out_f32)
+            y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2, out_f32=out_f32, residual_lo=lo2, want_lo=stream)
         ctx.host, ctx.lora = host, lora
         ctx.wg = current_wgrad()
         ctx.train_w, ctx.train_b = hw is not None, hb is not None
         ctx.save_for_backward(x2 if (lora is not None or hw is not None) else None, T)
         ctx.xshape = shp
         ctx.has_res = residual is not None
+        ctx.stream, ctx.has_lo = stream, residual_lo is not None
+        if stream:
+            ctx.set_materialize_grads(False)           # the lo image of the last block has no consumer: its gradient stays None
+            return y[0].view(*shp[:-1], y[0].shape[-1]), y[1].view(*shp[:-1], y[1].shape[-1])
         return y.view(*shp[:-1], y.shape[-1])
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy_lo=None):
+        if dy is None:                                 # (stream mode, nothing downstream took the gradient)
+            assert dy_lo is None
+            return (None,) * 11
         x2, T = ctx.saved_tensors
         host, lora = ctx.host, ctx.lora
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -197,7 +189,9 @@ class _LinearFn(torch.autograd.Function):
             K.colsum(dy2, grad_buffer(host.bias))
         if dx is not None:
             dx = dx.view(ctx.xshape)
-        return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None
+        # the stream's gradient is a (hi | lo) pair as well: the GEMMs above read its hi image (the reference's autograd casts the fp32
+        # stream gradient to bf16 in front of the same mm), the residual path hands both images on untouched
+        return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None, (dy_lo if ctx.has_lo else None), None
 
 
 def linear(x, host, lora=None, residual=None, out_f32=False):
@@ -207,6 +201,14 @@ def linear(x, host, lora=None, residual=None, out_f32=False):
     if out_f32 and (lora is not None or x.requires_grad or hw is not None or hb is not None):
         raise NotImplementedError("hcp_diffusion_amd: fp32 linear output is only provided for the gradient-free time-embedding path")
     return _LinearFn.apply(x, residual, wd, wu, host, lora, out_f32, hw, hb)
+
+
+def linear_stream(x, host, lora, hi, lo):
+    """(y_hi, y_lo) = split(x W^T [+ LoRA] + bias + hi + lo): a Linear whose residual is a (hi | lo) residual stream (lo: None where the
+    stream starts).  See GemmParams::residual_lo (csrc/gemm_params.h)."""
+    wd = lora.layer.W_down if lora is not None else None
+    wu = lora.layer.W_up if lora is not None else None
+    return _LinearFn.apply(x, hi, wd, wu, host, lora, False, _tr(host.weight), _tr(host.bias), lo, True)
 
 
 class _LinearGroupFn(torch.autograd.Function):
@@ -285,8 +287,7 @@ class _CtxKVFn(torch.autograd.Function):
     def backward(ctx, *dkvs):
         x2, T_all = ctx.saved_tensors
         batch, dall = ctx.batch, ctx.dkv_all
-        joint = (T_all is not None and batch.all_have_lora() and all(d is not None for d in dkvs)
-                 and os.environ.get("HCP_LAB_NO_U_BATCH") != "1")                                   # (lab switch: A/B runs)
+        joint = T_all is not None and batch.all_have_lora() and all(d is not None for d in dkvs)
         for g, off, d in zip(batch.groups, batch.n_off, dkvs):
             if d is None or not g.has_lora:
                 continue
@@ -500,27 +501,42 @@ class _LayerNormForkFn(torch.autograd.Function):
     """(layer_norm(x), x) for pre-norm residual blocks; see _GroupNormForkFn."""
 
     @staticmethod
-    def forward(ctx, x, ln, hw=None, hb=None):
+    def forward(ctx, x, ln, hw=None, hb=None, x_lo=None, stream=False):
+        """stream: x is the hi image of a (hi | lo) residual stream, x_lo its lo image (None where the stream starts); returns
+        (LN(x + x_lo), x, x_lo) and takes the skip gradient back as a pair."""
         g, b = ln.f32_params()
-        y, stats = K.layernorm_fwd(x, g, b, ln.eps)
-        ctx.save_for_backward(x, stats)
-        ctx.ln, ctx.train = ln, hw is not None
+        y, stats = K.layernorm_fwd(x, g, b, ln.eps, x_lo=x_lo)
+        ctx.save_for_backward(x, stats, x_lo)
+        ctx.ln, ctx.train, ctx.stream = ln, hw is not None, stream
+        if stream:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x), (x_lo.view_as(x_lo) if x_lo is not None else None)
         return y, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dy, dskip):
-        x, stats = ctx.saved_tensors
+    def backward(ctx, dy, dskip, dskip_lo=None):
+        x, stats, x_lo = ctx.saved_tensors
         g, _ = ctx.ln.f32_params()
         if dy is None:
-            return dskip, None, None, None
+            return dskip, None, None, None, dskip_lo, None
         dy = dy.contiguous()
         if ctx.train:
             K.layernorm_affine_grad(x, dy, stats, grad_buffer(ctx.ln.weight), grad_buffer(ctx.ln.bias))
-        return K.layernorm_bwd(x, dy, g, stats, dskip.contiguous() if dskip is not None else None), None, None, None
+        if ctx.stream:
+            want_lo = x_lo is not None                 # the stream's first norm hands ONE bf16 gradient back to the producer of x
+            r = K.layernorm_bwd(x, dy, g, stats, dskip.contiguous() if dskip is not None else None, x_lo=x_lo,
+                                addend_lo=dskip_lo.contiguous() if (dskip_lo is not None and dskip is not None) else None, want_lo=want_lo)
+            return (r[0], None, None, None, r[1], None) if want_lo else (r, None, None, None, None, None)
+        return K.layernorm_bwd(x, dy, g, stats, dskip.contiguous() if dskip is not None else None), None, None, None, None, None
 
 
 def layernorm_fork(x, ln):
     return _LayerNormForkFn.apply(x, ln, *_norm_tr(ln))
+
+
+def layernorm_fork_stream(hi, lo, ln):
+    """(LN(hi + lo), hi, lo) on a (hi | lo) residual stream; lo may be None (the stream's first norm)."""
+    return _LayerNormForkFn.apply(hi, ln, *_norm_tr(ln), lo, True)
 
 
 class _GegluFn(torch.autograd.Function):
@@ -546,28 +562,36 @@ class _GegluLinearFn(torch.autograd.Function):
     _GegluFn + _LinearFn (the epilogue rounds dY_ff to bf16 before the two products, as the two-kernel form does)."""
 
     @staticmethod
-    def forward(ctx, hg, residual, w_down, w_up, host, lora, hw=None, hb=None):
+    def forward(ctx, hg, residual, w_down, w_up, host, lora, hw=None, hb=None, residual_lo=None, stream=False):
         shp = hg.shape
         hg2 = hg.reshape(-1, shp[-1])
         x2 = K.geglu_fwd(hg2)
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
+        lo2 = residual_lo.reshape(-1, residual_lo.shape[-1]) if residual_lo is not None else None
         pk = host.packed()
         T = None
         if lora is not None:
             lp = lora.packed()
-            y, T = K.gemm_lora(x2, pk.w, lp.ad, lp.bu, bias=pk.bias, residual=res2)
+            y, T = K.gemm_lora(x2, pk.w, lp.ad, lp.bu, bias=pk.bias, residual=res2, residual_lo=lo2, want_lo=stream)
         else:
-            y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2)
+            y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2, residual_lo=lo2, want_lo=stream)
         ctx.host, ctx.lora = host, lora
         ctx.wg = current_wgrad()
         ctx.train_w, ctx.train_b = hw is not None, hb is not None
         ctx.save_for_backward(hg2, x2 if (lora is not None or hw is not None) else None, T)
         ctx.hshape = shp
         ctx.has_res = residual is not None
+        ctx.has_lo = residual_lo is not None
+        if stream:                                     # (hi | lo) residual stream: see _LinearFn
+            ctx.set_materialize_grads(False)
+            return y[0].view(*shp[:-1], y[0].shape[-1]), y[1].view(*shp[:-1], y[1].shape[-1])
         return y.view(*shp[:-1], y.shape[-1])
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy_lo=None):
+        if dy is None:
+            assert dy_lo is None
+            return (None,) * 10
         hg2, x2, T = ctx.saved_tensors
         host, lora = ctx.host, ctx.lora
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -593,12 +617,15 @@ class _GegluLinearFn(torch.autograd.Function):
             K.colsum(dy2, grad_buffer(host.bias))
         if dhg is not None:
             dhg = dhg.view(ctx.hshape)
-        return dhg, (dy if ctx.has_res else None), None, None, None, None, None, None
+        return dhg, (dy if ctx.has_res else None), None, None, None, None, None, None, (dy_lo if ctx.has_lo else None), None
 
 
 def geglu_linear(hg, host, lora=None, residual=None):
+    """residual: a tensor, or the (hi, lo) pair of a (hi | lo) residual stream — the result is then a pair too."""
     wd = lora.layer.W_down if lora is not None else None
     wu = lora.layer.W_up if lora is not None else None
+    if isinstance(residual, tuple):
+        return _GegluLinearFn.apply(hg, residual[0], wd, wu, host, lora, _tr(host.weight), _tr(host.bias), residual[1], True)
     return _GegluLinearFn.apply(hg, residual, wd, wu, host, lora, _tr(host.weight), _tr(host.bias))
 
 
@@ -777,6 +804,14 @@ class _MergedLoraFn(torch.autograd.Function):
 
 
 _MERGED_EVAL_CACHE = {}   # id(host) -> (key, shadow): gradient-free calls (the sampler: one per denoising step) reuse W_eff and its operand pack
+_MERGED_GEN = [0]
+
+
+def invalidate_merged_cache():
+    """Called by everything that writes trained parameters WITHOUT moving a torch version counter: the fused clip + AdamW
+    kernel takes raw pointers, a captured optimizer step replays without running any Python — NativeTrainer bumps this after every
+    optimizer step (eager or replayed), LoraBucket.pack() / HostBucket.repack() whenever they re-derive operands (loads, EMA swaps)."""
+    _MERGED_GEN[0] += 1
 
 
 def merged_lora_call(host, blocks, x, residual=None, x2=None, rowbias=None, upsample=False):
@@ -785,7 +820,8 @@ def merged_lora_call(host, blocks, x, residual=None, x2=None, rowbias=None, upsa
                                           any(p.requires_grad for p in factors) or host.weight.requires_grad or
                                           (host.bias is not None and host.bias.requires_grad))
     if not needs:                                              # no inner autograd graph, no re-merge / re-pack while nothing changed
-        key = (host.weight._version, host.weight.data_ptr()) + tuple((p._version, p.data_ptr()) for p in factors) + tuple(b.alpha_f for b in blocks)
+        key = ((_MERGED_GEN[0], host.weight._version, host.weight.data_ptr()) + tuple((p._version, p.data_ptr()) for p in factors) +
+               tuple(b.alpha_f for b in blocks))
         hit = _MERGED_EVAL_CACHE.get(id(host))
         if hit is None or hit[0] != key or hit[2]() is not host:
             import weakref

@@ -127,7 +127,7 @@ class _WarmupComm(NullComm):
 class NativeTrainer:
     def __init__(self, unet, lora_cfg=None, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  scale_lr_factor=1.0, process_group=None, use_graph=False, loss_weight=1.0, num_train_timesteps=1000,
-                 overlap_wgrad=False, grouped_wgrad=True, wgrad_chunk_layers=0, train_cfg=None, plugins=None, ema=None, loss_cfg=None, text_encoder=None,
+                 overlap_wgrad=False, grouped_wgrad=True, train_cfg=None, plugins=None, ema=None, loss_cfg=None, text_encoder=None,
                  lora_te_cfg=None, comm=None, shard_optimizer=None, gradient_accumulation_steps=1, loss_type="eps",
                  overlap_exchange=False, grad_wire="fp32", param_wire="fp32"):
         """lora_cfg: the reference's ``lora_unet`` list ({layers, rank, alpha, lr, ...}); train_cfg: its ``unet`` list
@@ -234,8 +234,7 @@ class NativeTrainer:
         # every fork/join edge of the hipGraph costs more than the overlap buys); one grouped launch at the end wins.
         self.overlap_wgrad = overlap_wgrad and self.device.type == "cuda"
         self.grouped_wgrad = grouped_wgrad
-        self._wgrad_ctx = ops.WgradContext(grouped=grouped_wgrad, side_stream=self.overlap_wgrad,   # this trainer's own (no process-global switch)
-                                           chunk_layers=wgrad_chunk_layers if self.device.type == "cuda" else 0)
+        self._wgrad_ctx = ops.WgradContext(grouped=grouped_wgrad, side_stream=self.overlap_wgrad)   # this trainer's own (no process-global switch)
         self._xstream = torch.cuda.Stream(self.device) if (self._overlap and self.device.type == "cuda") else None
         self._graph_cache = {}           # batch signature -> (forward/backward graph, static inputs, loss tensor), least recently used first
         self.max_graph_signatures = 32   # aspect-ratio buckets x context lengths kept captured (each holds its static inputs; the pool is shared)
@@ -549,6 +548,7 @@ class NativeTrainer:
                 self.optimizer_step(early_sent=sent)
             else:
                 self.optimizer_step()
+            ops.invalidate_merged_cache()      # the parameters moved (raw-pointer kernels, possibly a graph replay: no version counter saw it)
         return self.loss
 
     def _signature(self, data_list):

@@ -44,7 +44,15 @@ def _per_block(v, i):
 
 
 def _call_res(mod, x, residual):
-    """Call a (possibly LoRA-wrapped / hooked) leaf, fusing the residual add when the callee supports it."""
+    """Call a (possibly LoRA-wrapped / hooked) leaf, fusing the residual add when the callee supports it.
+    residual = (hi, lo): a (hi | lo) residual stream (BasicTransformerBlock) — the result is a pair too.  A leaf that cannot take the
+    pair (hooked, foreign, dropout, conv host, rank > 32) gets the hi image as an ordinary residual: that one add then rounds to bf16
+    as the plain stream does, and the stream goes on without a lo image."""
+    if isinstance(residual, tuple):
+        leaf = _ff_out_leaf(mod)
+        if leaf is not None:
+            return ops.linear_stream(x, leaf[0], leaf[1], residual[0], residual[1])
+        return _call_res(mod, x, residual[0]), None
     if getattr(mod, "supports_fused_residual", False):
         return mod(x, residual=residual)
     return ops.add(mod(x), residual)     # e.g. the reference's own LoraPatchContainer swallows extra kwargs
@@ -141,7 +149,7 @@ def _fusable_linear(m):
     from .lora import LoraHipContainer
     host, blk = m, None
     if isinstance(m, LoraHipContainer):
-        if len(m.plugin_names) != 1:
+        if type(m) is not LoraHipContainer or len(m.plugin_names) != 1:      # (a subclass — DAPPHipContainer — splits the batch in its own forward)
             return None
         host, blk = m._host, m[m.plugin_names[0]]
         if m._forward_hooks or m._forward_pre_hooks:
@@ -157,8 +165,6 @@ def _fusable_linear(m):
     return host, blk
 
 
-_LAB_FP32_STREAM = False          # lab probe, see BasicTransformerBlock.forward
-_LAB_NO_GEGLU_FUSE = bool(os.environ.get("HCP_LAB_NO_GEGLU_FUSE"))      # same-box A/B switch (tools/lab): the two-node path
 
 
 def _ff_out_leaf(m):
@@ -166,7 +172,7 @@ def _ff_out_leaf(m):
     LoRA container of rank <= 32 without active dropout, and nobody hooked it; else None (module-by-module path)."""
     from .lora import LoraHipContainer
     if isinstance(m, LoraHipContainer):
-        if (len(m.plugin_names) != 1 or m._forward_hooks or m._forward_pre_hooks or type(m._host) is not HipLinear
+        if (type(m) is not LoraHipContainer or len(m.plugin_names) != 1 or m._forward_hooks or m._forward_pre_hooks or type(m._host) is not HipLinear
                 or m._host._forward_hooks or m._host._forward_pre_hooks):
             return None
         blk = m[m.plugin_names[0]]
@@ -220,7 +226,7 @@ class CrossAttention(nn.Module):
             # (folded into the packed q weights and that block's LoRA alpha): the kernels exponentiate the accumulator as it is
             g = self._group((self.to_q, self.to_k, self.to_v), (qc, 1.0, 1.0))
             gq = gkv = None
-            if g is None and os.environ.get("HCP_LAB_NO_QKV_SPLIT") != "1":   # the three blocks' rank slots exceed one 32-wide slot group (rank 16: SDXL's configs[3]):
+            if g is None:                              # the three blocks' rank slots exceed one 32-wide slot group (rank 16: SDXL's configs[3]):
                 gkv = self._group((self.to_k, self.to_v))                  # q alone + k|v together, the cross-attention form with context = x
                 gq = self._group((self.to_q,), (qc,)) if gkv is not None else None
             if g is not None:
@@ -261,7 +267,7 @@ class FeedForward(nn.Module):
 
     def forward(self, x, residual=None):
         leaf = _ff_out_leaf(self.net[2]) if not (self.net[0]._forward_hooks or self.net[0]._forward_pre_hooks) and self.net[1].p == 0.0 else None
-        if leaf is not None and type(self.net[0]) is GEGLU and not _LAB_NO_GEGLU_FUSE:
+        if leaf is not None and type(self.net[0]) is GEGLU:
             # GEGLU + output projection as one autograd node: the GEGLU backward rides in the epilogue of the projection's
             # input-gradient GEMM (ops._GegluLinearFn).  A hooked / foreign / dropout leaf keeps the module-by-module path below.
             return ops.geglu_linear(self.net[0].proj(x), leaf[0], leaf[1], residual)
@@ -280,16 +286,16 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = HipLayerNorm(dim)
 
     def forward(self, x, context):
+        """x: [B, N, C] bf16, or the (hi, lo) pair of a (hi | lo) residual stream (Transformer2DModel.hi_lo_stream) — the block then
+        returns a pair: the three residual adds and the three norms see x = hi + lo, 16 mantissa bits instead of 8."""
         context, key_bias = context if isinstance(context, tuple) else (context, None)   # (states, additive key mask)
-        if _LAB_FP32_STREAM and not torch.is_grad_enabled():
-            # LAB PROBE (tools/diag/sdxl_stream_probe.py; forward only, torch ops): the residual stream of the transformer blocks in fp32 —
-            # what the reference's LoRA layers produce under autocast (their mm(...) + fp32 bias promotes to_out / ff.net.2 outputs to fp32,
-            # lora_layers_patch.py:50-55).  Measures what a native fp32 stream would buy before any kernel is written.
-            ln = lambda m, v: torch.nn.functional.layer_norm(v, (v.shape[-1],), m.weight.float(), m.bias.float(), m.eps).to(BF16)
-            x32 = x.float()
-            x32 = x32 + self.attn1(ln(self.norm1, x32)).float()
-            x32 = x32 + self.attn2(ln(self.norm2, x32), context, key_bias=key_bias).float()
-            return x32 + self.ff(ln(self.norm3, x32)).float()
+        if isinstance(x, tuple):
+            h, hi, lo = ops.layernorm_fork_stream(x[0], x[1], self.norm1)
+            x = self.attn1(h, residual=(hi, lo))
+            h, hi, lo = ops.layernorm_fork_stream(x[0], x[1], self.norm2)
+            x = self.attn2(h, context, residual=(hi, lo), key_bias=key_bias)
+            h, hi, lo = ops.layernorm_fork_stream(x[0], x[1], self.norm3)
+            return self.ff(h, residual=(hi, lo))
         h, x = self.norm1(x, fork=True)                        # (LN(x), x): the fork fuses the residual-gradient add
         x = self.attn1(h, residual=x)
         h, x = self.norm2(x, fork=True)
@@ -308,15 +314,26 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, ctx_dim, heads) for _ in range(depth)])
         self.proj_out = HipLinear(dim, dim) if linear_proj else HipConv2d(dim, dim, 1)
         self.gradient_checkpointing = False
+        # (hi | lo) residual stream through the transformer blocks: "auto" = on for stacks of two or more blocks (SDXL: 2 / 10 per level),
+        # where the bf16 rounding of every residual add compounds; True / False force it.  The reference's LoRA layers keep this stream
+        # in fp32 under autocast (their mm + fp32 bias promotes, lora_layers_patch.py:50-57); DESIGN section 4.
+        self.hi_lo_stream = "auto"
+
+    def _use_stream(self):
+        if self.hi_lo_stream == "auto":
+            return len(self.transformer_blocks) >= 2
+        return bool(self.hi_lo_stream)
 
     def forward(self, x, context):
         B, H, W, C = x.shape
         h, x = self.norm(x, silu=False, fork=True)
         h = self.proj_in(h.view(B, H * W, C)) if isinstance(self.proj_in, nn.Linear) else self.proj_in(h).view(B, H * W, C)
+        if self._use_stream():
+            h = (h, None)                                      # the stream starts here: proj_in's output is the first hi image
         for blk in self.transformer_blocks:
             h = blk(h, context)
-        if h.dtype != BF16:                                    # (lab probe: fp32 residual stream)
-            h = h.to(BF16)
+        if isinstance(h, tuple):
+            h = h[0]                                           # proj_out reads bf16(x), as autocast casts the reference's fp32 stream
         if isinstance(self.proj_out, nn.Linear):
             return _call_res(self.proj_out, h, x.view(B, H * W, C)).view(B, H, W, C)
         return _call_res(self.proj_out, h.view(B, H, W, C), x)
@@ -525,6 +542,13 @@ class NativeUNet2DConditionModel(nn.Module):
                 m.gradient_checkpointing = True
         self._hcp_capturable = None
 
+    def set_residual_stream(self, mode="auto"):
+        """(hi | lo) residual stream of the transformer blocks (Transformer2DModel.hi_lo_stream): "auto" (stacks of >= 2 blocks), True, False."""
+        for m in self.modules():
+            if isinstance(m, Transformer2DModel):
+                m.hi_lo_stream = mode
+        self._hcp_capturable = None
+
     def disable_gradient_checkpointing(self):
         for m in self.modules():
             if hasattr(m, "gradient_checkpointing"):
@@ -556,7 +580,7 @@ class NativeUNet2DConditionModel(nn.Module):
         """Every cross-attention layer projects the SAME prompt states to its keys and values: when all of those projection pairs are
         fusable (frozen bias-free hosts, bare or with one native LoRA block of rank <= 16 each, no dropout, no hooks) and the states need
         no gradient, evaluate them as one GEMM up front (lora.CtxBatch: 32 launches -> 3 for SD1.5) and hand each layer its column slice."""
-        if not torch.is_tensor(ctx) or ctx.requires_grad or os.environ.get("HCP_LAB_NO_CTX_BATCH") == "1":    # (lab switch: A/B runs)
+        if not torch.is_tensor(ctx) or ctx.requires_grad:
             return
         pairs = [(m.attn2, m.attn2._group((m.attn2.to_k, m.attn2.to_v))) for m in self.modules() if isinstance(m, BasicTransformerBlock)]
         pairs = [(a, g) for a, g in pairs if g is not None and g.k == ctx.shape[-1]]      # (trainable / hooked layers keep their own call)

@@ -27,8 +27,9 @@ int hcp_is_emulated(void); /* 0 for the product library */
 /* Revision of this header.  hcp_abi_version() returns the value the library was built with; a binding made for another revision must
  * refuse to call it (hcp_diffusion_amd/_lib.py does).  1: rounds 1-5.  2: round 6 — workspace arguments on the LoRA weight-gradient
  * entry points (slabs + ordered reduce instead of fp32 atomics), 152-byte grouped descriptors; earlier in-place argument insertions
- * (ldt on hcp_gemm_lora_bf16 / hcp_gemm_geglu_bwd_bf16, l_lo, ldu / ldt) are covered by the same bump. */
-#define HCP_ABI_VERSION 2
+ * (ldt on hcp_gemm_lora_bf16 / hcp_gemm_geglu_bwd_bf16, l_lo, ldu / ldt) are covered by the same bump.  3: round 6 — the (hi | lo)
+ * residual stream: residual_lo / D_lo on hcp_gemm_bf16 / hcp_gemm_lora_bf16, x_lo / addend_lo / dx_lo on hcp_layernorm_fwd / _bwd. */
+#define HCP_ABI_VERSION 3
 int hcp_abi_version(void);
 /* Device self-check of the fp32 atomic path (no reference counterpart: the reference's sums are torch's).  workgroups x 256 threads add
  * small integers into line[16] and into bucket[i * stride], i < nb (both cleared here first); exact expected values:
@@ -41,8 +42,12 @@ int hcp_selfcheck_atomics(float* line, float* bucket, int nb, int stride, int wo
  * (A2,B2) is the rank-r side path (x W_down^T, alpha*W_up) appended to the reduction. */
 int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int ldd, int M, int N, int K, const void* A2,
                   int lda2, const void* B2, int ldb2, int K2, const float* bias, const float* rowbias, int rowbias_ld,
-                  int rows_per_group, const void* residual, int ldr, float alpha, int out_f32, void* workspace,
-                  size_t workspace_bytes, hcpStream_t stream);
+                  int rows_per_group, const void* residual, int ldr, const void* residual_lo, void* D_lo, float alpha, int out_f32,
+                  void* workspace, size_t workspace_bytes, hcpStream_t stream);
+/* (hi | lo) residual stream, ABI 3: residual_lo / D_lo (both optional, bf16, leading dimensions ldr / ldd).  A transformer block's
+ * residual stream x is carried as hi = bf16(x) and lo = bf16(x - hi): the epilogue adds residual + residual_lo in fp32 and writes
+ * D = bf16(v), D_lo = bf16(v - D) — the 16 mantissa bits the reference's LoRA layers keep on that stream by returning
+ * mm(x, W^T) [bf16 under autocast] + bias [fp32] = fp32 (lora_layers_patch.py:50-57).  NULL, NULL = the plain bf16 epilogue. */
 /* Fused LoRA linear, forward and input-gradient: T = A L^T (rank slot 32, written to Tout if non-NULL),
  * D = A B^T + T E^T + bias + residual in ONE launch (the block accumulates its T tile from the A tiles it streams);
  * deep-K / small-M shapes run as two launches (T GEMM, then split-K K-extension GEMM) and then require Tout.
@@ -52,8 +57,8 @@ int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int l
  * (the two-launch form keeps the rounded T and zeroes the residual half).
  * Replaces LoraPatchContainer.forward's weight merge + mm (lora_base_patch.py:20-35,61-74). */
 int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, int ldt, void* D,
-                       int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, void* workspace,
-                       size_t workspace_bytes, hcpStream_t stream);
+                       int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, const void* residual_lo, void* D_lo,
+                       void* workspace, size_t workspace_bytes, hcpStream_t stream);
 /* FF-out input-gradient with the GEGLU backward in its epilogue: dY_ff = A B^T (+ the LoRA side path as hcp_gemm_lora_bf16's backward
  * form: L = W_up^T, E = alpha W_down^T, Tout = dY W_up; L = E = NULL for a plain host) is never written; with (h | g) = HG[M, 2F] saved
  * by the forward, DHG[m, n] = dY_ff gelu(g), DHG[m, F + n] = dY_ff h gelu'(g).  Replaces the dX GEMM of FeedForward.net[2] + the
@@ -105,11 +110,13 @@ int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* gamma, co
                            const void* addend /* optional residual-path gradient, added in the same pass */, void* dx,
                            void* workspace, int B, int HW, int C, int G, int silu, hcpStream_t stream);
 
-/* LayerNorm over the last dim; stats[M,2] = (mean, rstd).  Replaces F.layer_norm (unet_struct.txt:44-46). */
-int hcp_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int C, float eps,
-                      hcpStream_t stream);
-int hcp_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* stats, const void* addend, void* dx,
-                      int M, int C, hcpStream_t stream);
+/* LayerNorm over the last dim; stats[M,2] = (mean, rstd).  Replaces F.layer_norm (unet_struct.txt:44-46).
+ * x_lo / addend_lo / dx_lo (optional, ABI 3): the lo images of a (hi | lo) residual stream (see hcp_gemm_bf16) — the row normalised is
+ * x + x_lo, the gradient arriving on the residual path is addend + addend_lo, and the result leaves as dx = bf16(g), dx_lo = bf16(g - dx). */
+int hcp_layernorm_fwd(const void* x, const void* x_lo, const float* gamma, const float* beta, void* y, float* stats, int M, int C,
+                      float eps, hcpStream_t stream);
+int hcp_layernorm_bwd(const void* x, const void* x_lo, const void* dy, const float* gamma, const float* stats, const void* addend,
+                      const void* addend_lo, void* dx, void* dx_lo, int M, int C, hcpStream_t stream);
 
 /* y[M,F] = h[:, :F] * gelu(h[:, F:])   (diffusers GEGLU, unet_struct.txt:28-30) */
 int hcp_geglu_fwd(const void* h, void* y, long M, int F, hcpStream_t stream);
@@ -230,18 +237,7 @@ int hcp_cast_bf16_f32(const void* src_bf16, float* dst, long n, hcpStream_t stre
 int hcp_cfg_ddim_step(const float* x, const float* eps2, float* out, long n, int guided, float guidance_scale,
                       float alpha_cumprod_t, float alpha_cumprod_prev, hcpStream_t stream);
 
-/* ---- tuning / ablation hooks: ONLY in builds made with -DHCP_TOOLS (libhcp_mi355x_tools.so, used by tools/*.py and by the
- * tests that force kernel variants).  They set process-global knobs and are therefore not part of the product ABI. */
-#ifdef HCP_TOOLS
-int hcp_debug_gemm_table_stats(long* hits, long* misses); /* tools only: dispatch-table lookups since the last call; resets */
-int hcp_debug_set_gemm_config(int cfg); /* tools/tune_gemm.py only: force tile id + 16*nsplit, -1 = heuristic */
-int hcp_debug_set_gemm_ablation(int flags); /* tools only (wrong results when != 0): 1 no DMA, 2 no MFMA, 4 no LDS reads */
-int hcp_debug_set_gn_target(int workgroups);   /* tools only: workgroups a two-launch GroupNorm aims for (default 512); -1 / -2: one-launch slab path off / on */
-int hcp_debug_set_gemm_loaders(int mode); /* tools only: -1 table, 0 never, 1 / 3 / 4 loader-wave variant with a 2 / 3 / 4 tile LDS ring */
-int hcp_debug_set_gemm_glds(int on);    /* tools only: 1 = default (v2 main loop where eligible), 0/2 = first LDS-DMA loop everywhere */
-int hcp_debug_set_attention_config(int cfg); /* tools only: bit0/1/2 = 32 rows per wave in fwd / dQ / dK,dV; -1 = heuristic */
-int hcp_debug_set_wgrad_tile(int wx);
-#endif
+/* (the tuning / ablation hooks of the -DHCP_TOOLS build are declared in include/hcp_mi355x_tools.h: they are not part of this ABI) */
 
 /* ---- data-parallel exchange: RCCL over xGMI on flat buffers (csrc/comm.hip).  Replaces accelerator.backward's DDP gradient
  * all-reduce (reference train_ac.py:117-123,175,482).  One process per GPU; `comm` is an opaque handle owned by the caller;

@@ -11,14 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols(tools=False):
-    """Symbols the header declares: the product ABI, or (tools=True) the hooks inside its `#ifdef HCP_TOOLS` block."""
-    src = open(os.path.join(ROOT, "include", "hcp_mi355x.h")).read()
+    """Symbols a header declares: the product ABI (include/hcp_mi355x.h), or (tools=True) the hooks of include/hcp_mi355x_tools.h."""
+    src = open(os.path.join(ROOT, "include", "hcp_mi355x_tools.h" if tools else "hcp_mi355x.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    blocks = re.findall(r"#ifdef HCP_TOOLS(.*?)#endif", src, flags=re.S)
-    if tools:
-        src = "\n".join(blocks)
-    else:
-        src = re.sub(r"#ifdef HCP_TOOLS.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(hcp_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -74,9 +69,9 @@ def test_product_path_fails_loudly_without_gpu_tensors():
 
 def test_argument_validation_returns_error_codes():
     lib = _lib.load()
-    rc = lib.hcp_gemm_bf16(None, 8, None, 8, None, 8, 8, 8, 8, None, 0, None, 0, 0, None, None, 0, 1, None, 0, 1.0, 0, None, 0, None)
+    rc = lib.hcp_gemm_bf16(None, 8, None, 8, None, 8, 8, 8, 8, None, 0, None, 0, 0, None, None, 0, 1, None, 0, None, None, 1.0, 0, None, 0, None)
     assert rc < 0 and b"null" in lib.hcp_last_error()
-    rc = lib.hcp_layernorm_fwd(None, None, None, None, None, 4, 7, 1e-5, None)
+    rc = lib.hcp_layernorm_fwd(None, None, None, None, None, None, 4, 7, 1e-5, None)
     assert rc < 0 and b"bad shape" in lib.hcp_last_error()
 
 
@@ -87,14 +82,14 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
     N = None
     bad = {
         "hcp_conv3x3_bf16": (N, 8, N, 0, 1, 4, 4, 4, 4, 0, 1, 0, 1, N, 8, N, 8, N, N, 0, N, 0, 0, N, N, N, 0, N),
-        "hcp_gemm_lora_bf16": (N, 8, N, 8, N, N, N, 32, N, 8, 8, 8, 8, N, N, 0, N, 0, N),
+        "hcp_gemm_lora_bf16": (N, 8, N, 8, N, N, N, 32, N, 8, 8, 8, 8, N, N, 0, N, N, N, 0, N),
         "hcp_gemm_geglu_bwd_bf16": (N, 8, N, 8, N, N, N, 32, N, N, 8, 8, 8, N, 0, N),
         "hcp_attention_fwd": (N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, 0, N),
         "hcp_attention_bwd": (N, N, N, N, N, N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, 0, N, 0, N),
         "hcp_groupnorm_silu_fwd": (N, N, N, N, N, N, 1, 16, 30, 32, 1e-5, 1, N),          # C % G != 0
         "hcp_groupnorm_silu_bwd": (N, N, N, N, N, N, N, N, 1, 16, 32, 32, 1, N),
         "hcp_groupnorm_affine_grad": (N, N, N, N, N, N, N, 1, 16, 32, 32, 1, N),
-        "hcp_layernorm_bwd": (N, N, N, N, N, N, 4, 8, N),
+        "hcp_layernorm_bwd": (N, N, N, N, N, N, N, N, N, 4, 8, N),
         "hcp_layernorm_affine_grad": (N, N, N, N, N, 4, 8, N),
         "hcp_wgrad_linear_bf16": (N, 8, N, 8, N, 8, 8, 8, 8, N, 0, N),
         "hcp_wgrad_conv3x3_bf16": (N, 8, N, 8, N, 0, N, 8, 1, 4, 4, 4, 4, 8, 1, 0, N, 0, N),

@@ -22,13 +22,13 @@ def test_bench_refuses_a_world_that_is_not_one_rank_per_gpu():
 @pytest.mark.slow
 @pytest.mark.parametrize("n", [2, 4])
 def test_bench_launcher_runs_n_ranks_end_to_end(n):
-    """`python bench.py --gpus N` is its own launcher (re-executes under torch.distributed.run, one rank per device).  With the test switch
-    HCP_BENCH_BACKEND=emu the very same code path — exec, rendezvous on 127.0.0.1, process group, NativeTrainer with the exchange, timed
+    """`python bench.py --gpus N` is its own launcher (re-executes under torch.distributed.run, one rank per device).  Through the test
+    launcher tests/emu/bench_emu.py (bench.main(emu=True) on the interpreter build) the very same code path — exec, rendezvous on 127.0.0.1, process group, NativeTrainer with the exchange, timed
     loop, MAX over ranks, ONE JSON line from rank 0 — runs on the CPU interpreter with gloo: the first 2-rank execution of this file
     must not be the driver's."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(HCP_BENCH_BACKEND="emu", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "1", "--rank-lora", "4"],
+    env.update(OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "emu" / "bench_emu.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "1", "--rank-lora", "4"],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -44,8 +44,8 @@ def test_bench_launcher_two_ranks_sharded_overlapped_bf16_exchange():
     """The host-bucket path of the same launcher: `--workload dreambooth --exchange overlap-bf16` on 2 gloo ranks of the interpreter —
     sharded optimizer, chunks reduce-scattered from backward hooks, bf16 gradient and parameter wires — end to end through bench.py."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(HCP_BENCH_BACKEND="emu", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", "--workload", "dreambooth",
+    env.update(OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "emu" / "bench_emu.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", "--workload", "dreambooth",
                         "--exchange", "overlap-bf16"], env=env, capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

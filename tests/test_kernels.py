@@ -1029,6 +1029,73 @@ def test_gemm_pingpong_variants(tbackend, cfg, ring):
         L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1)
 
 
+def _split_hi_lo(x):
+    hi = x.to(BF)
+    return hi, (x - hi.float()).to(BF)
+
+
+@pytest.mark.parametrize("variant", ["dispatched", "loaders", "pingpong", "first_dma_loop", "splitk"])
+def test_hi_lo_residual_stream_gemm(tbackend, variant):
+    """(hi | lo) residual stream (ABI 3): D = bf16(v), D_lo = bf16(v - D) with v = A B^T (+ LoRA) + bias + residual + residual_lo in fp32 — on
+    every main loop of the family (their epilogues differ) and through the split-K reduce; hi + lo carries 16 mantissa bits of v."""
+    to = tbackend.to
+    L = K.lib()
+    torch.manual_seed(5)
+    M, N, Kd = (200, 320, 192) if not tbackend.is_gpu else (3000, 640, 1280)
+    a, b = rnd(M, Kd), rnd(N, Kd) * 0.1
+    bias = torch.randn(N)
+    stream = torch.randn(M, N) * 8
+    hi, lo = _split_hi_lo(stream)
+    l, e = rnd(32, Kd) * 0.2, rnd(N, 32) * 0.2
+    ref = a.float() @ b.float().T + bias + hi.float() + lo.float()
+    ref_l = ref + (a.float() @ l.float().T).to(BF).float() @ e.float().T
+    try:
+        if variant == "loaders":
+            L.hcp_debug_set_gemm_loaders(3); L.hcp_debug_set_gemm_config(13 + 16)
+        elif variant == "pingpong":
+            L.hcp_debug_set_gemm_loaders(8 + 3); L.hcp_debug_set_gemm_config(14 + 16)
+        elif variant == "first_dma_loop":
+            L.hcp_debug_set_gemm_glds(0)
+        elif variant == "splitk":
+            L.hcp_debug_set_gemm_config(4 + 16 * 2)
+        o, o_lo = K.gemm(to(a), to(b), bias=to(bias), residual=to(hi), residual_lo=to(lo), want_lo=True)
+        assert bool((o_lo.float().abs() <= o.float().abs() * 2.0 ** -8 + 1e-30).all()), "lo stays within half an ulp of hi"
+        assert relerr(o.float() + o_lo.float(), ref) < 1e-4 and relerr(o, ref) < 1e-2
+        assert relerr(o.float() + o_lo.float(), ref) < 0.1 * relerr(o, ref)
+        only_hi = K.gemm(to(a), to(b), bias=to(bias), residual=to(hi), want_lo=True)           # the stream's first add: no lo image yet
+        assert relerr(only_hi[0].float() + only_hi[1].float(), ref - lo.float()) < 1e-4
+        if variant != "splitk":
+            (ol, ol_lo), t = K.gemm_lora(to(a), to(b), to(l.contiguous()), to(e.contiguous()), bias=to(bias), residual=to(hi), residual_lo=to(lo),
+                                         want_lo=True)
+            assert relerr(ol.float() + ol_lo.float(), ref_l) < (1e-4 if K.T_SPLIT else 2e-3) and relerr(ol, ref_l) < 1e-2
+    finally:
+        L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1); L.hcp_debug_set_gemm_glds(1)
+
+
+@pytest.mark.parametrize("M,C", [(9, 64), (37, 640), (50, 1280), (40, 2560)])
+def test_hi_lo_residual_stream_layernorm(backend, M, C):
+    """LayerNorm on a (hi | lo) stream: the row is hi + lo; backward adds both images of the skip gradient and returns the pair."""
+    torch.manual_seed(C)
+    to = backend.to
+    x = torch.randn(M, C) * 3 + 1
+    hi, lo = _split_hi_lo(x)
+    gamma = torch.randn(C) * 0.5 + 1; beta = torch.randn(C) * 0.2; dy = rnd(M, C)
+    skip = torch.randn(M, C); shi, slo = _split_hi_lo(skip)
+    xr = (hi.float() + lo.float()).requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    yr.backward(dy.float())
+    y, stats = K.layernorm_fwd(to(hi), to(gamma), to(beta), 1e-5, x_lo=to(lo))
+    assert relerr(y, yr) < 1e-2
+    y_hi_only, _ = K.layernorm_fwd(to(hi), to(gamma), to(beta), 1e-5)
+    assert (y.float().cpu() - yr.detach()).norm() <= (y_hi_only.float().cpu() - yr.detach()).norm() * 1.001      # never worse than without lo
+    want = xr.grad + shi.float() + slo.float()
+    dx, dx_lo = K.layernorm_bwd(to(hi), to(dy), to(gamma), stats, addend=to(shi), x_lo=to(lo), addend_lo=to(slo), want_lo=True)
+    assert bool((dx_lo.float().abs() <= dx.float().abs() * 2.0 ** -8 + 1e-30).all())
+    assert relerr(dx.float() + dx_lo.float(), want) < 1e-4
+    one = K.layernorm_bwd(to(hi), to(dy), to(gamma), stats, addend=to(shi), x_lo=to(lo), addend_lo=to(slo))       # the stream's first norm: one bf16 gradient
+    assert torch.equal(one.cpu(), dx.cpu())
+
+
 def _geglu_bwd_ref(dff, hg, Fd):
     h, g = hg.float()[:, :Fd], hg.float()[:, Fd:]
     dff = dff.to(BF).float()

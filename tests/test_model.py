@@ -84,9 +84,11 @@ def test_tiny_forward_with_encoder_attention_mask(backend):
     assert ((yo - yo_nomask).norm() / yo.norm()).item() > 5e-2          # the mask matters for this input
 
 
-def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42, pooled_dim=None, loss_cfg=None):
+def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42, pooled_dim=None, loss_cfg=None, stream=None):
     dev = backend.device
     ora, nat = _pair(cfg, dev)
+    if stream is not None:
+        nat.set_residual_stream(stream)
     ora.requires_grad_(False)
     wr = wrap_lora(ora, PATS, rank=rank)
     tr = NativeTrainer(nat, [dict(layers=PATS, rank=rank)], lr=1e-3, loss_cfg=loss_cfg)
@@ -179,6 +181,34 @@ def test_tiny_sdxl_lora_train_step_vs_oracle(backend, t_split, monkeypatch):
     a1 = next(m for n, m in tr.unet.named_modules() if n.endswith("attn1"))
     built = sorted(len(k) for k, (g, _) in a1._groups.items() if g is not None)
     assert built == [1, 2] and any(g is None and len(k) == 3 for k, (g, _) in a1._groups.items())
+
+
+def test_hi_lo_residual_stream_train_step(backend, monkeypatch):
+    """The transformer blocks' residual stream as a (hi | lo) bf16 pair (Transformer2DModel.hi_lo_stream; "auto" = stacks of >= 2 blocks,
+    forced on / off here for every stack): both forms train the SDXL miniature within the usual tolerances, the pair form really runs
+    (every to_out / ff.net.2 add and every norm of a block takes the stream entry points, forward and backward), and it is not further
+    from the fp32 oracle than the bf16 stream."""
+    from hcp_diffusion_amd import ops
+    calls = {"lin": 0, "ln": 0, "ln_bwd_lo": 0}
+    lin, lnf, lnb = ops.linear_stream, ops.layernorm_fork_stream, K.layernorm_bwd
+    monkeypatch.setattr(ops, "linear_stream", lambda *a, **k: (calls.__setitem__("lin", calls["lin"] + 1), lin(*a, **k))[1])
+    monkeypatch.setattr(ops, "layernorm_fork_stream", lambda *a, **k: (calls.__setitem__("ln", calls["ln"] + 1), lnf(*a, **k))[1])
+    monkeypatch.setattr(K, "layernorm_bwd", lambda *a, **k: (calls.__setitem__("ln_bwd_lo", calls["ln_bwd_lo"] + (1 if k.get("want_lo") else 0)), lnb(*a, **k))[1])
+    res = {}
+    for mode in (False, True):
+        lo, ln, go, tr, _ = _train_step_pair(TINY_SDXL_CONFIG, backend, 16, (2, 4, 8, 8), 77, 64, pooled_dim=64, stream=mode)
+        cos = F.cosine_similarity(go.double(), tr.bucket.grads.cpu().double(), dim=0).item()
+        assert abs(lo - ln) / abs(lo) < 2e-2 and cos > 0.999
+        res[mode] = (abs(lo - ln) / abs(lo), 1.0 - cos)
+        if not mode:
+            assert calls == {"lin": 0, "ln": 0, "ln_bwd_lo": 0}
+    nblk = sum(len(m.transformer_blocks) for m in tr.unet.modules() if hasattr(m, "transformer_blocks"))
+    # per block: attn1.to_out + attn2.to_out through linear_stream (ff.net.2 rides in geglu_linear), three norms; all but each stack's first
+    # norm return a gradient pair
+    nstacks = sum(1 for m in tr.unet.modules() if hasattr(m, "transformer_blocks"))
+    assert calls["lin"] == 2 * nblk and calls["ln"] == 3 * nblk and calls["ln_bwd_lo"] == 3 * nblk - nstacks
+    print(f"hi|lo stream: loss rel {res[True][0]:.2e} (bf16 stream {res[False][0]:.2e}), 1-cos {res[True][1]:.2e} (bf16 stream {res[False][1]:.2e})")
+    assert res[True][1] <= res[False][1] * 1.10
 
 
 def _full_ft_pair(cfg, backend, shape, ctx_len, ctx_dim, pooled_dim=None, seed=11):
@@ -1079,6 +1109,21 @@ def test_merged_lora_host_gradient_and_bf16_host(backend, host_mode):
         blk.layer.W_up.mul_(2.0)
         y3 = parent.c(backend.to(x))
         assert not torch.equal(y1, y3)
+        # the trainer's optimizer writes the factors through raw pointers (hcp_adamw_clip_fused) — no torch version counter
+        # moves; LoraBucket.pack() (and NativeTrainer after every step) invalidate the cached merge
+        from hcp_diffusion_amd.lora import LoraBucket
+        bucket = LoraBucket([blk])
+        y4 = parent.c(backend.to(x))
+        n = bucket.params.numel()
+        g = torch.ones(n, device=dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+        lr = torch.tensor([0.1], device=dev); step = torch.zeros(1, dtype=torch.int32, device=dev)
+        before = bucket.params.clone()
+        ver = bucket.params._version
+        K.adamw_clip_fused(bucket.params, g, m, v, lr, step)
+        assert bucket.params._version == ver and not torch.equal(before, bucket.params), "the raw-pointer step moved the parameters unseen"
+        bucket.pack()
+        y5 = parent.c(backend.to(x))
+        assert not torch.equal(y4, y5), "a gradient-free call after an optimizer step must see the new factors"
 
 
 def test_lora_dropout_and_svd_init(backend):

@@ -177,33 +177,6 @@ def test_graph_two_datasets_equal_eager(grouped):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_chunked_wgrad_on_a_parallel_branch_equals_one_grouped_launch(use_graph):
-    """wgrad_chunk_layers: the grouped LoRA weight-gradient launch cut into pieces that go to a side stream (a parallel branch of the captured
-    graph) while backward continues — same gradients as the single launch at the end (fp32 atomics: tolerance on the order), eager and
-    captured, over several steps (the pieces' descriptor tables replay from their own staging slots)."""
-    dev = _gpu()
-    b = _batch(dev, 1, B=2)
-    res = []
-    for chunk in (0, 3):
-        tr = _trainer(dev, use_graph=use_graph, wgrad_chunk_layers=chunk)
-        _fix_noise(tr, dev)
-        grads = []
-        tr.optimizer_step = lambda: None
-        for step in range(3):
-            tr._opt_graph = None
-            tr.train_one_step(b["latents"], b["encoder_hidden_states"])
-            torch.cuda.synchronize()
-            grads.append(tr.bucket.grads.clone())
-            tr.bucket.grads.zero_()
-        if chunk:
-            assert tr._wgrad_ctx.stream is not None and not tr._wgrad_ctx.side_keep and not tr._wgrad_ctx.items     # pieces ran on the side stream, all joined
-        res.append(grads)
-    for g0, g1 in zip(*res):
-        assert g0.abs().max().item() > 0 and ((g0 - g1).norm() / g0.norm()).item() < 1e-5
-
-
-@pytest.mark.gpu
 def test_graph_cache_per_latent_shape():
     """Aspect-ratio buckets: steps alternate between two resolutions (and context lengths); each gets its own captured graph and
     the trajectory equals eager mode's."""

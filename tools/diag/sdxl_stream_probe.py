@@ -1,5 +1,5 @@
 """GPU lab probe: prediction error of the native SDXL forward (configs[3] fixture inputs, LoRA rank 16 as in the fixture) against the fp32
-oracle fixture, with the transformer blocks' residual stream in bf16 (product) and in fp32 (torch-op prototype, unet._LAB_FP32_STREAM) —
+oracle fixture, with the transformer blocks' residual stream in bf16 and as the (hi | lo) pair (unet.set_residual_stream; round 5 ran a torch-op fp32 prototype here) —
 the reference's LoRA layers under autocast keep that stream in fp32 (mm + fp32 bias, lora_layers_patch.py:50-55); the calibration's
 autocast figure is printed beside.  python tools/diag/sdxl_stream_probe.py"""
 import os, sys
@@ -24,8 +24,8 @@ x0, ehs, noise, t, added = sdxl_b2_inputs()
 added = {k: v.to(dev) for k, v in added.items()}
 ref = g["pred"].float()
 for stream in (False, True):
-    U._LAB_FP32_STREAM = stream
+    nat.set_residual_stream(stream)
     with torch.no_grad():
         pred = nat(K.add_noise(x0.to(dev), noise.to(dev), t.to(dev), tr.acp), t.to(dev), ehs.to(dev), added_cond_kwargs=added).sample.cpu()
     r = ((pred - ref).norm() / ref.norm()).item()
-    print(f"residual stream {'fp32 (prototype)' if stream else 'bf16 (product) '}: prediction rel-L2 {r:.4e}   ratio to autocast calibration ({cal['pred_rel']:.4e}): {r / cal['pred_rel']:.2f}", flush=True)
+    print(f"residual stream {'(hi | lo) pair' if stream else 'bf16         '}: prediction rel-L2 {r:.4e}   ratio to autocast calibration ({cal['pred_rel']:.4e}): {r / cal['pred_rel']:.2f}", flush=True)

@@ -3,7 +3,7 @@
 // variants (hcp_debug_set_gemm_config / _loaders), each timed COLD-ish (rotating over NSETS distinct operand sets > the L2s) with
 // hipEvents around REPS launches, interleaved over ROUNDS rounds (median and min reported); outputs of every variant are compared
 // with the first variant's (max relative difference) and re-run once to screen for run-to-run differences (races).
-//   build:  hipcc -O2 -std=c++17 tools/probes/gemm_pp_probe.cpp -o tools/probes/gemm_pp_probe -Lhcp_diffusion_amd -lhcp_mi355x_tools -Wl,-rpath,'$ORIGIN/../../hcp_diffusion_amd'
+//   build:  hipcc -O2 -std=c++17 -DHCP_TOOLS tools/probes/gemm_pp_probe.cpp -o tools/probes/gemm_pp_probe -Lhcp_diffusion_amd -lhcp_mi355x_tools -Wl,-rpath,'$ORIGIN/../../hcp_diffusion_amd'
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -14,22 +14,7 @@
 #include <string>
 #include <vector>
 
-extern "C" {
-int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int ldd, int M, int N, int K, const void* A2, int lda2,
-                  const void* B2, int ldb2, int K2, const float* bias, const float* rowbias, int rowbias_ld, int rows_per_group,
-                  const void* residual, int ldr, float alpha, int out_f32, void* workspace, size_t workspace_bytes, hipStream_t stream);
-int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, void* D, int ldd, int M,
-                       int N, int K, const float* bias, const void* residual, int ldr, void* workspace, size_t workspace_bytes,
-                       hipStream_t stream);
-int hcp_conv3x3_bf16(const void* X1, int C1, const void* X2, int C2, int B, int Hs, int Ws, int Ho, int Wo, int mode, int stride,
-                     int upsample, int pad, const void* Wp, int Cout, void* D, int ldd, const float* bias, const float* rowbias,
-                     int rowbias_ld, const void* residual, int ldr, int out_f32, const void* A2, const void* B2, void* workspace,
-                     size_t workspace_bytes, hipStream_t stream);
-int hcp_debug_set_gemm_config(int cfg);
-int hcp_debug_set_gemm_loaders(int mode);
-int hcp_debug_set_gemm_ablation(int flags);
-const char* hcp_last_error(void);
-}
+#include "../../include/hcp_mi355x_tools.h"      // the ABI as shipped (this file used to restate the prototypes and went stale twice)
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -128,8 +113,8 @@ int main(int argc, char** argv) {
         float* rowbias = s.res == 2 ? dev_random_f32((size_t)16 * s.N) : nullptr;
         if (s.kind == 1) { Lw = dev_random_bf16((size_t)32 * s.K, 0.05f); Ew = dev_random_bf16((size_t)s.N * 32, 0.05f); CK(hipMalloc(&T, (size_t)s.M * 32 * 2)); }
         auto run = [&](int i) -> int {
-            if (s.kind == 0) return hcp_gemm_bf16(A[i], s.K, Bw[i], s.K, D[i], s.N, s.M, s.N, s.K, nullptr, 0, nullptr, 0, 0, bias, nullptr, 0, 1, R[i], s.N, 1.0f, 0, ws, ws_bytes, st);
-            if (s.kind == 1) return hcp_gemm_lora_bf16(A[i], s.K, Bw[i], s.K, Lw, Ew, T, D[i], s.N, s.M, s.N, s.K, bias, R[i], s.N, ws, ws_bytes, st);
+            if (s.kind == 0) return hcp_gemm_bf16(A[i], s.K, Bw[i], s.K, D[i], s.N, s.M, s.N, s.K, nullptr, 0, nullptr, 0, 0, bias, nullptr, 0, 1, R[i], s.N, nullptr, nullptr, 1.0f, 0, ws, ws_bytes, st);
+            if (s.kind == 1) return hcp_gemm_lora_bf16(A[i], s.K, Bw[i], s.K, Lw, Ew, T, 32, D[i], s.N, s.M, s.N, s.K, bias, R[i], s.N, nullptr, nullptr, ws, ws_bytes, st);
             return hcp_conv3x3_bf16(A[i], s.C, nullptr, 0, s.B, s.H, s.H, s.H, s.H, s.kind == 2 ? 0 : 1, 1, 0, 1, Bw[i], s.N, D[i], s.N, bias, rowbias, s.N, R[i], s.N, 0, nullptr, nullptr, ws, ws_bytes, st);
         };
         const double flop = 2.0 * s.M * s.N * (s.K + (s.kind == 1 ? 32 : 0));
@@ -173,9 +158,9 @@ int main(int argc, char** argv) {
             void* xa = dev_random_bf16((size_t)4096 * 640, 1.0f); void* xb = dev_random_bf16((size_t)5120 * 640, 0.05f); void* xd; CK(hipMalloc(&xd, (size_t)4096 * 5120 * 2));
             void* xl = dev_random_bf16((size_t)32 * 640, 0.05f); void* xe = dev_random_bf16((size_t)5120 * 32, 0.05f); void* xt; CK(hipMalloc(&xt, (size_t)4096 * 32 * 2));
             auto others = [&]() {                             // three other kernel templates (fused-LoRA 128x160 v2, plain 64x160, split-K + reduce)
-                hcp_gemm_lora_bf16(xa, 640, xb, 640, xl, xe, xt, xd, 640, 4096, 640, 640, nullptr, nullptr, 0, ws, ws_bytes, st);
-                hcp_gemm_bf16(xa, 640, xb, 640, xd, 1280, 1024, 1280, 640, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0, 1.0f, 0, ws, ws_bytes, st);
-                hcp_gemm_bf16(xa, 640, xb, 640, xd, 320, 256, 320, 640, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0, 1.0f, 0, ws, ws_bytes, st);
+                hcp_gemm_lora_bf16(xa, 640, xb, 640, xl, xe, xt, 32, xd, 640, 4096, 640, 640, nullptr, nullptr, 0, nullptr, nullptr, ws, ws_bytes, st);
+                hcp_gemm_bf16(xa, 640, xb, 640, xd, 1280, 1024, 1280, 640, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, 1.0f, 0, ws, ws_bytes, st);
+                hcp_gemm_bf16(xa, 640, xb, 640, xd, 320, 256, 320, 640, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, 1.0f, 0, ws, ws_bytes, st);
             };
             for (int mode = 0; mode < 2; ++mode) {
                 std::vector<float> ts;
