@@ -21,10 +21,10 @@ _PROTOTYPES = {
     # line, bucket, nb, stride, workgroups, stream
     "hcp_selfcheck_atomics": (I, [P, P, I, I, I, P]),
     # A, lda, B, ldb, D, ldd, M, N, K, A2, lda2, B2, ldb2, K2, bias, rowbias, rowbias_ld, rows_per_group,
-    # residual, ldr, residual_lo, D_lo, alpha, out_f32, workspace, workspace_bytes, stream
-    "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, P, P, F, I, P, c_size_t, P]),
-    # A, lda, B, ldb, L, E, Tout, ldt, D, ldd, M, N, K, bias, residual, ldr, residual_lo, D_lo, workspace, workspace_bytes, stream
-    "hcp_gemm_lora_bf16": (I, [P, I, P, I, P, P, P, I, P, I, I, I, I, P, P, I, P, P, P, c_size_t, P]),
+    # residual, ldr, residual_lo, D_lo, gact, alpha, out_f32, workspace, workspace_bytes, stream
+    "hcp_gemm_bf16": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, P, I, I, P, I, P, P, P, F, I, P, c_size_t, P]),
+    # A, lda, B, ldb, L, E, Tout, ldt, D, ldd, M, N, K, bias, residual, ldr, residual_lo, D_lo, gact, workspace, workspace_bytes, stream
+    "hcp_gemm_lora_bf16": (I, [P, I, P, I, P, P, P, I, P, I, I, I, I, P, P, I, P, P, P, P, c_size_t, P]),
     # A, lda, B, ldb, L, E, Tout, HG, DHG, M, F, K, workspace, workspace_bytes, stream
     "hcp_gemm_geglu_bwd_bf16": (I, [P, I, P, I, P, P, P, I, P, P, I, I, I, P, c_size_t, P]),
     "hcp_gemm_workspace_bytes": (c_size_t, [I, I]),

@@ -23,6 +23,8 @@
 #include "hcp_common.h"
 #include "gemm_params.h"
 
+extern "C" int hcp_geglu_fwd(const void* h, void* y, long M, int F, hipStream_t stream);      // pointwise.hip
+
 namespace {
 
 using namespace hcp_gemm;
@@ -424,8 +426,8 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
     const unsigned a_chunk = (unsigned)(((kc ^ ((lrow >> 1) & 7)) << 3) * 2);
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int r = lrow + RPP * i, n = n0 + r;
-        vb[i] = (r < BN && n < p.N) ? (unsigned)(((size_t)n * p.ldb + ((kc ^ ((r >> 1) & 7)) << 3)) * 2) : HCP_BUF_OOB;
+        const int r = lrow + RPP * i, nl = n0 + r, n = geglu_col(p, BN, nl);
+        vb[i] = (r < BN && nl < p.N) ? (unsigned)(((size_t)n * p.ldb + ((kc ^ ((r >> 1) & 7)) << 3)) * 2) : HCP_BUF_OOB;
     }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -505,8 +507,8 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
             if ((i + 1) * RPP <= BN || wave * 8 + RPP * i < BN) {
-                const int r = lrow + RPP * i, n = n0 + r, k = (kc ^ ((r >> 1) & 7)) << 3;
-                hcp_buf_glds16(rb, (n < p.N && k < p.K2) ? (unsigned)(((size_t)n * p.ldb2 + k) * 2) : HCP_BUF_OOB, lb + (wave * 8 + RPP * i) * BK);
+                const int r = lrow + RPP * i, nl = n0 + r, n = geglu_col(p, BN, nl), k = (kc ^ ((r >> 1) & 7)) << 3;
+                hcp_buf_glds16(rb, (nl < p.N && k < p.K2) ? (unsigned)(((size_t)n * p.ldb2 + k) * 2) : HCP_BUF_OOB, lb + (wave * 8 + RPP * i) * BK);
             }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
@@ -584,9 +586,9 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
     auto load_epilogue_operands = [&]() {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + 4 * fg;
+            const int nl = n0 + wn * WTN + j * 16 + 4 * fg, n = geglu_col(p, BN, nl);
             hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            bias_v[j] = (p.bias && n < p.N) ? *(const hcp_f32x4*)(p.bias + n) : z;
+            bias_v[j] = (p.bias && nl < p.N) ? *(const hcp_f32x4*)(p.bias + n) : z;
         }
         if (p.residual) {
 #pragma unroll
@@ -607,8 +609,8 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         if (LORA) {                                         // E rows n0 .. n0+BN, 64 bytes each: 16 rows per DMA instruction
             const hcp_rsrc re = hcp_make_rsrc(p.E);
             for (int g = wave; g < BN / 16; g += NLD) {
-                const int n = n0 + g * 16 + (lane >> 2);
-                hcp_buf_glds16(re, n < p.N ? (unsigned)(((size_t)n * 32 + (lane & 3) * 8) * 2) : HCP_BUF_OOB, le_early + g * 16 * 32);
+                const int nl = n0 + g * 16 + (lane >> 2), n = geglu_col(p, BN, nl);
+                hcp_buf_glds16(re, nl < p.N ? (unsigned)(((size_t)n * 32 + (lane & 3) * 8) * 2) : HCP_BUF_OOB, le_early + g * 16 * 32);
             }
         }
         // every loader wave issues the same IPT instructions per tile (whole 8-row groups: static_assert below), so "tile t+1
@@ -638,7 +640,7 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
             hcp_barrier_keep_dma();                         // tile t+1 is in LDS, tile t is consumed
         }
         if (LORA) HCP_SYNC();                               // the compute waves' epilogue barrier
-        if (p.geglu_hg && p.nsplit == 1) { if (LORA) HCP_SYNC(); HCP_SYNC(); }       // ... and those of the GEGLU-backward tile
+        if ((p.geglu_hg || p.geglu_out) && p.nsplit == 1) { if (LORA) HCP_SYNC(); HCP_SYNC(); }       // ... and those of the GEGLU tiles
         return;
     }
     if (NLD == 0) { if (nprim > 0) issue(0); else if (has_ext) issue_ext(0); }
@@ -677,7 +679,7 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
             for (int c = tid_all; c < BN * 4; c += NTC) {
                 const int r = c >> 2, q = c & 3;
                 hcp_bf16x8 v = hcp_zero8();
-                if (n0 + r < p.N) v = *(const hcp_bf16x8*)(p.E + (size_t)(n0 + r) * 32 + q * 8);
+                if (n0 + r < p.N) v = *(const hcp_bf16x8*)(p.E + (size_t)geglu_col(p, BN, n0 + r) * 32 + q * 8);
                 *(hcp_bf16x8*)(le + r * TS2 + q * 8) = v;
             }
         }
@@ -723,6 +725,29 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
             for (int j = 0; j < TN; ++j) geglu_tile_put(lds, geglu_tile_ld(BN), wm * WTM + i * 16 + fr, wn * WTN + j * 16 + 4 * fg, acc[i][j], p.alpha);
         HCP_SYNC();
         geglu_tile_apply<BM, BN, NTC>(p, lds, m0, n0, tid_all);
+        return;
+    }
+    if (p.geglu_out) {                                      // GEGLU-forward epilogue (gemm_params.h: geglu_out): D = bf16(h | g), geglu_out = bf16(h gelu(g))
+        static_assert((size_t)BM * BN * 2 <= (size_t)2 * BUF_ELEMS * sizeof(hcp_bf16), "the gelu(g) tile fits the ring");
+        if (!EARLY) load_epilogue_operands();
+        if (LORA) HCP_SYNC();                               // the LoRA tail's T / E images live in the same LDS
+        hcp_f32x4 v[TM][TN];
+        int rows[TM], cols[TN];
+        constexpr int HW = WGN / 2;                         // wave columns per half: waves wn < HW hold h, the others the matching g
+        const bool is_g = wn >= HW;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) cols[j] = tile_n * (BN / 2) + (wn - (is_g ? HW : 0)) * WTN + j * 16 + 4 * fg;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + fr;
+            rows[i] = m;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                v[i][j] = acc[i][j] * p.alpha + bias_v[j];
+                if (m < p.M) store_hi_lo(p, m, cols[j] + (is_g ? (p.N >> 1) : 0), v[i][j]);
+            }
+        }
+        geglu_fwd_pair<TM, TN>(v, is_g, wm * HW + (wn - (is_g ? HW : 0)), lane, (hcp_f32x4*)lds, [] { HCP_SYNC(); }, p.geglu_out, p.N >> 1, rows, p.M, cols);
         return;
     }
     // epilogue: ALL of the lane's bias / row-bias / residual loads are issued before the first store (one vmcnt wait instead
@@ -791,6 +816,10 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
             (size_t)p.M * p.lda * 2 < (1ul << 31) && (size_t)p.N * p.ldb * 2 < (1ul << 31)) {
             constexpr size_t stage = (size_t)(BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
             constexpr size_t eimg = (LORA && NLD > 0) ? (size_t)BN * 32 * sizeof(hcp_bf16) : 0;   // loader variant: the E rows, behind the ring
+            if (p.geglu_out) {                               // GEGLU-forward epilogue: this tile must pair h and g columns (gemm_params.h)
+                if (MODE == 0 && WGN % 2 == 0 && p.nsplit == 1 && (p.N / 2) % (BN / 2) == 0) p.geglu_fused = 1;
+                else p.geglu_out = nullptr;
+            }
             size_t smem = 2 * stage;
             const size_t tail = (size_t)(2 * BM + BN) * 40 * sizeof(hcp_bf16);   // fused-LoRA tail images: T_hi, E, T_lo
             if (LORA && smem < tail) smem = tail;
@@ -818,6 +847,7 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
         }
     }
     {
+        p.geglu_out = nullptr;                               // (the first LDS-DMA loop has no pairing epilogue: the entry point runs hcp_geglu_fwd behind it)
         size_t smem = (size_t)NSTAGE * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
         const size_t tail = (size_t)(2 * BM + BN) * 40 * sizeof(hcp_bf16);  // fused-LoRA tail images: T_hi, E, T_lo
         if (LORA && smem < tail) smem = tail;
@@ -846,7 +876,13 @@ int try_pp(int id, int mode, bool fast_or_plain, bool lora, GemmParams& p, hipSt
     const int bm = kCfgs[id].bm, bn = kCfgs[id].bn;
     p.tiles_m = hcp_cdiv(p.M, bm);
     p.dbg = g_dbg_ablate;
+    hcp_bf16* const gout = p.geglu_out;                     // GEGLU-forward epilogue: see launch_cfg
+    if (gout) {
+        if (mode == 0 && p.nsplit == 1 && (p.N / 2) % (bn / 2) == 0) p.geglu_fused = 1;
+        else p.geglu_out = nullptr;
+    }
     const int r = gemm_pp_launch(p, bm, bn, mode, lora, p.loaders - 8, stream);
+    if (r == -2) { p.geglu_out = gout; p.geglu_fused = 0; }     // not instantiated for this tile: the caller's own kernels decide again
     if (r != 0 || p.nsplit <= 1) return r;
     long nv = (long)p.M * (p.N / 4);
     int g = (int)((nv + 255) / 256); if (g > 2048) g = 2048;
@@ -952,6 +988,7 @@ int dispatch_gemm(GemmParams& p, float* ws, size_t ws_bytes, hipStream_t stream)
     if (g_force_cfg >= 0) { id = g_force_cfg % 16; nsplit = g_force_cfg / 16 > 0 ? g_force_cfg / 16 : 1; }
     p.loaders = g_force_loaders >= 0 ? g_force_loaders : deepest_ring(ld);
     if (nsplit > 1 && (size_t)nsplit * p.M * p.N * sizeof(float) > ws_bytes) nsplit = 1;
+    if (p.geglu_out) nsplit = 1;                             // the pairing epilogue lives in the GEMM kernels, not in the split-K reduce
     const int nk1 = hcp_cdiv(p.K, BK);
     p.nsplit = nsplit;
     p.kt_per_split = hcp_cdiv(nk1, nsplit);
@@ -969,6 +1006,20 @@ int check_common(const GemmParams& p) {
     HCP_REQUIRE(!p.residual || p.ldr % 4 == 0, "gemm: ldr must be a multiple of 4");
     HCP_REQUIRE(!p.rowbias || p.rows_per_group > 0, "gemm: rows_per_group must be > 0");
     return 0;
+}
+
+// GEGLU-forward output (gact [M, N/2] = bf16(h gelu(g)) for D = (h | g) [M, N]): argument rules, and the second launch when the
+// dispatched kernel could not pair the halves in its epilogue (GemmParams::geglu_out)
+int check_gact(GemmParams& p, void* gact, const char* who) {
+    if (!gact) return 0;
+    HCP_REQUIRE(!p.out_f32 && !p.residual && !p.rowbias && !p.D_lo && p.alpha == 1.0f && p.N % 16 == 0 && p.ldd == p.N,
+                "%s: the GEGLU output needs a contiguous bf16 (h | g) [M, N] (N %% 16 == 0) with no residual / row bias / alpha", who);
+    p.geglu_out = (hcp_bf16*)gact; p.geglu_fused = 0;
+    return 0;
+}
+int finish_gact(const GemmParams& p, void* gact, hipStream_t stream) {
+    if (!gact || p.geglu_fused) return 0;
+    return hcp_geglu_fwd(p.D, gact, p.M, p.N / 2, stream);
 }
 
 // tile choice + launch of a fused-LoRA problem (p.L / p.E / p.Tout set): measured table, else the fallback rule; deep-K / small-M
@@ -1034,8 +1085,8 @@ HCP_API size_t hcp_gemm_workspace_bytes(int M, int N) { return (size_t)16 * M * 
 HCP_API int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int ldd, int M, int N, int K,
                           const void* A2, int lda2, const void* B2, int ldb2, int K2, const float* bias,
                           const float* rowbias, int rowbias_ld, int rows_per_group, const void* residual, int ldr,
-                          const void* residual_lo, void* D_lo, float alpha, int out_f32, void* workspace, size_t workspace_bytes,
-                          hipStream_t stream) {
+                          const void* residual_lo, void* D_lo, void* gact, float alpha, int out_f32, void* workspace,
+                          size_t workspace_bytes, hipStream_t stream) {
     GemmParams p = {};
     p.A = (const hcp_bf16*)A; p.lda = lda; p.B = (const hcp_bf16*)B; p.ldb = ldb;
     p.A2 = (const hcp_bf16*)A2; p.lda2 = lda2; p.B2 = (const hcp_bf16*)B2; p.ldb2 = ldb2; p.K2 = K2;
@@ -1047,7 +1098,9 @@ HCP_API int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* 
     HCP_REQUIRE((!residual_lo || residual) && (!D_lo || !out_f32), "hcp_gemm_bf16: residual_lo needs residual; D_lo needs a bf16 output");
     HCP_REQUIRE(lda % 8 == 0, "hcp_gemm_bf16: lda (%d) must be a multiple of 8", lda);
     if (int e = check_common(p)) return e;
-    return dispatch_gemm<0, false>(p, (float*)workspace, workspace ? workspace_bytes : 0, stream);
+    if (int e = check_gact(p, gact, "hcp_gemm_bf16")) return e;
+    if (int e = dispatch_gemm<0, false>(p, (float*)workspace, workspace ? workspace_bytes : 0, stream)) return e;
+    return finish_gact(p, gact, stream);
 }
 
 // Replaces F.conv2d(x, W[Cout,Cin,3,3], stride, padding=1) on NHWC bf16 activations:
@@ -1118,7 +1171,7 @@ HCP_API int hcp_gemm_geglu_bwd_bf16(const void* A, int lda, const void* B, int l
 // One launch replaces LoraPatchContainer.forward's weight merge + mm (reference lora_base_patch.py:20-35,61-74).
 HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, int ldt, void* D,
                                int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, const void* residual_lo,
-                               void* D_lo, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                               void* D_lo, void* gact, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     GemmParams p = {};
     p.A = (const hcp_bf16*)A; p.lda = lda; p.B = (const hcp_bf16*)B; p.ldb = ldb;
     p.M = M; p.N = N; p.K = K; p.D = D; p.ldd = ldd; p.out_f32 = 0;
@@ -1130,5 +1183,7 @@ HCP_API int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, c
     HCP_REQUIRE(ldt == 32 || ldt == 64, "hcp_gemm_lora_bf16: ldt (%d) is 32 (bf16 T) or 64 (split T: hi | lo)", ldt);
     HCP_REQUIRE(lda % 8 == 0, "hcp_gemm_lora_bf16: lda (%d) must be a multiple of 8", lda);
     if (int e = check_common(p)) return e;
-    return launch_lora_dispatched(p, workspace, workspace_bytes, stream);
+    if (int e = check_gact(p, gact, "hcp_gemm_lora_bf16")) return e;
+    if (int e = launch_lora_dispatched(p, workspace, workspace_bytes, stream)) return e;
+    return finish_gact(p, gact, stream);
 }

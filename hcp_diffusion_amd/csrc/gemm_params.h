@@ -42,6 +42,14 @@ struct GemmParams {
     // GEGLU-backward epilogue (hcp_gemm_geglu_bwd_bf16): the product is dY_ff = d(h * gelu(g)) [M, N = F]; hg [M, 2F] holds the forward's
     // (h | g); D is d(h | g) [M, 2F] (ldd = 2F): D[m, n] = v * gelu(g), D[m, F + n] = v * h * gelu'(g).  Null = ordinary epilogue.
     const hcp_bf16* geglu_hg; int geglu_ld;
+    // GEGLU-FORWARD epilogue (round 6): the product is (h | g) [M, N = 2F] of diffusers' GEGLU projection; geglu_out [M, F] receives
+    // bf16(h * gelu(g)) computed from the fp32 epilogue values (the reference's LoRA layer hands GEGLU an fp32 (h | g) under autocast,
+    // lora_layers_patch.py:50-57: one rounding instead of two), next to D = bf16(h | g) which the backward needs anyway.  A workgroup's N
+    // tile pairs the columns: tile j = h columns [j BN/2, (j+1) BN/2) then the matching g columns F + ..., so the wave that holds h and
+    // the wave that holds g of one (row, column) meet through LDS (geglu_col below maps tile columns to actual ones everywhere a column
+    // is used: B / E / bias rows, stores).  The launch site clears it when its kernel cannot pair (F % (BN / 2) != 0, split-K, first
+    // LDS-DMA loop) and the entry point then runs hcp_geglu_fwd behind the GEMM; geglu_fused reports which happened.
+    hcp_bf16* geglu_out; int geglu_fused;
     int loaders;                    // 1: launch the loader-wave variant of the v2 kernel where one is instantiated (dispatch table / tools)
     int dbg;                        // tools/ablate_gemm.py: 1 = skip the DMA after the first tile, 2 = skip the MFMAs, 4 = skip LDS reads + MFMAs
     ConvDesc cv;
@@ -78,6 +86,48 @@ HCP_DEVICE void add_residual_lo(const GemmParams& p, int m, int n, hcp_f32x4& v)
     const hcp_bf16x4 r = *(const hcp_bf16x4*)(p.residual_lo + (size_t)m * p.ldr + n);
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)r[q]);
+}
+
+// GEGLU-forward launches: logical column nl of the tiled problem -> the column of B / E / bias / D it stands for (see geglu_out).
+HCP_DEVICE int geglu_col(const GemmParams& p, int BN, int nl) {
+    if (!p.geglu_out) return nl;
+    const int half = BN >> 1, j = nl / BN, c = nl - j * BN;
+    return c < half ? j * half + c : (p.N >> 1) + j * half + (c - half);
+}
+// The pairing step of the GEGLU-forward epilogue.  v[i][j]: this wave's finished fp32 quads (TI row blocks x TJ column blocks, the MFMA
+// layout: lane (fr, fg) holds row fr, columns 4 fg .. 4 fg + 3 of a 16 x 16 block); is_g: the wave holds g columns; slot: index of the
+// (h wave, g wave) pair among the workgroup's pairs; xg: LDS, pairs * TI * TJ * 64 float4.  The g wave publishes gelu(g), the h wave
+// multiplies and stores bf16(h * gelu(g)) at out[m, nh .. nh + 3].  `sync`: the workgroup barrier of the calling kernel.
+template <int TI, int TJ, typename SYNC>
+HCP_DEVICE void geglu_fwd_pair(hcp_f32x4 (&v)[TI][TJ], bool is_g, int slot, int lane, hcp_f32x4* xg, SYNC&& sync,
+                               hcp_bf16* out, int F, const int (&rows)[TI], int M, const int (&cols)[TJ]) {
+    hcp_f32x4* mine = xg + (size_t)slot * TI * TJ * 64 + lane;
+    if (is_g) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                hcp_f32x4 ge;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ge[q] = hcp_gelu_erf(v[i][j][q]);
+                mine[(i * TJ + j) * 64] = ge;
+            }
+    }
+    sync();
+    if (!is_g) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            if (rows[i] >= M) continue;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const hcp_f32x4 ge = mine[(i * TJ + j) * 64];
+                hcp_bf16x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (short)hcp_f2bf(v[i][j][q] * ge[q]);
+                *(hcp_bf16x4*)(out + (size_t)rows[i] * F + cols[j]) = o;
+            }
+        }
+    }
 }
 
 // One 4-column piece of the GEGLU-backward epilogue (replaces the stand-alone geglu_bwd pass over dY_ff, h|g and d(h|g)).

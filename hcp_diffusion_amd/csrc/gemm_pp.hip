@@ -82,8 +82,8 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         const unsigned a_chunk = (unsigned)(((kc ^ ((lrow >> 1) & 7)) << 3) * 2);     // rows RPP apart share their swizzle term
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int r = lrow + RPP * i, n = n0 + r;
-            vb[i] = n < p.N ? (unsigned)(((size_t)n * p.ldb + ((kc ^ ((r >> 1) & 7)) << 3)) * 2) : HCP_BUF_OOB;
+            const int r = lrow + RPP * i, nl = n0 + r, n = geglu_col(p, BN, nl);
+            vb[i] = nl < p.N ? (unsigned)(((size_t)n * p.ldb + ((kc ^ ((r >> 1) & 7)) << 3)) * 2) : HCP_BUF_OOB;
         }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
@@ -165,8 +165,8 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < B_IT; ++i)
                     if (i >= q0 && i < q1) {
-                        const int r = lrow + RPP * i, n = n0 + r, k = (kc ^ ((r >> 1) & 7)) << 3;
-                        hcp_buf_glds16(rb, (n < p.N && k < p.K2) ? (unsigned)(((size_t)n * p.ldb2 + k) * 2) : HCP_BUF_OOB, lb + (wave * 8 + RPP * i) * BK);
+                        const int r = lrow + RPP * i, nl = n0 + r, n = geglu_col(p, BN, nl), k = (kc ^ ((r >> 1) & 7)) << 3;
+                        hcp_buf_glds16(rb, (nl < p.N && k < p.K2) ? (unsigned)(((size_t)n * p.ldb2 + k) * 2) : HCP_BUF_OOB, lb + (wave * 8 + RPP * i) * BK);
                     }
                 if (LORA && B_IT >= q0 && B_IT < q1) hcp_buf_glds16(rb, HCP_BUF_OOB, lb + B_ELEMS + (wave * 8) * BK);      // keeps IPT uniform (LORA has no K2)
                 constexpr int qa = B_IT + (LORA ? 1 : 0);
@@ -193,8 +193,8 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         if (LORA) {                                       // E rows n0 .. n0+BN, 64 bytes each: 16 rows per DMA instruction
             const hcp_rsrc re = hcp_make_rsrc(p.E);
             for (int gq = wave; gq < BN / 16; gq += NLD) {
-                const int n = n0 + gq * 16 + (lane >> 2);
-                hcp_buf_glds16(re, n < p.N ? (unsigned)(((size_t)n * 32 + (lane & 3) * 8) * 2) : HCP_BUF_OOB, lds_e + gq * 16 * 32);
+                const int nl = n0 + gq * 16 + (lane >> 2), n = geglu_col(p, BN, nl);
+                hcp_buf_glds16(re, nl < p.N ? (unsigned)(((size_t)n * 32 + (lane & 3) * 8) * 2) : HCP_BUF_OOB, lds_e + gq * 16 * 32);
             }
         }
         // every loader issues the same IPT instructions per tile and loads return in order: "tile x has landed" = at most
@@ -260,7 +260,7 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         hcp_barrier_only();                               // #2U
         hcp_barrier_only(); hcp_barrier_only();          // the exchange of the compute groups
         if (LORA) HCP_SYNC();                             // the compute waves' tail barrier
-        if (p.geglu_hg && p.nsplit == 1) { if (LORA) HCP_SYNC(); HCP_SYNC(); }       // ... and those of the GEGLU-backward tile
+        if ((p.geglu_hg || p.geglu_out) && p.nsplit == 1) { if (LORA) HCP_SYNC(); HCP_SYNC(); }       // ... and those of the GEGLU tiles
         return;
     }
 
@@ -297,7 +297,7 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
     auto load_bias = [&]() {                              // 640 bytes shared by every workgroup of the N tile: an L2 hit, requested late
         const hcp_rsrc rbias = hcp_make_rsrc_n(p.bias, p.bias ? (unsigned)p.N * 4u : 0u);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bias_v[j] = hcp_buf_load16f(rbias, (unsigned)(n0 + col0 + j * 16 + 4 * fg) * 4u);
+        for (int j = 0; j < TN; ++j) bias_v[j] = hcp_buf_load16f(rbias, (unsigned)geglu_col(p, BN, n0 + col0 + j * 16 + 4 * fg) * 4u);
     };
     // Rows past M need no select: their offset is >= the resource's num_records (ldr >= N), so the hardware range check returns zeros —
     // and a `m < M ? offset : OOB` select here compiled to divergent branches with a WAW `s_waitcnt vmcnt(0)` between the loads: TMF
@@ -453,6 +453,27 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
             for (int j = 0; j < TN; ++j) geglu_tile_put(ring, geglu_tile_ld(BN), frow0 + i * 16 + fr, col0 + j * 16 + 4 * fg, acc[i][j], p.alpha);
         HCP_SYNC();
         geglu_tile_apply<BM, BN, NTC>(p, ring, m0, n0, tid_all);
+        return;
+    }
+    if (p.geglu_out) {                                      // GEGLU-forward epilogue (gemm_params.h: geglu_out): D = bf16(h | g), geglu_out = bf16(h gelu(g))
+        static_assert((size_t)BM * BN * 2 <= (size_t)NST * BUF_ELEMS * sizeof(hcp_bf16), "the gelu(g) tile fits the ring");
+        if (LORA) HCP_SYNC();                               // the LoRA tail's T image lives in the ring
+        hcp_f32x4 v[TMF][TN];
+        int rows[TMF], cols[TN];
+        const bool is_g = gn == 1;                          // wave column 0 holds h, wave column 1 the matching g (WTN = BN / 2)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) cols[j] = tile_n * (BN / 2) + j * 16 + 4 * fg;
+#pragma unroll
+        for (int i = 0; i < TMF; ++i) {
+            const int m = m0 + frow0 + i * 16 + fr;
+            rows[i] = m;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                v[i][j] = acc[i][j] * p.alpha + bias_v[j];
+                if (m < p.M) store_hi_lo(p, m, cols[j] + (is_g ? (p.N >> 1) : 0), v[i][j]);
+            }
+        }
+        geglu_fwd_pair<TMF, TN>(v, is_g, wave_all >> 1, lane, (hcp_f32x4*)ring, [] { HCP_SYNC(); }, p.geglu_out, p.N >> 1, rows, p.M, cols);
         return;
     }
 #pragma unroll

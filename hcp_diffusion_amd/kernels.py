@@ -99,9 +99,10 @@ def _lo_pair(residual, residual_lo, want_lo, M, N, dev):
 
 
 def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, residual=None, alpha=1.0,
-         out_f32=False, out=None, residual_lo=None, want_lo=False):
+         out_f32=False, out=None, residual_lo=None, want_lo=False, want_gact=False):
     """out[M,N] = alpha*(a[M,K] @ b[N,K]^T + a2 @ b2^T) + bias + rowbias[m // rows_per_group] + residual.
-    (hi | lo) residual stream: residual_lo joins the sum in fp32; want_lo returns (out, out_lo) with out_lo = bf16(v - bf16(v))."""
+    (hi | lo) residual stream: residual_lo joins the sum in fp32; want_lo returns (out, out_lo) with out_lo = bf16(v - bf16(v)).
+    want_gact (out = (h | g) of a GEGLU projection): returns (out, gact), gact [M, N/2] = bf16(h * gelu(g)) from the fp32 epilogue values."""
     _bf16_2d(a, "a"); _bf16_2d(b, "b")
     M, K = a.shape
     N = b.shape[0]
@@ -125,11 +126,14 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_group=1, r
     ws = _workspace(a)
     assert not want_lo or (out.dtype == BF16 and out.is_contiguous())
     out_lo = _lo_pair(residual, residual_lo, want_lo, M, N, a.device)
+    gact = torch.empty((M, N // 2), dtype=BF16, device=a.device) if want_gact else None
     _chk(lib().hcp_gemm_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K,
                              _p(a2), a2.stride(0) if a2 is not None else 0, _p(b2), b2.stride(0) if b2 is not None else 0,
                              K2, _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, rows_per_group,
-                             _p(residual), residual.stride(0) if residual is not None else 0, _p(residual_lo), _p(out_lo), float(alpha),
+                             _p(residual), residual.stride(0) if residual is not None else 0, _p(residual_lo), _p(out_lo), _p(gact), float(alpha),
                              1 if out.dtype == torch.float32 else 0, _p(ws), ws.numel(), _stream(a)), "hcp_gemm_bf16")
+    if want_gact:
+        return out, gact
     return (out, out_lo) if want_lo else out
 
 
@@ -147,9 +151,9 @@ def t_lo(t):
     return 32 if (t is not None and T_SPLIT and t.shape[1] == 64 and t.stride(0) == 64) else 0
 
 
-def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True, residual_lo=None, want_lo=False):
+def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True, residual_lo=None, want_lo=False, want_gact=False):
     """(D, T): T = a @ l[32,K]^T;  D[M,N] = a @ b[N,K]^T + T @ e[N,32]^T + bias + residual — one launch.
-    (hi | lo) residual stream (see gemm): residual_lo; want_lo returns ((D, D_lo), T).
+    (hi | lo) residual stream (see gemm): residual_lo; want_lo returns ((D, D_lo), T); want_gact (see gemm) returns ((D, gact), T).
     T_SPLIT: T [M,64] = (bf16(T) | bf16(T - bf16(T))) and the product takes both halves; else T [M,32] rounded to bf16."""
     _bf16_2d(a, "a"); _bf16_2d(b, "b"); _bf16_2d(l, "l"); _bf16_2d(e, "e")
     M, Kd = a.shape
@@ -166,10 +170,13 @@ def gemm_lora(a, b, l, e, *, bias=None, residual=None, want_t=True, residual_lo=
         _bf16_2d(residual, "residual"); assert residual.shape == (M, N)
     ws = _workspace(a)
     out_lo = _lo_pair(residual, residual_lo, want_lo, M, N, a.device)
+    gact = torch.empty((M, N // 2), dtype=BF16, device=a.device) if want_gact else None
     _chk(lib().hcp_gemm_lora_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(l), _p(e), _p(t), ldt, _p(out), N, M, N, Kd, _p(bias),
-                                  _p(residual), residual.stride(0) if residual is not None else 0, _p(residual_lo), _p(out_lo),
+                                  _p(residual), residual.stride(0) if residual is not None else 0, _p(residual_lo), _p(out_lo), _p(gact),
                                   _p(ws), ws.numel(), _stream(a)),
          "hcp_gemm_lora_bf16")
+    if want_gact:
+        return (out, gact), t
     return ((out, out_lo) if want_lo else out), t
 
 

@@ -118,9 +118,12 @@ class _LinearFn(torch.autograd.Function):
     LoraPatchContainer.forward / LoraBlock.post_forward (lora_base_patch.py:20-35,68-74)."""
 
     @staticmethod
-    def forward(ctx, x, residual, w_down, w_up, host, lora, out_f32=False, hw=None, hb=None, residual_lo=None, stream=False):
+    def forward(ctx, x, residual, w_down, w_up, host, lora, out_f32=False, hw=None, hb=None, residual_lo=None, stream=False, geglu=False):
         """stream: the residual is a (hi | lo) residual stream (residual, residual_lo — lo may be None where the stream starts) and the
-        result is the pair (y_hi, y_lo); their gradients come back as a pair too and pass to the residual inputs as they are."""
+        result is the pair (y_hi, y_lo); their gradients come back as a pair too and pass to the residual inputs as they are.
+        geglu: the layer is diffusers' GEGLU projection — returns ((h | g), bf16(h * gelu(g))), the second formed in the GEMM epilogue
+        from the fp32 values (K.gemm(want_gact)); it carries no gradient of its own: _GegluLinearFn, which consumes both, sends the
+        whole gradient back through (h | g)."""
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
@@ -130,12 +133,12 @@ class _LinearFn(torch.autograd.Function):
         if lora is not None and getattr(lora, "wide", False):      # rank > 32: skinny side GEMM + K-extension
             lp = lora.packed()
             T = K.gemm(x2, lp.ad)
-            y = K.gemm(x2, pk.w, a2=T, b2=lp.bu, bias=pk.bias, residual=res2, residual_lo=lo2, want_lo=stream)
+            y = K.gemm(x2, pk.w, a2=T, b2=lp.bu, bias=pk.bias, residual=res2, residual_lo=lo2, want_lo=stream, want_gact=geglu)
         elif lora is not None:
             lp = lora.packed()
-            y, T = K.gemm_lora(x2, pk.w, lp.ad, lp.bu, bias=pk.bias, residual=res2, residual_lo=lo2, want_lo=stream)
+            y, T = K.gemm_lora(x2, pk.w, lp.ad, lp.bu, bias=pk.bias, residual=res2, residual_lo=lo2, want_lo=stream, want_gact=geglu)
         else:
-            y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2, out_f32=out_f32, residual_lo=lo2, want_lo=stream)
+            y = K.gemm(x2, pk.w, bias=pk.bias, residual=res2, out_f32=out_f32, residual_lo=lo2, want_lo=stream, want_gact=geglu)
         ctx.host, ctx.lora = host, lora
         ctx.wg = current_wgrad()
         ctx.train_w, ctx.train_b = hw is not None, hb is not None
@@ -143,6 +146,10 @@ class _LinearFn(torch.autograd.Function):
         ctx.xshape = shp
         ctx.has_res = residual is not None
         ctx.stream, ctx.has_lo = stream, residual_lo is not None
+        if geglu:
+            act = y[1].view(*shp[:-1], y[1].shape[-1])
+            ctx.mark_non_differentiable(act)
+            return y[0].view(*shp[:-1], y[0].shape[-1]), act
         if stream:
             ctx.set_materialize_grads(False)           # the lo image of the last block has no consumer: its gradient stays None
             return y[0].view(*shp[:-1], y[0].shape[-1]), y[1].view(*shp[:-1], y[1].shape[-1])
@@ -152,7 +159,7 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy, dy_lo=None):
         if dy is None:                                 # (stream mode, nothing downstream took the gradient)
             assert dy_lo is None
-            return (None,) * 11
+            return (None,) * 12
         x2, T = ctx.saved_tensors
         host, lora = ctx.host, ctx.lora
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -191,7 +198,14 @@ class _LinearFn(torch.autograd.Function):
             dx = dx.view(ctx.xshape)
         # the stream's gradient is a (hi | lo) pair as well: the GEMMs above read its hi image (the reference's autograd casts the fp32
         # stream gradient to bf16 in front of the same mm), the residual path hands both images on untouched
-        return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None, (dy_lo if ctx.has_lo else None), None
+        return dx, (dy if ctx.has_res else None), None, None, None, None, None, None, None, (dy_lo if ctx.has_lo else None), None, None
+
+
+def linear_geglu(x, host, lora=None):
+    """((h | g), bf16(h * gelu(g))) of diffusers' GEGLU projection in one launch; hand both to geglu_linear."""
+    wd = lora.layer.W_down if lora is not None else None
+    wu = lora.layer.W_up if lora is not None else None
+    return _LinearFn.apply(x, None, wd, wu, host, lora, False, _tr(host.weight), _tr(host.bias), None, False, True)
 
 
 def linear(x, host, lora=None, residual=None, out_f32=False):
@@ -562,10 +576,11 @@ class _GegluLinearFn(torch.autograd.Function):
     _GegluFn + _LinearFn (the epilogue rounds dY_ff to bf16 before the two products, as the two-kernel form does)."""
 
     @staticmethod
-    def forward(ctx, hg, residual, w_down, w_up, host, lora, hw=None, hb=None, residual_lo=None, stream=False):
+    def forward(ctx, hg, residual, w_down, w_up, host, lora, hw=None, hb=None, residual_lo=None, stream=False, gact=None):
+        """gact: bf16(h * gelu(g)) already formed by the projection's epilogue (linear_geglu), else the stand-alone pass runs here."""
         shp = hg.shape
         hg2 = hg.reshape(-1, shp[-1])
-        x2 = K.geglu_fwd(hg2)
+        x2 = gact.reshape(-1, gact.shape[-1]) if gact is not None else K.geglu_fwd(hg2)
         res2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
         lo2 = residual_lo.reshape(-1, residual_lo.shape[-1]) if residual_lo is not None else None
         pk = host.packed()
@@ -591,7 +606,7 @@ class _GegluLinearFn(torch.autograd.Function):
     def backward(ctx, dy, dy_lo=None):
         if dy is None:
             assert dy_lo is None
-            return (None,) * 10
+            return (None,) * 11
         hg2, x2, T = ctx.saved_tensors
         host, lora = ctx.host, ctx.lora
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -617,16 +632,17 @@ class _GegluLinearFn(torch.autograd.Function):
             K.colsum(dy2, grad_buffer(host.bias))
         if dhg is not None:
             dhg = dhg.view(ctx.hshape)
-        return dhg, (dy if ctx.has_res else None), None, None, None, None, None, None, (dy_lo if ctx.has_lo else None), None
+        return dhg, (dy if ctx.has_res else None), None, None, None, None, None, None, (dy_lo if ctx.has_lo else None), None, None
 
 
-def geglu_linear(hg, host, lora=None, residual=None):
-    """residual: a tensor, or the (hi, lo) pair of a (hi | lo) residual stream — the result is then a pair too."""
+def geglu_linear(hg, host, lora=None, residual=None, gact=None):
+    """residual: a tensor, or the (hi, lo) pair of a (hi | lo) residual stream — the result is then a pair too.
+    gact: the second output of linear_geglu (the GEGLU product from the projection's own epilogue)."""
     wd = lora.layer.W_down if lora is not None else None
     wu = lora.layer.W_up if lora is not None else None
     if isinstance(residual, tuple):
-        return _GegluLinearFn.apply(hg, residual[0], wd, wu, host, lora, _tr(host.weight), _tr(host.bias), residual[1], True)
-    return _GegluLinearFn.apply(hg, residual, wd, wu, host, lora, _tr(host.weight), _tr(host.bias))
+        return _GegluLinearFn.apply(hg, residual[0], wd, wu, host, lora, _tr(host.weight), _tr(host.bias), residual[1], True, gact)
+    return _GegluLinearFn.apply(hg, residual, wd, wu, host, lora, _tr(host.weight), _tr(host.bias), None, False, gact)
 
 
 class _AttentionFn(torch.autograd.Function):

@@ -270,6 +270,12 @@ class FeedForward(nn.Module):
         if leaf is not None and type(self.net[0]) is GEGLU:
             # GEGLU + output projection as one autograd node: the GEGLU backward rides in the epilogue of the projection's
             # input-gradient GEMM (ops._GegluLinearFn).  A hooked / foreign / dropout leaf keeps the module-by-module path below.
+            pleaf = _ff_out_leaf(self.net[0].proj)
+            if pleaf is not None:
+                # ... and the GEGLU product itself comes out of the PROJECTION's epilogue (round 6): formed from the fp32 (h | g), one
+                # rounding instead of two (what the reference's fp32-returning LoRA layer gives GEGLU), no stand-alone pass
+                hg, act = ops.linear_geglu(x, pleaf[0], pleaf[1])
+                return ops.geglu_linear(hg, leaf[0], leaf[1], residual, gact=act)
             return ops.geglu_linear(self.net[0].proj(x), leaf[0], leaf[1], residual)
         h = self.net[0](x)
         return _call_res(self.net[2], h, residual) if residual is not None else self.net[2](h)

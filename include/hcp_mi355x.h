@@ -28,7 +28,8 @@ int hcp_is_emulated(void); /* 0 for the product library */
  * refuse to call it (hcp_diffusion_amd/_lib.py does).  1: rounds 1-5.  2: round 6 — workspace arguments on the LoRA weight-gradient
  * entry points (slabs + ordered reduce instead of fp32 atomics), 152-byte grouped descriptors; earlier in-place argument insertions
  * (ldt on hcp_gemm_lora_bf16 / hcp_gemm_geglu_bwd_bf16, l_lo, ldu / ldt) are covered by the same bump.  3: round 6 — the (hi | lo)
- * residual stream: residual_lo / D_lo on hcp_gemm_bf16 / hcp_gemm_lora_bf16, x_lo / addend_lo / dx_lo on hcp_layernorm_fwd / _bwd. */
+ * residual stream: residual_lo / D_lo on hcp_gemm_bf16 / hcp_gemm_lora_bf16, x_lo / addend_lo / dx_lo on hcp_layernorm_fwd / _bwd; the
+ * GEGLU-forward output gact on hcp_gemm_bf16 / hcp_gemm_lora_bf16. */
 #define HCP_ABI_VERSION 3
 int hcp_abi_version(void);
 /* Device self-check of the fp32 atomic path (no reference counterpart: the reference's sums are torch's).  workgroups x 256 threads add
@@ -42,12 +43,16 @@ int hcp_selfcheck_atomics(float* line, float* bucket, int nb, int stride, int wo
  * (A2,B2) is the rank-r side path (x W_down^T, alpha*W_up) appended to the reduction. */
 int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int ldd, int M, int N, int K, const void* A2,
                   int lda2, const void* B2, int ldb2, int K2, const float* bias, const float* rowbias, int rowbias_ld,
-                  int rows_per_group, const void* residual, int ldr, const void* residual_lo, void* D_lo, float alpha, int out_f32,
-                  void* workspace, size_t workspace_bytes, hcpStream_t stream);
+                  int rows_per_group, const void* residual, int ldr, const void* residual_lo, void* D_lo, void* gact, float alpha,
+                  int out_f32, void* workspace, size_t workspace_bytes, hcpStream_t stream);
 /* (hi | lo) residual stream, ABI 3: residual_lo / D_lo (both optional, bf16, leading dimensions ldr / ldd).  A transformer block's
  * residual stream x is carried as hi = bf16(x) and lo = bf16(x - hi): the epilogue adds residual + residual_lo in fp32 and writes
  * D = bf16(v), D_lo = bf16(v - D) — the 16 mantissa bits the reference's LoRA layers keep on that stream by returning
- * mm(x, W^T) [bf16 under autocast] + bias [fp32] = fp32 (lora_layers_patch.py:50-57).  NULL, NULL = the plain bf16 epilogue. */
+ * mm(x, W^T) [bf16 under autocast] + bias [fp32] = fp32 (lora_layers_patch.py:50-57).  NULL, NULL = the plain bf16 epilogue.
+ * GEGLU forward, ABI 3: gact (optional, bf16 [M, N/2]).  D = (h | g) is the output of diffusers' GEGLU projection (FeedForward.net[0].proj,
+ * cfgs/unet_struct.txt:27-30): gact = bf16(h * gelu(g)) is formed in the same epilogue from the fp32 values (the stand-alone hcp_geglu_fwd
+ * pass and one rounding disappear: the reference's LoRA layer hands GEGLU an fp32 (h | g) too).  Needs a contiguous bf16 D (ldd = N),
+ * N % 16 == 0, no residual / row bias / alpha; where the dispatched tile cannot pair the halves the library runs hcp_geglu_fwd itself. */
 /* Fused LoRA linear, forward and input-gradient: T = A L^T (rank slot 32, written to Tout if non-NULL),
  * D = A B^T + T E^T + bias + residual in ONE launch (the block accumulates its T tile from the A tiles it streams);
  * deep-K / small-M shapes run as two launches (T GEMM, then split-K K-extension GEMM) and then require Tout.
@@ -58,7 +63,7 @@ int hcp_gemm_bf16(const void* A, int lda, const void* B, int ldb, void* D, int l
  * Replaces LoraPatchContainer.forward's weight merge + mm (lora_base_patch.py:20-35,61-74). */
 int hcp_gemm_lora_bf16(const void* A, int lda, const void* B, int ldb, const void* L, const void* E, void* Tout, int ldt, void* D,
                        int ldd, int M, int N, int K, const float* bias, const void* residual, int ldr, const void* residual_lo, void* D_lo,
-                       void* workspace, size_t workspace_bytes, hcpStream_t stream);
+                       void* gact, void* workspace, size_t workspace_bytes, hcpStream_t stream);
 /* FF-out input-gradient with the GEGLU backward in its epilogue: dY_ff = A B^T (+ the LoRA side path as hcp_gemm_lora_bf16's backward
  * form: L = W_up^T, E = alpha W_down^T, Tout = dY W_up; L = E = NULL for a plain host) is never written; with (h | g) = HG[M, 2F] saved
  * by the forward, DHG[m, n] = dY_ff gelu(g), DHG[m, F + n] = dY_ff h gelu'(g).  Replaces the dX GEMM of FeedForward.net[2] + the

@@ -69,7 +69,7 @@ def test_product_path_fails_loudly_without_gpu_tensors():
 
 def test_argument_validation_returns_error_codes():
     lib = _lib.load()
-    rc = lib.hcp_gemm_bf16(None, 8, None, 8, None, 8, 8, 8, 8, None, 0, None, 0, 0, None, None, 0, 1, None, 0, None, None, 1.0, 0, None, 0, None)
+    rc = lib.hcp_gemm_bf16(None, 8, None, 8, None, 8, 8, 8, 8, None, 0, None, 0, 0, None, None, 0, 1, None, 0, None, None, None, 1.0, 0, None, 0, None)
     assert rc < 0 and b"null" in lib.hcp_last_error()
     rc = lib.hcp_layernorm_fwd(None, None, None, None, None, None, 4, 7, 1e-5, None)
     assert rc < 0 and b"bad shape" in lib.hcp_last_error()
@@ -82,7 +82,7 @@ def test_every_entry_point_rejects_bad_arguments_without_launching():
     N = None
     bad = {
         "hcp_conv3x3_bf16": (N, 8, N, 0, 1, 4, 4, 4, 4, 0, 1, 0, 1, N, 8, N, 8, N, N, 0, N, 0, 0, N, N, N, 0, N),
-        "hcp_gemm_lora_bf16": (N, 8, N, 8, N, N, N, 32, N, 8, 8, 8, 8, N, N, 0, N, N, N, 0, N),
+        "hcp_gemm_lora_bf16": (N, 8, N, 8, N, N, N, 32, N, 8, 8, 8, 8, N, N, 0, N, N, N, N, 0, N),
         "hcp_gemm_geglu_bwd_bf16": (N, 8, N, 8, N, N, N, 32, N, N, 8, 8, 8, N, 0, N),
         "hcp_attention_fwd": (N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, 0, N),
         "hcp_attention_bwd": (N, N, N, N, N, N, N, N, N, N, 1, 1, 8, 8, 40, 0, 40, 0, 40, 0, 40, 0, 40, 0.1, N, 0, 0, N, 0, N),

@@ -1029,6 +1029,50 @@ def test_gemm_pingpong_variants(tbackend, cfg, ring):
         L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1)
 
 
+@pytest.mark.parametrize("variant", ["dispatched", "loaders", "pingpong", "sixteen_waves", "first_dma_loop", "unpairable_tile"])
+@pytest.mark.parametrize("lora", [False, True])
+def test_gemm_geglu_fwd_epilogue(tbackend, variant, lora):
+    """GEGLU forward in the projection's epilogue (GemmParams::geglu_out): D = bf16(h | g) and gact = bf16(h * gelu(g)) from the fp32 epilogue
+    values, the tile pairing h columns with their g columns — on every main loop that has the pairing epilogue, through the library's
+    own two-launch form where a kernel has none (first LDS-DMA loop) or the tile cannot pair (F % (BN / 2) != 0), with and without
+    the fused-LoRA tail."""
+    to = tbackend.to
+    L = K.lib()
+    torch.manual_seed(11)
+    M, Fd, Kd = (200, 160, 192) if not tbackend.is_gpu else (3000, 1280, 640)
+    if variant == "unpairable_tile":
+        Fd = 176 if not tbackend.is_gpu else 1296           # a multiple of 16, not of 80 / 64
+    a, b = rnd(M, Kd), rnd(2 * Fd, Kd) * 0.1
+    bias = torch.randn(2 * Fd)
+    l, e = rnd(32, Kd) * 0.2, rnd(2 * Fd, 32) * 0.2
+    hg = a.float() @ b.float().T + bias
+    if lora:
+        hg = hg + (a.float() @ l.float().T).to(BF).float() @ e.float().T
+    want = hg[:, :Fd] * F.gelu(hg[:, Fd:])
+    try:
+        if variant == "loaders":
+            L.hcp_debug_set_gemm_loaders(3); L.hcp_debug_set_gemm_config(13 + 16)
+        elif variant == "pingpong":
+            L.hcp_debug_set_gemm_loaders(8 + 3); L.hcp_debug_set_gemm_config(14 + 16)
+        elif variant == "sixteen_waves":
+            L.hcp_debug_set_gemm_config(12 + 16)
+        elif variant == "first_dma_loop":
+            L.hcp_debug_set_gemm_glds(0)
+        if lora:
+            (o, ga), t = K.gemm_lora(to(a), to(b), to(l.contiguous()), to(e.contiguous()), bias=to(bias), want_gact=True)
+            assert relerr(t_full(t), a.float() @ l.float().T) < (1e-4 if K.T_SPLIT else 1e-2)
+        else:
+            o, ga = K.gemm(to(a), to(b), bias=to(bias), want_gact=True)
+        assert relerr(o, hg) < 1e-2
+        assert relerr(ga, want) < 1e-2
+        two_pass = F.gelu(o.float().cpu()[:, Fd:]) * o.float().cpu()[:, :Fd]        # what the stand-alone pass computes from the ROUNDED (h | g)
+        e_fused = (ga.float().cpu() - want).norm().item(); e_two = (two_pass.to(BF).float() - want).norm().item()
+        if variant not in ("first_dma_loop", "unpairable_tile"):
+            assert e_fused < 0.9 * e_two, (e_fused, e_two)     # one rounding instead of two
+    finally:
+        L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1); L.hcp_debug_set_gemm_glds(1)
+
+
 def _split_hi_lo(x):
     hi = x.to(BF)
     return hi, (x - hi.float()).to(BF)

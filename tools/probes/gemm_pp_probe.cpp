@@ -113,8 +113,8 @@ int main(int argc, char** argv) {
         float* rowbias = s.res == 2 ? dev_random_f32((size_t)16 * s.N) : nullptr;
         if (s.kind == 1) { Lw = dev_random_bf16((size_t)32 * s.K, 0.05f); Ew = dev_random_bf16((size_t)s.N * 32, 0.05f); CK(hipMalloc(&T, (size_t)s.M * 32 * 2)); }
         auto run = [&](int i) -> int {
-            if (s.kind == 0) return hcp_gemm_bf16(A[i], s.K, Bw[i], s.K, D[i], s.N, s.M, s.N, s.K, nullptr, 0, nullptr, 0, 0, bias, nullptr, 0, 1, R[i], s.N, nullptr, nullptr, 1.0f, 0, ws, ws_bytes, st);
-            if (s.kind == 1) return hcp_gemm_lora_bf16(A[i], s.K, Bw[i], s.K, Lw, Ew, T, 32, D[i], s.N, s.M, s.N, s.K, bias, R[i], s.N, nullptr, nullptr, ws, ws_bytes, st);
+            if (s.kind == 0) return hcp_gemm_bf16(A[i], s.K, Bw[i], s.K, D[i], s.N, s.M, s.N, s.K, nullptr, 0, nullptr, 0, 0, bias, nullptr, 0, 1, R[i], s.N, nullptr, nullptr, nullptr, 1.0f, 0, ws, ws_bytes, st);
+            if (s.kind == 1) return hcp_gemm_lora_bf16(A[i], s.K, Bw[i], s.K, Lw, Ew, T, 32, D[i], s.N, s.M, s.N, s.K, bias, R[i], s.N, nullptr, nullptr, nullptr, ws, ws_bytes, st);
             return hcp_conv3x3_bf16(A[i], s.C, nullptr, 0, s.B, s.H, s.H, s.H, s.H, s.kind == 2 ? 0 : 1, 1, 0, 1, Bw[i], s.N, D[i], s.N, bias, rowbias, s.N, R[i], s.N, 0, nullptr, nullptr, ws, ws_bytes, st);
         };
         const double flop = 2.0 * s.M * s.N * (s.K + (s.kind == 1 ? 32 : 0));
@@ -158,9 +158,9 @@ int main(int argc, char** argv) {
             void* xa = dev_random_bf16((size_t)4096 * 640, 1.0f); void* xb = dev_random_bf16((size_t)5120 * 640, 0.05f); void* xd; CK(hipMalloc(&xd, (size_t)4096 * 5120 * 2));
             void* xl = dev_random_bf16((size_t)32 * 640, 0.05f); void* xe = dev_random_bf16((size_t)5120 * 32, 0.05f); void* xt; CK(hipMalloc(&xt, (size_t)4096 * 32 * 2));
             auto others = [&]() {                             // three other kernel templates (fused-LoRA 128x160 v2, plain 64x160, split-K + reduce)
-                hcp_gemm_lora_bf16(xa, 640, xb, 640, xl, xe, xt, 32, xd, 640, 4096, 640, 640, nullptr, nullptr, 0, nullptr, nullptr, ws, ws_bytes, st);
-                hcp_gemm_bf16(xa, 640, xb, 640, xd, 1280, 1024, 1280, 640, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, 1.0f, 0, ws, ws_bytes, st);
-                hcp_gemm_bf16(xa, 640, xb, 640, xd, 320, 256, 320, 640, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, 1.0f, 0, ws, ws_bytes, st);
+                hcp_gemm_lora_bf16(xa, 640, xb, 640, xl, xe, xt, 32, xd, 640, 4096, 640, 640, nullptr, nullptr, 0, nullptr, nullptr, nullptr, ws, ws_bytes, st);
+                hcp_gemm_bf16(xa, 640, xb, 640, xd, 1280, 1024, 1280, 640, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, 1.0f, 0, ws, ws_bytes, st);
+                hcp_gemm_bf16(xa, 640, xb, 640, xd, 320, 256, 320, 640, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0, nullptr, nullptr, nullptr, 1.0f, 0, ws, ws_bytes, st);
             };
             for (int mode = 0; mode < 2; ++mode) {
                 std::vector<float> ts;
