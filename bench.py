@@ -150,6 +150,28 @@ def dominant_kernel_roofline(dev):
     return out
 
 
+def family_roofline(batch):
+    """`roofline_family` (VERDICT r5 next #4d): the algorithmic FLOPs of the two MFMA families of the SD1.5 LoRA step divided by the
+    time their kernels take inside the captured step, from the committed rocprofv3 step summary (profiles/pmc_roofline.json "families",
+    written by tools/pmc_roofline.py) — the `roofline` object above is the BEST kernel of the GEMM family, this is the family.
+    FLOPs per image: UNet forward 803.3 G of which the attention cores 122.5 G; backward = the input-gradient
+    pass (x 1 for GEMMs / convs, x 2.5 for the attention cores)."""
+    rec = _pmc_record("families")
+    if not rec or not rec.get("gemm_ms") or not rec.get("attention_ms"):
+        return None
+    gemm_flops = (803.3e9 - 122.5e9) * 2 * batch
+    attn_flops = 122.5e9 * 3.5 * batch
+    out = {"bound": "mfma", "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "batch": batch,
+           "source": f"{rec.get('source')} (kernel sources at git {rec.get('git', '?')}); {rec.get('dispatches_per_step')} dispatches, "
+                     f"{rec.get('kernel_ms_per_step')} ms of kernel time per step under the profiler"}
+    for name, fl, ms, n in (("gemm_and_conv", gemm_flops, rec["gemm_ms"] + rec.get("splitk_reduce_ms", 0.0), rec.get("gemm_launches")),
+                            ("attention", attn_flops, rec["attention_ms"], rec.get("attention_launches"))):
+        ach = fl / (ms * 1e-3) / 1e12
+        out[name] = {"flops_per_step": fl, "ms_per_step": round(ms, 3), "launches_per_step": n, "achieved": round(ach, 1),
+                     "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4)}
+    return out
+
+
 def attention_roofline(dev):
     """Secondary roofline line, the north-star's named kernel: self-attention forward at the 64x64 level (B4 H8 N4096 d40)."""
     from hcp_diffusion_amd import kernels as K
@@ -542,6 +564,10 @@ def main(emu=False):
             return
         out["roofline"] = roof
         out["roofline_attention"] = roof_attn
+        if args.workload == "sd15" and B == 4:
+            fam = family_roofline(B)
+            if fam:
+                out["roofline_family"] = fam
         if world == 1 and not args.no_cpu_baseline and args.workload == "sd15":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

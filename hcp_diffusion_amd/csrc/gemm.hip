@@ -590,7 +590,7 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
             hcp_f32x4 z = {0.f, 0.f, 0.f, 0.f};
             bias_v[j] = (p.bias && nl < p.N) ? *(const hcp_f32x4*)(p.bias + n) : z;
         }
-        if (p.residual) {
+        if (p.residual && !p.epi_tile) {                    // (the tile epilogue reads the residual in its own 16-byte layout)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = m0 + wm * WTM + i * 16 + fr;
@@ -640,7 +640,7 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
             hcp_barrier_keep_dma();                         // tile t+1 is in LDS, tile t is consumed
         }
         if (LORA) HCP_SYNC();                               // the compute waves' epilogue barrier
-        if ((p.geglu_hg || p.geglu_out) && p.nsplit == 1) { if (LORA) HCP_SYNC(); HCP_SYNC(); }       // ... and those of the GEGLU tiles
+        if ((p.geglu_hg || p.geglu_out || p.epi_tile) && p.nsplit == 1) { if (LORA) HCP_SYNC(); HCP_SYNC(); }       // ... and those of the GEGLU / epilogue tiles
         return;
     }
     if (NLD == 0) { if (nprim > 0) issue(0); else if (has_ext) issue_ext(0); }
@@ -750,6 +750,26 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
         geglu_fwd_pair<TM, TN>(v, is_g, wm * HW + (wn - (is_g ? HW : 0)), lane, (hcp_f32x4*)lds, [] { HCP_SYNC(); }, p.geglu_out, p.N >> 1, rows, p.M, cols);
         return;
     }
+    if (p.epi_tile) {                                       // tile epilogue (gemm_params.h: epi_tile_store): 16-byte row pieces
+        if (!EARLY) load_epilogue_operands();
+        if (LORA) HCP_SYNC();                               // the LoRA tail's T / E images live in the same LDS
+        float* const tile = (float*)lds;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ml = wm * WTM + i * 16 + fr, m = m0 + ml;
+            const float* rbp = (p.rowbias && m < p.M) ? p.rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = wn * WTN + j * 16 + 4 * fg;
+                hcp_f32x4 v = acc[i][j] * p.alpha + bias_v[j];
+                if (rbp && n0 + nl < p.N) v += *(const hcp_f32x4*)(rbp + n0 + nl);
+                *(hcp_f32x4*)(tile + ml * epi_tile_ld(BN) + nl) = v;
+            }
+        }
+        HCP_SYNC();
+        epi_tile_store<BM, BN, NTC>(p, tile, m0, n0, tid_all);
+        return;
+    }
     // epilogue: ALL of the lane's bias / row-bias / residual loads are issued before the first store (one vmcnt wait instead
     // of one per 16x16 block: with K = 320 the serialized form cost as much as the whole main loop)
     if (!EARLY) load_epilogue_operands();
@@ -804,7 +824,18 @@ HCP_TUNABLE(int, g_dbg_ablate, 0);   // tools only, see GemmParams::dbg
 HCP_TUNABLE(int, g_use_glds, 1);     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
 HCP_TUNABLE(int, g_use_v2, 1);       // 1: buffer-addressed v2 main loop where its requirements hold (default), 0: gemm_glds_kernel everywhere
 
+HCP_TUNABLE(int, g_epi_tile, -1);    // tools: -1 = the rule below, 0 = lane-layout epilogue everywhere, 1 = tile epilogue wherever it is possible
 HCP_TUNABLE(int, g_force_loaders, -1);   // tools: -1 = as dispatched, 0 = no loader waves, 1 / 3 / 4 = loader-wave variant with a 2 / 3 / 4 tile ring
+
+// Tile epilogue (gemm_params.h: epi_tile_store) for this launch?  Needs an unsplit bf16 output in 16-byte pieces; the rule: outputs of
+// kEpiTileMinBytes or more (below that the launch is latency-bound and the extra LDS round trip + barrier only adds to it).
+constexpr size_t kEpiTileMinBytes = (size_t)1 << 62;       // (off until measured)
+bool want_epi_tile(const GemmParams& p) {
+    if (p.nsplit != 1 || p.out_f32 || p.geglu_hg || p.geglu_out || p.N % 8 || p.ldd % 8 || (p.residual && p.ldr % 8)) return false;
+    if ((((size_t)p.D) | ((size_t)p.D_lo) | ((size_t)p.residual) | ((size_t)p.residual_lo)) & 15) return false;
+    if (g_epi_tile >= 0) return g_epi_tile == 1;
+    return (size_t)p.M * p.N * sizeof(hcp_bf16) >= kEpiTileMinBytes;
+}
 
 template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false, int NSTAGE = 2, int NLD = 0>
 int launch_cfg(GemmParams& p, hipStream_t stream) {
@@ -820,16 +851,20 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
                 if (MODE == 0 && WGN % 2 == 0 && p.nsplit == 1 && (p.N / 2) % (BN / 2) == 0) p.geglu_fused = 1;
                 else p.geglu_out = nullptr;
             }
+            constexpr size_t tile_bytes = (size_t)BM * epi_tile_ld(BN) * sizeof(float);
+            p.epi_tile = want_epi_tile(p) && tile_bytes <= 160 * 1024 - eimg ? 1 : 0;
             size_t smem = 2 * stage;
             const size_t tail = (size_t)(2 * BM + BN) * 40 * sizeof(hcp_bf16);   // fused-LoRA tail images: T_hi, E, T_lo
             if (LORA && smem < tail) smem = tail;
+            if (p.epi_tile && smem < tile_bytes) smem = tile_bytes;
             [[maybe_unused]] const dim3 grid(p.tiles_m * tiles_n, p.nsplit);
             if constexpr (NLD > 0) {
                 // p.loaders: 1 (or 2) = two-stage ring, 3 / 4 = deeper ring where it fits the 160 KB of LDS
+                const size_t tb = p.epi_tile ? tile_bytes : 0;      // the epilogue tile re-uses the ring (the E image sits behind it)
                 if (p.loaders == 4 && 4 * stage + eimg <= 160 * 1024) {
-                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD, (4 * stage + eimg <= 160 * 1024 ? 4 : 2)>), grid, dim3(64 * (WGM * WGN + NLD)), 4 * stage + eimg, stream, p);
+                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD, (4 * stage + eimg <= 160 * 1024 ? 4 : 2)>), grid, dim3(64 * (WGM * WGN + NLD)), (4 * stage > tb ? 4 * stage : tb) + eimg, stream, p);
                 } else if (p.loaders >= 3 && 3 * stage + eimg <= 160 * 1024) {
-                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD, (3 * stage + eimg <= 160 * 1024 ? 3 : 2)>), grid, dim3(64 * (WGM * WGN + NLD)), 3 * stage + eimg, stream, p);
+                    HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD, (3 * stage + eimg <= 160 * 1024 ? 3 : 2)>), grid, dim3(64 * (WGM * WGN + NLD)), (3 * stage > tb ? 3 * stage : tb) + eimg, stream, p);
                 } else if (p.loaders) {
                     HCP_LAUNCH((gemm_v2_kernel<BM, BN, WGM, WGN, MODE, LORA, NLD>), grid, dim3(64 * (WGM * WGN + NLD)), smem + eimg, stream, p);
                 } else {
@@ -847,6 +882,7 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
         }
     }
     {
+        p.epi_tile = 0;
         p.geglu_out = nullptr;                               // (the first LDS-DMA loop has no pairing epilogue: the entry point runs hcp_geglu_fwd behind it)
         size_t smem = (size_t)NSTAGE * (BM + BN + (LORA ? 32 : 0)) * BK * sizeof(hcp_bf16);
         const size_t tail = (size_t)(2 * BM + BN) * 40 * sizeof(hcp_bf16);  // fused-LoRA tail images: T_hi, E, T_lo
@@ -876,6 +912,7 @@ int try_pp(int id, int mode, bool fast_or_plain, bool lora, GemmParams& p, hipSt
     const int bm = kCfgs[id].bm, bn = kCfgs[id].bn;
     p.tiles_m = hcp_cdiv(p.M, bm);
     p.dbg = g_dbg_ablate;
+    p.epi_tile = want_epi_tile(p) ? 1 : 0;                  // (gemm_pp_launch clears it where the tile does not fit)
     hcp_bf16* const gout = p.geglu_out;                     // GEGLU-forward epilogue: see launch_cfg
     if (gout) {
         if (mode == 0 && p.nsplit == 1 && (p.N / 2) % (bn / 2) == 0) p.geglu_fused = 1;
@@ -1074,6 +1111,8 @@ HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = 1; g_use_v2 = on == 1
 HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; return 0; }
 // TOOLS ONLY: -1 = as the dispatch table says, 0 = never, 1 = the loader-wave variant wherever one is instantiated (tile ids 12-15).
 HCP_API int hcp_debug_set_gemm_loaders(int mode) { g_force_loaders = mode; return 0; }
+// TOOLS ONLY: -1 = the size rule, 0 = lane-layout epilogue everywhere, 1 = tile epilogue (16-byte row pieces through LDS) wherever possible.
+HCP_API int hcp_debug_set_gemm_epilogue(int mode) { g_epi_tile = mode; return 0; }
 #endif
 
 // Bytes of fp32 split-K workspace that lets every launch of this shape use its preferred decomposition.

@@ -50,6 +50,9 @@ struct GemmParams {
     // is used: B / E / bias rows, stores).  The launch site clears it when its kernel cannot pair (F % (BN / 2) != 0, split-K, first
     // LDS-DMA loop) and the entry point then runs hcp_geglu_fwd behind the GEMM; geglu_fused reports which happened.
     hcp_bf16* geglu_out; int geglu_fused;
+    // "tile epilogue" (round 6): the finished fp32 values go through an LDS tile and leave in 16-byte pieces of full output rows (residual
+    // read the same way) instead of 8-byte pieces in the MFMA lane layout — see epi_tile_store below; set by the dispatcher.
+    int epi_tile;
     int loaders;                    // 1: launch the loader-wave variant of the v2 kernel where one is instantiated (dispatch table / tools)
     int dbg;                        // tools/ablate_gemm.py: 1 = skip the DMA after the first tile, 2 = skip the MFMAs, 4 = skip LDS reads + MFMAs
     ConvDesc cv;
@@ -86,6 +89,44 @@ HCP_DEVICE void add_residual_lo(const GemmParams& p, int m, int n, hcp_f32x4& v)
     const hcp_bf16x4 r = *(const hcp_bf16x4*)(p.residual_lo + (size_t)m * p.ldr + n);
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)r[q]);
+}
+
+// Tile epilogue.  In the MFMA layout a lane owns 4 consecutive columns of one row: the epilogue's global stores (and residual loads) are
+// 8-byte pieces, 16 rows x 32-byte runs per wave instruction — issue-bound long before HBM is (guide: the bf16 row-per-lane store tail).
+// Here the waves first park v = alpha acc + bias (+ row bias) as fp32 in LDS ([BM][BN + 4]: the 16 rows a wave stores at once start on
+// distinct bank quads), then every compute thread walks (row, 8 columns) pieces: one 16-byte residual load (+ one for a lo image), one
+// 16-byte store (+ one for D_lo), consecutive threads on consecutive pieces of a row.  Same arithmetic as the lane-layout epilogue.
+constexpr int epi_tile_ld(int BN) { return BN + 4; }
+template <int BM, int BN, int NTHREADS>
+HCP_DEVICE void epi_tile_store(const GemmParams& p, const float* tile, int m0, int n0, int tid) {
+    constexpr int LD = epi_tile_ld(BN), PIECES = BN / 8;
+    for (int idx = tid; idx < BM * PIECES; idx += NTHREADS) {
+        const int row = idx / PIECES, c8 = (idx - row * PIECES) * 8;
+        const int m = m0 + row, n = n0 + c8;
+        if (m >= p.M || n >= p.N) continue;                                   // (N % 8 == 0: a piece is inside or outside)
+        const hcp_f32x4 a = *(const hcp_f32x4*)(tile + row * LD + c8), b = *(const hcp_f32x4*)(tile + row * LD + c8 + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (p.residual) {
+            const hcp_bf16x8 r = *(const hcp_bf16x8*)(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += hcp_bf2f((unsigned short)r[q]);
+            if (p.residual_lo) {
+                const hcp_bf16x8 rl = *(const hcp_bf16x8*)(p.residual_lo + (size_t)m * p.ldr + n);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += hcp_bf2f((unsigned short)rl[q]);
+            }
+        }
+        hcp_bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (short)hcp_f2bf(v[q]);
+        *(hcp_bf16x8*)((hcp_bf16*)p.D + (size_t)m * p.ldd + n) = o;
+        if (p.D_lo) {
+            hcp_bf16x8 l;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) l[q] = (short)hcp_f2bf(v[q] - hcp_bf2f((unsigned short)o[q]));
+            *(hcp_bf16x8*)(p.D_lo + (size_t)m * p.ldd + n) = l;
+        }
+    }
 }
 
 // GEGLU-forward launches: logical column nl of the tiled problem -> the column of B / E / bias / D it stands for (see geglu_out).

@@ -260,7 +260,7 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         hcp_barrier_only();                               // #2U
         hcp_barrier_only(); hcp_barrier_only();          // the exchange of the compute groups
         if (LORA) HCP_SYNC();                             // the compute waves' tail barrier
-        if ((p.geglu_hg || p.geglu_out) && p.nsplit == 1) { if (LORA) HCP_SYNC(); HCP_SYNC(); }       // ... and those of the GEGLU tiles
+        if ((p.geglu_hg || p.geglu_out || p.epi_tile) && p.nsplit == 1) { if (LORA) HCP_SYNC(); HCP_SYNC(); }       // ... and those of the GEGLU / epilogue tiles
         return;
     }
 
@@ -313,7 +313,7 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         }
     };
 
-    if (EARLY && p.nsplit == 1) load_residual();
+    if (EARLY && p.nsplit == 1 && !p.epi_tile) load_residual();
     hcp_barrier_only();                                   // P
     if (g == 1) hcp_barrier_only();                       // #0: group 1 runs half a phase behind group 0
     for (int t = 0, st = 0; t < nk; ++t) {
@@ -411,7 +411,7 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
                 if (split) *(hcp_bf16x4*)(p.Tout + (size_t)(m0 + ml) * ldt + 32 + gn * 16 + 4 * fg) = o2;
             }
         }
-        if (!EARLY && p.nsplit == 1) load_residual();
+        if (!EARLY && p.nsplit == 1 && !p.epi_tile) load_residual();
         HCP_SYNC();
         hcp_bf16x8 ft[TMF], fe[TN];
 #pragma unroll
@@ -476,6 +476,25 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         geglu_fwd_pair<TMF, TN>(v, is_g, wave_all >> 1, lane, (hcp_f32x4*)ring, [] { HCP_SYNC(); }, p.geglu_out, p.N >> 1, rows, p.M, cols);
         return;
     }
+    if (p.epi_tile) {                                       // tile epilogue (gemm_params.h: epi_tile_store): 16-byte row pieces
+        if (LORA) HCP_SYNC();                               // the LoRA tail's T image lives in the ring
+        float* const tile = (float*)ring;
+#pragma unroll
+        for (int i = 0; i < TMF; ++i) {
+            const int ml = frow0 + i * 16 + fr, m = m0 + ml;
+            const float* rbp = (p.rowbias && m < p.M) ? p.rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld : nullptr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = col0 + j * 16 + 4 * fg;
+                hcp_f32x4 v = acc[i][j] * p.alpha + bias_v[j];
+                if (rbp && n0 + nl < p.N) v += *(const hcp_f32x4*)(rbp + n0 + nl);
+                *(hcp_f32x4*)(tile + ml * epi_tile_ld(BN) + nl) = v;
+            }
+        }
+        HCP_SYNC();
+        epi_tile_store<BM, BN, NTC>(p, tile, m0, n0, tid_all);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TMF; ++i) {
         const int m = m0 + frow0 + i * 16 + fr;
@@ -514,20 +533,21 @@ int launch_pp(GemmParams& p, int ring, hipStream_t stream) {
     constexpr int TMF = BM / 64;
     constexpr size_t xchg = (size_t)8 * TMF * (BN / 32) * 64 * 16 + (LORA ? (size_t)8 * TMF * 64 * 16 : 0);   // the groups' exchange area
     constexpr size_t tail = LORA ? (size_t)2 * BM * 40 * sizeof(hcp_bf16) : 0;   // T_hi and T_lo images
-    constexpr size_t floor_ = xchg > tail ? xchg : tail;
+    constexpr size_t tile_bytes = (size_t)BM * epi_tile_ld(BN) * sizeof(float);     // tile epilogue (lives in the ring like the exchange area)
+    if (p.epi_tile && tile_bytes + eimg > 160 * 1024) p.epi_tile = 0;
+    const size_t floor_ = (xchg > tail ? xchg : tail) > (p.epi_tile ? tile_bytes : 0) ? (xchg > tail ? xchg : tail) : tile_bytes;
     constexpr size_t cap = 160 * 1024;
     const dim3 grid(p.tiles_m * hcp_cdiv(p.N, BN), p.nsplit);
     if (ring >= 4 && 4 * stage + eimg <= cap) {
         constexpr int R = 4 * stage + eimg <= cap ? 4 : 2;
-        constexpr size_t sm = (R * stage > floor_ ? R * stage : floor_) + eimg;
+        const size_t sm = (R * stage > floor_ ? R * stage : floor_) + eimg;
         HCP_LAUNCH((gemm_pp_kernel<BM, BN, MODE, LORA, R>), grid, dim3(768), sm, stream, p);
     } else if (ring >= 3 && 3 * stage + eimg <= cap) {
         constexpr int R = 3 * stage + eimg <= cap ? 3 : 2;
-        constexpr size_t sm = (R * stage > floor_ ? R * stage : floor_) + eimg;
+        const size_t sm = (R * stage > floor_ ? R * stage : floor_) + eimg;
         HCP_LAUNCH((gemm_pp_kernel<BM, BN, MODE, LORA, R>), grid, dim3(768), sm, stream, p);
     } else {
-        constexpr size_t sm = (2 * stage > floor_ ? 2 * stage : floor_) + eimg;
-        static_assert(sm <= cap, "LDS budget");
+        const size_t sm = (2 * stage > floor_ ? 2 * stage : floor_) + eimg;
         HCP_LAUNCH((gemm_pp_kernel<BM, BN, MODE, LORA, 2>), grid, dim3(768), sm, stream, p);
     }
     HCP_LAUNCH_CHECK("gemm_pp_kernel");

@@ -149,6 +149,7 @@ class _LinearFn(torch.autograd.Function):
         if geglu:
             act = y[1].view(*shp[:-1], y[1].shape[-1])
             ctx.mark_non_differentiable(act)
+            ctx.set_materialize_grads(False)           # (else autograd fills a zero "gradient" of act for every backward: 16 launches per step)
             return y[0].view(*shp[:-1], y[0].shape[-1]), act
         if stream:
             ctx.set_materialize_grads(False)           # the lo image of the last block has no consumer: its gradient stays None

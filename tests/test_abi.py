@@ -134,8 +134,52 @@ def test_integration_doc_quotes_the_shipped_overlay():
     """INTEGRATION.md shows the seam-1 YAML a maintainer copies: it must BE the shipped file, not a paraphrase of it."""
     import pathlib
     root = pathlib.Path(__file__).resolve().parent.parent
-    yaml = (root / "cfgs" / "train" / "mi355x" / "lora_sd15_hip.yaml").read_text()
-    assert yaml in (root / "INTEGRATION.md").read_text()
+    doc = (root / "INTEGRATION.md").read_text()
+    for name in ("lora_sd15_hip.yaml", "lora_sdxl_hip.yaml"):
+        assert (root / "cfgs" / "train" / "mi355x" / name).read_text() in doc, name
+
+
+def test_every_overlay_parses_and_extends_a_reference_example():
+    """cfgs/train/mi355x/*.yaml: valid YAML, one `_base_` that names an example the reference ships (checked against /root/reference where
+    that tree exists), bf16, and every `_target_` under hcp_diffusion_amd resolves to a real attribute."""
+    import importlib
+    import pathlib
+    import yaml
+    root = pathlib.Path(__file__).resolve().parent.parent
+    files = sorted((root / "cfgs" / "train" / "mi355x").glob("*.yaml"))
+    assert {f.name for f in files} >= {"lora_sd15_hip.yaml", "lora_sdxl_hip.yaml", "lora_sd15_te_hip.yaml", "dreambooth_sd15_hip.yaml", "controlnet_sd15_hip.yaml"}
+
+    def targets(node):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                if k == "_target_":
+                    yield v
+                else:
+                    yield from targets(v)
+        elif isinstance(node, list):
+            for v in node:
+                yield from targets(v)
+    for f in files:
+        cfg = yaml.safe_load(f.read_text())
+        assert len(cfg["_base_"]) >= 1, f.name
+        for base in cfg["_base_"]:
+            if base.startswith("cfgs/train/mi355x/"):                    # an overlay on a sibling overlay inherits its settings
+                assert (root / base).exists(), (f.name, base)
+                continue
+            assert cfg["mixed_precision"] == "bf16", f.name
+            if os.path.isdir("/root/reference"):
+                assert os.path.exists(os.path.join("/root/reference", base)), (f.name, base)
+        for t in targets(cfg):
+            if t.startswith("hcp_diffusion_amd."):
+                mod, _, attr = t.rpartition(".")
+                obj = None
+                while mod:
+                    try:
+                        obj = importlib.import_module(mod); break
+                    except ModuleNotFoundError:
+                        mod, _, head = mod.rpartition("."); attr = head + "." + attr
+                for part in attr.split("."):
+                    obj = getattr(obj, part)
 
 
 def test_no_compiler_vmcnt_wait_drains_the_attention_tile_prefetch(tmp_path):

@@ -1073,6 +1073,47 @@ def test_gemm_geglu_fwd_epilogue(tbackend, variant, lora):
         L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1); L.hcp_debug_set_gemm_glds(1)
 
 
+@pytest.mark.parametrize("variant", ["dispatched", "loaders", "pingpong", "sixteen_waves"])
+def test_gemm_tile_epilogue_equals_lane_epilogue(tbackend, variant):
+    """The tile epilogue (gemm_params.h: epi_tile_store — fp32 values through an LDS tile, 16-byte row pieces out) gives the SAME bits as
+    the lane-layout epilogue it replaces on large outputs: bias, row bias, alpha, residual, the (hi | lo) stream, the K-extension, the
+    fused-LoRA tail and a forward convolution, ragged M, on every main loop that has it."""
+    to = tbackend.to
+    L = K.lib()
+    torch.manual_seed(21)
+    M, N, Kd = (200, 320, 192) if not tbackend.is_gpu else (3000, 640, 1280)
+    a, b, a2, b2 = rnd(M, Kd), rnd(N, Kd) * 0.1, rnd(M, 32), rnd(N, 32) * 0.1
+    bias = torch.randn(N); rpg = max(1, M // 4); rb = torch.randn((M + rpg - 1) // rpg, N)
+    hi, lo = _split_hi_lo(torch.randn(M, N) * 4)
+    l, e = rnd(32, Kd) * 0.2, rnd(N, 32) * 0.2
+    C1, H, Cout = (64, 6, 64) if not tbackend.is_gpu else (320, 32, 320)
+    x1 = rnd(2, H, H, C1); w = (rnd(Cout, C1, 3, 3) * 0.1).permute(0, 2, 3, 1).contiguous(); cres = rnd(2, H, H, Cout)
+
+    def run():
+        o1 = K.gemm(to(a), to(b), a2=to(a2), b2=to(b2), bias=to(bias), rowbias=to(rb), rows_per_group=rpg, residual=to(hi), alpha=0.5)
+        o2, o2l = K.gemm(to(a), to(b), bias=to(bias), residual=to(hi), residual_lo=to(lo), want_lo=True)
+        (o3, o3l), t = K.gemm_lora(to(a), to(b), to(l.contiguous()), to(e.contiguous()), bias=to(bias), residual=to(hi), residual_lo=to(lo), want_lo=True)
+        o4 = K.conv3x3(to(x1), to(w), Cout, bias=to(bias[:Cout]), residual=to(cres))
+        return [t_.cpu().clone() for t_ in (o1, o2, o2l, o3, o3l, t, o4)]
+    try:
+        if variant == "loaders":
+            L.hcp_debug_set_gemm_loaders(3); L.hcp_debug_set_gemm_config(13 + 16)
+        elif variant == "pingpong":
+            L.hcp_debug_set_gemm_loaders(8 + 3); L.hcp_debug_set_gemm_config(14 + 16)
+        elif variant == "sixteen_waves":
+            L.hcp_debug_set_gemm_config(12 + 16)
+        L.hcp_debug_set_gemm_epilogue(0)
+        lane = run()
+        L.hcp_debug_set_gemm_epilogue(1)
+        tile = run()
+    finally:
+        L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1); L.hcp_debug_set_gemm_epilogue(-1)
+    for x, y in zip(lane, tile):
+        assert torch.equal(x, y)
+    ref = 0.5 * (a.float() @ b.float().T + a2.float() @ b2.float().T) + bias + rb.repeat_interleave(rpg, 0)[:M] + hi.float()
+    assert relerr(tile[0], ref) < 1e-2
+
+
 def _split_hi_lo(x):
     hi = x.to(BF)
     return hi, (x - hi.float()).to(BF)

@@ -246,3 +246,75 @@ def test_full_finetune_parameter_selection_matches_the_reference(backend, patter
     theirs = sorted(ids[id(p)] for p in groups[0]["params"])
     assert ours == theirs and len(ours) > 0
     assert sorted(n for n, p in b.named_parameters() if p.requires_grad) == theirs      # and it switched exactly those to requires_grad
+
+
+# ---- Offline pins of the UNet restatement's building blocks: diffusers is not importable here and the reference holds no
+# vectors for its UNet, so oracle/unet_sd15.py as a WHOLE stays "parity unpinned"; what CAN be checked against independent installed
+# implementations is checked below.  It narrows what is unpinned to the block wiring (order of norms / residuals / concatenations, which
+# tests/test_oracle.py::test_oracle_unet_matches_reference_struct_dump pins by names and shapes) — it does not lift the cap.
+@pytest.mark.parametrize("B,H,Nq,Nk,d,masked", [(2, 8, 33, 33, 40, False), (2, 5, 17, 77, 64, False), (3, 4, 9, 77, 160, True)])
+def test_oracle_attention_core_is_torch_sdpa(B, H, Nq, Nk, d, masked):
+    """_attention_core (softmax(q k^T d^-0.5 + key bias) v) == the installed torch.nn.functional.scaled_dot_product_attention, which is what
+    diffusers' AttnProcessor2_0 calls for this layer (train_ac.py:258-260 reaches it through xformers / SDPA)."""
+    import torch.nn.functional as F
+    from oracle.unet_sd15 import _attention_core
+    g = torch.Generator().manual_seed(Nq)
+    q, k, v = (torch.randn(B, H, n, d, generator=g) for n in (Nq, Nk, Nk))
+    bias = None
+    if masked:
+        keep = torch.rand(B, Nk, generator=g) > 0.3
+        keep[:, 0] = True
+        bias = (1.0 - keep.float()) * -10000.0                                   # the additive form diffusers builds from encoder_attention_mask
+    got = _attention_core(q, k, v, bias, d ** -0.5)
+    want = F.scaled_dot_product_attention(q, k, v, attn_mask=bias[:, None, None, :] if masked else None)
+    assert (got - want).abs().max().item() < 2e-6
+
+
+def test_oracle_head_split_is_the_diffusers_layout():
+    """CrossAttention's view(B, N, heads, d).transpose(1, 2) == einops 'b n (h d) -> b h n d' (diffusers head_to_batch_dim): head h owns
+    the contiguous channel slice [h d, (h + 1) d) — the layout the native kernels read in place."""
+    from einops import rearrange
+    x = torch.arange(2 * 5 * 12, dtype=torch.float32).view(2, 5, 12)
+    assert torch.equal(x.view(2, 5, 3, 4).transpose(1, 2), rearrange(x, "b n (h d) -> b h n d", h=3))
+
+
+def test_oracle_geglu_is_hidden_times_exact_gelu_of_gate():
+    """GEGLU: first half of the projection is the value, second half the gate, gelu in its exact (erf) form — the same function as the
+    installed transformers' "gelu" activation (and NOT "gelu_new" / "gelu_pytorch_tanh", the tanh approximation)."""
+    from transformers.activations import ACT2FN
+    from oracle.unet_sd15 import GEGLU
+    torch.manual_seed(0)
+    m = GEGLU(16, 24)
+    x = torch.randn(7, 16) * 3
+    hg = m.proj(x)
+    want = hg[:, :24] * ACT2FN["gelu"](hg[:, 24:])
+    assert (m(x) - want).abs().max().item() < 1e-6
+    assert (m(x) - hg[:, :24] * ACT2FN["gelu_new"](hg[:, 24:])).abs().max().item() > 1e-5
+
+
+def test_oracle_timestep_embedding_closed_form():
+    """Timesteps(flip_sin_to_cos=True, downscale_freq_shift=0): emb[b, i] = cos(t_b f_i), emb[b, half + i] = sin(t_b f_i),
+    f_i = 10000^(-i / half) — an independent float64 restatement, plus the values that fix the [cos | sin] order and the exponent's
+    denominator (half, not half - 1)."""
+    import numpy as np
+    from oracle.unet_sd15 import timestep_embedding
+    t = torch.tensor([0, 1, 250, 999])
+    e = timestep_embedding(t, 320).double().numpy()
+    i = np.arange(160, dtype=np.float64)
+    f = 10000.0 ** (-i / 160.0)
+    want = np.concatenate([np.cos(t.numpy()[:, None] * f), np.sin(t.numpy()[:, None] * f)], 1)
+    assert np.abs(e - want).max() < 2e-4                                        # fp32 arguments up to 999 rad
+    assert np.allclose(e[0, :160], 1.0) and np.allclose(e[0, 160:], 0.0)        # t = 0: cos block first
+    assert abs(e[1, 160] - np.sin(1.0)) < 1e-6 and abs(e[1, 159] - np.cos(10000.0 ** (-159 / 160))) < 1e-6
+
+
+def test_oracle_ddpm_schedule_known_answers():
+    """scaled_linear betas 0.00085 -> 0.012 over 1000 steps (Stable Diffusion's scheduler_config.json): the published end points of
+    alphas_cumprod, and add_noise against its closed form."""
+    from oracle.unet_sd15 import add_noise, ddpm_alphas_cumprod
+    acp = ddpm_alphas_cumprod()
+    assert abs(acp[0].item() - 0.99915) < 1e-5 and abs(acp[-1].item() - 0.0046602) < 2e-6 and bool((acp[1:] < acp[:-1]).all())
+    x0, n = torch.randn(3, 4, 5, 5), torch.randn(3, 4, 5, 5)
+    t = torch.tensor([0, 500, 999])
+    want = torch.stack([acp[ti].sqrt() * x0[i] + (1 - acp[ti]).sqrt() * n[i] for i, ti in enumerate(t)])
+    assert torch.equal(add_noise(x0, n, t, acp), want)

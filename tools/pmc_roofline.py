@@ -39,6 +39,25 @@ def in_step_averages(summary_md):
     return res
 
 
+def family_times(summary_md):
+    """ms per step of the kernel families and the launch count, from the head of tools/prof_step_summary.py's table (the committed step
+    summary): what bench.py's `roofline_family` divides the families' algorithmic FLOPs by (VERDICT r5 next #4d: the `roofline` object
+    shows the best kernel of its family, this one the family)."""
+    import re
+    fam, head = {}, open(summary_md).readline()
+    for line in open(summary_md):
+        m = re.match(r"\| ([^|]+?) \| (\d+) \| ([\d.]+) \| ([\d.]+) \|$", line.strip())
+        if m and m.group(1) not in ("family",):
+            fam[m.group(1)] = (int(m.group(2)), float(m.group(3)))
+        if line.startswith("| kernel"):
+            break
+    d = re.search(r"(\d+) dispatches per step, kernel time ([\d.]+) ms", head)
+    return {"gemm_ms": fam.get("gemm / implicit conv", (0, 0.0))[1], "gemm_launches": fam.get("gemm / implicit conv", (0, 0.0))[0],
+            "attention_ms": fam.get("attention", (0, 0.0))[1], "attention_launches": fam.get("attention", (0, 0.0))[0],
+            "splitk_reduce_ms": fam.get("split-K reduce", (0, 0.0))[1],
+            "dispatches_per_step": int(d.group(1)) if d else None, "kernel_ms_per_step": float(d.group(2)) if d else None, "source": summary_md}
+
+
 def main(passdir, out, step_summary=None):
     vals = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(f"{passdir}/p*/**/*counter_collection.csv", recursive=True):
@@ -73,6 +92,8 @@ def main(passdir, out, step_summary=None):
             if key in rec:
                 rec[key]["avg_launch_us_in_step"] = us
                 rec[key]["in_step_source"] = step_summary
+    if step_summary:
+        rec["families"] = dict(family_times(step_summary), git=git)
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec, indent=1))
 
