@@ -227,6 +227,7 @@ def main(emu=False):
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="one wgrad launch per layer instead of one grouped launch")
     ap.add_argument("--residual-stream", choices=["auto", "on", "off"], default="auto",
                     help="(hi | lo) residual stream of the transformer blocks (unet.set_residual_stream): auto = stacks of >= 2 blocks (SDXL)")
+    ap.add_argument("--geglu-epilogue", action="store_true", help="opt-in: GEGLU product in the FF projection's epilogue (unet.set_geglu_epilogue; measured slower)")
     ap.add_argument("--grad-ckpt", action="store_true", help="enable_gradient_checkpointing() as the reference defaults to "
                     "(train_base.yaml:69): +1 forward per step; a secondary line, the headline runs without (288 GB HBM)")
     ap.add_argument("--seam", action="store_true", help="secondary line: time the step the way the REFERENCE's Trainer drives the native "
@@ -323,6 +324,8 @@ def main(emu=False):
         unet.enable_gradient_checkpointing()
     if args.residual_stream != "auto":
         unet.set_residual_stream(args.residual_stream == "on")
+    if args.geglu_epilogue:
+        unet.set_geglu_epilogue(True)
     plugin_input = None
     frozen_te_leg = False
     xkw = dict(overlap_exchange=args.exchange != "plain", **(dict(grad_wire="bf16", param_wire="bf16") if args.exchange == "overlap-bf16" else {}))

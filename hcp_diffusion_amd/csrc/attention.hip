@@ -10,7 +10,6 @@
 // rows per wave, argument checks.  Backward = dQ kernel (which also produces delta) + dK/dV kernel: no atomics on the
 // self-attention path, deterministic.
 #include "attn_dma.h"     // second generation: LDS-DMA tiles, one VALU op per score + shared parameter block
-#include "attn_sw.h"      // third generation (forward): softmax(k), QK^T(k+1) and PV(k-1) software-pipelined inside each wave
 
 namespace {
 using namespace hcp_attn;
@@ -38,7 +37,7 @@ HCP_KERNEL(256) attn_dkv_convert_kernel(AttnParams p, int B, int C) {
 }
 
 constexpr int kMinQTilesPerSplit = 16, kSplitTargetWgs = 256;   // cross-attention dK/dV query-loop split (tools/tune_attn_split.py: 8 / 512 gave 78.5 us for the 64x64 backward, 16 / 256 gives 64.0; finer splits lose to the fp32 atomics)
-HCP_TUNABLE(int, g_attn_cfg, -1);   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32, bit3 fwd 8-wave workgroups, bit4 = keep the heuristic for bits 0-3, bit5 / bit6 = force / forbid the generation-3 (software-pipelined) kernels, bits 8-15 / 16-19 = min query tiles per dK/dV split / target workgroups / 256; -1 = heuristic
+HCP_TUNABLE(int, g_attn_cfg, -1);   // tools: bit0 fwd rows/wave 32 (else 16), bit1 dQ 32, bit2 dK/dV 32, bit3 fwd 8-wave workgroups, bit4 = keep the heuristic for bits 0-3, bits 8-15 / 16-19 = min query tiles per dK/dV split / target workgroups / 256; -1 = heuristic
 
 constexpr int VAR_FWD = VAR_PRODUCT | VAR_LSUM;      // forward: lazy rescale from the row sums (exact fallback inside the kernel)
 constexpr int VAR_PRE_BASE = VAR_XCD | VAR_ONES | VAR_PRE;   // Q pre-scaled by its projection: no multiply in front of v_exp_f32
@@ -52,19 +51,6 @@ int launch_fwd(AttnParams& p, int B, hipStream_t stream) {
     else if (p.pre) HCP_LAUNCH((attn2_fwd_kernel<D, QT, false, VAR_FWD_PRE, NW>), dim3(n), dim3(64 * NW), fwd_smem<D>(), stream, p);
     else HCP_LAUNCH((attn2_fwd_kernel<D, QT, false, VAR_FWD, NW>), dim3(n), dim3(64 * NW), fwd_smem<D>(), stream, p);
     HCP_LAUNCH_CHECK("attn_fwd");
-}
-template <int D>
-int launch_fwd3(AttnParams& p, int B, hipStream_t stream) {
-    const int n = hcp_cdiv(p.Nq, 128) * p.H * B;
-    HCP_LAUNCH((attn4_fwd_kernel<D, VAR_PRODUCT, 4>), dim3(n), dim3(256), sw_fwd_smem<D>(), stream, p);
-    HCP_LAUNCH_CHECK("attn_fwd_sw");
-}
-// Generation 3 (software-pipelined waves) serves the long self-attention problems without a key mask: enough 128-row workgroups to
-// fill the chip and enough key tiles for the pipeline to matter.  tools: bit5 forces it wherever it is defined, bit6 forbids it.
-inline bool use_sw(const AttnParams& p, int B, int rows_per_wg) {
-    if (p.kbias || p.causal) return false;
-    (void)B; (void)rows_per_wg;
-    return !p.pre && g_attn_cfg >= 0 && (g_attn_cfg & 32) && !(g_attn_cfg & 64);   // measured no faster than generation 2 + LSUM: tools / tests only
 }
 template <int D, int QT>
 int launch_dq(AttnParams& p, int B, hipStream_t stream) {
@@ -123,9 +109,6 @@ int run_fwd(AttnParams& p, int B, hipStream_t stream) {
     bool wide = kWide<D> && bh * hcp_cdiv(p.Nq, 128) >= 512;
     bool w8 = (D == 40 || D == 80) && bh * hcp_cdiv(p.Nq, D == 40 ? 256 : 128) >= 256;
     if (g_attn_cfg >= 0 && !(g_attn_cfg & 16)) { wide = kWide<D> && (g_attn_cfg & 1); w8 = (D == 40 || D == 80) && (g_attn_cfg & 8); }
-    if constexpr (D == 40 || D == 64 || D == 80) {
-        if (use_sw(p, B, 128)) return launch_fwd3<D>(p, B, stream);
-    }
     if constexpr (D == 40) {
         if (w8) return wide ? launch_fwd<D, 2, 8>(p, B, stream) : launch_fwd<D, 1, 8>(p, B, stream);
         return wide ? launch_fwd<D, 2, 4>(p, B, stream) : launch_fwd<D, 1, 4>(p, B, stream);

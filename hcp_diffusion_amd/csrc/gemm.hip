@@ -827,14 +827,18 @@ HCP_TUNABLE(int, g_use_v2, 1);       // 1: buffer-addressed v2 main loop where i
 HCP_TUNABLE(int, g_epi_tile, -1);    // tools: -1 = the rule below, 0 = lane-layout epilogue everywhere, 1 = tile epilogue wherever it is possible
 HCP_TUNABLE(int, g_force_loaders, -1);   // tools: -1 = as dispatched, 0 = no loader waves, 1 / 3 / 4 = loader-wave variant with a 2 / 3 / 4 tile ring
 
-// Tile epilogue (gemm_params.h: epi_tile_store) for this launch?  Needs an unsplit bf16 output in 16-byte pieces; the rule: outputs of
-// kEpiTileMinBytes or more (below that the launch is latency-bound and the extra LDS round trip + barrier only adds to it).
-constexpr size_t kEpiTileMinBytes = (size_t)1 << 62;       // (off until measured)
-bool want_epi_tile(const GemmParams& p) {
+// Tile epilogue (gemm_params.h: epi_tile_store) for this launch?  Needs an unsplit bf16 output in 16-byte pieces.  The rule, from
+// tools/lab/epilogue_ab.py on rotating operand sets (profiles/r6_ab_tile_epilogue.txt): it wins where the epilogue READS — a plain GEMM
+// (MODE 0) with a residual: to_out / ff.net.2 at 64x64 -5 ... -7 %, neutral at the smaller levels, more with the two extra images of a
+// (hi | lo) stream — because the lane layout fetches the residual in 8-byte pieces that a 5-20 tile main loop cannot hide; it LOSES on
+// pure stores (ff.net.0.proj at 64x64 +20 %: the LDS round trip and its barrier buy nothing, the 8-byte stores were not the limit) and on
+// the convolutions (+5 %: their long K loop already hides the early residual request).  Whole step, tile everywhere: -0.8 % (SD1.5),
+// -1.2 % (SDXL).
+bool want_epi_tile(const GemmParams& p, int mode) {
     if (p.nsplit != 1 || p.out_f32 || p.geglu_hg || p.geglu_out || p.N % 8 || p.ldd % 8 || (p.residual && p.ldr % 8)) return false;
     if ((((size_t)p.D) | ((size_t)p.D_lo) | ((size_t)p.residual) | ((size_t)p.residual_lo)) & 15) return false;
     if (g_epi_tile >= 0) return g_epi_tile == 1;
-    return (size_t)p.M * p.N * sizeof(hcp_bf16) >= kEpiTileMinBytes;
+    return mode == 0 && p.residual != nullptr;
 }
 
 template <int BM, int BN, int WGM, int WGN, int MODE, bool FAST, bool LORA = false, int NSTAGE = 2, int NLD = 0>
@@ -852,7 +856,7 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
                 else p.geglu_out = nullptr;
             }
             constexpr size_t tile_bytes = (size_t)BM * epi_tile_ld(BN) * sizeof(float);
-            p.epi_tile = want_epi_tile(p) && tile_bytes <= 160 * 1024 - eimg ? 1 : 0;
+            p.epi_tile = want_epi_tile(p, MODE) && tile_bytes <= 160 * 1024 - eimg ? 1 : 0;
             size_t smem = 2 * stage;
             const size_t tail = (size_t)(2 * BM + BN) * 40 * sizeof(hcp_bf16);   // fused-LoRA tail images: T_hi, E, T_lo
             if (LORA && smem < tail) smem = tail;
@@ -912,7 +916,7 @@ int try_pp(int id, int mode, bool fast_or_plain, bool lora, GemmParams& p, hipSt
     const int bm = kCfgs[id].bm, bn = kCfgs[id].bn;
     p.tiles_m = hcp_cdiv(p.M, bm);
     p.dbg = g_dbg_ablate;
-    p.epi_tile = want_epi_tile(p) ? 1 : 0;                  // (gemm_pp_launch clears it where the tile does not fit)
+    p.epi_tile = want_epi_tile(p, mode) ? 1 : 0;            // (gemm_pp_launch clears it where the tile does not fit)
     hcp_bf16* const gout = p.geglu_out;                     // GEGLU-forward epilogue: see launch_cfg
     if (gout) {
         if (mode == 0 && p.nsplit == 1 && (p.N / 2) % (bn / 2) == 0) p.geglu_fused = 1;
@@ -1111,7 +1115,7 @@ HCP_API int hcp_debug_set_gemm_glds(int on) { g_use_glds = 1; g_use_v2 = on == 1
 HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; return 0; }
 // TOOLS ONLY: -1 = as the dispatch table says, 0 = never, 1 = the loader-wave variant wherever one is instantiated (tile ids 12-15).
 HCP_API int hcp_debug_set_gemm_loaders(int mode) { g_force_loaders = mode; return 0; }
-// TOOLS ONLY: -1 = the size rule, 0 = lane-layout epilogue everywhere, 1 = tile epilogue (16-byte row pieces through LDS) wherever possible.
+// TOOLS ONLY: -1 = the rule (want_epi_tile), 0 = lane-layout epilogue everywhere, 1 = tile epilogue (16-byte row pieces through LDS) wherever possible.
 HCP_API int hcp_debug_set_gemm_epilogue(int mode) { g_epi_tile = mode; return 0; }
 #endif
 

@@ -261,6 +261,8 @@ class GEGLU(nn.Module):
 
 
 class FeedForward(nn.Module):
+    geglu_in_epilogue = False      # see forward()
+
     def __init__(self, dim):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), HipLinear(dim * 4, dim)])
@@ -270,10 +272,13 @@ class FeedForward(nn.Module):
         if leaf is not None and type(self.net[0]) is GEGLU:
             # GEGLU + output projection as one autograd node: the GEGLU backward rides in the epilogue of the projection's
             # input-gradient GEMM (ops._GegluLinearFn).  A hooked / foreign / dropout leaf keeps the module-by-module path below.
-            pleaf = _ff_out_leaf(self.net[0].proj)
+            pleaf = _ff_out_leaf(self.net[0].proj) if self.geglu_in_epilogue else None
             if pleaf is not None:
-                # ... and the GEGLU product itself comes out of the PROJECTION's epilogue (round 6): formed from the fp32 (h | g), one
-                # rounding instead of two (what the reference's fp32-returning LoRA layer gives GEGLU), no stand-alone pass
+                # OPT-IN (FeedForward.geglu_in_epilogue / unet.set_geglu_epilogue): the GEGLU product out of the PROJECTION's epilogue,
+                # formed from the fp32 (h | g) — one rounding instead of two (what the reference's fp32-returning LoRA layer gives GEGLU),
+                # no stand-alone pass, 16 launches fewer per SD1.5 step.  Off by default: same-box A/B +0.3 % (SD1.5) / +1.7 % (SDXL) —
+                # the projection's epilogue is where that kernel already spends its time (K = C, N = 8 C) — and the SDXL parity
+                # ratios do not move (profiles/r6_ab_geglu_epilogue.txt)
                 hg, act = ops.linear_geglu(x, pleaf[0], pleaf[1])
                 return ops.geglu_linear(hg, leaf[0], leaf[1], residual, gact=act)
             return ops.geglu_linear(self.net[0].proj(x), leaf[0], leaf[1], residual)
@@ -553,6 +558,13 @@ class NativeUNet2DConditionModel(nn.Module):
         for m in self.modules():
             if isinstance(m, Transformer2DModel):
                 m.hi_lo_stream = mode
+        self._hcp_capturable = None
+
+    def set_geglu_epilogue(self, on=True):
+        """Opt-in: form the GEGLU product in the FF projection's GEMM epilogue (FeedForward.forward)."""
+        for m in self.modules():
+            if isinstance(m, FeedForward):
+                m.geglu_in_epilogue = bool(on)
         self._hcp_capturable = None
 
     def disable_gradient_checkpointing(self):

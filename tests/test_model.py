@@ -84,11 +84,13 @@ def test_tiny_forward_with_encoder_attention_mask(backend):
     assert ((yo - yo_nomask).norm() / yo.norm()).item() > 5e-2          # the mask matters for this input
 
 
-def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42, pooled_dim=None, loss_cfg=None, stream=None):
+def _train_step_pair(cfg, backend, rank, shape, ctx_len, ctx_dim, seed=42, pooled_dim=None, loss_cfg=None, stream=None, geglu_epilogue=False):
     dev = backend.device
     ora, nat = _pair(cfg, dev)
     if stream is not None:
         nat.set_residual_stream(stream)
+    if geglu_epilogue:
+        nat.set_geglu_epilogue(True)
     ora.requires_grad_(False)
     wr = wrap_lora(ora, PATS, rank=rank)
     tr = NativeTrainer(nat, [dict(layers=PATS, rank=rank)], lr=1e-3, loss_cfg=loss_cfg)
@@ -181,6 +183,19 @@ def test_tiny_sdxl_lora_train_step_vs_oracle(backend, t_split, monkeypatch):
     a1 = next(m for n, m in tr.unet.named_modules() if n.endswith("attn1"))
     built = sorted(len(k) for k, (g, _) in a1._groups.items() if g is not None)
     assert built == [1, 2] and any(g is None and len(k) == 3 for k, (g, _) in a1._groups.items())
+
+
+def test_geglu_epilogue_option_train_step(backend, monkeypatch):
+    """unet.set_geglu_epilogue(True): the GEGLU product comes out of the FF projection's GEMM epilogue (ops.linear_geglu) — same step
+    within the usual tolerances, with the (hi | lo) stream on top, and the stand-alone geglu_fwd pass is really gone."""
+    calls = {"n": 0}
+    gf = K.geglu_fwd
+    monkeypatch.setattr(K, "geglu_fwd", lambda *a, **k: (calls.__setitem__("n", calls["n"] + 1), gf(*a, **k))[1])
+    lo, ln, go, tr, _ = _train_step_pair(TINY_SDXL_CONFIG, backend, 16, (2, 4, 8, 8), 77, 64, pooled_dim=64, stream=True, geglu_epilogue=True)
+    assert calls["n"] == 0
+    assert abs(lo - ln) / abs(lo) < 2e-2 and F.cosine_similarity(go, tr.bucket.grads.cpu(), dim=0).item() > 0.999
+    lo, ln, go, tr, _ = _train_step_pair(TINY_CONFIG, backend, 4, (2, 4, 8, 8), 77, 64)
+    assert calls["n"] > 0                              # the default keeps the two-pass form (measured faster, DESIGN section 3)
 
 
 def test_hi_lo_residual_stream_train_step(backend, monkeypatch):
