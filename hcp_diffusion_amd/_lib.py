@@ -114,6 +114,7 @@ _TOOLS_PROTOTYPES = {
     "hcp_debug_set_gemm_glds": (I, [I]),
     "hcp_debug_set_gemm_loaders": (I, [I]),
     "hcp_debug_set_gemm_epilogue": (I, [I]),
+    "hcp_debug_set_conv_patch": (I, [I]),
     "hcp_debug_set_gn_target": (I, [I]),
     "hcp_debug_set_gemm_ablation": (I, [I]),
     "hcp_debug_set_attention_config": (I, [I]),

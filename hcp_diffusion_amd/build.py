@@ -11,7 +11,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(__file__).resolve().parent / "libhcp_mi355x.so"
 TOOLS_LIB_PATH = Path(__file__).resolve().parent / "libhcp_mi355x_tools.so"   # same kernels + the hcp_debug_* tuning hooks (-DHCP_TOOLS)
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "norm.hip", "pointwise.hip", "lora.hip", "optim.hip", "wgrad.hip", "pack.hip", "comm.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "conv_patch.hip", "attention.hip", "norm.hip", "pointwise.hip", "lora.hip", "optim.hip", "wgrad.hip", "pack.hip", "comm.hip"]
 
 
 def _hipcc():

@@ -460,6 +460,19 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
     // conv: (tap, channel cursor) of the NEXT tile to issue; advanced by one K tile per issue
     int tap = 0, cb = 0;
     if (MODE != 0) { const int k0 = kt_begin * BK; tap = k0 / Ctot; cb = k0 - tap * Ctot; }
+    // conv: loop-invariant byte offsets per source tensor + "tap invalid" as bit 31 of the offset (see gemm_pp.hip: the per-tile multiply /
+    // compare / select chain was VALU work in front of the MFMAs)
+    unsigned vo1[MODE != 0 ? A_IT : 1], vo2[MODE != 0 ? A_IT : 1], a_nmsk[(A_IT + 2) / 3];
+    if (MODE != 0) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const bool live = va[i] != HCP_BUF_OOB;
+            vo1[i] = live ? va[i] * (unsigned)(2 * p.cv.C1) + a_chunk : HCP_BUF_OOB;
+            vo2[i] = live ? va[i] * (unsigned)(2 * p.cv.C2) + a_chunk : HCP_BUF_OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < (A_IT + 2) / 3; ++i) a_nmsk[i] = ~a_msk[i];
+    }
     const hcp_bf16* Ab = p.A + (size_t)kt_begin * BK;      // MODE 0: first element of this split's first A tile column block
     const hcp_bf16* Bb = p.B + (size_t)kt_begin * BK;
     const hcp_bf16* Lb = LORA ? p.L + (size_t)kt_begin * BK : nullptr;      // fused LoRA: 32 rows of L [32, K], staged by waves 0..3
@@ -493,8 +506,8 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i)
                 if ((i + 1) * RPP <= BM || wave * 8 + RPP * i < BM) {
-                    const unsigned v = ((a_msk[i / 3] >> (9 * (i % 3) + tap)) & 1) ? va[i] * (unsigned)(2 * (first ? p.cv.C1 : p.cv.C2)) + a_chunk : HCP_BUF_OOB;
-                    hcp_buf_glds16(ra, v, la + (wave * 8 + RPP * i) * BK);
+                    const unsigned dead = (a_nmsk[i / 3] >> (9 * (i % 3) + tap)) & 1u;
+                    hcp_buf_glds16(ra, (first ? vo1[i] : vo2[i]) | (dead << 31), la + (wave * 8 + RPP * i) * BK);
                 }
             cb += BK;
             if (cb >= Ctot) { cb -= Ctot; ++tap; }
@@ -824,6 +837,7 @@ HCP_TUNABLE(int, g_dbg_ablate, 0);   // tools only, see GemmParams::dbg
 HCP_TUNABLE(int, g_use_glds, 1);     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
 HCP_TUNABLE(int, g_use_v2, 1);       // 1: buffer-addressed v2 main loop where its requirements hold (default), 0: gemm_glds_kernel everywhere
 
+HCP_TUNABLE(int, g_conv_patch, 1);   // tools: 0 = the ping-pong kernel for every convolution (A/B of conv_patch.hip)
 HCP_TUNABLE(int, g_epi_tile, -1);    // tools: -1 = the rule below, 0 = lane-layout epilogue everywhere, 1 = tile epilogue wherever it is possible
 HCP_TUNABLE(int, g_force_loaders, -1);   // tools: -1 = as dispatched, 0 = no loader waves, 1 / 3 / 4 = loader-wave variant with a 2 / 3 / 4 tile ring
 
@@ -922,7 +936,9 @@ int try_pp(int id, int mode, bool fast_or_plain, bool lora, GemmParams& p, hipSt
         if (mode == 0 && p.nsplit == 1 && (p.N / 2) % (bn / 2) == 0) p.geglu_fused = 1;
         else p.geglu_out = nullptr;
     }
-    const int r = gemm_pp_launch(p, bm, bn, mode, lora, p.loaders - 8, stream);
+    int r = -2;
+    if (mode != 0 && !lora && g_conv_patch) r = conv_patch_launch(p, bm, bn, mode, p.loaders - 8, stream);     // LDS-resident input patch where eligible
+    if (r == -2) r = gemm_pp_launch(p, bm, bn, mode, lora, p.loaders - 8, stream);
     if (r == -2) { p.geglu_out = gout; p.geglu_fused = 0; }     // not instantiated for this tile: the caller's own kernels decide again
     if (r != 0 || p.nsplit <= 1) return r;
     long nv = (long)p.M * (p.N / 4);
@@ -1117,6 +1133,8 @@ HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; retur
 HCP_API int hcp_debug_set_gemm_loaders(int mode) { g_force_loaders = mode; return 0; }
 // TOOLS ONLY: -1 = the rule (want_epi_tile), 0 = lane-layout epilogue everywhere, 1 = tile epilogue (16-byte row pieces through LDS) wherever possible.
 HCP_API int hcp_debug_set_gemm_epilogue(int mode) { g_epi_tile = mode; return 0; }
+// TOOLS ONLY: 1 = default (eligible 3x3 convolutions keep their input as a pixel patch in LDS, conv_patch.hip), 0 = ping-pong kernel only.
+HCP_API int hcp_debug_set_conv_patch(int on) { g_conv_patch = on; return 0; }
 #endif
 
 // Bytes of fp32 split-K workspace that lets every launch of this shape use its preferred decomposition.

@@ -226,5 +226,8 @@ HCP_DEVICE void geglu_tile_apply(const GemmParams& p, const hcp_bf16* tile, int 
 // nsplit, kt_per_split and slabs set by the dispatcher; ring = depth of the LDS ring (2..4, lowered to what fits 160 KB).
 // Returns -2 when no kernel is instantiated for (bm, bn, mode, lora) — the caller then keeps its own kernels.
 int gemm_pp_launch(GemmParams& p, int bm, int bn, int mode, bool lora, int ring, hipStream_t stream);
+// conv_patch.hip — the same workgroup shape with the convolution's input held in LDS as a pixel patch (3x3, stride 1, pad 1, forward and
+// data gradient).  Returns -2 when the launch is not eligible; may round p.kt_per_split up to whole 64-channel chunks (9 K tiles).
+int conv_patch_launch(GemmParams& p, int bm, int bn, int mode, int ring, hipStream_t stream);
 
 }  // namespace hcp_gemm

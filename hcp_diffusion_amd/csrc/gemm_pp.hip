@@ -113,6 +113,22 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
         }
         int tap = 0, cb = 0;                              // conv: (tap, channel cursor) of the NEXT tile to issue
         if (MODE != 0) { const int k0 = kt_begin * BK; tap = k0 / Ctot; cb = k0 - tap * Ctot; }
+        // conv: the per-tile offset of row i is (tap valid ? pixel * 2 C + chunk : out of range).  Formed per tile that was a bit test, a
+        // compare, a 32-bit multiply (quarter rate), an add and a select per row — ~25 VALU issues per K tile in every loader wave, and on gfx950
+        // VALU work of ANY wave on a SIMD holds up the MFMAs of the compute waves it shares the SIMD with (measured with conv_patch.hip,
+        // LAB_NOTEBOOK round 6).  Now: the products are loop invariants (one set per source tensor of a concat) and an invalid tap ORs bit 31
+        // into the offset (>= num_records = out of range): one v_bfe + one v_lshl_or per row.
+        unsigned vo1[MODE != 0 ? A_IT : 1], vo2[MODE != 0 ? A_IT : 1], a_nmsk[(A_IT + 2) / 3];
+        if (MODE != 0) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const bool live = va[i] != HCP_BUF_OOB;
+                vo1[i] = live ? va[i] * (unsigned)(2 * p.cv.C1) + a_chunk : HCP_BUF_OOB;
+                vo2[i] = live ? va[i] * (unsigned)(2 * p.cv.C2) + a_chunk : HCP_BUF_OOB;
+            }
+#pragma unroll
+            for (int i = 0; i < (A_IT + 2) / 3; ++i) a_nmsk[i] = ~a_msk[i];
+        }
         const hcp_bf16* Ab = p.A + (size_t)kt_begin * BK;
         const hcp_bf16* Bb = p.B + (size_t)kt_begin * BK;
         const hcp_bf16* Lb = LORA ? p.L + (size_t)kt_begin * BK : nullptr;
@@ -151,11 +167,11 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
                         const bool first = cb < p.cv.C1;
                         const hcp_bf16* base = first ? p.cv.X1 + (long)doff * p.cv.C1 + cb : p.cv.X2 + (long)doff * p.cv.C2 + (cb - p.cv.C1);
                         const hcp_rsrc ra = hcp_make_rsrc(base);
-                        const unsigned cs2 = (unsigned)(2 * (first ? p.cv.C1 : p.cv.C2));
 #pragma unroll
                         for (int i = 0; i < A_IT; ++i)
                             if (qa + i >= q0 && qa + i < q1) {
-                                const unsigned v = ((a_msk[i / 3] >> (9 * (i % 3) + tap)) & 1) ? va[i] * cs2 + a_chunk : HCP_BUF_OOB;
+                                const unsigned dead = (a_nmsk[i / 3] >> (9 * (i % 3) + tap)) & 1u;
+                                const unsigned v = (first ? vo1[i] : vo2[i]) | (dead << 31);
                                 hcp_buf_glds16(ra, v, la + (wave * 8 + RPP * i) * BK);
                             }
                     }

@@ -1114,6 +1114,47 @@ def test_gemm_tile_epilogue_equals_lane_epilogue(tbackend, variant):
     assert relerr(tile[0], ref) < 1e-2
 
 
+@pytest.mark.parametrize("cfg,ring", [(13, 3), (13, 2), (15, 3)])
+@pytest.mark.parametrize("geom", [(2, 16, 16, 64, 64), (1, 8, 16, 128, 0), (2, 32, 32, 64, 0), (1, 64, 64, 64, 0), (3, 16, 8, 64, 0)])
+def test_conv_patch_kernel(tbackend, cfg, ring, geom):
+    """conv_patch.hip: the 3x3 / stride 1 / pad 1 convolution with its input held in LDS as a pixel patch (forward with bias, residual, a
+    concatenated second input; data gradient; split-K on chunk boundaries) against F.conv2d and against the ping-pong kernel on the same
+    launches (hcp_debug_set_conv_patch(0)); image sizes whose 128-pixel tiles span 2 / 4 / 8 / 16 image rows, one that is not eligible
+    (8 x 16 with W = 8 ... stays on the ping-pong kernel) — forced through the tuning hooks."""
+    B, H, W, C1, C2 = geom
+    if not tbackend.is_gpu and H * W * B > 2048:
+        pytest.skip("large image: GPU only")
+    to = tbackend.to
+    L = K.lib()
+    torch.manual_seed(cfg * 7 + H)
+    Cout = 160 if cfg == 13 else 128
+    x1 = rnd(B, H, W, C1); x2 = rnd(B, H, W, C2) if C2 else None
+    w = rnd(Cout, C1 + C2, 3, 3) * 0.1
+    bias = torch.randn(Cout); res = rnd(B, H, W, Cout)
+    xr = (torch.cat([x1, x2], -1) if C2 else x1).permute(0, 3, 1, 2).float()
+    ref = F.conv2d(xr, w.float(), bias, padding=1).permute(0, 2, 3, 1) + res.float()
+    dy = rnd(B, H, W, Cout)
+    wd = rnd(Cout, C1, 3, 3) * 0.1
+    ref_d = F.conv_transpose2d(dy.permute(0, 3, 1, 2).float(), wd.float(), stride=1, padding=1).permute(0, 2, 3, 1)
+    wp, wdp = to(w.permute(0, 2, 3, 1).contiguous()), to(wd.permute(1, 2, 3, 0).contiguous())
+    outs = {}
+    try:
+        L.hcp_debug_set_gemm_loaders(8 + ring)
+        for patch in (1, 0):
+            L.hcp_debug_set_conv_patch(patch)
+            for split in (1, 2):
+                L.hcp_debug_set_gemm_config(cfg + 16 * split)
+                o = K.conv3x3(to(x1), wp, Cout, x2=to(x2) if C2 else None, bias=to(bias), residual=to(res), out_f32=True)
+                d = K.conv3x3(to(dy), wdp, C1, mode=1, out_hw=(H, W), out_f32=True)
+                assert relerr(o, ref) < 2e-5 * (C1 + C2) ** 0.5 and relerr(d, ref_d) < 2e-5 * Cout ** 0.5, (patch, split)
+                outs[(patch, split)] = (o.cpu(), d.cpu())
+        o16 = K.conv3x3(to(x1), wp, Cout, x2=to(x2) if C2 else None, bias=to(bias), residual=to(res))
+        assert relerr(o16, ref) < 1e-2
+    finally:
+        L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1); L.hcp_debug_set_conv_patch(1)
+    assert relerr(outs[(1, 1)][0], outs[(0, 1)][0]) < 1e-5 and relerr(outs[(1, 2)][1], outs[(0, 1)][1]) < 1e-5
+
+
 def _split_hi_lo(x):
     hi = x.to(BF)
     return hi, (x - hi.float()).to(BF)
