@@ -460,19 +460,6 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
     // conv: (tap, channel cursor) of the NEXT tile to issue; advanced by one K tile per issue
     int tap = 0, cb = 0;
     if (MODE != 0) { const int k0 = kt_begin * BK; tap = k0 / Ctot; cb = k0 - tap * Ctot; }
-    // conv: loop-invariant byte offsets per source tensor + "tap invalid" as bit 31 of the offset (see gemm_pp.hip: the per-tile multiply /
-    // compare / select chain was VALU work in front of the MFMAs)
-    unsigned vo1[MODE != 0 ? A_IT : 1], vo2[MODE != 0 ? A_IT : 1], a_nmsk[(A_IT + 2) / 3];
-    if (MODE != 0) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const bool live = va[i] != HCP_BUF_OOB;
-            vo1[i] = live ? va[i] * (unsigned)(2 * p.cv.C1) + a_chunk : HCP_BUF_OOB;
-            vo2[i] = live ? va[i] * (unsigned)(2 * p.cv.C2) + a_chunk : HCP_BUF_OOB;
-        }
-#pragma unroll
-        for (int i = 0; i < (A_IT + 2) / 3; ++i) a_nmsk[i] = ~a_msk[i];
-    }
     const hcp_bf16* Ab = p.A + (size_t)kt_begin * BK;      // MODE 0: first element of this split's first A tile column block
     const hcp_bf16* Bb = p.B + (size_t)kt_begin * BK;
     const hcp_bf16* Lb = LORA ? p.L + (size_t)kt_begin * BK : nullptr;      // fused LoRA: 32 rows of L [32, K], staged by waves 0..3
@@ -506,8 +493,8 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i)
                 if ((i + 1) * RPP <= BM || wave * 8 + RPP * i < BM) {
-                    const unsigned dead = (a_nmsk[i / 3] >> (9 * (i % 3) + tap)) & 1u;
-                    hcp_buf_glds16(ra, (first ? vo1[i] : vo2[i]) | (dead << 31), la + (wave * 8 + RPP * i) * BK);
+                    const unsigned v = ((a_msk[i / 3] >> (9 * (i % 3) + tap)) & 1) ? va[i] * (unsigned)(2 * (first ? p.cv.C1 : p.cv.C2)) + a_chunk : HCP_BUF_OOB;
+                    hcp_buf_glds16(ra, v, la + (wave * 8 + RPP * i) * BK);
                 }
             cb += BK;
             if (cb >= Ctot) { cb -= Ctot; ++tap; }

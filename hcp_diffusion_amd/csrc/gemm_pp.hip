@@ -167,13 +167,19 @@ HCP_KERNEL(768) gemm_pp_kernel(GemmParams p) {
                         const bool first = cb < p.cv.C1;
                         const hcp_bf16* base = first ? p.cv.X1 + (long)doff * p.cv.C1 + cb : p.cv.X2 + (long)doff * p.cv.C2 + (cb - p.cv.C1);
                         const hcp_rsrc ra = hcp_make_rsrc(base);
+                        // (two copies of the loop under a wave-uniform branch: `first ? vo1[i] : vo2[i]` made hipcc keep both arrays in SCRATCH —
+                        //  a scratch load per row inside the loop, whose vmcnt wait drains the DMA queue: +25 % on every convolution)
+                        if (first) {
 #pragma unroll
-                        for (int i = 0; i < A_IT; ++i)
-                            if (qa + i >= q0 && qa + i < q1) {
-                                const unsigned dead = (a_nmsk[i / 3] >> (9 * (i % 3) + tap)) & 1u;
-                                const unsigned v = (first ? vo1[i] : vo2[i]) | (dead << 31);
-                                hcp_buf_glds16(ra, v, la + (wave * 8 + RPP * i) * BK);
-                            }
+                            for (int i = 0; i < A_IT; ++i)
+                                if (qa + i >= q0 && qa + i < q1)
+                                    hcp_buf_glds16(ra, vo1[i] | (((a_nmsk[i / 3] >> (9 * (i % 3) + tap)) & 1u) << 31), la + (wave * 8 + RPP * i) * BK);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < A_IT; ++i)
+                                if (qa + i >= q0 && qa + i < q1)
+                                    hcp_buf_glds16(ra, vo2[i] | (((a_nmsk[i / 3] >> (9 * (i % 3) + tap)) & 1u) << 31), la + (wave * 8 + RPP * i) * BK);
+                        }
                     }
                 }
             } else {                                      // the rank-32 K-extension tile: plain rows of A2 / B2, k < K2 only
