@@ -39,7 +39,7 @@ def main():
     by_shape = collections.defaultdict(lambda: [0, 0.0])      # GEMM family per (kernel template, workgroups x split-K slabs, threads)
     for s, e, n, shape in sel:
         agg[n][0] += 1; agg[n][1] += (e - s) / 1e3
-        if "gemm_" in n or "attn2_" in n:
+        if "gemm_" in n or "conv_patch" in n or "attn2_" in n:
             by_shape[(n, shape)][0] += 1; by_shape[(n, shape)][1] += (e - s) / 1e3
     # per launch POSITION inside the step (same problem in every step): average over the steps, then cluster per geometry row
     per_step = (hi - lo) // steps
@@ -47,7 +47,7 @@ def main():
     if per_step * steps == hi - lo and all(sel[j][2] == sel[j + per_step][2] for j in range(0, hi - lo - per_step, 37)):
         for j in range(per_step):
             n, shape = sel[j][2], sel[j][3]
-            if "gemm_" in n or "attn2_" in n:
+            if "gemm_" in n or "conv_patch" in n or "attn2_" in n:
                 by_pos[(n, shape)].append(sum((sel[j + k * per_step][1] - sel[j + k * per_step][0]) for k in range(steps)) / steps / 1e3)
 
     def clusters(v):
@@ -61,7 +61,7 @@ def main():
     tot = sum(v[1] for v in agg.values())
     fam = collections.defaultdict(lambda: [0, 0.0])
     for n, (c, t) in agg.items():
-        k = ("attention" if "attn" in n else "gemm / implicit conv" if "gemm_" in n else "split-K reduce" if "splitk" in n else
+        k = ("attention" if "attn" in n else "gemm / implicit conv" if ("gemm_" in n or "conv_patch" in n) else "split-K reduce" if "splitk" in n else
              "GroupNorm" if n.startswith("gn_") else "LayerNorm" if n.startswith("ln_") else "GEGLU" if "geglu" in n else
              "weight gradients" if "wgrad" in n else "optimizer" if "adamw" in n else "torch (at::)" if "at::" in n else "other")
         fam[k][0] += c; fam[k][1] += t
