@@ -139,6 +139,17 @@ def test_integration_doc_quotes_the_shipped_overlay():
         assert (root / "cfgs" / "train" / "mi355x" / name).read_text() in doc, name
 
 
+def test_integration_doc_ctypes_stub_matches_the_binding():
+    """INTEGRATION.md section 3 shows a ctypes stub for hcp_gemm_bf16: its argtypes list and ABI revision must be the binding's own."""
+    import pathlib
+    doc = (pathlib.Path(__file__).resolve().parent.parent / "INTEGRATION.md").read_text()
+    m = re.search(r"lib\.hcp_gemm_bf16\.argtypes = \[(.*?)\]", doc)
+    names = {"P": ctypes.c_void_p, "I": ctypes.c_int, "F": ctypes.c_float, "ctypes.c_size_t": ctypes.c_size_t}
+    got = [names[t.strip()] for t in m.group(1).split(",")]
+    assert got == list(_lib._PROTOTYPES["hcp_gemm_bf16"][1])
+    assert f"lib.hcp_abi_version() == {_lib.ABI_VERSION}" in doc
+
+
 def test_every_overlay_parses_and_extends_a_reference_example():
     """cfgs/train/mi355x/*.yaml: valid YAML, one `_base_` that names an example the reference ships (checked against /root/reference where
     that tree exists), bf16, and every `_target_` under hcp_diffusion_amd resolves to a real attribute."""
