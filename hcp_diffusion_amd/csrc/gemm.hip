@@ -460,6 +460,17 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
     // conv: (tap, channel cursor) of the NEXT tile to issue; advanced by one K tile per issue
     int tap = 0, cb = 0;
     if (MODE != 0) { const int k0 = kt_begin * BK; tap = k0 / Ctot; cb = k0 - tap * Ctot; }
+    // conv with ONE source tensor (every convolution but the up blocks' concat inputs): the row's byte offset pixel * 2 C + chunk is a loop
+    // invariant — kept in va[] itself — and an invalid tap ORs bit 31 into it (>= num_records: zeros); the per-tile form below (bit test,
+    // compare, 32-bit multiply, add, select per row) is VALU work in front of this wave's own MFMAs (gemm_pp.hip, LAB_NOTEBOOK round 6).
+    // (no second array for the concat case: a select between two register arrays sent both to scratch)
+    const bool pre_off = MODE != 0 && p.cv.C2 == 0;
+    if (MODE != 0 && pre_off) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) va[i] = va[i] != HCP_BUF_OOB ? va[i] * (unsigned)(2 * p.cv.C1) + a_chunk : HCP_BUF_OOB;
+#pragma unroll
+        for (int i = 0; i < (A_IT + 2) / 3; ++i) a_msk[i] = ~a_msk[i];
+    }
     const hcp_bf16* Ab = p.A + (size_t)kt_begin * BK;      // MODE 0: first element of this split's first A tile column block
     const hcp_bf16* Bb = p.B + (size_t)kt_begin * BK;
     const hcp_bf16* Lb = LORA ? p.L + (size_t)kt_begin * BK : nullptr;      // fused LoRA: 32 rows of L [32, K], staged by waves 0..3
@@ -490,12 +501,19 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
             const bool first = cb < p.cv.C1;
             const hcp_bf16* base = first ? p.cv.X1 + (long)doff * p.cv.C1 + cb : p.cv.X2 + (long)doff * p.cv.C2 + (cb - p.cv.C1);
             const hcp_rsrc ra = hcp_make_rsrc(base);
+            if (pre_off) {
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i)
-                if ((i + 1) * RPP <= BM || wave * 8 + RPP * i < BM) {
-                    const unsigned v = ((a_msk[i / 3] >> (9 * (i % 3) + tap)) & 1) ? va[i] * (unsigned)(2 * (first ? p.cv.C1 : p.cv.C2)) + a_chunk : HCP_BUF_OOB;
-                    hcp_buf_glds16(ra, v, la + (wave * 8 + RPP * i) * BK);
-                }
+                for (int i = 0; i < A_IT; ++i)
+                    if ((i + 1) * RPP <= BM || wave * 8 + RPP * i < BM)
+                        hcp_buf_glds16(ra, va[i] | (((a_msk[i / 3] >> (9 * (i % 3) + tap)) & 1u) << 31), la + (wave * 8 + RPP * i) * BK);
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i)
+                    if ((i + 1) * RPP <= BM || wave * 8 + RPP * i < BM) {
+                        const unsigned v = ((a_msk[i / 3] >> (9 * (i % 3) + tap)) & 1) ? va[i] * (unsigned)(2 * (first ? p.cv.C1 : p.cv.C2)) + a_chunk : HCP_BUF_OOB;
+                        hcp_buf_glds16(ra, v, la + (wave * 8 + RPP * i) * BK);
+                    }
+            }
             cb += BK;
             if (cb >= Ctot) { cb -= Ctot; ++tap; }
         }

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_step_summary_clusters_launch_positions(tmp_path):
-    conv = "void hcp_gemm::(anonymous namespace)::gemm_pp_kernel<128, 160, 1, false, 4>(hcp_gemm::GemmParams)"
+    conv = "void hcp_gemm::(anonymous namespace)::conv_patch_kernel<128, 160, 1, 3>(hcp_gemm::GemmParams)"
     dq = "void hcp_attn::attn2_bwd_dq_kernel<40, 2, false, 515>(hcp_attn::AttnParams)"
     seq = [(conv, 256 * 768, 1, 768, d) for d in (37, 38, 61, 37, 90, 37, 61, 37, 37, 37)]
     seq += [(dq, 1024 * 256, 1, 256, d) for d in (190, 12, 191, 12)]
@@ -31,7 +31,7 @@ def test_step_summary_clusters_launch_positions(tmp_path):
     out = tmp_path / "summary.md"
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_step_summary.py"), str(tmp_path / "trace"), str(out), "20"], check=True, capture_output=True)
     text = out.read_text()
-    row = next(l for l in text.splitlines() if l.startswith("| hcp_gemm::gemm_pp_kernel<128, 160, 1, false, 4> | 256 | 1 |"))
+    row = next(l for l in text.splitlines() if l.startswith("| hcp_gemm::conv_patch_kernel<128, 160, 1, 3> | 256 | 1 |"))
     cols = [c.strip() for c in row.strip("|").split("|")]
     assert cols[4] == "10.0" and abs(float(cols[5]) - 47.2) < 1.0                 # the row's plain average mixes three problems ...
     cl = [c.split(" x") for c in cols[7].split(" . ")]
@@ -44,14 +44,21 @@ def test_step_summary_clusters_launch_positions(tmp_path):
 
 
 def test_committed_step_summary_carries_the_clusters():
-    """profiles/r5_step_kernel_summary.md (what bench.py's avg_launch_us_in_step is read from) has the position column, and the
-    committed roofline record agrees with it."""
+    """profiles/r6_step_kernel_summary.md (what bench.py's avg_launch_us_in_step and roofline_family are read from) has the position
+    column and the family table, and the committed roofline record agrees with it."""
     import json
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_roofline
-    rec = pmc_roofline.in_step_averages(os.path.join(ROOT, "profiles", "r5_step_kernel_summary.md"))
+    rec = pmc_roofline.in_step_averages(os.path.join(ROOT, "profiles", "r6_step_kernel_summary.md"))
     js = json.load(open(os.path.join(ROOT, "profiles", "pmc_roofline.json")))
     assert set(rec) >= {"conv3x3_c320_64x64_b4", "attn_fwd_b4_h8_n4096_d40", "attn_dq_b4_h8_n4096_d40", "attn_dkv_b4_h8_n4096_d40"}
     for k, v in rec.items():
         assert abs(js[k]["avg_launch_us_in_step"] - v) < 1e-6
     assert 30.0 < rec["conv3x3_c320_64x64_b4"] < 45.0
+    fam = pmc_roofline.family_times(os.path.join(ROOT, "profiles", "r6_step_kernel_summary.md"))
+    assert abs(js["families"]["gemm_ms"] - fam["gemm_ms"]) < 1e-6 and abs(js["families"]["attention_ms"] - fam["attention_ms"]) < 1e-6
+    assert 8.0 < fam["gemm_ms"] < 14.0 and 3.0 < fam["attention_ms"] < 5.0 and 700 < fam["dispatches_per_step"] < 1000
+    sys.path.insert(0, ROOT)
+    import bench
+    rf = bench.family_roofline(4)
+    assert rf and 0.1 < rf["gemm_and_conv"]["frac"] < 0.4 and 0.1 < rf["attention"]["frac"] < 0.4
