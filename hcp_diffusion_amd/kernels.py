@@ -665,24 +665,29 @@ def lora_wgrad_grouped(items):
     L = lib()
     assert L.hcp_lora_wgrad_group_desc_bytes() == 152
     qt0, qt1, sp, rows = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    buf = bytearray()
-    begin = tiles = units = 0
+    ws = _workspace(items[0][1])
     target = max(8, min(256, WGRAD_GRID_BLOCKS // len(items)))     # the layers share one grid: a few thousand workgroups fill the chip
-    for item in items:
-        (U, x, gd, T, dy, gu, r, scale) = item[:8]
-        slot0 = item[8] if len(item) > 8 else 0          # first rank column of this layer inside U / T (fused groups)
-        ulo, tlo = (item[9], item[10]) if len(item) > 10 else (0, 0)
-        M, Kd = x.shape
-        N = dy.shape[1]
-        nb = L.hcp_lora_wgrad_group_geometry(M, Kd, N, r, target, ctypes.byref(qt0), ctypes.byref(qt1), ctypes.byref(sp), ctypes.byref(rows))
-        assert U.stride(1) == 1 and T.stride(1) == 1 and U.stride(0) % 8 == 0 and T.stride(0) % 8 == 0
-        buf += struct.pack("<QiiQi4xQiiii", U.data_ptr(), U.stride(0), ulo, x.data_ptr(), x.stride(0), gd.data_ptr(), Kd, Kd, 0, slot0)
-        buf += struct.pack("<QiiQi4xQiiii", T.data_ptr(), T.stride(0), tlo, dy.data_ptr(), dy.stride(0), gu.data_ptr(), r, N, 1, slot0)
-        buf += struct.pack("<iifiiiiiii", M, r, float(scale), rows.value, qt0.value, qt1.value, sp.value, begin, units, tiles)
-        begin += nb
-        tiles += qt0.value + qt1.value
-        if sp.value > 1:
-            units += nb * r                           # a workgroup's slab: r x 128 floats (a layer with one token range writes its gradient itself)
+    while True:
+        buf = bytearray()
+        begin = tiles = units = 0
+        for item in items:
+            (U, x, gd, T, dy, gu, r, scale) = item[:8]
+            slot0 = item[8] if len(item) > 8 else 0          # first rank column of this layer inside U / T (fused groups)
+            ulo, tlo = (item[9], item[10]) if len(item) > 10 else (0, 0)
+            M, Kd = x.shape
+            N = dy.shape[1]
+            nb = L.hcp_lora_wgrad_group_geometry(M, Kd, N, r, target, ctypes.byref(qt0), ctypes.byref(qt1), ctypes.byref(sp), ctypes.byref(rows))
+            assert U.stride(1) == 1 and T.stride(1) == 1 and U.stride(0) % 8 == 0 and T.stride(0) % 8 == 0
+            buf += struct.pack("<QiiQi4xQiiii", U.data_ptr(), U.stride(0), ulo, x.data_ptr(), x.stride(0), gd.data_ptr(), Kd, Kd, 0, slot0)
+            buf += struct.pack("<QiiQi4xQiiii", T.data_ptr(), T.stride(0), tlo, dy.data_ptr(), dy.stride(0), gu.data_ptr(), r, N, 1, slot0)
+            buf += struct.pack("<iifiiiiiii", M, r, float(scale), rows.value, qt0.value, qt1.value, sp.value, begin, units, tiles)
+            begin += nb
+            tiles += qt0.value + qt1.value
+            if sp.value > 1:
+                units += nb * r                           # a workgroup's slab: r x 128 floats (a layer with one token range writes its gradient itself)
+        if units * 512 <= ws.numel() or target <= 1:      # the slabs fit the workspace (a large model at a large batch: fewer token ranges per layer)
+            break
+        target //= 2
     dev = items[0][1].device
     src = torch.frombuffer(buf, dtype=torch.uint8)
     if dev.type == "cuda":
@@ -713,7 +718,6 @@ def lora_wgrad_grouped(items):
         host, table = slot["host"], slot["table"]
     else:
         host, table = src, src.clone()
-    ws = _workspace(items[0][1])
     _chk(L.hcp_lora_wgrad_grouped(_p(table), len(items), begin, tiles, units, _p(ws), ws.numel(), _stream(table)), "hcp_lora_wgrad_grouped")
     return host, table
 

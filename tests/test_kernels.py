@@ -825,6 +825,24 @@ def test_lora_wgrad_slabs_are_ordered_sums_without_atomics(backend, M, Kd, N, r,
         assert relerr(gd1 - 0.25, rd) < 2e-2 and relerr(gu1 + 0.5, ru) < 2e-2
 
 
+def test_lora_wgrad_grouped_fits_its_slabs_to_the_workspace(backend, monkeypatch):
+    """The partial slabs live in the shared workspace: when a model / batch would need more than it holds, the wrapper lowers the number of
+    token ranges per layer until they fit (down to one range = no slab at all) instead of failing (round 6: SDXL at a grid target of 65536
+    asked for 314 MB of a 256 MB workspace)."""
+    torch.manual_seed(9)
+    to = backend.to
+    dev = backend.device
+    M, Kd, N, r = 1500, 136, 264, 5
+    U, T, x, dy = rnd(M, 32), rnd(M, 32), rnd(M, Kd), rnd(M, N)
+    rd = U.float()[:, :r].T @ x.float(); ru = dy.float().T @ T.float()[:, :r]
+    small = torch.empty(40 * 1024, dtype=torch.uint8, device=dev)            # holds 80 slab units; the default geometry of this layer wants more
+    monkeypatch.setattr(K, "_workspace", lambda t: small)
+    gd = torch.zeros(r, Kd, device=dev); gu = torch.zeros(N, r, device=dev)
+    keep = K.lora_wgrad_grouped([(to(U), to(x), gd, to(T), to(dy), gu, r, 1.0)])
+    assert relerr(gd, rd) < 2e-2 and relerr(gu, ru) < 2e-2
+    del keep
+
+
 def test_lora_wgrad_grouped_takes_a_gradient_named_twice_in_two_passes(backend):
     """The reduce adds without atomics, so one call must not hold two descriptors for the same gradient rows: the wrapper runs the
     second use as a second pass on the stream (a layer that ran twice in one forward)."""
