@@ -6,7 +6,12 @@ the fp32 oracle's INPUT of that module (recorded in one fp32 oracle forward on t
   (b) the same oracle module under torch.autocast(bfloat16) — the reference's execution mode (train_ac.py:449),
 and both outputs are compared with the fp32 oracle's output of the module: per-module rel-L2 of each and their ratio.  Nothing accumulates:
 a ratio well above 1 names the module kind whose native arithmetic is less precise than autocast's.
-   python tools/diag/sdxl_block_diag.py [sd15]        (sd15: the SD1.5 B = 4 benchmark shape instead)
+   python tools/diag/sdxl_block_diag.py [sd15] [lora] [stream-off]
+        sd15: the SD1.5 B = 4 benchmark shape instead.
+        lora (round 6): both models carry the LoRA of the configuration (rank 16 / 8 on attention + feed-forward, seeded non-zero factors) — the
+        oracle through the reference-form layers (oracle/lora_ref.py: mm + fp32 bias, so (b) is the reference's MIXED fp32 / bf16 mode, the
+        baseline of tests/test_full_configs.py), the native one through NativeTrainer's LoRA blocks; stream-off: native transformer stacks
+        with the plain bf16 residual stream (default: (hi | lo) pair where the model turns it on).
 """
 import collections
 import os
@@ -22,7 +27,8 @@ from hcp_diffusion_amd.unet import NativeUNet2DConditionModel                  #
 from oracle.make_golden import sd15_b4_inputs, sdxl_b2_inputs                   # noqa: E402
 from oracle.unet_sd15 import SDXL_CONFIG, OracleUNet2DConditionModel, add_noise, ddpm_alphas_cumprod, seeded_init_   # noqa: E402
 
-sd15 = len(sys.argv) > 1 and sys.argv[1] == "sd15"
+sd15 = "sd15" in sys.argv[1:]
+with_lora = "lora" in sys.argv[1:]
 smoke = os.environ.get("HCP_DIAG_EMU") == "1"                   # CPU smoke test of this script: interpreter kernels, tiny SDXL config
 dev = torch.device("cpu" if smoke else "cuda:0")
 cfg = {} if sd15 else SDXL_CONFIG
@@ -37,6 +43,21 @@ ora = seeded_init_(OracleUNet2DConditionModel(**cfg), 1)
 with torch.device("meta"):
     nat = NativeUNet2DConditionModel(**cfg)
 nat = seeded_init_(nat.to_empty(device=dev), 1)
+if "stream-off" in sys.argv[1:]:
+    nat.set_residual_stream(False)
+if with_lora:
+    from hcp_diffusion_amd.trainer import NativeTrainer
+    from oracle.lora_ref import wrap_lora
+    from oracle.make_golden import sd15_lora_init_
+    PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
+    rank = 8 if sd15 else 16
+    ora.requires_grad_(False)
+    wrap_lora(ora, PATS, rank=rank)
+    sd15_lora_init_([(n, p) for n, p in ora.named_parameters() if "lora_block_" in n])
+    _tr = NativeTrainer(nat, [dict(layers=PATS, rank=rank)], lr=1e-4)
+    sd15_lora_init_([(n, p) for n, p in nat.named_parameters() if "lora_block_" in n])
+    _tr.bucket.pack()
+    assert sorted(n for n, _ in ora.named_parameters() if "lora_block_" in n) == sorted(n for n, _ in nat.named_parameters() if "lora_block_" in n)
 if sd15:
     x0, ehs, noise, t = sd15_b4_inputs(); added = None
 else:
@@ -114,7 +135,7 @@ for n in bnames:
     en, ea = ((bound["native"][n] - r).norm() / r.norm()).item(), ((bound["autocast"][n] - r).norm() / r.norm()).item()
     print(f"  {n:18s} native {en:.3e}  autocast {ea:.3e}  ratio {en / ea:.2f}")
 rel = lambda a: ((a - pred32).norm() / pred32.norm()).item()
-print(f"END TO END (no LoRA): native rel-L2 {rel(pred_n):.3e}, autocast-oracle rel-L2 {rel(pred_a):.3e}, ratio {rel(pred_n) / rel(pred_a):.2f}", flush=True)
+print(f"END TO END ({'with LoRA: (b) is the reference mixed-precision mode' if with_lora else 'no LoRA'}): native rel-L2 {rel(pred_n):.3e}, autocast-oracle rel-L2 {rel(pred_a):.3e}, ratio {rel(pred_n) / rel(pred_a):.2f}", flush=True)
 print(f"native forward with substituted inputs: {time.time() - t0:.1f} s", flush=True)
 
 rows = []
