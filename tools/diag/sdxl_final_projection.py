@@ -1,0 +1,103 @@
+"""GPU-box diagnostic (round 6): WHERE does the native SDXL prediction pick up its excess over the reference's mixed-precision LoRA mode?
+tools/diag/sdxl_block_diag.py lora shows every module at or below the reference mode's error and the CUMULATIVE error at the last block
+boundary (conv_norm_out + SiLU) equal to it (1.92e-2 vs 1.90e-2), yet the predictions differ 2.48e-2 vs 2.06e-2 — the excess appears across
+conv_out, a 2880 -> 4 projection.  This script takes the three feature tensors in front of conv_out (fp32 oracle, oracle under autocast with
+the reference LoRA layers, native) and
+  (1) pushes each through the EXACT fp32 conv_out: what the upstream error alone does to the prediction;
+  (2) splits each feature error into its per-(sample, channel) mean over pixels — a coherent component a 3x3 x 320 projection adds up
+      linearly — and the rest, which adds up like noise;
+  (3) runs conv_out itself three ways on the fp32 features (module error of conv_out).
+   python tools/diag/sdxl_final_projection.py [stream-off]"""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from hcp_diffusion_amd import kernels as K                                     # noqa: E402
+from hcp_diffusion_amd.trainer import NativeTrainer                            # noqa: E402
+from hcp_diffusion_amd.unet import NativeUNet2DConditionModel                  # noqa: E402
+from oracle.lora_ref import wrap_lora                                          # noqa: E402
+from oracle.make_golden import sd15_lora_init_, sdxl_b2_inputs                 # noqa: E402
+from oracle.unet_sd15 import SDXL_CONFIG, OracleUNet2DConditionModel, add_noise, ddpm_alphas_cumprod, seeded_init_   # noqa: E402
+
+smoke = os.environ.get("HCP_DIAG_EMU") == "1"
+dev = torch.device("cpu" if smoke else "cuda:0")
+cfg = SDXL_CONFIG
+if smoke:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import emu_cdll
+    from oracle.unet_sd15 import TINY_SDXL_CONFIG
+    K._set_backend_for_tests(emu_cdll())
+    cfg = TINY_SDXL_CONFIG
+t0 = time.time()
+PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
+ora = seeded_init_(OracleUNet2DConditionModel(**cfg), 1)
+with torch.device("meta"):
+    nat = NativeUNet2DConditionModel(**cfg)
+nat = seeded_init_(nat.to_empty(device=dev), 1)
+if "stream-off" in sys.argv[1:]:
+    nat.set_residual_stream(False)
+ora.requires_grad_(False)
+wrap_lora(ora, PATS, rank=16)
+sd15_lora_init_([(n, p) for n, p in ora.named_parameters() if "lora_block_" in n])
+tr = NativeTrainer(nat, [dict(layers=PATS, rank=16)], lr=1e-4)
+sd15_lora_init_([(n, p) for n, p in nat.named_parameters() if "lora_block_" in n])
+tr.bucket.pack()
+x0, ehs, noise, t, added = sdxl_b2_inputs()
+if smoke:
+    g2 = torch.Generator().manual_seed(1)
+    x0 = torch.randn(2, 4, 16, 16, generator=g2); ehs = torch.randn(2, 24, 64, generator=g2); noise = torch.randn(2, 4, 16, 16, generator=g2)
+    added = dict(text_embeds=torch.randn(2, 64, generator=g2), time_ids=added["time_ids"])
+xt = add_noise(x0, noise, t, ddpm_alphas_cumprod())
+
+feat = {}
+
+
+def grab(tag, native):
+    def f(m, a):
+        x = a[0]
+        feat[tag] = (x.permute(0, 3, 1, 2) if native else x).float().cpu()      # the input of conv_out: silu(conv_norm_out(.)), NCHW fp32
+    return f
+
+
+h = ora.conv_out.register_forward_pre_hook(grab("fp32", False))
+with torch.no_grad():
+    p32 = ora(xt, t, ehs, added_cond_kwargs=added).sample
+    h.remove(); h = ora.conv_out.register_forward_pre_hook(grab("ref", False))
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        pref = ora(xt, t, ehs, added_cond_kwargs=added).sample.float()
+    h.remove(); h = nat.conv_out.register_forward_pre_hook(grab("nat", True))
+    pnat = nat(xt.to(dev), t.to(dev), ehs.to(dev), added_cond_kwargs={k: v.to(dev) for k, v in added.items()}).sample.float().cpu()
+    h.remove()
+rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+print(f"forwards done in {time.time() - t0:.0f} s")
+print(f"prediction rel-L2 vs fp32: reference mode {rel(pref, p32):.3e}   native {rel(pnat, p32):.3e}   ratio {rel(pnat, p32) / rel(pref, p32):.2f}")
+print(f"features in front of conv_out: reference mode {rel(feat['ref'], feat['fp32']):.3e}   native {rel(feat['nat'], feat['fp32']):.3e}")
+w, b = ora.conv_out.weight.float(), ora.conv_out.bias.float()
+exact = lambda x: F.conv2d(x, w, b, padding=1)
+pe = {k: exact(v) for k, v in feat.items()}
+print(f"(1) the features through the EXACT fp32 conv_out: reference mode {rel(pe['ref'], pe['fp32']):.3e}   native {rel(pe['nat'], pe['fp32']):.3e}   "
+      f"ratio {rel(pe['nat'], pe['fp32']) / rel(pe['ref'], pe['fp32']):.2f}")
+for k in ("ref", "nat"):
+    e = feat[k] - feat["fp32"]
+    coh = e.mean(dim=(2, 3), keepdim=True)                                      # per (sample, channel) mean over pixels
+    sm = F.avg_pool2d(e, 8)                                                     # 8 x 8 pixel block means: low spatial frequencies
+    n = feat["fp32"].norm()
+    print(f"(2) {k}: error {e.norm() / n:.3e} = per-channel mean part {(coh.expand_as(e)).norm() / n:.3e} + rest {(e - coh).norm() / n:.3e};  "
+          f"8x8-block-mean part {(F.interpolate(sm, scale_factor=8)).norm() / n:.3e};  through exact conv_out: mean part alone "
+          f"{(exact(feat['fp32'] + coh.expand_as(e)) - pe['fp32']).norm() / pe['fp32'].norm():.3e}, rest alone {(exact(feat['fp32'] + e - coh) - pe['fp32']).norm() / pe['fp32'].norm():.3e}")
+    # relative scale error per (sample, channel): <e, f> / <f, f>
+    f32 = feat["fp32"]
+    sc = (e * f32).sum(dim=(2, 3)) / (f32 * f32).sum(dim=(2, 3))
+    print(f"    per-channel scale error <e,f>/<f,f>: mean {sc.mean():+.3e}, rms {sc.pow(2).mean().sqrt():.3e}; scale part of the error {(sc[:, :, None, None] * f32).norm() / n:.3e}, "
+          f"through exact conv_out {(exact(f32 * (1 + sc[:, :, None, None])) - pe['fp32']).norm() / pe['fp32'].norm():.3e}")
+with torch.no_grad():
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        m_ref = ora.conv_out(feat["fp32"].to(torch.bfloat16)).float()
+    m_nat = nat.conv_out(feat["fp32"].permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)).float().cpu()
+print(f"(3) conv_out alone on the fp32 features: reference mode {rel(m_ref, pe['fp32']):.3e}   native {rel(m_nat, pe['fp32']):.3e}")
+print(f"total {time.time() - t0:.0f} s")
