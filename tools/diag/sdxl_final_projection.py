@@ -7,7 +7,7 @@ the reference LoRA layers, native) and
   (2) splits each feature error into its per-(sample, channel) mean over pixels — a coherent component a 3x3 x 320 projection adds up
       linearly — and the rest, which adds up like noise;
   (3) runs conv_out itself three ways on the fp32 features (module error of conv_out).
-   python tools/diag/sdxl_final_projection.py [stream-off]"""
+   python tools/diag/sdxl_final_projection.py [stream-off] [seeds=N]      (seeds=N: the fixture, then N - 1 other random inputs of the same shapes)"""
 import os
 import sys
 import time
@@ -47,57 +47,70 @@ sd15_lora_init_([(n, p) for n, p in ora.named_parameters() if "lora_block_" in n
 tr = NativeTrainer(nat, [dict(layers=PATS, rank=16)], lr=1e-4)
 sd15_lora_init_([(n, p) for n, p in nat.named_parameters() if "lora_block_" in n])
 tr.bucket.pack()
-x0, ehs, noise, t, added = sdxl_b2_inputs()
-if smoke:
-    g2 = torch.Generator().manual_seed(1)
-    x0 = torch.randn(2, 4, 16, 16, generator=g2); ehs = torch.randn(2, 24, 64, generator=g2); noise = torch.randn(2, 4, 16, 16, generator=g2)
-    added = dict(text_embeds=torch.randn(2, 64, generator=g2), time_ids=added["time_ids"])
-xt = add_noise(x0, noise, t, ddpm_alphas_cumprod())
+def run(seed):
+    global feat
+    feat = {}
+    x0, ehs, noise, t, added = sdxl_b2_inputs()
+    if seed:                                          # other inputs of the same shapes: how much of the prediction ratio is this ONE fixture's draw?
+        g3 = torch.Generator().manual_seed(1000 + seed)
+        x0 = torch.randn(x0.shape, generator=g3); ehs = torch.randn(ehs.shape, generator=g3); noise = torch.randn(noise.shape, generator=g3)
+        t = torch.randint(0, 1000, t.shape, generator=g3)
+        added = dict(text_embeds=torch.randn(added['text_embeds'].shape, generator=g3), time_ids=added['time_ids'])
+    if smoke:
+        g2 = torch.Generator().manual_seed(1)
+        x0 = torch.randn(2, 4, 16, 16, generator=g2); ehs = torch.randn(2, 24, 64, generator=g2); noise = torch.randn(2, 4, 16, 16, generator=g2)
+        added = dict(text_embeds=torch.randn(2, 64, generator=g2), time_ids=added["time_ids"])
+    xt = add_noise(x0, noise, t, ddpm_alphas_cumprod())
 
-feat = {}
 
 
-def grab(tag, native):
-    def f(m, a):
-        x = a[0]
-        feat[tag] = (x.permute(0, 3, 1, 2) if native else x).float().cpu()      # the input of conv_out: silu(conv_norm_out(.)), NCHW fp32
-    return f
+    def grab(tag, native):
+        def f(m, a):
+            x = a[0]
+            feat[tag] = (x.permute(0, 3, 1, 2) if native else x).float().cpu()      # the input of conv_out: silu(conv_norm_out(.)), NCHW fp32
+        return f
 
 
-h = ora.conv_out.register_forward_pre_hook(grab("fp32", False))
-with torch.no_grad():
-    p32 = ora(xt, t, ehs, added_cond_kwargs=added).sample
-    h.remove(); h = ora.conv_out.register_forward_pre_hook(grab("ref", False))
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        pref = ora(xt, t, ehs, added_cond_kwargs=added).sample.float()
-    h.remove(); h = nat.conv_out.register_forward_pre_hook(grab("nat", True))
-    pnat = nat(xt.to(dev), t.to(dev), ehs.to(dev), added_cond_kwargs={k: v.to(dev) for k, v in added.items()}).sample.float().cpu()
-    h.remove()
-rel = lambda a, b: ((a - b).norm() / b.norm()).item()
-print(f"forwards done in {time.time() - t0:.0f} s")
-print(f"prediction rel-L2 vs fp32: reference mode {rel(pref, p32):.3e}   native {rel(pnat, p32):.3e}   ratio {rel(pnat, p32) / rel(pref, p32):.2f}")
-print(f"features in front of conv_out: reference mode {rel(feat['ref'], feat['fp32']):.3e}   native {rel(feat['nat'], feat['fp32']):.3e}")
-w, b = ora.conv_out.weight.float(), ora.conv_out.bias.float()
-exact = lambda x: F.conv2d(x, w, b, padding=1)
-pe = {k: exact(v) for k, v in feat.items()}
-print(f"(1) the features through the EXACT fp32 conv_out: reference mode {rel(pe['ref'], pe['fp32']):.3e}   native {rel(pe['nat'], pe['fp32']):.3e}   "
-      f"ratio {rel(pe['nat'], pe['fp32']) / rel(pe['ref'], pe['fp32']):.2f}")
-for k in ("ref", "nat"):
-    e = feat[k] - feat["fp32"]
-    coh = e.mean(dim=(2, 3), keepdim=True)                                      # per (sample, channel) mean over pixels
-    sm = F.avg_pool2d(e, 8)                                                     # 8 x 8 pixel block means: low spatial frequencies
-    n = feat["fp32"].norm()
-    print(f"(2) {k}: error {e.norm() / n:.3e} = per-channel mean part {(coh.expand_as(e)).norm() / n:.3e} + rest {(e - coh).norm() / n:.3e};  "
-          f"8x8-block-mean part {(F.interpolate(sm, scale_factor=8)).norm() / n:.3e};  through exact conv_out: mean part alone "
-          f"{(exact(feat['fp32'] + coh.expand_as(e)) - pe['fp32']).norm() / pe['fp32'].norm():.3e}, rest alone {(exact(feat['fp32'] + e - coh) - pe['fp32']).norm() / pe['fp32'].norm():.3e}")
-    # relative scale error per (sample, channel): <e, f> / <f, f>
-    f32 = feat["fp32"]
-    sc = (e * f32).sum(dim=(2, 3)) / (f32 * f32).sum(dim=(2, 3))
-    print(f"    per-channel scale error <e,f>/<f,f>: mean {sc.mean():+.3e}, rms {sc.pow(2).mean().sqrt():.3e}; scale part of the error {(sc[:, :, None, None] * f32).norm() / n:.3e}, "
-          f"through exact conv_out {(exact(f32 * (1 + sc[:, :, None, None])) - pe['fp32']).norm() / pe['fp32'].norm():.3e}")
-with torch.no_grad():
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        m_ref = ora.conv_out(feat["fp32"].to(torch.bfloat16)).float()
-    m_nat = nat.conv_out(feat["fp32"].permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)).float().cpu()
-print(f"(3) conv_out alone on the fp32 features: reference mode {rel(m_ref, pe['fp32']):.3e}   native {rel(m_nat, pe['fp32']):.3e}")
-print(f"total {time.time() - t0:.0f} s")
+    h = ora.conv_out.register_forward_pre_hook(grab("fp32", False))
+    with torch.no_grad():
+        p32 = ora(xt, t, ehs, added_cond_kwargs=added).sample
+        h.remove(); h = ora.conv_out.register_forward_pre_hook(grab("ref", False))
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            pref = ora(xt, t, ehs, added_cond_kwargs=added).sample.float()
+        h.remove(); h = nat.conv_out.register_forward_pre_hook(grab("nat", True))
+        pnat = nat(xt.to(dev), t.to(dev), ehs.to(dev), added_cond_kwargs={k: v.to(dev) for k, v in added.items()}).sample.float().cpu()
+        h.remove()
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    print(f"forwards done in {time.time() - t0:.0f} s")
+    print(f"prediction rel-L2 vs fp32: reference mode {rel(pref, p32):.3e}   native {rel(pnat, p32):.3e}   ratio {rel(pnat, p32) / rel(pref, p32):.2f}")
+    print(f"features in front of conv_out: reference mode {rel(feat['ref'], feat['fp32']):.3e}   native {rel(feat['nat'], feat['fp32']):.3e}")
+    w, b = ora.conv_out.weight.float(), ora.conv_out.bias.float()
+    exact = lambda x: F.conv2d(x, w, b, padding=1)
+    pe = {k: exact(v) for k, v in feat.items()}
+    print(f"(1) the features through the EXACT fp32 conv_out: reference mode {rel(pe['ref'], pe['fp32']):.3e}   native {rel(pe['nat'], pe['fp32']):.3e}   "
+          f"ratio {rel(pe['nat'], pe['fp32']) / rel(pe['ref'], pe['fp32']):.2f}")
+    for k in ("ref", "nat"):
+        e = feat[k] - feat["fp32"]
+        coh = e.mean(dim=(2, 3), keepdim=True)                                      # per (sample, channel) mean over pixels
+        sm = F.avg_pool2d(e, 8)                                                     # 8 x 8 pixel block means: low spatial frequencies
+        n = feat["fp32"].norm()
+        print(f"(2) {k}: error {e.norm() / n:.3e} = per-channel mean part {(coh.expand_as(e)).norm() / n:.3e} + rest {(e - coh).norm() / n:.3e};  "
+              f"8x8-block-mean part {(F.interpolate(sm, scale_factor=8)).norm() / n:.3e};  through exact conv_out: mean part alone "
+              f"{(exact(feat['fp32'] + coh.expand_as(e)) - pe['fp32']).norm() / pe['fp32'].norm():.3e}, rest alone {(exact(feat['fp32'] + e - coh) - pe['fp32']).norm() / pe['fp32'].norm():.3e}")
+        # relative scale error per (sample, channel): <e, f> / <f, f>
+        f32 = feat["fp32"]
+        sc = (e * f32).sum(dim=(2, 3)) / (f32 * f32).sum(dim=(2, 3))
+        print(f"    per-channel scale error <e,f>/<f,f>: mean {sc.mean():+.3e}, rms {sc.pow(2).mean().sqrt():.3e}; scale part of the error {(sc[:, :, None, None] * f32).norm() / n:.3e}, "
+              f"through exact conv_out {(exact(f32 * (1 + sc[:, :, None, None])) - pe['fp32']).norm() / pe['fp32'].norm():.3e}")
+    with torch.no_grad():
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            m_ref = ora.conv_out(feat["fp32"].to(torch.bfloat16)).float()
+        m_nat = nat.conv_out(feat["fp32"].permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)).float().cpu()
+    print(f"(3) conv_out alone on the fp32 features: reference mode {rel(m_ref, pe['fp32']):.3e}   native {rel(m_nat, pe['fp32']):.3e}")
+    print(f"total {time.time() - t0:.0f} s")
+
+
+seeds = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("seeds=")]
+for sd in range(seeds[0] if seeds else 1):
+    print(f"==== inputs: {'the configs[3] fixture' if sd == 0 else 'random draw %d' % sd}", flush=True)
+    run(sd)
