@@ -245,10 +245,10 @@ def test_attention_query_split_dkv_clears_its_own_accumulators(tbackend):
 
 @pytest.mark.gpu
 def test_attention_query_split_backward_replayed_as_a_hipgraph():
-    """Regression (round 5): the 64x64 cross-attention backward (B4 H8, 4096 queries x 77 keys: query-split dK/dV with fp32 atomics into the
-    shared workspace) captured in a hipGraph and replayed 200 times with the workspace re-poisoned between replays.  With a
-    hipMemsetAsync NODE clearing the accumulators, replays of the training step intermittently summed onto stale workspace contents
-    (absurd to_k / to_v LoRA gradients, NaN losses in bench.py --seam --seam-graph); the dQ kernel clears them now."""
+    """Regression (round 5): the 64x64 cross-attention backward (B4 H8, 4096 queries x 77 keys: query-split dK/dV through the shared
+    workspace) captured in a hipGraph and replayed 200 times with the workspace re-poisoned between replays.  With a hipMemsetAsync NODE
+    clearing fp32-atomic accumulators, replays of the training step intermittently summed onto stale workspace contents (absurd to_k / to_v
+    LoRA gradients, NaN losses in bench.py --seam --seam-graph).  Round 6: no accumulator at all — one slab per split, summed in order."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     K._set_backend_for_tests(None)
@@ -275,8 +275,9 @@ def test_attention_query_split_backward_replayed_as_a_hipgraph():
         if i % 20 == 19:
             torch.cuda.synchronize()
             assert torch.isfinite(out[1].float()).all() and torch.isfinite(out[2].float()).all(), i
-            # (dK / dV: fp32 atomics in a different order each replay, then one bf16 rounding; dQ is deterministic)
-            assert relerr(out[1], dk0.float().cpu()) < 1e-2 and relerr(out[2], dv0.float().cpu()) < 1e-2 and relerr(out[0], dq0.float().cpu()) < 1e-6, i
+            # round 6: the splits' partials are slabs summed in split order — every replay gives the eager call's bits (rounds 2-5: fp32
+            # atomics in arrival order, compared at 1e-2)
+            assert torch.equal(out[1], dk0) and torch.equal(out[2], dv0) and torch.equal(out[0], dq0), i
 
 
 @pytest.mark.parametrize("cfg", [0, 7, 8, 15])
