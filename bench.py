@@ -135,7 +135,7 @@ def dominant_kernel_roofline(dev):
     dt = _time_rotating([(lambda x=x, w=w: K.conv3x3(x, w, C)) for x, w in sets], rounds=2)
     flops = 2.0 * B * H * H * C * 9 * C
     ach = flops / dt / 1e12
-    out = {"bound": "mfma", "kernel": "implicit-GEMM conv3x3 C320->320 @64x64, B=4 (conv_patch_kernel<128,160,MODE 1, ring 3>: LDS-resident input patch)", "achieved": round(ach, 1),
+    out = {"bound": "mfma", "kernel": "implicit-GEMM conv3x3 C320->320 @64x64, B=4 (gemm_pp_kernel<128,160,MODE 1, ring 4>)", "achieved": round(ach, 1),
            "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach * 1e12 / MFMA_BF16_PEAK, 4),
            "algorithmic_bytes": 22.8e6, "avg_launch_us": round(dt * 1e6, 1), "timing": "HIP events, 24 rotating operand sets (296 MB of inputs), 48 launches",
            "traffic": None}

@@ -842,7 +842,7 @@ HCP_TUNABLE(int, g_dbg_ablate, 0);   // tools only, see GemmParams::dbg
 HCP_TUNABLE(int, g_use_glds, 1);     // 1: LDS-DMA main loop (default), 0: register-staged main loop (kept for A/B measurements)
 HCP_TUNABLE(int, g_use_v2, 1);       // 1: buffer-addressed v2 main loop where its requirements hold (default), 0: gemm_glds_kernel everywhere
 
-HCP_TUNABLE(int, g_conv_patch, 1);   // tools: 0 = the ping-pong kernel for every convolution (A/B of conv_patch.hip)
+HCP_TUNABLE(int, g_conv_patch, 1);   // tools: 0 = the ping-pong kernel for every convolution, 1 = the rule in try_pp, 2 = conv_patch.hip wherever eligible
 HCP_TUNABLE(int, g_epi_tile, -1);    // tools: -1 = the rule below, 0 = lane-layout epilogue everywhere, 1 = tile epilogue wherever it is possible
 HCP_TUNABLE(int, g_force_loaders, -1);   // tools: -1 = as dispatched, 0 = no loader waves, 1 / 3 / 4 = loader-wave variant with a 2 / 3 / 4 tile ring
 
@@ -942,7 +942,11 @@ int try_pp(int id, int mode, bool fast_or_plain, bool lora, GemmParams& p, hipSt
         else p.geglu_out = nullptr;
     }
     int r = -2;
-    if (mode != 0 && !lora && g_conv_patch) r = conv_patch_launch(p, bm, bn, mode, p.loaders - 8, stream);     // LDS-resident input patch where eligible
+    // LDS-resident input patch (conv_patch.hip) where it wins (profiles/r6_ab_conv_patch.txt): data gradients (-4 ... -7 %) and split-K
+    // launches (its chunk-aligned split needs fewer slabs: SDXL C640 @64x64 -25 %); unsplit forward convolutions are 1-10 % faster on the
+    // ping-pong kernel.  tools: g_conv_patch 0 = never, 2 = wherever eligible.
+    if (mode != 0 && !lora && (g_conv_patch == 2 || (g_conv_patch == 1 && (mode == 2 || p.nsplit > 1))))
+        r = conv_patch_launch(p, bm, bn, mode, p.loaders - 8, stream);
     if (r == -2) r = gemm_pp_launch(p, bm, bn, mode, lora, p.loaders - 8, stream);
     if (r == -2) { p.geglu_out = gout; p.geglu_fused = 0; }     // not instantiated for this tile: the caller's own kernels decide again
     if (r != 0 || p.nsplit <= 1) return r;
@@ -1138,7 +1142,7 @@ HCP_API int hcp_debug_set_gemm_ablation(int flags) { g_dbg_ablate = flags; retur
 HCP_API int hcp_debug_set_gemm_loaders(int mode) { g_force_loaders = mode; return 0; }
 // TOOLS ONLY: -1 = the rule (want_epi_tile), 0 = lane-layout epilogue everywhere, 1 = tile epilogue (16-byte row pieces through LDS) wherever possible.
 HCP_API int hcp_debug_set_gemm_epilogue(int mode) { g_epi_tile = mode; return 0; }
-// TOOLS ONLY: 1 = default (eligible 3x3 convolutions keep their input as a pixel patch in LDS, conv_patch.hip), 0 = ping-pong kernel only.
+// TOOLS ONLY: 1 = default (conv_patch.hip for data gradients and split-K launches), 2 = for every eligible 3x3 convolution, 0 = ping-pong kernel only.
 HCP_API int hcp_debug_set_conv_patch(int on) { g_conv_patch = on; return 0; }
 #endif
 

@@ -12,7 +12,7 @@ int hcp_debug_set_gemm_config(int cfg); /* tools/tune_gemm.py only: force tile i
 int hcp_debug_set_gemm_ablation(int flags); /* tools only (wrong results when != 0): 1 no DMA, 2 no MFMA, 4 no LDS reads */
 int hcp_debug_set_gn_target(int workgroups);   /* tools only: workgroups a two-launch GroupNorm aims for (default 512); -1 / -2: one-launch slab path off / on */
 int hcp_debug_set_gemm_epilogue(int mode); /* tools only: -1 size rule, 0 lane-layout epilogue, 1 tile epilogue (16-byte row pieces through LDS) where possible */
-int hcp_debug_set_conv_patch(int on); /* tools only: 0 = no LDS-resident-patch convolution kernel (csrc/conv_patch.hip), 1 = default */
+int hcp_debug_set_conv_patch(int on); /* tools only: 0 = no LDS-resident-patch convolution kernel (csrc/conv_patch.hip), 1 = default rule (data gradients, split-K), 2 = every eligible conv */
 int hcp_debug_set_gemm_loaders(int mode); /* tools only: -1 table, 0 never, 1 / 3 / 4 loader-wave variant with a 2 / 3 / 4 tile LDS ring */
 int hcp_debug_set_gemm_glds(int on);    /* tools only: 1 = default (v2 main loop where eligible), 0/2 = first LDS-DMA loop everywhere */
 int hcp_debug_set_attention_config(int cfg); /* tools only: bit0/1/2 = 32 rows per wave in fwd / dQ / dK,dV; -1 = heuristic */

@@ -1159,7 +1159,7 @@ def test_conv_patch_kernel(tbackend, cfg, ring, geom):
     outs = {}
     try:
         L.hcp_debug_set_gemm_loaders(8 + ring)
-        for patch in (1, 0):
+        for patch in (2, 0):
             L.hcp_debug_set_conv_patch(patch)
             for split in (1, 2):
                 L.hcp_debug_set_gemm_config(cfg + 16 * split)
@@ -1171,7 +1171,7 @@ def test_conv_patch_kernel(tbackend, cfg, ring, geom):
         assert relerr(o16, ref) < 1e-2
     finally:
         L.hcp_debug_set_gemm_config(-1); L.hcp_debug_set_gemm_loaders(-1); L.hcp_debug_set_conv_patch(1)
-    assert relerr(outs[(1, 1)][0], outs[(0, 1)][0]) < 1e-5 and relerr(outs[(1, 2)][1], outs[(0, 1)][1]) < 1e-5
+    assert relerr(outs[(2, 1)][0], outs[(0, 1)][0]) < 1e-5 and relerr(outs[(2, 2)][1], outs[(0, 1)][1]) < 1e-5
 
 
 def _split_hi_lo(x):

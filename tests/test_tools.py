@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_step_summary_clusters_launch_positions(tmp_path):
-    conv = "void hcp_gemm::(anonymous namespace)::conv_patch_kernel<128, 160, 1, 3>(hcp_gemm::GemmParams)"
+    conv = "void hcp_gemm::(anonymous namespace)::gemm_pp_kernel<128, 160, 1, false, 4>(hcp_gemm::GemmParams)"
     dq = "void hcp_attn::attn2_bwd_dq_kernel<40, 2, false, 515>(hcp_attn::AttnParams)"
     seq = [(conv, 256 * 768, 1, 768, d) for d in (37, 38, 61, 37, 90, 37, 61, 37, 37, 37)]
     seq += [(dq, 1024 * 256, 1, 256, d) for d in (190, 12, 191, 12)]
@@ -31,7 +31,7 @@ def test_step_summary_clusters_launch_positions(tmp_path):
     out = tmp_path / "summary.md"
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_step_summary.py"), str(tmp_path / "trace"), str(out), "20"], check=True, capture_output=True)
     text = out.read_text()
-    row = next(l for l in text.splitlines() if l.startswith("| hcp_gemm::conv_patch_kernel<128, 160, 1, 3> | 256 | 1 |"))
+    row = next(l for l in text.splitlines() if l.startswith("| hcp_gemm::gemm_pp_kernel<128, 160, 1, false, 4> | 256 | 1 |"))
     cols = [c.strip() for c in row.strip("|").split("|")]
     assert cols[4] == "10.0" and abs(float(cols[5]) - 47.2) < 1.0                 # the row's plain average mixes three problems ...
     cl = [c.split(" x") for c in cols[7].split(" . ")]

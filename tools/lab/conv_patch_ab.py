@@ -1,7 +1,7 @@
 """GPU lab: the 3x3 convolutions of the SD1.5 / SDXL steps with the LDS-resident input patch (csrc/conv_patch.hip) vs the ping-pong kernel
 (hcp_debug_set_conv_patch), default dispatch, rotating operand sets (cold L2), tools library; then bench.py's step both ways.
    python tools/lab/conv_patch_ab.py                     per-shape table
-   python tools/lab/conv_patch_ab.py step ON <bench args>"""
+   python tools/lab/conv_patch_ab.py step MODE <bench args>      (MODE: 0 never, 1 the product rule, 2 wherever eligible)"""
 import os
 import sys
 
@@ -50,11 +50,11 @@ def table():
         else:
             calls = [(lambda s=s: K.conv3x3(s[0], s[2], Co, mode=1, out_hw=(H, H))) for s in sets]
         t = {}
-        for on in (0, 1, 0, 1):
+        for on in (0, 2, 0, 2):
             L.hcp_debug_set_conv_patch(on)
             t.setdefault(on, []).append(time_rot(calls))
         L.hcp_debug_set_conv_patch(1)
-        a, b = min(t[0]), min(t[1])
+        a, b = min(t[0]), min(t[2])
         fl = 2.0 * B * H * H * Co * 9 * (C1 + C2)
         rows.append((name, a, b))
         print(f"{name:28s} ping-pong {a:8.1f} us   patch {b:8.1f} us   x{b / a:5.3f}   ({fl / b / 1e6:6.0f} TFLOP/s = {fl / b / 1e6 / 2500:.3f} of peak)", flush=True)

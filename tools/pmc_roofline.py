@@ -9,7 +9,7 @@ import subprocess
 import sys
 from collections import defaultdict
 
-KEYS = {"conv3x3_c320_64x64_b4": ("conv_patch_kernel<128, 160, 1", ""),      # MODE = 1 (forward conv), LDS-resident patch (round 6; rounds 4-5: gemm_pp_kernel<128, 160, 1, false)
+KEYS = {"conv3x3_c320_64x64_b4": ("gemm_pp_kernel<128, 160, 1, false", ""),      # MODE = 1 (forward conv), plain (no LoRA), ping-pong loop (conv_patch.hip takes the data gradients and split-K launches)
         "attn_fwd_b4_h8_n4096_d40": ("attn2_fwd_kernel<40", ""),
         "attn_dq_b4_h8_n4096_d40": ("attn2_bwd_dq_kernel<40", ""),
         "attn_dkv_b4_h8_n4096_d40": ("attn2_bwd_dkv_kernel<40", "")}
