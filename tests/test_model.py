@@ -198,6 +198,61 @@ def test_geglu_epilogue_option_train_step(backend, monkeypatch):
     assert calls["n"] > 0                              # the default keeps the two-pass form (measured faster)
 
 
+def test_native_step_matches_the_reference_mixed_precision_mode_over_input_draws(backend):
+    """What tests/test_full_configs.py measures on ONE full-size fixture, here on the SDXL miniature over three input draws: the native step's
+    distance from the fp32 oracle (prediction rel-L2, LoRA-gradient 1 - cos) against the distance of the REFERENCE's execution mode — the
+    same oracle with the reference-form LoRA layers under torch.autocast(bfloat16), whose mm + fp32 bias keeps the transformer stream in
+    fp32.  Round 6 found the full-size fixture's ratios (1.21 / 1.38) to be one draw of quantities that scatter around 1 (DESIGN section 4:
+    the prediction is a 2880 -> 4 projection of an error whose coherent part is a handful of numbers); the mean over draws is the
+    statement, the single draws are printed."""
+    dev = backend.device
+    ora, nat = _pair(TINY_SDXL_CONFIG, dev)
+    ora.requires_grad_(False)
+    wr = wrap_lora(ora, PATS, rank=16)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=16)], lr=1e-3)
+    o_named = sorted((n, p) for n, p in ora.named_parameters() if "lora_block_" in n)
+    n_named = sorted((n, p) for n, p in nat.named_parameters() if "lora_block_" in n)
+    assert [a for a, _ in o_named] == [a for a, _ in n_named]
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for (_, po), (_, pn) in zip(o_named, n_named):
+            po.copy_(torch.randn(po.shape, generator=gen) * (0.05 if po.shape[1] == 16 else po.shape[1] ** -0.5))
+            pn.copy_(po)
+    tr.bucket.pack()
+    acp = ddpm_alphas_cumprod()
+    rp, rg = [], []
+    for draw in range(3):
+        g2 = torch.Generator().manual_seed(100 + draw)
+        x0 = torch.randn(2, 4, 16, 16, generator=g2); ehs = torch.randn(2, 24, 64, generator=g2); noise = torch.randn(2, 4, 16, 16, generator=g2)
+        t = torch.randint(0, 1000, (2,), generator=g2)
+        added = dict(text_embeds=torch.randn(2, 64, generator=g2), time_ids=torch.tensor([[128.0, 128.0, 0.0, 0.0, 128.0, 128.0]] * 2))
+        xt = add_noise(x0, noise, t, acp)
+        res = {}
+        for mode in ("fp32", "ref"):
+            for _, p in o_named:
+                p.grad = None
+            if mode == "ref":
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    pred = ora(xt, t, ehs, added_cond_kwargs=added).sample
+            else:
+                pred = ora(xt, t, ehs, added_cond_kwargs=added).sample
+            F.mse_loss(pred.float(), noise).backward()
+            res[mode] = (pred.detach().float(), torch.cat([p.grad.flatten().double() for _, p in o_named]))
+        tr.bucket.grads.zero_()
+        tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
+        dadd = {k: v.to(dev) for k, v in added.items()}
+        with torch.no_grad():
+            pn = nat(K.add_noise(x0.to(dev), noise.to(dev), t.to(dev), tr.acp), t.to(dev), ehs.to(dev), added_cond_kwargs=dadd).sample.float().cpu()
+        tr.forward_backward(x0.to(dev), ehs.to(dev), None, dadd)
+        gn = torch.cat([p.grad.detach().flatten().double().cpu() for _, p in n_named])
+        p32, g32 = res["fp32"]
+        e = lambda a: ((a - p32).norm() / p32.norm()).item()
+        c = lambda a: 1.0 - float(a @ g32 / (a.norm() * g32.norm()))
+        rp.append(e(pn) / e(res["ref"][0])); rg.append(c(gn) / c(res["ref"][1]))
+    print(f"native / reference-mode error over draws: prediction {[round(v, 2) for v in rp]} mean {sum(rp) / 3:.2f}; gradient (1 - cos) {[round(v, 2) for v in rg]} mean {sum(rg) / 3:.2f}")
+    assert sum(rp) / 3 < 1.15 and sum(rg) / 3 < 1.25 and max(rp) < 1.5 and max(rg) < 1.7
+
+
 def test_hi_lo_residual_stream_train_step(backend, monkeypatch):
     """The transformer blocks' residual stream as a (hi | lo) bf16 pair (Transformer2DModel.hi_lo_stream; "auto" = stacks of >= 2 blocks,
     forced on / off here for every stack): both forms train the SDXL miniature within the usual tolerances, the pair form really runs
