@@ -97,7 +97,9 @@ def test_dreambooth_full_size_two_dataset_step_vs_golden():
 
 # native error / reference-under-autocast error (both against the fp32 oracle), as measured on MI355X + margin; see the test body
 # measured r4: 1.45 / 2.18 (median class 1.59) / 1.29 / 2.61; r5 (split T/U run): 1.46 / 2.15 / 1.29 / 2.96;
-# r6 with the (hi | lo) residual stream (on by default for SDXL's stacks): 1.38-1.41 / 1.92-1.99 (median 1.49-1.52) / 1.20-1.21 / 1.79-1.93
+# r6 with the (hi | lo) residual stream (on by default for SDXL's stacks): 1.38-1.41 / 1.92-1.99 (median 1.49-1.52) / 1.20-1.21 / 1.79-1.93.
+# These are the ratios of THIS fixture's input draw: tools/diag/sdxl_grad_draws.py repeats the comparison on six other draws — prediction
+# 0.90 ... 1.05, flat gradient 0.65 ... 1.17, means of the seven 1.01 / 1.02 (profiles/r6_diag_sdxl_grad_draws.txt).
 R_SDXL_FLAT, R_SDXL_CLASS, R_SDXL_PRED, R_SDXL_TENSOR = 1.6, 2.4, 1.35, 2.4
 
 
