@@ -368,6 +368,19 @@ def sdxl_b2_inputs():
     return x0, ehs, noise, t, added
 
 
+def sdxl_b2_draw_inputs(draw):
+    """Inputs of the configs[3] shape for another DRAW (round 6: the parity ratios of one fixture are one draw of quantities that scatter,
+    DESIGN section 4): draw 0 = sdxl_b2_inputs(); draw d > 0 = latents, prompt / pooled states, noise and timesteps from seed 1000 + d.
+    Used by tools/diag/sdxl_grad_draws.py (which writes tests/golden/sdxl_b2_draw<d>_oracle.pt on the GPU box's host cores) and by the test."""
+    x0, ehs, noise, t, added = sdxl_b2_inputs()
+    if draw:
+        g3 = torch.Generator().manual_seed(1000 + draw)
+        x0 = torch.randn(x0.shape, generator=g3); ehs = torch.randn(ehs.shape, generator=g3); noise = torch.randn(noise.shape, generator=g3)
+        t = torch.randint(0, 1000, t.shape, generator=g3)
+        added = dict(text_embeds=torch.randn(added["text_embeds"].shape, generator=g3), time_ids=added["time_ids"])
+    return x0, ehs, noise, t, added
+
+
 def sdxl_b2_vectors():
     """Full SDXL-base (2.567 B parameters), LoRA rank 16 on attn / ff (700 layers, 41,861,120 LoRA parameters): prediction, loss and
     the ENTIRE flat LoRA gradient (int8, one absmax scale per tensor) of the fp32 oracle with the reference-form merged-weight LoRA."""

@@ -166,6 +166,46 @@ def test_sdxl_full_size_b2_1024px_full_lora_gradient_vs_golden():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("draw", [1, 2])
+def test_sdxl_full_size_b2_other_input_draws_vs_golden(draw):
+    """configs[3] on OTHER input draws than the fixture above (round 6): tests/golden/sdxl_b2_draw<d>_oracle.pt holds, for
+    latents / prompt states / noise / timesteps from seed 1000 + d, the fp32 oracle's prediction, a seeded 2 M-element sketch of its flat LoRA
+    gradient and the distances of the REFERENCE's mixed-precision LoRA mode (the same oracle under autocast) from both — written by
+    tools/diag/sdxl_grad_draws.py save=... on the GPU box's host cores.  The first fixture's ratios (prediction 1.20, gradient 1.38) are
+    the worst of seven draws; on these two the native step must be within 1.2 x the reference mode's error on BOTH counts (measured:
+    0.96 / 0.65 and 0.97 / 0.82) — the bar VERDICT r5 set for the flat ratio."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle.make_golden import sd15_lora_init_, sdxl_b2_draw_inputs
+    K._set_backend_for_tests(None)
+    dev = torch.device("cuda:0")
+    g = torch.load(os.path.join(GOLD, f"sdxl_b2_draw{draw}_oracle.pt"))
+    nat = _native_full(dev, SDXL_CONFIG)
+    tr = NativeTrainer(nat, [dict(layers=PATS, rank=16)], lr=1e-4)
+    named = sorted((n, p) for n, p in nat.named_parameters() if "lora_block_" in n)
+    assert [n for n, _ in named] == g["names"]
+    sd15_lora_init_(named)
+    tr.bucket.pack()
+    x0, ehs, noise, t, added = sdxl_b2_draw_inputs(draw)
+    added = {k: v.to(dev) for k, v in added.items()}
+    tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
+    with torch.no_grad():
+        pred = nat(K.add_noise(x0.to(dev), noise.to(dev), t.to(dev), tr.acp), t.to(dev), ehs.to(dev), added_cond_kwargs=added).sample.float().cpu()
+    ref_pred = g["pred"].float()
+    r_pred = ((pred - ref_pred).norm() / ref_pred.norm()).item() / g["pred_rel_ref"]
+    tr.forward_backward(x0.to(dev), ehs.to(dev), None, added)
+    flat = torch.cat([p.grad.detach().flatten().double().cpu() for _, p in named])
+    idx = torch.randint(0, flat.numel(), (g["sketch_n"],), generator=torch.Generator().manual_seed(g["sketch_seed"]))
+    sk, ref = flat[idx], g["sketch_fp32"].double() * g["sketch_scale"]
+    cos = float(sk @ ref / (sk.norm() * ref.norm()))
+    r_grad = (1.0 - cos) / (1.0 - g["ref_sketch_cos"])
+    print(f"[sdxl b2 draw {draw}] native / reference-mode error: prediction {r_pred:.2f}, LoRA gradient (1 - cos, 2 M-element sketch) {r_grad:.2f} "
+          f"(reference mode: pred rel-L2 {g['pred_rel_ref']:.3e}, sketch cos {g['ref_sketch_cos']:.5f}); |g| {flat.norm().item():.5f} vs {g['grad_norm']:.5f}")
+    assert r_pred < 1.2 and r_grad < 1.2
+    assert abs(flat.norm().item() - g["grad_norm"]) / g["grad_norm"] < 2e-2
+
+
+@pytest.mark.gpu
 def test_controlnet_full_size_b4_branch_gradients_vs_golden():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

@@ -5,7 +5,8 @@ tools/diag/sdxl_final_projection.py showed the prediction ratio of the fixture (
 loss gradient dL/dpred carries the prediction error into EVERY LoRA gradient, so the gradient ratios should scatter with it; this script
 measures that: per draw one fp32 and one autocast forward + backward of the oracle with the reference-form LoRA layers on the host cores
 (~15 minutes), one native step on the GPU.
-   python tools/diag/sdxl_grad_draws.py first=1 n=2        (draw 0 = the fixture's inputs)"""
+   python tools/diag/sdxl_grad_draws.py first=1 n=2 [stream-off] [save=DIR]       (draw 0 = the fixture's inputs; save: a compact fixture per
+   draw — fp32 prediction, a 2 M-element seeded sketch of the fp32 LoRA gradient, the reference mode's distances — for tests/test_full_configs.py)"""
 import os
 import sys
 import time
@@ -20,7 +21,7 @@ from hcp_diffusion_amd.trainer import NativeTrainer                            #
 from hcp_diffusion_amd.unet import NativeUNet2DConditionModel                  # noqa: E402
 import oracle.unet_sd15 as U                                                   # noqa: E402
 from oracle.lora_ref import wrap_lora                                          # noqa: E402
-from oracle.make_golden import lora_tensor_class, sd15_lora_init_, sdxl_b2_inputs   # noqa: E402
+from oracle.make_golden import lora_tensor_class, sd15_lora_init_, sdxl_b2_draw_inputs   # noqa: E402
 from oracle.unet_sd15 import SDXL_CONFIG, OracleUNet2DConditionModel, add_noise, ddpm_alphas_cumprod, seeded_init_   # noqa: E402
 
 smoke = os.environ.get("HCP_DIAG_EMU") == "1"
@@ -31,7 +32,9 @@ if smoke:
     from conftest import emu_cdll
     K._set_backend_for_tests(emu_cdll())
     cfg = U.TINY_SDXL_CONFIG
-arg = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}
+arg_s = {a.split("=")[0]: a.split("=")[1] for a in sys.argv[1:] if "=" in a}
+arg = {k: int(v) for k, v in arg_s.items() if v.isdigit()}
+SKETCH = 2_000_000
 first, n = arg.get("first", 1), arg.get("n", 2)
 U.ATTN_RECOMPUTE = True                                  # identical arithmetic; the N x N score tensors are not kept for backward
 PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
@@ -78,16 +81,11 @@ def cosines(flat, ref):
 
 
 for d in range(first, first + n):
-    x0, ehs, noise, t, added = sdxl_b2_inputs()
+    x0, ehs, noise, t, added = sdxl_b2_draw_inputs(d)
     if smoke:
-        g2 = torch.Generator().manual_seed(1)
+        g2 = torch.Generator().manual_seed(1 + d)
         x0 = torch.randn(2, 4, 16, 16, generator=g2); ehs = torch.randn(2, 24, 64, generator=g2); noise = torch.randn(2, 4, 16, 16, generator=g2)
         added = dict(text_embeds=torch.randn(2, 64, generator=g2), time_ids=added["time_ids"])
-    if d:
-        g3 = torch.Generator().manual_seed(1000 + d)           # the draws of tools/diag/sdxl_final_projection.py
-        x0 = torch.randn(x0.shape, generator=g3); ehs = torch.randn(ehs.shape, generator=g3); noise = torch.randn(noise.shape, generator=g3)
-        t = torch.randint(0, 1000, t.shape, generator=g3)
-        added = dict(text_embeds=torch.randn(added["text_embeds"].shape, generator=g3), time_ids=added["time_ids"])
     inputs = (x0, ehs, noise, t, added)
     p32, g32 = oracle_step(inputs, False)
     print(f"draw {d}: fp32 oracle step done at {time.time() - t0:.0f} s", flush=True)
@@ -103,6 +101,15 @@ for d in range(first, first + n):
     cr, clr = cosines(gac, g32)
     cn, cln = cosines(gn, g32)
     ratios = sorted((1 - cln[k]) / max(1 - clr[k], 1e-12) for k in cln)
+    if "save" in arg_s:                                  # a compact fixture of this draw for tests/test_full_configs.py (oracle/ is the checker: the
+        gs = torch.Generator().manual_seed(77 + d)        # numbers below are the ORACLE's, the test recomputes the native side)
+        idx = torch.randint(0, g32.numel(), (SKETCH,), generator=gs)
+        sk32, skac = g32[idx], gac[idx]
+        sc = float(sk32.abs().max())
+        torch.save(dict(draw=d, pred=p32.half(), pred_rel_ref=rel(pac), sketch_seed=77 + d, sketch_n=SKETCH, sketch_scale=sc,
+                        sketch_fp32=(sk32 / sc).half(), ref_sketch_cos=float(skac @ sk32 / (skac.norm() * sk32.norm())), ref_flat_cos=cr,
+                        native_at_generation=dict(pred_rel=rel(pn), flat_cos=cn), grad_norm=float(g32.norm()), names=[a for a, _ in o_named]),
+                   os.path.join(arg_s["save"], f"sdxl_b2_draw{d}_oracle.pt"))
     print(f"draw {d}: prediction rel-L2 reference mode {rel(pac):.3e} native {rel(pn):.3e} ratio {rel(pn) / rel(pac):.2f};  flat gradient 1 - cos reference mode "
           f"{1 - cr:.3e} native {1 - cn:.3e} ratio {(1 - cn) / (1 - cr):.2f};  per class: median {ratios[len(ratios) // 2]:.2f}, worst {ratios[-1]:.2f}", flush=True)
 print(f"total {time.time() - t0:.0f} s")
