@@ -16,6 +16,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
+def pytest_xdist_auto_num_workers(config):
+    """`-n auto` (pytest.ini): workers for the CPU suite (interpreted kernels: CPU-bound, ~1 GB each), none for a run that selects the GPU
+    tests (one device, full-size SD1.5 / SDXL models: they must not run side by side)."""
+    expr = (config.getoption("markexpr", "") or "").replace(" ", "")
+    if "gpu" in expr and "notgpu" not in expr:
+        return 0
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(6, n - 2 if n > 3 else n))
+
+
 _emu_cdll = None
 
 
