@@ -5,6 +5,7 @@ tools/diag/sdxl_final_projection.py showed the prediction ratio of the fixture (
 loss gradient dL/dpred carries the prediction error into EVERY LoRA gradient, so the gradient ratios should scatter with it; this script
 measures that: per draw one fp32 and one autocast forward + backward of the oracle with the reference-form LoRA layers on the host cores
 (~15 minutes), one native step on the GPU.
+   python tools/diag/sdxl_grad_draws.py [sd15] first=1 n=2 [stream-off] [save=DIR]       (sd15: BASELINE configs[1] instead — SD1.5, B 4, rank 8)
    python tools/diag/sdxl_grad_draws.py first=1 n=2 [stream-off] [save=DIR]       (draw 0 = the fixture's inputs; save: a compact fixture per
    draw — fp32 prediction, a 2 M-element seeded sketch of the fp32 LoRA gradient, the reference mode's distances — for tests/test_full_configs.py)"""
 import os
@@ -21,12 +22,14 @@ from hcp_diffusion_amd.trainer import NativeTrainer                            #
 from hcp_diffusion_amd.unet import NativeUNet2DConditionModel                  # noqa: E402
 import oracle.unet_sd15 as U                                                   # noqa: E402
 from oracle.lora_ref import wrap_lora                                          # noqa: E402
-from oracle.make_golden import lora_tensor_class, sd15_lora_init_, sdxl_b2_draw_inputs   # noqa: E402
+from oracle.make_golden import lora_tensor_class, sd15_b4_inputs, sd15_lora_init_, sdxl_b2_draw_inputs   # noqa: E402
 from oracle.unet_sd15 import SDXL_CONFIG, OracleUNet2DConditionModel, add_noise, ddpm_alphas_cumprod, seeded_init_   # noqa: E402
 
 smoke = os.environ.get("HCP_DIAG_EMU") == "1"
 dev = torch.device("cpu" if smoke else "cuda:0")
-cfg = SDXL_CONFIG
+sd15 = "sd15" in sys.argv[1:]
+cfg = {} if sd15 else SDXL_CONFIG
+RANK = 8 if sd15 else 16
 if smoke:
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import emu_cdll
@@ -41,7 +44,7 @@ PATS = [r"re:.*\.attn.?$", r"re:.*\.ff$"]
 t0 = time.time()
 ora = seeded_init_(OracleUNet2DConditionModel(**cfg), 1)
 ora.requires_grad_(False)
-wrap_lora(ora, PATS, rank=16)
+wrap_lora(ora, PATS, rank=RANK)
 o_named = sorted((nm, p) for nm, p in ora.named_parameters() if "lora_block_" in nm)
 sd15_lora_init_(o_named)
 with torch.device("meta"):
@@ -49,12 +52,18 @@ with torch.device("meta"):
 nat = seeded_init_(nat.to_empty(device=dev), 1)
 if "stream-off" in sys.argv[1:]:
     nat.set_residual_stream(False)
-tr = NativeTrainer(nat, [dict(layers=PATS, rank=16)], lr=1e-4)
+tr = NativeTrainer(nat, [dict(layers=PATS, rank=RANK)], lr=1e-4)
 n_named = sorted((nm, p) for nm, p in nat.named_parameters() if "lora_block_" in nm)
 assert [a for a, _ in o_named] == [a for a, _ in n_named]
 sd15_lora_init_(n_named)
 tr.bucket.pack()
 acp = ddpm_alphas_cumprod()
+
+
+def okw(added, device=None):
+    if added is None:
+        return {}
+    return {"added_cond_kwargs": {k: (v.to(device) if device is not None else v) for k, v in added.items()}}
 
 
 def oracle_step(inputs, autocast):
@@ -64,9 +73,9 @@ def oracle_step(inputs, autocast):
     xt = add_noise(x0, noise, t, acp)
     if autocast:
         with torch.autocast("cpu", dtype=torch.bfloat16):
-            pred = ora(xt, t, ehs, added_cond_kwargs=added).sample
+            pred = ora(xt, t, ehs, **okw(added)).sample
     else:
-        pred = ora(xt, t, ehs, added_cond_kwargs=added).sample
+        pred = ora(xt, t, ehs, **okw(added)).sample
     F.mse_loss(pred.float(), noise).backward()
     return pred.detach().float(), torch.cat([p.grad.flatten().double() for _, p in o_named])
 
@@ -81,8 +90,15 @@ def cosines(flat, ref):
 
 
 for d in range(first, first + n):
-    x0, ehs, noise, t, added = sdxl_b2_draw_inputs(d)
-    if smoke:
+    if sd15:
+        x0, ehs, noise, t = sd15_b4_inputs(); added = None
+        if d:
+            g3 = torch.Generator().manual_seed(2000 + d)
+            x0 = torch.randn(x0.shape, generator=g3); ehs = torch.randn(ehs.shape, generator=g3); noise = torch.randn(noise.shape, generator=g3)
+            t = torch.randint(0, 1000, t.shape, generator=g3)
+    else:
+        x0, ehs, noise, t, added = sdxl_b2_draw_inputs(d)
+    if smoke and not sd15:
         g2 = torch.Generator().manual_seed(1 + d)
         x0 = torch.randn(2, 4, 16, 16, generator=g2); ehs = torch.randn(2, 24, 64, generator=g2); noise = torch.randn(2, 4, 16, 16, generator=g2)
         added = dict(text_embeds=torch.randn(2, 64, generator=g2), time_ids=added["time_ids"])
@@ -94,8 +110,8 @@ for d in range(first, first + n):
     tr.bucket.grads.zero_()
     tr.make_noise = lambda lat: (K.add_noise(lat, noise.to(dev), t.to(dev), tr.acp), noise.to(dev), t.to(dev))
     with torch.no_grad():
-        pn = nat(K.add_noise(x0.to(dev), noise.to(dev), t.to(dev), tr.acp), t.to(dev), ehs.to(dev), added_cond_kwargs={k: v.to(dev) for k, v in added.items()}).sample.float().cpu()
-    tr.forward_backward(x0.to(dev), ehs.to(dev), None, {k: v.to(dev) for k, v in added.items()})
+        pn = nat(K.add_noise(x0.to(dev), noise.to(dev), t.to(dev), tr.acp), t.to(dev), ehs.to(dev), **okw(added, dev)).sample.float().cpu()
+    tr.forward_backward(x0.to(dev), ehs.to(dev), None, {k: v.to(dev) for k, v in added.items()} if added else None)
     gn = torch.cat([p.grad.detach().flatten().double().cpu() for _, p in n_named])
     rel = lambda a: ((a - p32).norm() / p32.norm()).item()
     cr, clr = cosines(gac, g32)
