@@ -6,6 +6,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd $root
+python tools/box_info.py > $out/box.json 2>/dev/null      # which box produced this evidence (unique id, partitions, driver, firmware)
 (timeout 1500 python -X faulthandler -m pytest tests -m gpu -v -rP -p no:cacheprovider > $out/gpu_tests.log 2>&1; echo "rc=$?" >> $out/gpu_tests.log)   # verbose + faulthandler: a crash names its test; -rP: the parity lines the full-size tests print
 tail -2 $out/gpu_tests.log
 python bench.py --steps 100 --warmup 20 > $out/bench_sd15.json 2> $out/bench_sd15.err
