@@ -31,16 +31,17 @@ class LoraHipContainer(PatchPluginContainer):
     def forward(self, x, residual=None, **kwargs):
         return self._run(tuple(self.plugin_names), x, residual, **kwargs)
 
-    def _run(self, names, x, residual=None, **kwargs):
+    def _run(self, names, x, residual=None, drop_block=None, **kwargs):
         """The host layer with the LoRA blocks `names` (plugin names of this container) applied — all of them for the plain container;
-        one branch's for DAPPHipContainer."""
+        one branch's for DAPPHipContainer.  drop_block: the block whose dropout acts on the output (default: the last of `names`; the
+        DAPP container hands the container's LAST plugin to BOTH halves, lora_layers_patch.py:132-133)."""
         blocks = [self[n] for n in names]
         b0 = blocks[0]
         if b0.merged or (b0.host_type == "conv" and len(blocks) > 1 and
                          (sum(8 * ((b.rank + 7) // 8) for b in blocks) > RANK_SLOT or any(b.wide for b in blocks))):
             # conv_in / conv_out, or stacked blocks on a 3x3 conv whose ranks do not fit the 32 rank slots: the reference's merged-weight
             # form through the host's own kernels (ops._MergedLoraFn) — any number of blocks, any ranks
-            last = blocks[-1]
+            last = drop_block if drop_block is not None else blocks[-1]
             drop = last.dropout.p > 0.0 and last.training
             y = ops.merged_lora_call(self._host, blocks, x, residual=None if drop else residual, **kwargs)
             return self._dropped(y, last, residual) if drop else y
@@ -50,7 +51,7 @@ class LoraHipContainer(PatchPluginContainer):
                 if self._multis is None:
                     self._multis = {}
                 multi = self._multis[names] = MultiLora(blocks, names)
-            last = blocks[-1]                          # the reference applies the LAST block's dropout (lora_base_patch.py:35)
+            last = drop_block if drop_block is not None else blocks[-1]      # the reference applies the LAST block's dropout (lora_base_patch.py:35)
             drop = last.dropout.p > 0.0 and last.training
             if multi.host_type == "conv":              # 3x3 host: T = conv3x3(x, [W_down_0; W_down_1; ...]) fills the shared rank slots
                 host = self._host
@@ -63,16 +64,17 @@ class LoraHipContainer(PatchPluginContainer):
                 return self._dropped(ops.linear(x, self._host, multi, None), last, residual)
             return ops.linear(x, self._host, multi, residual)
         blk = blocks[0]
-        drop = blk.dropout.p > 0.0 and blk.training
+        dblk = drop_block if drop_block is not None else blk
+        drop = dblk.dropout.p > 0.0 and dblk.training
         if blk.host_type == "conv":                    # 3x3 host: same keyword surface as HipConv2d.forward
             host = self._host
             y = ops.conv3x3(x, host, x2=kwargs.pop("x2", None), rowbias=kwargs.pop("rowbias", None), residual=None if drop else residual,
                             stride=host.stride[0], upsample=kwargs.pop("upsample", False), lora=blk, **kwargs)
-            return self._dropped(y, blk, residual) if drop else y
+            return self._dropped(y, dblk, residual) if drop else y
         if kwargs:
             raise NotImplementedError(f"LoraHipContainer: unsupported call arguments {list(kwargs)}")
         if drop:
-            return self._dropped(ops.linear(x, self._host, blk, None), blk, residual)
+            return self._dropped(ops.linear(x, self._host, blk, None), dblk, residual)
         return ops.linear(x, self._host, blk, residual)
 
     @staticmethod
@@ -245,14 +247,14 @@ class DAPPHipContainer(LoraHipContainer):
         if not names["p"] or not names["n"]:
             raise ValueError("dapp_hip: a host needs at least one 'p' and one 'n' branch block (the reference adds None to the host weight "
                              "otherwise, lora_layers_patch.py:131-133)")
-        if kwargs:
-            raise NotImplementedError(f"dapp_hip: unsupported call arguments {list(kwargs)}")
         B = x.shape[0] // 2
-        last = self.plugin_names[-1]                    # post_forward of the LAST plugin (its dropout), lora_layers_patch.py:132-133
-        order = lambda ns: tuple(n for n in ns if n != last) + ((last,) if last in ns else ())
-        rn, rp = (residual[:B], residual[B:]) if residual is not None else (None, None)
-        y_n = self._run(order(names["n"]), x[:B], rn)
-        y_p = self._run(order(names["p"]), x[B:], rp)
+        last = self[self.plugin_names[-1]]              # post_forward of the LAST plugin — its dropout — for BOTH halves (lora_layers_patch.py:132-133)
+        half = lambda t, lo: None if t is None else (t[:B] if lo else t[B:])
+        # per-sample call arguments of a conv host (ResnetBlock2D: rowbias = the time-embedding projection, x2 = a concatenated input) follow
+        # their half of the batch; `upsample` is a flag
+        kw = lambda lo: {k: (half(v, lo) if torch.is_tensor(v) else v) for k, v in kwargs.items()}
+        y_n = self._run(names["n"], x[:B], half(residual, True), drop_block=last, **kw(True))
+        y_p = self._run(names["p"], x[B:], half(residual, False), drop_block=last, **kw(False))
         return torch.cat([y_n, y_p], dim=0)
 
 

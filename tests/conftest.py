@@ -16,6 +16,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
+@pytest.hookimpl(optionalhook=True)      # xdist's hook: absent under `-p no:xdist`
 def pytest_xdist_auto_num_workers(config):
     """`-n auto` (pytest.ini): workers for the CPU suite (interpreted kernels: CPU-bound, ~1 GB each), none for a run that selects the GPU
     tests (one device, full-size SD1.5 / SDXL models: they must not run side by side)."""

@@ -802,6 +802,30 @@ def test_dapp_layer_positive_and_negative_branches(backend):
     assert rel(y.detach(), yr.detach()) < 2e-2 and rel(xn.grad, xr.grad) < 2e-2
     for b in (bp0, bn, bp1):
         assert rel(b.layer.W_down.grad, fac[b][0].grad) < 3e-2 and rel(b.layer.W_up.grad, fac[b][1].grad) < 3e-2
+    # the LAST plugin's dropout acts on BOTH halves (lora_layers_patch.py:132-133: `self[name].post_forward` after the loop), whichever
+    # branch that plugin belongs to: with p = 1 on the last ('p') block the 'n' half is dropped too and only the fused residual remains
+    bp1.dropout.p = 1.0
+    parent.fc.train()
+    y1 = parent.fc(backend.to(x), residual=backend.to(res))
+    assert torch.equal(y1.detach().cpu(), res)
+    bp1.dropout.p = 0.0
+    # per-sample keyword arguments of a 3x3 conv host follow their half of the batch
+    from hcp_diffusion_amd.layers import HipConv2d
+    cpar = torch.nn.Module(); cpar.cv = HipConv2d(64, 64, 3, padding=1).to(dev)
+    cpar.requires_grad_(False)
+    cblk = [DAPPHipLayer.wrap_model(i, cpar.cv, parent_block=cpar, host_name="cv", rank=4, alpha=1.0, branch=br)[""] for i, br in enumerate("pn")]
+    with torch.no_grad():
+        for b in cblk:
+            b.layer.W_up.normal_(0, 0.1)
+    xc = torch.randn(4, 8, 8, 64).to(torch.bfloat16); rb = torch.randn(4, 64)
+    yc = cpar.cv(backend.to(xc), rowbias=backend.to(rb))
+    chost = cpar.cv._host
+    wc = lambda b: chost.weight.detach().float().cpu() + float(b.alpha) * torch.einsum(
+        "or,rikl->oikl", b.layer.W_up.detach().float().cpu()[:, :, 0, 0], b.layer.W_down.detach().float().cpu())
+    xcr = xc.float().permute(0, 3, 1, 2)
+    ycr = torch.cat([torch.nn.functional.conv2d(xcr[:2], wc(cblk[1]), chost.bias.detach().float().cpu(), padding=1),
+                     torch.nn.functional.conv2d(xcr[2:], wc(cblk[0]), chost.bias.detach().float().cpu(), padding=1)]) + rb[:, :, None, None]
+    assert rel(yc.detach().permute(0, 3, 1, 2), ycr) < 2e-2
     # one branch only: refused like the reference (which adds None to the host weight)
     solo = torch.nn.Module(); solo.fc = HipLinear(64, 48).to(dev)
     DAPPHipLayer.wrap_model(0, solo.fc, parent_block=solo, host_name="fc", rank=4, branch="p")
