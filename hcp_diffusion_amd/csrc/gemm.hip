@@ -825,15 +825,53 @@ HCP_KERNEL(64 * (WGM * WGN + NLD)) gemm_v2_kernel(GemmParams p) {
     }
 }
 
-// sum the split-K slabs and apply the epilogue
+// Sum the split-K slabs in split order and apply the epilogue.  One thread per output quad; the quad index is the slab offset / 4 (rows are
+// N floats), 32-bit throughout (the slabs of one launch fit the workspace: M * N <= 2^26).  A thread's loads are independent of each
+// other, so they are requested in batches — the epilogue's operands with the first one, four slabs at a time after that — instead of one
+// round trip to memory per slab (the round-5 form: a load and an `s_waitcnt vmcnt(0)` per split, and a 64-bit division per quad).
 HCP_KERNEL(256) splitk_reduce_kernel(GemmParams p) {
-    const int nv = p.N / 4;
-    const long total = (long)p.M * nv;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(i / nv), n = (int)(i - (long)m * nv) * 4;
-        hcp_f32x4 v = *(const hcp_f32x4*)(p.slabs + (size_t)m * p.N + n);
-        for (int s = 1; s < p.nsplit; ++s) v += *(const hcp_f32x4*)(p.slabs + ((size_t)s * p.M + m) * p.N + n);
-        epilogue_store(p, m, n, v);
+    const unsigned nv = (unsigned)p.N / 4;
+    const unsigned total = (unsigned)p.M * nv;
+    const size_t slab = (size_t)p.M * p.N;
+    const int ns = p.nsplit;
+    const bool plain = !p.geglu_hg;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int m = (int)(i / nv), n = (int)(i - (unsigned)m * nv) * 4;
+        const float* src = p.slabs + (size_t)i * 4;
+        hcp_f32x4 v = *(const hcp_f32x4*)src;
+        // (an operand the launch does not have is read from the zero page and not used: no branch, so no wait at a join)
+        const void* const zp = g_zero_page;
+        const hcp_f32x4 bias = *(const hcp_f32x4*)(plain && p.bias ? (const void*)(p.bias + n) : zp);
+        const hcp_f32x4 rowb = *(const hcp_f32x4*)(plain && p.rowbias ? (const void*)(p.rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld + n) : zp);
+        const hcp_bf16x4 res = *(const hcp_bf16x4*)(plain && p.residual ? (const void*)(p.residual + (size_t)m * p.ldr + n) : zp);
+        const hcp_bf16x4 res_lo = *(const hcp_bf16x4*)(plain && p.residual && p.residual_lo ? (const void*)(p.residual_lo + (size_t)m * p.ldr + n) : zp);
+        int s = 1;
+        for (; s + 4 <= ns; s += 4) {
+            const hcp_f32x4 a = *(const hcp_f32x4*)(src + (size_t)s * slab), b = *(const hcp_f32x4*)(src + (size_t)(s + 1) * slab);
+            const hcp_f32x4 c = *(const hcp_f32x4*)(src + (size_t)(s + 2) * slab), d = *(const hcp_f32x4*)(src + (size_t)(s + 3) * slab);
+            v += a; v += b; v += c; v += d;
+        }
+        if (s + 2 <= ns) {
+            const hcp_f32x4 a = *(const hcp_f32x4*)(src + (size_t)s * slab), b = *(const hcp_f32x4*)(src + (size_t)(s + 1) * slab);
+            v += a; v += b;
+            s += 2;
+        }
+        if (s < ns) v += *(const hcp_f32x4*)(src + (size_t)s * slab);
+        if (!plain) { epilogue_geglu_bwd(p, m, n, v); continue; }
+        // epilogue_store's arithmetic, on the operands requested above
+        v = v * p.alpha;
+        if (p.bias) v += bias;
+        if (p.rowbias) v += rowb;
+        if (p.residual) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)res[q]);
+            if (p.residual_lo) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += hcp_bf2f((unsigned short)res_lo[q]);
+            }
+        }
+        if (p.out_f32) *(hcp_f32x4*)((float*)p.D + (size_t)m * p.ldd + n) = v;
+        else store_hi_lo(p, m, n, v);
     }
 }
 
