@@ -136,6 +136,7 @@ HCP_DEVICE int hcp_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); } 
 // instructions earlier in every iteration (seen in the attention kernels' ISA).
 HCP_DEVICE void hcp_force_ready(hcp_bf16x8& v) { asm volatile("" : "+v"(v)); }
 HCP_DEVICE void hcp_force_ready(float& v) { asm volatile("" : "+v"(v)); }
+HCP_DEVICE void hcp_force_ready(int& v) { asm volatile("" : "+v"(v)); }      // (also: "recompute this, do not keep it live")
 #define HCP_DEVICE_GLOBAL __device__
 HCP_DEVICE bool hcp_all(bool pred) { return __all(pred); }   // wave-uniform vote
 // Counted wait on the vector-memory counter (LDS-DMA loads are VM operations): returns when at most n of this wave's
@@ -270,7 +271,14 @@ HCP_DEVICE float hcp_wave_max(float v) {
     return v;
 }
 HCP_DEVICE hcp_bf16x8 hcp_zero8() { hcp_bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
+#if defined(HCP_EMU)
 HCP_DEVICE float hcp_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+#else
+// 1 / (1 + e^-x) on the hardware's v_exp_f32 and v_rcp_f32 (1 ulp each; ~6 instructions).  The library expf + the IEEE division are
+// ~30: the GroupNorm+SiLU kernels are VALU-bound on exactly this (one slab per workgroup, half the chip), and what leaves them is bf16.
+// x -> -inf: e^-x = +inf, rcp = 0; x -> +inf: e^-x flushes to 0, rcp(1) = 1.
+HCP_DEVICE float hcp_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+#endif
 HCP_DEVICE float hcp_silu(float x) { return x * hcp_sigmoid(x); }
 // exact (erf) GELU and its derivative: diffusers GEGLU's gate activation (reference cfgs/unet_struct.txt:28-30)
 HCP_DEVICE float hcp_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

@@ -45,11 +45,21 @@ HCP_KERNEL(1024) gn_fwd_partial(const hcp_bf16* x, float* ws, int HW, int C, int
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
     const hcp_bf16* xb = x + (size_t)b * HW * C + cx * 8;
-    for (int r = r0 + ry; r < r1; r += R) {
-        hcp_bf16x8 v = *(const hcp_bf16x8*)(xb + (size_t)r * C);
+    auto row = [&](const hcp_bf16x8& v) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { float f = hcp_bf2f((unsigned short)v[i]); s[i] += f; q[i] += f * f; }
+    };
+    // four rows requested before the first is used (the rolled loop was one load -> s_waitcnt vmcnt(0) -> adds per row: with two
+    // waves per SIMD the pass ran at the latency of a memory round trip per row); same accumulation order
+    int r = r0 + ry;
+    for (; r + 3 * R < r1; r += 4 * R) {
+        hcp_bf16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const hcp_bf16x8*)(xb + (size_t)(r + u * R) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row(v[u]);
     }
+    for (; r < r1; r += R) row(*(const hcp_bf16x8*)(xb + (size_t)r * C));
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s_sum[ry * C + cx * 8 + i] = s[i]; s_sq[ry * C + cx * 8 + i] = q[i]; }
     HCP_SYNC();
@@ -152,8 +162,7 @@ HCP_KERNEL(1024) gn_fwd_apply(const hcp_bf16* x, const float* gamma, const float
         a8[i] = a; b8[i] = beta[c] - s_st[g * 2] * a;
     }
     const size_t base = (size_t)b * HW * C + cx * 8;
-    for (int r = r0 + ry; r < r1; r += R) {
-        hcp_bf16x8 v = *(const hcp_bf16x8*)(x + base + (size_t)r * C);
+    auto row = [&](const hcp_bf16x8& v, int r) {
         hcp_bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -162,7 +171,16 @@ HCP_KERNEL(1024) gn_fwd_apply(const hcp_bf16* x, const float* gamma, const float
             o[i] = (short)hcp_f2bf(z);
         }
         *(hcp_bf16x8*)(y + base + (size_t)r * C) = o;
+    };
+    int r = r0 + ry;
+    for (; r + 3 * R < r1; r += 4 * R) {                 // four rows in flight (see gn_fwd_partial)
+        hcp_bf16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const hcp_bf16x8*)(x + base + (size_t)(r + u * R) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row(v[u], r + u * R);
     }
+    for (; r < r1; r += R) row(*(const hcp_bf16x8*)(x + base + (size_t)r * C), r);
 }
 
 // dz = dy * silu'(z) ; dxhat = dz * gamma ; S1 = sum dxhat ; S2 = sum dxhat * xhat   (per batch, group)
@@ -185,9 +203,7 @@ HCP_KERNEL(1024) gn_bwd_partial(const hcp_bf16* x, const hcp_bf16* dy, const flo
         g8[i] = gamma[c]; be8[i] = beta[c]; s1[i] = 0.f; s2[i] = 0.f;
     }
     const size_t base = (size_t)b * HW * C + cx * 8;
-    for (int r = r0 + ry; r < r1; r += R) {
-        hcp_bf16x8 v = *(const hcp_bf16x8*)(x + base + (size_t)r * C);
-        hcp_bf16x8 d = *(const hcp_bf16x8*)(dy + base + (size_t)r * C);
+    auto row = [&](const hcp_bf16x8& v, const hcp_bf16x8& d) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float xh = (hcp_bf2f((unsigned short)v[i]) - mean8[i]) * rstd8[i];
@@ -196,7 +212,19 @@ HCP_KERNEL(1024) gn_bwd_partial(const hcp_bf16* x, const hcp_bf16* dy, const flo
             float dxh = dz * g8[i];
             s1[i] += dxh; s2[i] += dxh * xh;
         }
+    };
+    int r = r0 + ry;
+    for (; r + 1 * R < r1; r += 2 * R) {                 // two rows of both tensors in flight (see gn_fwd_partial; four rows spill); same accumulation order
+        hcp_bf16x8 v[2], d[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            v[u] = *(const hcp_bf16x8*)(x + base + (size_t)(r + u * R) * C);
+            d[u] = *(const hcp_bf16x8*)(dy + base + (size_t)(r + u * R) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) row(v[u], d[u]);
     }
+    for (; r < r1; r += R) row(*(const hcp_bf16x8*)(x + base + (size_t)r * C), *(const hcp_bf16x8*)(dy + base + (size_t)r * C));
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s_1[ry * C + cx * 8 + i] = s1[i]; s_2[ry * C + cx * 8 + i] = s2[i]; }
     HCP_SYNC();
@@ -237,10 +265,7 @@ HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float
         g8[i] = gamma[c]; be8[i] = beta[c]; c1[i] = s_c12[g * 2]; c2[i] = s_c12[g * 2 + 1];
     }
     const size_t base = (size_t)b * HW * C + cx * 8;
-    for (int r = r0 + ry; r < r1; r += R) {
-        hcp_bf16x8 v = *(const hcp_bf16x8*)(x + base + (size_t)r * C);
-        hcp_bf16x8 d = *(const hcp_bf16x8*)(dy + base + (size_t)r * C);
-        hcp_bf16x8 ad = addend ? *(const hcp_bf16x8*)(addend + base + (size_t)r * C) : hcp_zero8();
+    auto row = [&](const hcp_bf16x8& v, const hcp_bf16x8& d, const hcp_bf16x8& ad, int r) {
         hcp_bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -251,7 +276,24 @@ HCP_KERNEL(1024) gn_bwd_apply(const hcp_bf16* x, const hcp_bf16* dy, const float
             o[i] = (short)hcp_f2bf(rstd8[i] * (dxh - c1[i] - xh * c2[i]) + (addend ? hcp_bf2f((unsigned short)ad[i]) : 0.f));
         }
         *(hcp_bf16x8*)(dx + base + (size_t)r * C) = o;
+    };
+    // the skip gradient is read from dy's rows where there is none (uniform select of the base pointer, no branch) and ignored
+    const hcp_bf16* const adp = addend ? addend : dy;
+    int r = r0 + ry;
+    for (; r + 1 * R < r1; r += 2 * R) {                 // two rows of the three tensors in flight (see gn_fwd_partial)
+        hcp_bf16x8 v[2], d[2], ad[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            v[u] = *(const hcp_bf16x8*)(x + base + (size_t)(r + u * R) * C);
+            d[u] = *(const hcp_bf16x8*)(dy + base + (size_t)(r + u * R) * C);
+            ad[u] = *(const hcp_bf16x8*)(adp + base + (size_t)(r + u * R) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) row(v[u], d[u], ad[u], r + u * R);
     }
+    for (; r < r1; r += R)
+        row(*(const hcp_bf16x8*)(x + base + (size_t)r * C), *(const hcp_bf16x8*)(dy + base + (size_t)r * C),
+            *(const hcp_bf16x8*)(adp + base + (size_t)r * C), r);
 }
 
 // ------------------------------------------------------------------ GroupNorm, one launch: a (sample, group) slab per workgroup
@@ -283,27 +325,39 @@ typedef float hcp_f32x2 __attribute__((ext_vector_type(2)));
 template <> struct GNChunk<4> { typedef hcp_bf16x4 T; typedef hcp_f32x4 F; };
 template <> struct GNChunk<2> { typedef hcp_bf16x2 T; typedef hcp_f32x2 F; };
 
+// Both kernels are latency-bound, not bandwidth-bound (128 workgroups of one slab each: nothing else runs on the CU), so what counts is the
+// number of DEPENDENT memory round trips.  The first form loaded a chunk under `if (c < total)` and used it at once — the unrolled loop
+// became NCH blocks of load -> s_waitcnt vmcnt(0) -> arithmetic, and the passes that need gamma / beta fetched those per chunk as well.
+// Now every pass requests all its chunks first (dead chunks read chunk 0 and are masked afterwards, so the loads are unconditional and the
+// compiler keeps them together), and the group's gamma / beta sit in LDS (Cg floats each, staged once, behind s_red).
 template <int NCH, int CE>
 HCP_KERNEL(1024) gn_slab_fwd(const hcp_bf16* x, const float* gamma, const float* beta, float* stats, hcp_bf16* y, int HW, int C,
                              int G, int cpr, unsigned cpr_magic, int silu, float eps) {
     typedef typename GNChunk<CE>::T V;
+    typedef typename GNChunk<CE>::F FV;
     HCP_DYN_SMEM(smem);
-    float* s_red = (float*)smem;                          // [waves]
+    float* s_red = (float*)smem;                          // [32 waves at most]
     const int tid = threadIdx.x, NT = blockDim.x;
     const int g = blockIdx.x, b = blockIdx.y;
     const int Cg = C / G, total = HW * cpr;
+    float* s_ga = s_red + 32;                             // [Cg] gamma, [Cg] beta of this group (visible behind the first block sum's barrier)
+    float* s_be = s_ga + Cg;
+    for (int j = tid; j < Cg; j += NT) { s_ga[j] = gamma[g * Cg + j]; s_be[j] = beta[g * Cg + j]; }
     const size_t base = (size_t)b * HW * C + (size_t)g * Cg;
     V v[NCH];
-    float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + i * NT;
         int cg;
+        v[i] = *(const V*)(x + base + gn_slab_off<CE>(c < total ? c : 0, cpr, cpr_magic, C, &cg));
+        if (NCH > 8 && i % 8 == 7) hcp_sched_fence();      // (addresses of at most 8 chunks at a time)
+    }
+    float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < CE; ++e) v[i][e] = 0;
-        if (c < total) v[i] = *(const V*)(x + base + gn_slab_off<CE>(c, cpr, cpr_magic, C, &cg));
+    for (int i = 0; i < NCH; ++i) {
+        const bool live = tid + i * NT < total;
 #pragma unroll
-        for (int e = 0; e < CE; ++e) s += hcp_bf2f((unsigned short)v[i][e]);
+        for (int e = 0; e < CE; ++e) { v[i][e] = live ? v[i][e] : (short)0; s += hcp_bf2f((unsigned short)v[i][e]); }
     }
     const float n = (float)HW * Cg;
     const float mean = gn_block_sum(s, s_red, tid, NT) / n;
@@ -322,8 +376,7 @@ HCP_KERNEL(1024) gn_slab_fwd(const hcp_bf16* x, const float* gamma, const float*
         if (c >= total) continue;
         int cg;
         const size_t off = gn_slab_off<CE>(c, cpr, cpr_magic, C, &cg);
-        typedef typename GNChunk<CE>::F FV;
-        const FV ga = *(const FV*)(gamma + g * Cg + cg), be = *(const FV*)(beta + g * Cg + cg);   // (one vector load each, not CE scalar ones)
+        const FV ga = *(const FV*)(s_ga + cg), be = *(const FV*)(s_be + cg);
         V o;
 #pragma unroll
         for (int e = 0; e < CE; ++e) {
@@ -340,19 +393,44 @@ template <int NCH, int CE>
 HCP_KERNEL(1024) gn_slab_bwd(const hcp_bf16* x, const hcp_bf16* dy, const float* gamma, const float* beta, const float* stats,
                              const hcp_bf16* addend, hcp_bf16* dx, int HW, int C, int G, int cpr, unsigned cpr_magic, int silu) {
     typedef typename GNChunk<CE>::T V;
+    typedef typename GNChunk<CE>::F FV;
     HCP_DYN_SMEM(smem);
     float* s_red = (float*)smem;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int g = blockIdx.x, b = blockIdx.y;
     const int Cg = C / G, total = HW * cpr;
+    float* s_ga = s_red + 32;
+    float* s_be = s_ga + Cg;
+    for (int j = tid; j < Cg; j += NT) { s_ga[j] = gamma[g * Cg + j]; s_be[j] = beta[g * Cg + j]; }
     const size_t base = (size_t)b * HW * C + (size_t)g * Cg;
     const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
-    // the lane's chunks of x and dy stay in registers as loaded (bf16); xhat / dxhat are recomputed in the second pass
-    V v[NCH], d[NCH];
-    float s1 = 0.f, s2 = 0.f;
+    // the lane's chunks of x and dy stay in registers as loaded (bf16); xhat / dxhat are recomputed in the second pass.  The skip
+    // gradient (addend) is requested with them where the registers allow (<= 32 elements per lane and tensor): it arrives while the
+    // block sums run; the two largest shapes request it in the second pass, eight chunks at a time (anything more spills).
+    constexpr bool EARLY_AD = NCH * CE <= 32;
+    constexpr int GB = NCH < 8 ? NCH : 8;
+    V v[NCH], d[NCH], ad[EARLY_AD ? NCH : 1];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * NT;
+        int cg;
+        const size_t off = gn_slab_off<CE>(c < total ? c : 0, cpr, cpr_magic, C, &cg);
+        v[i] = *(const V*)(x + base + off); d[i] = *(const V*)(dy + base + off);
+        if (NCH > 8 && i % 8 == 7) hcp_sched_fence();      // (addresses of at most 8 chunks at a time: 32 chunks' worth spills)
+    }
+    if constexpr (EARLY_AD) {
+        if (addend) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + i * NT;
+                int cg;
+                ad[i] = *(const V*)(addend + base + gn_slab_off<CE>(c < total ? c : 0, cpr, cpr_magic, C, &cg));
+            }
+        }
+    }
+    HCP_SYNC();                                           // gamma / beta staged
     auto terms = [&](int i, int cg, float (&h)[CE], float (&dh)[CE]) {
-        typedef typename GNChunk<CE>::F FV;
-        const FV ga = *(const FV*)(gamma + g * Cg + cg), be = *(const FV*)(beta + g * Cg + cg);
+        const FV ga = *(const FV*)(s_ga + cg), be = *(const FV*)(s_be + cg);
 #pragma unroll
         for (int e = 0; e < CE; ++e) {
             h[e] = (hcp_bf2f((unsigned short)v[i][e]) - mean) * rstd;
@@ -361,41 +439,67 @@ HCP_KERNEL(1024) gn_slab_bwd(const hcp_bf16* x, const hcp_bf16* dy, const float*
             dh[e] = dz * ga[e];
         }
     };
+    // dxhat of the lane's elements is KEPT for the second pass where the registers allow (<= 32 elements per lane; xhat is two
+    // instructions from the bf16 x that stays anyway): the kernel is VALU-bound (one workgroup per CU on half the chip, the SiLU
+    // derivative per element in both passes), not memory-bound; the larger shapes recompute it.
+    constexpr bool KEEP = NCH * CE <= 32;
+    float dhk[KEEP ? NCH : 1][CE];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int c = tid + i * NT;
-#pragma unroll
-        for (int e = 0; e < CE; ++e) { v[i][e] = 0; d[i][e] = 0; }
+        int c = tid + i * NT;
+        if (NCH > 16) hcp_force_ready(c);               // (32 chunks: recompute the chunk's position instead of keeping 32 of them live)
         if (c < total) {
             int cg;
-            const size_t off = gn_slab_off<CE>(c, cpr, cpr_magic, C, &cg);
-            v[i] = *(const V*)(x + base + off); d[i] = *(const V*)(dy + base + off);
+            gn_slab_off<CE>(c, cpr, cpr_magic, C, &cg);
             float h[CE], dh[CE];
             terms(i, cg, h, dh);
 #pragma unroll
-            for (int e = 0; e < CE; ++e) { s1 += dh[e]; s2 += dh[e] * h[e]; }
+            for (int e = 0; e < CE; ++e) {
+                s1 += dh[e]; s2 += dh[e] * h[e];
+                if constexpr (KEEP) dhk[i][e] = dh[e];
+            }
         }
+        if (NCH > 16 && i % 8 == 7) hcp_sched_fence();     // (32 chunks: their gamma / beta reads hoisted together spill)
     }
     const float n = (float)HW * Cg;
     const float c1 = gn_block_sum(s1, s_red, tid, NT) / n;
     const float c2 = gn_block_sum(s2, s_red, tid, NT) / n;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = tid + i * NT;
-        if (c >= total) continue;
-        int cg;
-        const size_t off = gn_slab_off<CE>(c, cpr, cpr_magic, C, &cg);
-        V ad;
+    for (int i0 = 0; i0 < NCH; i0 += GB) {
+        V adg[GB];
+        if (addend) {
 #pragma unroll
-        for (int e = 0; e < CE; ++e) ad[e] = 0;
-        if (addend) ad = *(const V*)(addend + base + off);
-        float h[CE], dh[CE];
-        terms(i, cg, h, dh);
-        V o;
+            for (int j = 0; j < GB; ++j) {
+                if constexpr (EARLY_AD) adg[j] = ad[i0 + j];
+                else {
+                    int c = tid + (i0 + j) * NT;
+                    if (NCH > 16) hcp_force_ready(c);
+                    int cg;
+                    adg[j] = *(const V*)(addend + base + gn_slab_off<CE>(c < total ? c : 0, cpr, cpr_magic, C, &cg));
+                }
+            }
+        }
 #pragma unroll
-        for (int e = 0; e < CE; ++e)
-            o[e] = (short)hcp_f2bf(rstd * (dh[e] - c1 - h[e] * c2) + (addend ? hcp_bf2f((unsigned short)ad[e]) : 0.f));
-        *(V*)(dx + base + off) = o;
+        for (int j = 0; j < GB; ++j) {
+            const int i = i0 + j;
+            int c = tid + i * NT;
+            if (NCH > 16) hcp_force_ready(c);
+            if (c >= total) continue;
+            int cg;
+            const size_t off = gn_slab_off<CE>(c, cpr, cpr_magic, C, &cg);
+            float h[CE], dh[CE];
+            if constexpr (KEEP) {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { h[e] = (hcp_bf2f((unsigned short)v[i][e]) - mean) * rstd; dh[e] = dhk[i][e]; }
+            } else terms(i, cg, h, dh);
+            V o;
+#pragma unroll
+            for (int e = 0; e < CE; ++e)
+                o[e] = (short)hcp_f2bf(rstd * (dh[e] - c1 - h[e] * c2) + (addend ? hcp_bf2f((unsigned short)adg[j][e]) : 0.f));
+            *(V*)(dx + base + off) = o;
+        }
+        if (NCH > 16) hcp_sched_fence();
     }
 }
 
@@ -406,7 +510,7 @@ GNSlab gn_slab_geom(int HW, int C, int G) {
     const int Cg = C / G;
     if (Cg % 2) return r;
     const int ce = Cg % 4 == 0 ? 4 : 2;
-    if ((long)HW * Cg > 65536) return r;                      // 128 KB of bf16 per slab: <= 64 elements per thread and tensor
+    if ((long)HW * Cg > 65536 || Cg > 2048) return r;         // 128 KB of bf16 per slab: <= 64 elements per thread and tensor; gamma | beta of the group in LDS
     if (ce == 2 && HW > 1024) return r;                       // C = 320 at 64x64: rows of 20 bytes, measured 0.95 ms/step SLOWER than two launches
     const long total = (long)HW * (Cg / ce);
     r.ce = ce; r.cpr = Cg / ce;
@@ -646,7 +750,7 @@ HCP_API int hcp_groupnorm_silu_fwd(const void* x, const float* gamma, const floa
     if (sl.nch && g_gn_slab) {
         const hcp_bf16* xp = (const hcp_bf16*)x; hcp_bf16* yp = (hcp_bf16*)y;
         const dim3 grid(G, B), blk(sl.nt);
-        const size_t sm = 32 * sizeof(float);
+        const size_t sm = (32 + 2 * (size_t)(C / G)) * sizeof(float);     // block-sum scratch + the group's gamma | beta
         HCP_GN_SLAB_SWITCH(gn_slab_fwd, xp, gamma, beta, stats, yp, HW, C, G, sl.cpr, sl.magic, silu, eps);
         HCP_LAUNCH_CHECK("groupnorm_fwd (slab)");
     }
@@ -670,7 +774,7 @@ HCP_API int hcp_groupnorm_silu_bwd(const void* x, const void* dy, const float* g
     if (sl.nch && g_gn_slab) {
         const hcp_bf16 *xp = (const hcp_bf16*)x, *dp = (const hcp_bf16*)dy, *ap = (const hcp_bf16*)addend; hcp_bf16* op = (hcp_bf16*)dx;
         const dim3 grid(G, B), blk(sl.nt);
-        const size_t sm = 32 * sizeof(float);
+        const size_t sm = (32 + 2 * (size_t)(C / G)) * sizeof(float);     // block-sum scratch + the group's gamma | beta
         HCP_GN_SLAB_SWITCH(gn_slab_bwd, xp, dp, gamma, beta, stats, ap, op, HW, C, G, sl.cpr, sl.magic, silu);
         HCP_LAUNCH_CHECK("groupnorm_bwd (slab)");
     }

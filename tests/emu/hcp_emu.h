@@ -164,6 +164,7 @@ HCP_DEVICE void hcp_dma_wait_all() { hcp_emu::dma_drain(0); }
 HCP_DEVICE int hcp_uniform(int v) { return v; }
 HCP_DEVICE void hcp_force_ready(hcp_bf16x8&) {}
 HCP_DEVICE void hcp_force_ready(float&) {}
+HCP_DEVICE void hcp_force_ready(int&) {}
 #define HCP_DEVICE_GLOBAL static
 HCP_DEVICE void hcp_wait_vmcnt(int n) { hcp_emu::dma_drain(n); }
 HCP_DEVICE void hcp_barrier_keep_dma() { hcp_emu::yield_barrier(); }
